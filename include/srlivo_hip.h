@@ -1,0 +1,180 @@
+/*
+ * srlivo_hip.h -- C-ABI of libsrlivo_hip.so: the MI355X (gfx950) implementation of SR-LIVO's LIO
+ * scan-matching hot path (reference: ZikangYuan/sr_livo, src/optimize.cpp).
+ *
+ * The reference has no FFI/plugin API for this path: it sits behind member functions of
+ * `class lioOptimization` (include/lioOptimization.h:334-357).  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference root).  The C++ host mirror that
+ * keeps the reference's class surfaces (lioOptimization / eskfEstimator / cloudMap types) lives in
+ * sr_livo_amd/csrc/host/ and forwards to this ABI; INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions: plain pointers and sizes, caller-owned HOST buffers unless a parameter says
+ * "device"; all floating point is FP64 except stored map positions (FP32, cloudMap.h:54) and voxel
+ * keys (int16, cloudMap.h:124-145); matrices ROW-MAJOR; quaternions (w,x,y,z).  Every function
+ * returns SRL_OK (0) or a negative srl_status; no exceptions cross the ABI.  There is NO CPU
+ * fallback: without a HIP device srl_ctx_create fails with SRL_ERR_NO_DEVICE.
+ */
+#ifndef SRLIVO_HIP_H
+#define SRLIVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRL_VOXEL_CAP 20        /* max_num_points_in_voxel of the LIO map (config/r3live.yaml:50, ntu.yaml:49) */
+#define SRL_MAX_NEIGHBORS 32    /* upper bound supported for icpOptions::max_number_neighbors (shipped: 20) */
+
+typedef enum srl_status {
+    SRL_OK = 0,
+    SRL_ERR_NO_DEVICE = -1,     /* no HIP device / HIP runtime failure at create */
+    SRL_ERR_HIP = -2,           /* a HIP call failed (see srl_last_error) */
+    SRL_ERR_BAD_ARG = -3,
+    SRL_ERR_UNSUPPORTED = -4,   /* option outside the supported envelope (cap != 20, K > 32, nb_voxels > 2) */
+    SRL_ERR_NO_MAP = -5,
+    SRL_ERR_NO_SWEEP = -6,
+    SRL_ERR_COMM = -7,          /* RCCL failure */
+    SRL_ERR_NAN_PLANARITY = -8, /* optimize.cpp:348-350: a2D is NaN -> the reference throws std::runtime_error("error") */
+    SRL_ERR_NOT_ENOUGH_RESIDUALS = -9  /* optimize.cpp:110-123: summary.success = false */
+} srl_status;
+
+typedef struct srl_ctx srl_ctx;
+
+/* mirrors the fields of icpOptions the path reads (include/parameters.h:8-56) */
+typedef struct srl_icp_opts {
+    int32_t threshold_voxel_occupancy;  /* parameters.h:13 */
+    int32_t init_num_frames;            /* parameters.h:15 */
+    double  size_voxel_map;             /* parameters.h:17 */
+    int32_t num_iters_icp;              /* parameters.h:19 */
+    int32_t min_number_neighbors;       /* parameters.h:21 */
+    int32_t voxel_neighborhood;         /* parameters.h:23 */
+    double  power_planarity;            /* parameters.h:25 */
+    int32_t max_number_neighbors;       /* parameters.h:30 */
+    double  max_dist_to_plane_icp;      /* parameters.h:32 */
+    double  threshold_orientation_norm; /* parameters.h:34 */
+    double  threshold_translation_norm; /* parameters.h:36 */
+    int32_t max_num_residuals;          /* parameters.h:40 */
+    double  weight_alpha;               /* parameters.h:46 */
+    double  weight_neighborhood;        /* parameters.h:48 */
+    int32_t select_mode;                /* ours: 0 = auto, 1 = force the streaming-extraction selection (test hook) */
+} srl_icp_opts;
+
+/* per-iteration pose + frame constants read by buildPlaneResiduals (optimize.cpp:21-28,83) */
+typedef struct srl_frame {
+    double  q[4];        /* p_frame->p_state->rotation (w,x,y,z), NOT normalised by the caller */
+    double  t[3];        /* p_frame->p_state->translation */
+    double  t_last[3];   /* all_cloud_frame[id-1]->p_state->translation (optimize.cpp:25) */
+    double  R_il[9];     /* R_imu_lidar (lioOptimization.h:227) */
+    double  t_il[3];     /* t_imu_lidar (lioOptimization.h:228) */
+    int32_t frame_id;    /* p_frame->frame_id (selects init mode, optimize.cpp:21-23) */
+} srl_frame;
+
+/* what one buildPlaneResiduals pass hands to updateIEKF (optimize.cpp:160-170,235,239) */
+typedef struct srl_normal_eq {
+    double  HtH[36];         /* H_x^T H_x, 6x6 row-major */
+    double  Hth[6];          /* H_x^T h */
+    double  loss_sum;        /* sum of distance^2 over accepted residuals (optimize.cpp:104) */
+    int32_t num_residuals;   /* optimizeSummary.num_residuals_used */
+    int32_t success;         /* optimizeSummary.success (optimize.cpp:110) */
+    int64_t sum_candidates;  /* sum over keypoints of resident points visited (P_k), whole sweep */
+    int64_t last_visited;    /* global index of the last keypoint the sequential loop would visit (cut-off) */
+    int32_t nan_error;       /* 1 if a NaN planarity was met among visited keypoints */
+    int32_t num_fallback;    /* keypoints that took the streaming-extraction selection path */
+} srl_normal_eq;
+
+/* ------------------------------------------------------------------ context */
+int         srl_device_count(int *count);
+int         srl_ctx_create(int device, srl_ctx **out);
+int         srl_ctx_destroy(srl_ctx *ctx);
+const char *srl_last_error(const srl_ctx *ctx);      /* text of the last failure on this context */
+const char *srl_status_str(int status);
+void        srl_icp_opts_default(srl_icp_opts *o);   /* effective values of config/r3live.yaml:57-69 */
+
+/* ------------------------------------------------------------------ voxel map
+ * replaces: voxelHashMap voxel_map (lioOptimization.h:274; cloudMap.h:171 tsl::robin_map<voxel, voxelBlock>).
+ * srl_map_upload installs a map built elsewhere (voxels in creation order; point id = voxel*cap + slot). */
+int srl_map_upload(srl_ctx *ctx, const int16_t *keys_xyz /* V x 3 */, const int32_t *counts /* V */,
+                   const float *xyz /* V x cap x 3, AoS */, int num_voxels, int cap);
+/* replaces lioOptimization::addPointsToMap / addPointToMap (lioOptimization.cpp:520-554, 400-446):
+ * order-dependent insert of world points (AoS n x 3, FP64) into the device-resident map. */
+int srl_map_insert(srl_ctx *ctx, const double *world_xyz, int n, double voxel_size, int cap,
+                   double min_distance_points, int min_num_points, int *num_added);
+/* replaces lioOptimization::mapSize (lioOptimization.cpp:574-581) */
+int srl_map_size(srl_ctx *ctx, int64_t *num_points, int32_t *num_voxels);
+/* copies the device map back in creation order (same layout as srl_map_upload) */
+int srl_map_download(srl_ctx *ctx, int16_t *keys_xyz, int32_t *counts, float *xyz, int max_voxels);
+
+/* ------------------------------------------------------------------ sweep
+ * replaces: the `keypoints` vector handed to updateIEKF (optimize.cpp:133; point3D::raw_point,
+ * cloudMap.h:40).  AoS n x 3 FP64 in the lidar frame, in keypoint order.  Uploaded once per sweep.
+ * With a communicator attached this rank keeps the contiguous range [rank*n/R, (rank+1)*n/R). */
+int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n);
+int srl_sweep_shard(srl_ctx *ctx, int *begin, int *count, int *total);
+
+/* ------------------------------------------------------------------ hot path
+ * replaces: lioOptimization::buildPlaneResiduals (optimize.cpp:18-131) incl. searchNeighbors
+ * (:365-426), computeNeighborhoodDistribution (:316-353), and the H_x^T H_x / H_x^T h contraction
+ * of updateIEKF (:235,:239).  One call per ESIKF iteration.  With a communicator the result is
+ * all-reduced (RCCL) and identical on every rank.  Returns SRL_OK even when out->success == 0. */
+int srl_build_residuals(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts *opts, srl_normal_eq *out);
+
+/* enable/disable the per-keypoint parity taps written by srl_build_residuals (off by default) */
+int srl_set_taps(srl_ctx *ctx, int enable);
+
+/* parity taps for the LAST srl_build_residuals on this rank's shard (any pointer may be NULL).
+ * status: 0 = < min_number_neighbors, 1 = plane built but distance gate rejected, 2 = accepted,
+ * 3 = not visited by the sequential loop (after the max_num_residuals cut-off). */
+int srl_fetch_neighbors(srl_ctx *ctx, int32_t *ids /* n x K, -1 padded */, uint8_t *status /* n */,
+                        int32_t *num_candidates /* n */);
+int srl_fetch_residuals(srl_ctx *ctx, double *normal /* n x 3 */, double *a2D, double *weight,
+                        double *norm_offset, double *distance, double *jacobian /* n x 6 */);
+
+/* replaces: lioOptimization::searchNeighbors for a batch of WORLD points (optimize.cpp:365-426) */
+int srl_search_neighbors(srl_ctx *ctx, const double *world_xyz, int n, int nb_voxels_visited,
+                         double size_voxel_map, int max_num_neighbors, int threshold_voxel_capacity,
+                         int32_t *ids /* n x K */, float *nb_xyz /* n x K x 3, may be NULL */,
+                         int32_t *num_found /* n */);
+
+/* replaces: the re-transform loop at the end of optimize() (optimize.cpp:441-445 -> utility.cpp:314-318):
+ * out = R(q) * (R_il * raw + t_il) + t for n points (AoS, host buffers). */
+int srl_transform_points(srl_ctx *ctx, const double *raw_xyz, int n, const double q[4], const double t[3],
+                         const double R_il[9], const double t_il[3], double *out_xyz);
+
+/* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI)
+ * one context per process/GPU; the only exchange step is the all-reduce of the normal equations. */
+#define SRL_COMM_ID_BYTES 128
+int srl_comm_unique_id(void *id /* SRL_COMM_ID_BYTES */);
+int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id);
+int srl_comm_destroy(srl_ctx *ctx);
+/* test hook: a host all-reduce callback (sum over ranks of `count` doubles, in place) used INSTEAD of
+ * RCCL when set -- lets the sharded logic run over gloo/MPI or G logical shards on one device. */
+typedef int (*srl_allreduce_fn)(double *buf, int count, void *user);
+typedef int (*srl_allgather_i64_fn)(const int64_t *mine, int64_t *all /* nranks */, void *user);
+int srl_comm_set_host_callbacks(srl_ctx *ctx, int nranks, int rank, srl_allreduce_fn ar,
+                                srl_allgather_i64_fn ag, void *user);
+
+/* pure helpers of the sharded path (also used internally): the contiguous point range of a rank
+ * (SURVEY.md 8(e)), and the residual budget a rank may still spend given the accepted counts of all
+ * shards (reproduces the sequential early exit, optimize.cpp:107, across ordered shards).
+ * mode: 0 = spend up to *budget, 1 = visit only the first keypoint, 2 = visit nothing. */
+void srl_shard_range(int n, int nranks, int rank, int *begin, int *count);
+void srl_shard_budget(int max_num_residuals, const int64_t *accepted_per_rank, int nranks, int rank,
+                      int64_t *budget, int *mode);
+
+/* ------------------------------------------------------------------ measurement
+ * HIP-event timings (ms) of the last srl_build_residuals on the context's own stream. */
+typedef struct srl_timing {
+    float assoc_ms;       /* association + plane fit + residual kernel */
+    float reduce_ms;      /* ordered cut-off + final reduction kernel(s) */
+    float total_ms;       /* first launch -> results on host */
+    int64_t algorithmic_bytes; /* sum_k (24 + 12*(2r+1)^3 + 12*P_k) for this rank's shard */
+} srl_timing;
+int srl_get_timing(srl_ctx *ctx, srl_timing *t);
+int srl_set_profiling(srl_ctx *ctx, int enable);   /* event timing on/off (off by default) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,93 @@
+/*
+ * srlivo_host.h -- C handles onto the C++ host mirror (sr_livo_amd/csrc/host/: lioOptimization,
+ * eskfEstimator, cloudMap types with the reference's member names).  A C++ consumer (the ROS node)
+ * includes the mirror headers directly; these handles exist so that non-C++ harnesses (the Python
+ * parity tests and bench.py, via ctypes) drive exactly the same C++ code.  Exported by
+ * libsrlivo_hip.so next to the kernel-level ABI of srlivo_hip.h.
+ */
+#ifndef SRLIVO_HOST_H
+#define SRLIVO_HOST_H
+
+#include "srlivo_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srl_lio srl_lio;
+
+/* device >= 0: lioOptimization on the HIP backend (fails with SRL_ERR_NO_DEVICE without a GPU).
+ * device <  0: host-only object; only srl_lio_update_iekf_provided() may be used on it. */
+int      srl_lio_create(int device, srl_lio **out);
+int      srl_lio_destroy(srl_lio *lio);
+srl_ctx *srl_lio_ctx(srl_lio *lio);                         /* the context behind voxel_map (NULL if host-only) */
+const char *srl_lio_last_error(srl_lio *lio);
+
+/* members of class lioOptimization the path reads (lioOptimization.h:221,227-228) */
+int srl_lio_set_extrinsics(srl_lio *lio, const double R_il[9], const double t_il[3]);
+int srl_lio_set_laser_point_cov(srl_lio *lio, double cov);
+
+/* eskfEstimator accessors (eskfEstimator.h:74-108).  state = p(3) q(wxyz,4) v(3) ba(3) bg(3) g(3) */
+int srl_lio_eskf_get_state(srl_lio *lio, double s[19]);
+int srl_lio_eskf_set_state(srl_lio *lio, const double s[19]);
+int srl_lio_eskf_get_cov(srl_lio *lio, double P[289]);
+int srl_lio_eskf_set_cov(srl_lio *lio, const double P[289]);
+int srl_lio_eskf_set_noise(srl_lio *lio, double acc_cov, double gyr_cov, double b_acc_cov, double b_gyr_cov);
+int srl_lio_eskf_init_imu(srl_lio *lio, const double acc0[3], const double gyr0[3]);
+int srl_lio_eskf_scale_init_cov(srl_lio *lio);
+int srl_lio_eskf_predict(srl_lio *lio, double dt, const double acc1[3], const double gyr1[3]);
+int srl_lio_eskf_observe(srl_lio *lio, const double dx[17]);
+
+/* lioOptimization::addPointsToMap / mapSize (lioOptimization.h:347-357) on the device map */
+int srl_lio_add_points_to_map(srl_lio *lio, const double *world_xyz, int n, double voxel_size,
+                              int max_num_points_in_voxel, double min_distance_points, int min_num_points);
+int srl_lio_map_size(srl_lio *lio, int64_t *num_points);
+
+/* keep a sweep resident in HBM for the next srl_lio_update_iekf (pass raw_xyz = NULL there) */
+int srl_lio_resident_sweep(srl_lio *lio, const double *raw_xyz, int n);
+
+/* lioOptimization::updateIEKF (optimize.cpp:133-314).
+ * state_io: p_frame->p_state = q(wxyz) t v ba bg (16 doubles) in/out; t_last = previous frame's
+ * translation; log (optional): per iteration HtH(36) Hth(6) d_x(17) num_residuals loss = 61 doubles.
+ * Returns SRL_OK with *iters >= 1, or SRL_ERR_NOT_ENOUGH_RESIDUALS / SRL_ERR_NAN_PLANARITY / ... */
+int srl_lio_update_iekf(srl_lio *lio, const srl_icp_opts *opts, const double *raw_xyz, int n,
+                        double state_io[16], const double t_last[3], int frame_id, double *log,
+                        int max_log_iters, int *iters, int *num_residuals_used);
+
+/* same update, the per-iteration normal equations coming from `provider` (multi-process CPU tests of
+ * the sharded host logic; never used by the product path). */
+typedef int (*srl_normal_eq_provider)(const srl_frame *frame, const srl_icp_opts *opts, srl_normal_eq *out, void *user);
+int srl_lio_update_iekf_provided(srl_lio *lio, const srl_icp_opts *opts, srl_normal_eq_provider provider,
+                                 void *user, int n, double state_io[16], const double t_last[3], int frame_id,
+                                 double *log, int max_log_iters, int *iters, int *num_residuals_used);
+
+/* lioOptimization::optimize (optimize.cpp:428-448): gridSampling -> updateIEKF -> re-transform.
+ * frame_raw / frame_world: point3D::raw_point / ::point of p_frame->point_frame (n x 3 each);
+ * frame_world is overwritten with the re-transformed points on success; keypoint_index (optional,
+ * capacity n) receives the indices gridSampling selected, in keypoint order. */
+int srl_lio_optimize(srl_lio *lio, const srl_icp_opts *opts, double sample_voxel_size, const double *frame_raw,
+                     double *frame_world, int n, double state_io[16], const double t_last[3], int frame_id,
+                     int32_t *keypoint_index, int *num_keypoints, int *iters, int *num_residuals_used);
+
+/* lioOptimization::searchNeighbors / computeNeighborhoodDistribution single-call forms */
+int srl_lio_search_neighbors(srl_lio *lio, const double point[3], int nb_voxels_visited, double size_voxel_map,
+                             int max_num_neighbors, int threshold_voxel_capacity, double *out_xyz /* K x 3 */,
+                             int16_t *out_voxels /* K x 3 or NULL */, int *num_found);
+int srl_lio_neighborhood(srl_lio *lio, const double *pts, int n, double center[3], double normal[3],
+                         double cov[9], double *a2D);
+
+/* lioOptimization::buildPlaneResiduals, signature-compatible form (materialises the residual list):
+ * outputs for the accepted residuals in order: raw_point(3) norm_vector(3) jacobians(6) norm_offset
+ * distance weight = 15 doubles each, capacity max_out rows. */
+int srl_lio_build_plane_residuals(srl_lio *lio, const srl_icp_opts *opts, const double *raw_xyz, int n,
+                                  const double state[16], const double t_last[3], int frame_id,
+                                  double *out_rows, int max_out, int *num_out, double *loss_sum,
+                                  int *success, double *keypoint_world /* n x 3 or NULL */);
+
+/* gridSampling (utility.cpp:188-201) alone: indices of the selected points, in output order */
+int srl_grid_sampling(const double *world_xyz, int n, double size_voxel, int32_t *index_out, int *num_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

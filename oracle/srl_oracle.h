@@ -1,0 +1,154 @@
+/*
+ * srl_oracle.h -- C ABI of the CPU ORACLE for the SR-LIVO LIO scan-matching hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and there
+ * only as the checker / the timed CPU baseline -- never as the thing shipped.
+ *
+ * PARITY UNPINNED: the reference (ZikangYuan/sr_livo) ships no tests, golden vectors or
+ * fixtures for this path and its own sources cannot be compiled
+ * here (Eigen/ROS/PCL/OpenCV/Ceres absent).  The oracle is a line-by-line restatement of
+ *   src/optimize.cpp:18-448, include/cloudMap.h:37-184, src/cloudMap.cpp:5-29,
+ *   src/lioOptimization.cpp:400-446,520-554,574-581, src/eskfEstimator.cpp:3-21,166-230,
+ *   include/utility.h:191-331, src/utility.cpp:146-153
+ * pinned instead by (1) an independent NumPy implementation in tests/, (2) analytic cases,
+ * (3) the known-answer values of SURVEY.md Appendix D, and (4) a build against the real
+ * vendored tsl::robin_map (oracle/_ref/, see oracle/Makefile).
+ *
+ * All matrices are ROW-MAJOR in this ABI.  Quaternions are (w, x, y, z).
+ */
+#ifndef SRL_ORACLE_H
+#define SRL_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mirrors icpOptions (include/parameters.h:8-56); defaults = effective r3live.yaml values */
+typedef struct orc_icp_opts {
+    int    threshold_voxel_occupancy;   /* 1   */
+    int    init_num_frames;             /* 20  */
+    double size_voxel_map;              /* 1.0 */
+    int    num_iters_icp;               /* 5   */
+    int    min_number_neighbors;        /* 20  */
+    int    voxel_neighborhood;          /* 1   */
+    double power_planarity;             /* 2.0 */
+    int    estimate_normal_from_neighborhood; /* 1 (always true in the reference) */
+    int    max_number_neighbors;        /* 20  */
+    double max_dist_to_plane_icp;       /* 0.3 */
+    double threshold_orientation_norm;  /* 0.1 deg */
+    double threshold_translation_norm;  /* 0.01 m  */
+    int    max_num_residuals;           /* 600 (shipped) */
+    double weight_alpha;                /* 0.9 */
+    double weight_neighborhood;         /* 0.1 */
+} orc_icp_opts;
+
+void orc_icp_opts_default(orc_icp_opts *o);
+
+/* ---- voxel map (cloudMap.h:124-184 + lioOptimization.cpp:400-446,520-554) ---- */
+typedef struct orc_map orc_map;
+orc_map *orc_map_create(void);
+void     orc_map_destroy(orc_map *m);
+/* addPointsToMap: xyz = AoS world points (n x 3 f64), inserted in order.  Returns #points added. */
+int      orc_map_add_points(orc_map *m, const double *xyz, int n, double voxel_size,
+                            int max_num_points_in_voxel, double min_distance_points, int min_num_points);
+size_t   orc_map_size(const orc_map *m);          /* mapSize(): total points */
+int      orc_map_num_voxels(const orc_map *m);
+/* export in voxel CREATION order: keys[V*3], counts[V], xyz[V*cap*3] (AoS f32, unused slots 0) */
+void     orc_map_export(const orc_map *m, int cap, int16_t *keys, int32_t *counts, float *xyz);
+/* std::hash<voxel> (cloudMap.h:173-184) */
+uint64_t orc_voxel_hash(int16_t x, int16_t y, int16_t z);
+/* static_cast<short>(v / size) (optimize.cpp:372) */
+int16_t  orc_voxel_coord(double v, double size);
+const char *orc_map_backend(void);                /* "tsl::robin_map" or "std::unordered_map" */
+
+/* ---- searchNeighbors (optimize.cpp:365-426) for one query point.
+ * out_xyz: up to K x 3 f64 ascending by distance, out_ids: voxel_index*cap + slot, out_dist: distances.
+ * *tie_flag = 1 when the K+1 smallest candidate distances contain an exact tie.
+ * *num_candidates = number of resident points visited (P_k).  Returns number of neighbours. */
+int orc_search_neighbors(orc_map *m, const double p[3], int nb_voxels_visited, double size_voxel_map,
+                         int max_num_neighbors, int threshold_voxel_capacity, int cap,
+                         double *out_xyz, int32_t *out_ids, double *out_dist, int *tie_flag,
+                         int *num_candidates);
+
+/* ---- computeNeighborhoodDistribution (optimize.cpp:316-353).  Returns 0, or -1 on NaN a2D. */
+int orc_neighborhood(const double *pts, int n, double center[3], double normal[3], double cov[9],
+                     double *a2D, double eigenvalues[3]);
+
+/* ---- buildPlaneResiduals (optimize.cpp:18-131) ----
+ * status per keypoint: 0 = fewer than min_number_neighbors, 1 = plane found but distance gate
+ * rejected, 2 = accepted residual, 3 = not visited (loop left at max_num_residuals).
+ * Any per-keypoint output pointer may be NULL. */
+typedef struct orc_residual_out {
+    uint8_t *status;      /* N      */
+    int32_t *ids;         /* N x K  (-1 padded) */
+    uint8_t *tie;         /* N      */
+    double  *point_world; /* N x 3  keypoint.point (optimize.cpp:38) */
+    double  *normal;      /* N x 3  unit normal after flip */
+    double  *a2D;         /* N      */
+    double  *weight;      /* N      */
+    double  *norm_offset; /* N      */
+    double  *distance;    /* N      */
+    double  *jacobian;    /* N x 6  */
+} orc_residual_out;
+
+typedef struct orc_normal_eq {
+    double  HtH[36];      /* H_x^T H_x   (optimize.cpp:235) */
+    double  Hth[6];       /* H_x^T h     (optimize.cpp:239) */
+    double  loss_sum;     /* sum d^2     (optimize.cpp:104) */
+    int32_t num_residuals;
+    int32_t success;      /* optimizeSummary.success (optimize.cpp:110-130) */
+    int64_t sum_candidates;   /* sum of P_k over visited keypoints */
+    int32_t num_visited;
+    int32_t num_ties;
+    int32_t nan_error;    /* NaN a2D encountered (optimize.cpp:348-350 would throw) */
+} orc_normal_eq;
+
+int orc_build_plane_residuals(orc_map *m, const orc_icp_opts *o, const double *raw_xyz, int n,
+                              const double q_wxyz[4], const double t[3], const double t_last[3],
+                              const double R_il[9], const double t_il[3], int frame_id, int cap,
+                              orc_residual_out *out, orc_normal_eq *neq);
+
+/* ---- eskfEstimator (eskfEstimator.cpp) ---- */
+typedef struct orc_eskf orc_eskf;
+orc_eskf *orc_eskf_create(void);                   /* ctor state, eskfEstimator.cpp:3-21 */
+void      orc_eskf_destroy(orc_eskf *e);
+/* state vector layout: p(3) q(wxyz,4) v(3) ba(3) bg(3) g(3) = 19 doubles */
+void orc_eskf_get_state(const orc_eskf *e, double s[19]);
+void orc_eskf_set_state(orc_eskf *e, const double s[19]);
+void orc_eskf_get_cov(const orc_eskf *e, double P[289]);
+void orc_eskf_set_cov(orc_eskf *e, const double P[289]);
+void orc_eskf_set_noise(orc_eskf *e, double acc_cov, double gyr_cov, double b_acc_cov, double b_gyr_cov);
+void orc_eskf_init_imu(orc_eskf *e, const double acc0[3], const double gyr0[3]);
+void orc_eskf_scale_init_cov(orc_eskf *e);         /* tryInit covariance scaling, eskfEstimator.cpp:74-76 */
+void orc_eskf_predict(orc_eskf *e, double dt, const double acc1[3], const double gyr1[3]);
+void orc_eskf_observe(orc_eskf *e, const double dx[17]);
+
+/* ---- updateIEKF (optimize.cpp:133-314) ----
+ * state_io: the frame's p_state (q wxyz, t, v, ba, bg) = 16 doubles, in/out.
+ * log (optional): per iteration HtH(36) Hth(6) dx(17) num_residuals loss = 61 doubles, max_log_iters rows.
+ * Returns number of iterations executed (>=1), negative on failure:
+ *   -1 not enough residuals (summary.success=false), -2 NaN planarity. */
+int orc_update_iekf(orc_map *m, orc_eskf *e, const orc_icp_opts *o, const double *raw_xyz, int n,
+                    double state_io[16], const double t_last[3], const double R_il[9],
+                    const double t_il[3], int frame_id, int cap, double laser_point_cov,
+                    double *log, int max_log_iters, int *num_residuals_used);
+
+/* small numeric helpers exported for unit tests (utility.h numType, utility.cpp:146-153) */
+void   orc_quat_to_rot(const double q_wxyz[4], double R[9]);
+void   orc_rot_to_quat(const double R[9], double q_wxyz[4]);
+void   orc_so3_to_rot(const double w[3], double R[9]);
+void   orc_so3_to_quat(const double w[3], double q_wxyz[4]);
+void   orc_rot_to_so3(const double R[9], double w[3]);
+double orc_angular_distance_so3(const double w[3]);
+void   orc_derivative_s2(const double g[3], double B[6]);
+int    orc_inverse17(const double A[289], double Ainv[289]);
+void   orc_eig3(const double A[9], double evals[3], double evecs[9]); /* ascending; evecs columns, row-major */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,497 @@
+"""ctypes bindings of libsrlivo_hip.so (include/srlivo_hip.h + include/srlivo_host.h).
+
+Mirrors the C declarations one to one; numpy arrays are passed as plain pointers.  Nothing here
+computes: if the shared library is missing, or no HIP device exists, the calls raise SrlError.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrlivo_hip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+SRL_OK = 0
+SRL_ERR_NO_DEVICE = -1
+SRL_ERR_NAN_PLANARITY = -8
+SRL_ERR_NOT_ENOUGH_RESIDUALS = -9
+SRL_COMM_ID_BYTES = 128
+
+
+class SrlError(RuntimeError):
+    def __init__(self, status, what, detail=""):
+        self.status = status
+        super().__init__(f"{what}: status {status} {detail}".strip())
+
+
+class IcpOpts(C.Structure):
+    _fields_ = [
+        ("threshold_voxel_occupancy", C.c_int32), ("init_num_frames", C.c_int32),
+        ("size_voxel_map", C.c_double), ("num_iters_icp", C.c_int32),
+        ("min_number_neighbors", C.c_int32), ("voxel_neighborhood", C.c_int32),
+        ("power_planarity", C.c_double), ("max_number_neighbors", C.c_int32),
+        ("max_dist_to_plane_icp", C.c_double), ("threshold_orientation_norm", C.c_double),
+        ("threshold_translation_norm", C.c_double), ("max_num_residuals", C.c_int32),
+        ("weight_alpha", C.c_double), ("weight_neighborhood", C.c_double),
+        ("select_mode", C.c_int32),
+    ]
+
+
+class Frame(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("t_last", C.c_double * 3),
+                ("R_il", C.c_double * 9), ("t_il", C.c_double * 3), ("frame_id", C.c_int32)]
+
+
+class NormalEq(C.Structure):
+    _fields_ = [("HtH", C.c_double * 36), ("Hth", C.c_double * 6), ("loss_sum", C.c_double),
+                ("num_residuals", C.c_int32), ("success", C.c_int32), ("sum_candidates", C.c_int64),
+                ("last_visited", C.c_int64), ("nan_error", C.c_int32), ("num_fallback", C.c_int32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("assoc_ms", C.c_float), ("reduce_ms", C.c_float), ("total_ms", C.c_float),
+                ("algorithmic_bytes", C.c_int64)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p)
+PROVIDER_FN = C.CFUNCTYPE(C.c_int, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq), C.c_void_p)
+
+_lib = None
+
+
+def load_library():
+    """Load libsrlivo_hip.so; raises SrlError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SrlError(-1, "libsrlivo_hip.so not built",
+                       f"(expected {LIB_PATH}; run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    lib = C.CDLL(LIB_PATH)
+    p = C.c_void_p
+    dp = C.POINTER(C.c_double)
+    sig = {
+        "srl_device_count": ([C.POINTER(C.c_int)], C.c_int),
+        "srl_ctx_create": ([C.c_int, C.POINTER(p)], C.c_int),
+        "srl_ctx_destroy": ([p], C.c_int),
+        "srl_last_error": ([p], C.c_char_p),
+        "srl_status_str": ([C.c_int], C.c_char_p),
+        "srl_icp_opts_default": ([C.POINTER(IcpOpts)], None),
+        "srl_map_upload": ([p, p, p, p, C.c_int, C.c_int], C.c_int),
+        "srl_map_insert": ([p, p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)], C.c_int),
+        "srl_map_size": ([p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)], C.c_int),
+        "srl_map_download": ([p, p, p, p, C.c_int], C.c_int),
+        "srl_sweep_upload": ([p, p, C.c_int], C.c_int),
+        "srl_sweep_shard": ([p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "srl_build_residuals": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq)], C.c_int),
+        "srl_set_taps": ([p, C.c_int], C.c_int),
+        "srl_fetch_neighbors": ([p, p, p, p], C.c_int),
+        "srl_fetch_residuals": ([p, p, p, p, p, p, p], C.c_int),
+        "srl_search_neighbors": ([p, p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, p, p, p], C.c_int),
+        "srl_transform_points": ([p, p, C.c_int, dp, dp, dp, dp, p], C.c_int),
+        "srl_comm_unique_id": ([p], C.c_int),
+        "srl_comm_init_rank": ([p, C.c_int, C.c_int, p], C.c_int),
+        "srl_comm_destroy": ([p], C.c_int),
+        "srl_comm_set_host_callbacks": ([p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, p], C.c_int),
+        "srl_shard_range": ([C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], None),
+        "srl_shard_budget": ([C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)], None),
+        "srl_get_timing": ([p, C.POINTER(Timing)], C.c_int),
+        "srl_set_profiling": ([p, C.c_int], C.c_int),
+        # host mirror handles
+        "srl_lio_create": ([C.c_int, C.POINTER(p)], C.c_int),
+        "srl_lio_destroy": ([p], C.c_int),
+        "srl_lio_ctx": ([p], p),
+        "srl_lio_last_error": ([p], C.c_char_p),
+        "srl_lio_set_extrinsics": ([p, dp, dp], C.c_int),
+        "srl_lio_set_laser_point_cov": ([p, C.c_double], C.c_int),
+        "srl_lio_eskf_get_state": ([p, dp], C.c_int),
+        "srl_lio_eskf_set_state": ([p, dp], C.c_int),
+        "srl_lio_eskf_get_cov": ([p, dp], C.c_int),
+        "srl_lio_eskf_set_cov": ([p, dp], C.c_int),
+        "srl_lio_eskf_set_noise": ([p, C.c_double, C.c_double, C.c_double, C.c_double], C.c_int),
+        "srl_lio_eskf_init_imu": ([p, dp, dp], C.c_int),
+        "srl_lio_eskf_scale_init_cov": ([p], C.c_int),
+        "srl_lio_eskf_predict": ([p, C.c_double, dp, dp], C.c_int),
+        "srl_lio_eskf_observe": ([p, dp], C.c_int),
+        "srl_lio_add_points_to_map": ([p, p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int], C.c_int),
+        "srl_lio_map_size": ([p, C.POINTER(C.c_int64)], C.c_int),
+        "srl_lio_resident_sweep": ([p, p, C.c_int], C.c_int),
+        "srl_lio_update_iekf": ([p, C.POINTER(IcpOpts), p, C.c_int, dp, dp, C.c_int, p, C.c_int,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "srl_lio_update_iekf_provided": ([p, C.POINTER(IcpOpts), PROVIDER_FN, p, C.c_int, dp, dp, C.c_int, p, C.c_int,
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "srl_lio_optimize": ([p, C.POINTER(IcpOpts), C.c_double, p, p, C.c_int, dp, dp, C.c_int, p,
+                              C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "srl_lio_search_neighbors": ([p, dp, C.c_int, C.c_double, C.c_int, C.c_int, p, p, C.POINTER(C.c_int)], C.c_int),
+        "srl_lio_neighborhood": ([p, p, C.c_int, dp, dp, dp, dp], C.c_int),
+        "srl_lio_build_plane_residuals": ([p, C.POINTER(IcpOpts), p, C.c_int, dp, dp, C.c_int, p, C.c_int,
+                                           C.POINTER(C.c_int), dp, C.POINTER(C.c_int), p], C.c_int),
+        "srl_grid_sampling": ([p, C.c_int, C.c_double, p, C.POINTER(C.c_int)], C.c_int),
+    }
+    for name, (argtypes, restype) in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def declared_symbols():
+    """Every function name declared in include/srlivo_hip.h and include/srlivo_host.h."""
+    names = []
+    for hdr in ("srlivo_hip.h", "srlivo_host.h"):
+        text = open(os.path.join(INCLUDE_DIR, hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(srl_[a-z0-9_]+)\s*\(", text)
+    skip = {"srl_allreduce_fn", "srl_allgather_i64_fn", "srl_normal_eq_provider"}
+    return sorted(set(n for n in names if n not in skip))
+
+
+def library_symbols():
+    lib = load_library()
+    return [n for n in declared_symbols() if hasattr(lib, n)]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def default_opts(**kw):
+    o = IcpOpts()
+    load_library().srl_icp_opts_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def shard_range(n, nranks, rank):
+    b, c = C.c_int(), C.c_int()
+    load_library().srl_shard_range(n, nranks, rank, C.byref(b), C.byref(c))
+    return b.value, c.value
+
+
+def shard_budget(max_num_residuals, accepted_per_rank, rank):
+    arr = np.ascontiguousarray(accepted_per_rank, dtype=np.int64)
+    b, m = C.c_int64(), C.c_int()
+    load_library().srl_shard_budget(int(max_num_residuals), arr.ctypes.data_as(C.POINTER(C.c_int64)), len(arr), rank,
+                                    C.byref(b), C.byref(m))
+    return b.value, m.value
+
+
+def grid_sampling(world_xyz, size_voxel):
+    w = _f64(world_xyz, (-1, 3))
+    idx = np.empty(len(w), dtype=np.int32)
+    n = C.c_int()
+    rc = load_library().srl_grid_sampling(_ptr(w), len(w), float(size_voxel), _ptr(idx), C.byref(n))
+    if rc:
+        raise SrlError(rc, "srl_grid_sampling")
+    return idx[: n.value].copy()
+
+
+def make_frame(q, t, t_last, R_il=None, t_il=None, frame_id=100):
+    f = Frame()
+    f.q[:] = list(np.asarray(q, dtype=np.float64))
+    f.t[:] = list(np.asarray(t, dtype=np.float64))
+    f.t_last[:] = list(np.asarray(t_last, dtype=np.float64))
+    f.R_il[:] = list(np.eye(3).ravel() if R_il is None else np.asarray(R_il, dtype=np.float64).ravel())
+    f.t_il[:] = list(np.zeros(3) if t_il is None else np.asarray(t_il, dtype=np.float64))
+    f.frame_id = int(frame_id)
+    return f
+
+
+class Context:
+    """Kernel-level C-ABI (srl_ctx)."""
+
+    def __init__(self, device=0, handle=None):
+        self.lib = load_library()
+        self._own = handle is None
+        if handle is None:
+            h = C.c_void_p()
+            rc = self.lib.srl_ctx_create(device, C.byref(h))
+            if rc:
+                raise SrlError(rc, "srl_ctx_create", self.lib.srl_status_str(rc).decode())
+            handle = h
+        self.h = handle
+        self._cb = None
+
+    def close(self):
+        if self.h and self._own:
+            self.lib.srl_ctx_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what, ok=()):
+        if rc and rc not in ok:
+            raise SrlError(rc, what, (self.lib.srl_last_error(self.h) or b"").decode())
+        return rc
+
+    def map_upload(self, keys, counts, xyz, cap=20):
+        keys = np.ascontiguousarray(keys, dtype=np.int16).reshape(-1, 3)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(len(counts), cap, 3)
+        self._chk(self.lib.srl_map_upload(self.h, _ptr(keys), _ptr(counts), _ptr(xyz), len(counts), cap), "srl_map_upload")
+
+    def map_insert(self, world_xyz, voxel_size=1.0, cap=20, min_dist=0.15, min_num_points=0):
+        w = _f64(world_xyz, (-1, 3))
+        added = C.c_int()
+        self._chk(self.lib.srl_map_insert(self.h, _ptr(w), len(w), voxel_size, cap, min_dist, min_num_points, C.byref(added)), "srl_map_insert")
+        return added.value
+
+    def map_size(self):
+        npnt, nv = C.c_int64(), C.c_int32()
+        self._chk(self.lib.srl_map_size(self.h, C.byref(npnt), C.byref(nv)), "srl_map_size")
+        return npnt.value, nv.value
+
+    def map_download(self, cap=20):
+        _, nv = self.map_size()
+        keys = np.zeros((nv, 3), dtype=np.int16)
+        counts = np.zeros(nv, dtype=np.int32)
+        xyz = np.zeros((nv, cap, 3), dtype=np.float32)
+        self._chk(self.lib.srl_map_download(self.h, _ptr(keys), _ptr(counts), _ptr(xyz), nv), "srl_map_download")
+        return keys, counts, xyz
+
+    def sweep_upload(self, raw_xyz):
+        r = _f64(raw_xyz, (-1, 3))
+        self._chk(self.lib.srl_sweep_upload(self.h, _ptr(r), len(r)), "srl_sweep_upload")
+
+    def sweep_shard(self):
+        b, c, t = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.lib.srl_sweep_shard(self.h, C.byref(b), C.byref(c), C.byref(t)), "srl_sweep_shard")
+        return b.value, c.value, t.value
+
+    def set_taps(self, on):
+        self._chk(self.lib.srl_set_taps(self.h, int(on)), "srl_set_taps")
+
+    def set_profiling(self, on):
+        self._chk(self.lib.srl_set_profiling(self.h, int(on)), "srl_set_profiling")
+
+    def timing(self):
+        t = Timing()
+        self._chk(self.lib.srl_get_timing(self.h, C.byref(t)), "srl_get_timing")
+        return t
+
+    def build_residuals(self, frame, opts, allow=(SRL_ERR_NAN_PLANARITY,)):
+        out = NormalEq()
+        rc = self._chk(self.lib.srl_build_residuals(self.h, C.byref(frame), C.byref(opts), C.byref(out)), "srl_build_residuals", ok=allow)
+        return out, rc
+
+    def fetch_neighbors(self, K=20):
+        _, n, _ = self.sweep_shard()
+        ids = np.empty((n, K), dtype=np.int32)
+        status = np.empty(n, dtype=np.uint8)
+        ncand = np.empty(n, dtype=np.int32)
+        self._chk(self.lib.srl_fetch_neighbors(self.h, _ptr(ids), _ptr(status), _ptr(ncand)), "srl_fetch_neighbors")
+        return ids, status, ncand
+
+    def fetch_residuals(self):
+        _, n, _ = self.sweep_shard()
+        normal = np.empty((n, 3)); a2d = np.empty(n); w = np.empty(n); off = np.empty(n); d = np.empty(n); J = np.empty((n, 6))
+        self._chk(self.lib.srl_fetch_residuals(self.h, _ptr(normal), _ptr(a2d), _ptr(w), _ptr(off), _ptr(d), _ptr(J)), "srl_fetch_residuals")
+        return dict(normal=normal, a2D=a2d, weight=w, norm_offset=off, distance=d, jacobian=J)
+
+    def search_neighbors(self, world_xyz, nb=1, size=1.0, K=20, thr=1):
+        q = _f64(world_xyz, (-1, 3))
+        ids = np.empty((len(q), K), dtype=np.int32)
+        xyz = np.empty((len(q), K, 3), dtype=np.float32)
+        nf = np.empty(len(q), dtype=np.int32)
+        self._chk(self.lib.srl_search_neighbors(self.h, _ptr(q), len(q), nb, size, K, thr, _ptr(ids), _ptr(xyz), _ptr(nf)), "srl_search_neighbors")
+        return ids, xyz, nf
+
+    def transform_points(self, raw_xyz, q, t, R_il=None, t_il=None):
+        r = _f64(raw_xyz, (-1, 3))
+        out = np.empty_like(r)
+        R_il = _f64(np.eye(3) if R_il is None else R_il).ravel()
+        t_il = _f64(np.zeros(3) if t_il is None else t_il)
+        self._chk(self.lib.srl_transform_points(self.h, _ptr(r), len(r), _dptr(_f64(q)), _dptr(_f64(t)), _dptr(R_il), _dptr(t_il), _ptr(out)), "srl_transform_points")
+        return out
+
+    # --- multi-GPU
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_ubyte * SRL_COMM_ID_BYTES)()
+        rc = load_library().srl_comm_unique_id(buf)
+        if rc:
+            raise SrlError(rc, "srl_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init_rank(self, nranks, rank, uid):
+        buf = (C.c_ubyte * SRL_COMM_ID_BYTES).from_buffer_copy(uid)
+        self._chk(self.lib.srl_comm_init_rank(self.h, nranks, rank, buf), "srl_comm_init_rank")
+
+    def comm_set_host_callbacks(self, nranks, rank, allreduce, allgather):
+        """allreduce(np.ndarray float64) -> in place sum; allgather(int) -> list of ints."""
+        def _ar(buf, count, _user):
+            a = np.ctypeslib.as_array(buf, shape=(count,))
+            allreduce(a)
+            return 0
+
+        def _ag(mine, allp, _user):
+            vals = allgather(int(mine[0]))
+            for i, v in enumerate(vals):
+                allp[i] = int(v)
+            return 0
+        self._cb = (ALLREDUCE_FN(_ar), ALLGATHER_FN(_ag))
+        self._chk(self.lib.srl_comm_set_host_callbacks(self.h, nranks, rank, self._cb[0], self._cb[1], None), "srl_comm_set_host_callbacks")
+
+
+class Lio:
+    """C++ host mirror (lioOptimization + eskfEstimator) through the srl_lio handles."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.srl_lio_create(device, C.byref(h))
+        if rc:
+            raise SrlError(rc, "srl_lio_create", self.lib.srl_status_str(rc).decode())
+        self.h = h
+        self._provider = None
+        ctxp = self.lib.srl_lio_ctx(self.h)
+        self.ctx = Context(handle=C.c_void_p(ctxp)) if ctxp else None
+
+    def close(self):
+        if self.h:
+            self.lib.srl_lio_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what, ok=()):
+        if rc and rc not in ok:
+            raise SrlError(rc, what, (self.lib.srl_lio_last_error(self.h) or b"").decode())
+        return rc
+
+    def set_extrinsics(self, R_il, t_il):
+        self._chk(self.lib.srl_lio_set_extrinsics(self.h, _dptr(_f64(R_il).ravel()), _dptr(_f64(t_il))), "set_extrinsics")
+
+    def set_laser_point_cov(self, c):
+        self._chk(self.lib.srl_lio_set_laser_point_cov(self.h, float(c)), "set_laser_point_cov")
+
+    def eskf_get_state(self):
+        s = np.empty(19)
+        self._chk(self.lib.srl_lio_eskf_get_state(self.h, _dptr(s)), "eskf_get_state")
+        return s
+
+    def eskf_set_state(self, s):
+        self._chk(self.lib.srl_lio_eskf_set_state(self.h, _dptr(_f64(s))), "eskf_set_state")
+
+    def eskf_get_cov(self):
+        P = np.empty(289)
+        self._chk(self.lib.srl_lio_eskf_get_cov(self.h, _dptr(P)), "eskf_get_cov")
+        return P.reshape(17, 17)
+
+    def eskf_set_cov(self, P):
+        self._chk(self.lib.srl_lio_eskf_set_cov(self.h, _dptr(_f64(P).ravel())), "eskf_set_cov")
+
+    def eskf_set_noise(self, acc, gyr, bacc, bgyr):
+        self._chk(self.lib.srl_lio_eskf_set_noise(self.h, acc, gyr, bacc, bgyr), "eskf_set_noise")
+
+    def eskf_init_imu(self, acc0, gyr0):
+        self._chk(self.lib.srl_lio_eskf_init_imu(self.h, _dptr(_f64(acc0)), _dptr(_f64(gyr0))), "eskf_init_imu")
+
+    def eskf_scale_init_cov(self):
+        self._chk(self.lib.srl_lio_eskf_scale_init_cov(self.h), "eskf_scale_init_cov")
+
+    def eskf_predict(self, dt, acc1, gyr1):
+        self._chk(self.lib.srl_lio_eskf_predict(self.h, float(dt), _dptr(_f64(acc1)), _dptr(_f64(gyr1))), "eskf_predict")
+
+    def eskf_observe(self, dx):
+        self._chk(self.lib.srl_lio_eskf_observe(self.h, _dptr(_f64(dx))), "eskf_observe")
+
+    def add_points_to_map(self, world_xyz, voxel_size=1.0, cap=20, min_dist=0.15, min_num_points=0):
+        w = _f64(world_xyz, (-1, 3))
+        self._chk(self.lib.srl_lio_add_points_to_map(self.h, _ptr(w), len(w), voxel_size, cap, min_dist, min_num_points), "add_points_to_map")
+
+    def map_size(self):
+        n = C.c_int64()
+        self._chk(self.lib.srl_lio_map_size(self.h, C.byref(n)), "map_size")
+        return n.value
+
+    def resident_sweep(self, raw_xyz):
+        r = _f64(raw_xyz, (-1, 3))
+        self._chk(self.lib.srl_lio_resident_sweep(self.h, _ptr(r), len(r)), "resident_sweep")
+        return len(r)
+
+    def update_iekf(self, opts, raw_xyz, state, t_last, frame_id=100, log_iters=0, n_resident=None,
+                    allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):
+        """raw_xyz=None uses the sweep pinned by resident_sweep (n_resident = its size)."""
+        st = _f64(state).copy()
+        log = np.zeros((max(log_iters, 1), 61)) if log_iters else None
+        iters, nres = C.c_int(), C.c_int()
+        if raw_xyz is None:
+            rp, n = None, int(n_resident)
+        else:
+            r = _f64(raw_xyz, (-1, 3))
+            rp, n = _ptr(r), len(r)
+        rc = self._chk(self.lib.srl_lio_update_iekf(self.h, C.byref(opts), rp, n, _dptr(st), _dptr(_f64(t_last)), int(frame_id),
+                                                    _ptr(log) if log is not None else None, log_iters, C.byref(iters), C.byref(nres)),
+                       "update_iekf", ok=allow)
+        return dict(rc=rc, state=st, iters=iters.value, num_residuals=nres.value, log=None if log is None else log[: iters.value])
+
+    def update_iekf_provided(self, opts, provider, n, state, t_last, frame_id=100, log_iters=0,
+                             allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):
+        """provider(frame: Frame, opts: IcpOpts, out: NormalEq) -> int status."""
+        def _p(fp, op, outp, _user):
+            return int(provider(fp.contents, op.contents, outp.contents))
+        self._provider = PROVIDER_FN(_p)
+        st = _f64(state).copy()
+        log = np.zeros((max(log_iters, 1), 61)) if log_iters else None
+        iters, nres = C.c_int(), C.c_int()
+        rc = self._chk(self.lib.srl_lio_update_iekf_provided(self.h, C.byref(opts), self._provider, None, int(n), _dptr(st),
+                                                             _dptr(_f64(t_last)), int(frame_id), _ptr(log) if log is not None else None,
+                                                             log_iters, C.byref(iters), C.byref(nres)), "update_iekf_provided", ok=allow)
+        return dict(rc=rc, state=st, iters=iters.value, num_residuals=nres.value, log=None if log is None else log[: iters.value])
+
+    def optimize(self, opts, sample_voxel_size, frame_raw, frame_world, state, t_last, frame_id=100,
+                 allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):
+        raw = _f64(frame_raw, (-1, 3))
+        world = _f64(frame_world, (-1, 3)).copy()
+        st = _f64(state).copy()
+        kidx = np.empty(len(raw), dtype=np.int32)
+        nk, iters, nres = C.c_int(), C.c_int(), C.c_int()
+        rc = self._chk(self.lib.srl_lio_optimize(self.h, C.byref(opts), float(sample_voxel_size), _ptr(raw), _ptr(world), len(raw), _dptr(st),
+                                                 _dptr(_f64(t_last)), int(frame_id), _ptr(kidx), C.byref(nk), C.byref(iters), C.byref(nres)),
+                       "optimize", ok=allow)
+        return dict(rc=rc, state=st, world=world, keypoint_index=kidx[: nk.value].copy(), iters=iters.value, num_residuals=nres.value)
+
+    def search_neighbors(self, point, nb=1, size=1.0, K=20, thr=1):
+        out = np.zeros((K, 3)); vox = np.zeros((K, 3), dtype=np.int16); nf = C.c_int()
+        self._chk(self.lib.srl_lio_search_neighbors(self.h, _dptr(_f64(point)), nb, size, K, thr, _ptr(out), _ptr(vox), C.byref(nf)), "search_neighbors")
+        return out[: nf.value], vox[: nf.value]
+
+    def neighborhood(self, pts):
+        P = _f64(pts, (-1, 3))
+        c = np.empty(3); n = np.empty(3); cov = np.empty(9); a = C.c_double()
+        self._chk(self.lib.srl_lio_neighborhood(self.h, _ptr(P), len(P), _dptr(c), _dptr(n), _dptr(cov), C.byref(a)), "neighborhood")
+        return dict(center=c, normal=n, covariance=cov.reshape(3, 3), a2D=a.value)
+
+    def build_plane_residuals(self, opts, raw_xyz, state, t_last, frame_id=100):
+        r = _f64(raw_xyz, (-1, 3))
+        rows = np.zeros((len(r), 15)); world = np.zeros((len(r), 3))
+        nout, succ = C.c_int(), C.c_int(); loss = C.c_double()
+        self._chk(self.lib.srl_lio_build_plane_residuals(self.h, C.byref(opts), _ptr(r), len(r), _dptr(_f64(state)), _dptr(_f64(t_last)), int(frame_id),
+                                                         _ptr(rows), len(r), C.byref(nout), C.byref(loss), C.byref(succ), _ptr(world)),
+                  "build_plane_residuals")
+        return dict(rows=rows[: nout.value], loss_sum=loss.value, success=bool(succ.value), keypoint_world=world)

@@ -1,0 +1,629 @@
+// srl_capi.cpp -- implementation of the C-ABI declared in include/srlivo_hip.h.
+// Host plumbing only (buffers, stream, hash-table build, RCCL); all arithmetic of the hot path runs
+// in the HIP kernels of srl_kernels.hip / srl_map_kernels.hip.  No CPU fallback exists.
+#include "../../include/srlivo_hip.h"
+#include "host/srl_la.h"
+#include "srl_device.h"
+#include "srl_hash.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// map kernels (srl_map_kernels.hip)
+struct SrlMapState;
+int srl_map_insert_device(struct srl_ctx *ctx, const double *world_xyz, int n, double voxel_size, int cap,
+                          double min_distance_points, int min_num_points, int *num_added);
+
+#include "srl_ctx.h"
+
+namespace {
+
+unsigned next_pow2(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return p; }
+
+int ensure_work(srl_ctx *ctx, int n) {
+    if (n <= ctx->work_cap) return SRL_OK;
+    const int cap = std::max(n, 1024);
+    const int nblocks = (cap + SRL_KPB - 1) / SRL_KPB;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_rec, (size_t)cap * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->d_status, (size_t)cap))) return rc;
+    if ((rc = ensure(ctx, ctx->d_partials, (size_t)nblocks * SRL_PART_STRIDE))) return rc;
+    if ((rc = ensure(ctx, ctx->d_binfo, (size_t)nblocks))) return rc;
+    ctx->work_cap = cap;
+    ctx->block_cap = nblocks;
+    return SRL_OK;
+}
+
+int ensure_taps(srl_ctx *ctx, int n, int K) {
+    if (n <= ctx->tap_cap && K <= ctx->tap_K) return SRL_OK;
+    const int cap = std::max(n, ctx->tap_cap), kk = std::max(K, ctx->tap_K);
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_tap_ids, (size_t)cap * kk))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tap_ncand, (size_t)cap))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tap_normal, (size_t)cap * 3))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tap_a2d, (size_t)cap))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tap_offset, (size_t)cap))) return rc;
+    ctx->tap_cap = cap;
+    ctx->tap_K = kk;
+    return SRL_OK;
+}
+
+}  // namespace
+
+// shared with srl_map_kernels.hip
+int srl_ctx_grow_map(srl_ctx *ctx, unsigned need_slabs, unsigned need_slots);
+
+extern "C" {
+
+int srl_device_count(int *count) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { if (count) *count = 0; return SRL_ERR_NO_DEVICE; }
+    if (count) *count = c;
+    return SRL_OK;
+}
+
+const char *srl_status_str(int s) {
+    switch (s) {
+        case SRL_OK: return "ok";
+        case SRL_ERR_NO_DEVICE: return "no HIP device (the product has no CPU fallback)";
+        case SRL_ERR_HIP: return "HIP runtime error";
+        case SRL_ERR_BAD_ARG: return "bad argument";
+        case SRL_ERR_UNSUPPORTED: return "option outside the supported envelope";
+        case SRL_ERR_NO_MAP: return "no map uploaded";
+        case SRL_ERR_NO_SWEEP: return "no sweep uploaded";
+        case SRL_ERR_COMM: return "RCCL error";
+        case SRL_ERR_NAN_PLANARITY: return "NaN planarity (optimize.cpp:348-350 throws)";
+        case SRL_ERR_NOT_ENOUGH_RESIDUALS: return "not enough residuals (optimize.cpp:110)";
+        default: return "unknown status";
+    }
+}
+
+void srl_icp_opts_default(srl_icp_opts *o) {
+    o->threshold_voxel_occupancy = 1;
+    o->init_num_frames = 20;
+    o->size_voxel_map = 1.0;
+    o->num_iters_icp = 5;
+    o->min_number_neighbors = 20;
+    o->voxel_neighborhood = 1;
+    o->power_planarity = 2.0;
+    o->max_number_neighbors = 20;
+    o->max_dist_to_plane_icp = 0.3;
+    o->threshold_orientation_norm = 0.1;
+    o->threshold_translation_norm = 0.01;
+    o->max_num_residuals = 600;
+    o->weight_alpha = 0.9;
+    o->weight_neighborhood = 0.1;
+    o->select_mode = 0;
+}
+
+int srl_ctx_create(int device, srl_ctx **out) {
+    if (!out) return SRL_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return SRL_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return SRL_ERR_NO_DEVICE;
+    srl_ctx *ctx = new srl_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SRL_ERR_NO_DEVICE; }
+    if (hipMalloc((void **)&ctx->d_out, sizeof(SrlDevOut)) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->h_out, sizeof(SrlDevOut)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_count, sizeof(long long)) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->h_count, sizeof(long long)) != hipSuccess) {
+        delete ctx;
+        return SRL_ERR_HIP;
+    }
+    for (int i = 0; i < 4; i++) hipEventCreate(&ctx->ev[i]);
+    *out = ctx;
+    return SRL_OK;
+}
+
+int srl_ctx_destroy(srl_ctx *ctx) {
+    if (!ctx) return SRL_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) ncclCommDestroy(ctx->comm);
+    void *bufs[] = {ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
+                    ctx->d_out, ctx->d_count, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
+                    ctx->d_tap_offset, ctx->d_gather};
+    for (void *b : bufs) if (b) hipFree(b);
+    if (ctx->h_out) hipHostFree(ctx->h_out);
+    if (ctx->h_count) hipHostFree(ctx->h_count);
+    for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SRL_OK;
+}
+
+const char *srl_last_error(const srl_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// ------------------------------------------------------------------------------------------ map
+int srl_map_upload(srl_ctx *ctx, const int16_t *keys_xyz, const int32_t *counts, const float *xyz, int V, int cap) {
+    if (!ctx || V < 0 || (V > 0 && (!keys_xyz || !counts || !xyz))) return SRL_ERR_BAD_ARG;
+    if (cap != SRL_VOXEL_CAP) { ctx->err = "max_num_points_in_voxel must be 20"; return SRL_ERR_UNSUPPORTED; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // capacity with headroom so that srl_map_insert can add voxels without an immediate rebuild
+    const unsigned slab_cap = std::max<unsigned>(1024u, (unsigned)V + (unsigned)V / 2u + 4096u);
+    const unsigned table_cap = next_pow2(std::max<unsigned>(2048u, 2u * slab_cap));
+    std::vector<SrlSlab> slabs((size_t)V);
+    std::vector<SrlMapSlot> table((size_t)table_cap);
+    for (auto &s : table) { s.key = SRL_EMPTY_KEY; s.slab = 0; s.count = 0; }
+    long long npts = 0;
+    const unsigned mask = table_cap - 1;
+    for (int v = 0; v < V; v++) {
+        SrlSlab &s = slabs[v];
+        std::memset(&s, 0, sizeof s);
+        const int c = counts[v];
+        if (c < 0 || c > cap) { ctx->err = "voxel count out of range"; return SRL_ERR_BAD_ARG; }
+        for (int i = 0; i < c; i++)
+            for (int d = 0; d < 3; d++) s.xyz[i][d] = xyz[((size_t)v * cap + i) * 3 + d];
+        s.count = (unsigned)c;
+        s.key = srl_pack_key(keys_xyz[3 * v], keys_xyz[3 * v + 1], keys_xyz[3 * v + 2]);
+        npts += c;
+        unsigned h = srl_hash_key(s.key) & mask;
+        while (table[h].key != SRL_EMPTY_KEY) {
+            if (table[h].key == s.key) { ctx->err = "duplicate voxel key in upload"; return SRL_ERR_BAD_ARG; }
+            h = (h + 1) & mask;
+        }
+        table[h].key = s.key;
+        table[h].slab = (unsigned)v;
+        table[h].count = (unsigned)c;
+    }
+    if (ctx->d_slabs) { HIPCHK(ctx, hipFree(ctx->d_slabs)); ctx->d_slabs = nullptr; }
+    if (ctx->d_table) { HIPCHK(ctx, hipFree(ctx->d_table)); ctx->d_table = nullptr; }
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_slabs, (size_t)slab_cap * SRL_SLAB_BYTES));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_table, (size_t)table_cap * sizeof(SrlMapSlot)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_slabs, 0, (size_t)slab_cap * SRL_SLAB_BYTES, ctx->stream));
+    if (V > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->d_slabs, slabs.data(), (size_t)V * SRL_SLAB_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_table, table.data(), (size_t)table_cap * sizeof(SrlMapSlot), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->slab_cap = slab_cap;
+    ctx->table_cap = table_cap;
+    ctx->num_voxels = V;
+    ctx->num_points = npts;
+    return SRL_OK;
+}
+
+int srl_map_size(srl_ctx *ctx, int64_t *num_points, int32_t *num_voxels) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (num_points) *num_points = ctx->num_points;
+    if (num_voxels) *num_voxels = ctx->num_voxels;
+    return SRL_OK;
+}
+
+int srl_map_download(srl_ctx *ctx, int16_t *keys_xyz, int32_t *counts, float *xyz, int max_voxels) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (!ctx->d_slabs) return SRL_ERR_NO_MAP;
+    const int V = ctx->num_voxels;
+    if (max_voxels < V) return SRL_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<SrlSlab> slabs((size_t)V);
+    if (V > 0) HIPCHK(ctx, hipMemcpyAsync(slabs.data(), ctx->d_slabs, (size_t)V * SRL_SLAB_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int v = 0; v < V; v++) {
+        short x, y, z;
+        srl_unpack_key(slabs[v].key, &x, &y, &z);
+        if (keys_xyz) { keys_xyz[3 * v] = x; keys_xyz[3 * v + 1] = y; keys_xyz[3 * v + 2] = z; }
+        if (counts) counts[v] = (int32_t)slabs[v].count;
+        if (xyz)
+            for (int i = 0; i < SRL_CAP; i++)
+                for (int d = 0; d < 3; d++)
+                    xyz[((size_t)v * SRL_CAP + i) * 3 + d] = (i < (int)slabs[v].count) ? slabs[v].xyz[i][d] : 0.0f;
+    }
+    return SRL_OK;
+}
+
+int srl_map_insert(srl_ctx *ctx, const double *world_xyz, int n, double voxel_size, int cap,
+                   double min_distance_points, int min_num_points, int *num_added) {
+    if (!ctx || n < 0 || (n > 0 && !world_xyz)) return SRL_ERR_BAD_ARG;
+    if (cap != SRL_VOXEL_CAP) { ctx->err = "max_num_points_in_voxel must be 20"; return SRL_ERR_UNSUPPORTED; }
+    return srl_map_insert_device(ctx, world_xyz, n, voxel_size, cap, min_distance_points, min_num_points, num_added);
+}
+
+// ------------------------------------------------------------------------------------------ sweep
+int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
+    if (!ctx || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int b = 0, cnt = 0;
+    srl_shard_range(n, ctx->nranks, ctx->rank, &b, &cnt);
+    ctx->total_n = n;
+    ctx->shard_begin = b;
+    ctx->n = cnt;
+    ctx->taps_valid = false;
+    if (cnt > ctx->sweep_cap) {
+        const int cap = std::max(cnt, 1024);
+        int rc = ensure(ctx, ctx->d_raw, (size_t)cap * 3);
+        if (rc) return rc;
+        ctx->sweep_cap = cap;
+    }
+    int rc = ensure_work(ctx, cnt);
+    if (rc) return rc;
+    if (cnt > 0) {
+        // stage AoS in the rec buffer (>= 8 doubles per keypoint), transpose to SoA on the device
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_rec, raw_xyz + (size_t)b * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, srl_launch_aos_to_soa(ctx->d_rec, cnt, ctx->d_raw, ctx->d_raw + ctx->sweep_cap, ctx->d_raw + 2 * (size_t)ctx->sweep_cap, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SRL_OK;
+}
+
+int srl_sweep_shard(srl_ctx *ctx, int *begin, int *count, int *total) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (begin) *begin = ctx->shard_begin;
+    if (count) *count = ctx->n;
+    if (total) *total = ctx->total_n;
+    return SRL_OK;
+}
+
+int srl_set_taps(srl_ctx *ctx, int enable) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    ctx->taps = enable != 0;
+    if (!ctx->taps) ctx->taps_valid = false;
+    return SRL_OK;
+}
+
+int srl_set_profiling(srl_ctx *ctx, int enable) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    ctx->profiling = enable != 0;
+    return SRL_OK;
+}
+
+int srl_get_timing(srl_ctx *ctx, srl_timing *t) {
+    if (!ctx || !t) return SRL_ERR_BAD_ARG;
+    *t = ctx->timing;
+    return SRL_OK;
+}
+
+// ------------------------------------------------------------------------------------------ hot path
+int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, srl_normal_eq *out) {
+    if (!ctx || !f || !o || !out) return SRL_ERR_BAD_ARG;
+    if (!ctx->d_table) return SRL_ERR_NO_MAP;
+    if (ctx->total_n <= 0 && ctx->n <= 0) return SRL_ERR_NO_SWEEP;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    // init-mode switches (optimize.cpp:21-23)
+    const bool init_mode = f->frame_id < o->init_num_frames;
+    const int nb = init_mode ? 2 : o->voxel_neighborhood;
+    const int thr = init_mode ? 1 : o->threshold_voxel_occupancy;
+    const int K = o->max_number_neighbors;
+    if (nb < 1 || nb > 2) { ctx->err = "voxel_neighborhood must be 1 or 2"; return SRL_ERR_UNSUPPORTED; }
+    if (K < 1 || K > SRL_MAX_NEIGHBORS) { ctx->err = "max_number_neighbors must be in [1,32]"; return SRL_ERR_UNSUPPORTED; }
+    if (!(o->size_voxel_map > 0.0)) return SRL_ERR_BAD_ARG;
+
+    SrlAssocArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.raw_x = ctx->d_raw;
+    a.raw_y = ctx->d_raw + ctx->sweep_cap;
+    a.raw_z = ctx->d_raw + 2 * (size_t)ctx->sweep_cap;
+    a.n = ctx->n;
+    a.table = ctx->d_table;
+    a.table_mask = ctx->table_cap - 1;
+    a.slabs = ctx->d_slabs;
+    {
+        const srl::Quat q(f->q[0], f->q[1], f->q[2], f->q[3]);
+        const srl::Mat3 Rn = q.normalized().toRotationMatrix();    // optimize.cpp:35
+        const srl::Mat3 R = q.toRotationMatrix();                  // optimize.cpp:95,101
+        std::memcpy(a.Rn, Rn.a, sizeof a.Rn);
+        std::memcpy(a.R, R.a, sizeof a.R);
+    }
+    std::memcpy(a.t, f->t, sizeof a.t);
+    std::memcpy(a.t_last, f->t_last, sizeof a.t_last);
+    std::memcpy(a.R_il, f->R_il, sizeof a.R_il);
+    std::memcpy(a.t_il, f->t_il, sizeof a.t_il);
+    a.size_voxel = o->size_voxel_map;
+    a.max_dist = o->max_dist_to_plane_icp;
+    {
+        double lw = std::abs(o->weight_alpha), ln = std::abs(o->weight_neighborhood);   // optimize.cpp:55-61
+        const double sum = lw + ln;
+        lw /= sum;
+        ln /= sum;
+        a.lambda_w = lw;
+        a.lambda_n = ln;
+    }
+    a.power_planarity = o->power_planarity;
+    a.nbr_scale = o->max_dist_to_plane_icp * o->min_number_neighbors;   // kMaxPointToPlane * kMinNumNeighbors
+    a.K = K;
+    a.min_nb = o->min_number_neighbors;
+    a.thr_cap = thr;
+    a.select_mode = o->select_mode;
+    a.rec = ctx->d_rec;
+    a.status = ctx->d_status;
+    a.partials = ctx->d_partials;
+    a.binfo = ctx->d_binfo;
+    ctx->taps_valid = false;
+    if (ctx->taps) {
+        int rc = ensure_taps(ctx, ctx->n, K);
+        if (rc) return rc;
+        a.tap_ids = ctx->d_tap_ids;
+        a.tap_ncand = ctx->d_tap_ncand;
+        a.tap_normal = ctx->d_tap_normal;
+        a.tap_a2d = ctx->d_tap_a2d;
+        a.tap_offset = ctx->d_tap_offset;
+        if (ctx->n > 0) {
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_tap_ids, 0xFF, (size_t)ctx->n * K * sizeof(int), ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_tap_normal, 0, (size_t)ctx->n * 3 * sizeof(double), ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_tap_a2d, 0, (size_t)ctx->n * sizeof(double), ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_tap_offset, 0, (size_t)ctx->n * sizeof(double), ctx->stream));
+        }
+    }
+    const int nblocks = (ctx->n + SRL_KPB - 1) / SRL_KPB;
+    const bool prof = ctx->profiling;
+
+    if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    HIPCHK(ctx, srl_launch_assoc(a, nb, ctx->stream));
+    if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+
+    // residual budget of this rank (sequential early exit, optimize.cpp:107, across ordered shards)
+    int64_t budget = o->max_num_residuals;
+    int mode = 0;
+    if (o->max_num_residuals <= 0 || ctx->nranks == 1) {
+        srl_shard_budget(o->max_num_residuals, nullptr, ctx->nranks, ctx->rank, &budget, &mode);
+    } else {
+        HIPCHK(ctx, srl_launch_count(ctx->d_binfo, nblocks, ctx->d_count, ctx->stream));
+        std::vector<long long> all((size_t)ctx->nranks, 0);
+        if (ctx->comm) {
+            NCCLCHK(ctx, ncclAllGather(ctx->d_count, ctx->d_gather, 1, ncclInt64, ctx->comm, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(all.data(), ctx->d_gather, sizeof(long long) * ctx->nranks, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_count, ctx->d_count, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (!ctx->cb_ag) { ctx->err = "nranks > 1 without communicator"; return SRL_ERR_COMM; }
+            int64_t mine = *ctx->h_count;
+            std::vector<int64_t> tmp((size_t)ctx->nranks, 0);
+            if (ctx->cb_ag(&mine, tmp.data(), ctx->cb_user) != 0) { ctx->err = "allgather callback failed"; return SRL_ERR_COMM; }
+            for (int r = 0; r < ctx->nranks; r++) all[r] = tmp[r];
+        }
+        std::vector<int64_t> all64(all.begin(), all.end());
+        srl_shard_budget(o->max_num_residuals, all64.data(), ctx->nranks, ctx->rank, &budget, &mode);
+    }
+
+    SrlReduceArgs ra;
+    ra.rec = ctx->d_rec;
+    ra.status = ctx->d_status;
+    ra.partials = ctx->d_partials;
+    ra.binfo = ctx->d_binfo;
+    ra.n = ctx->n;
+    ra.nblocks = nblocks;
+    ra.max_res = budget;
+    ra.out = ctx->d_out;
+    HIPCHK(ctx, srl_launch_reduce(ra, mode, ctx->stream));
+    if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+
+    // the one exchange step: sum of the normal equations over the point-range shards
+    const int n_red = 36 + 6 + 1 + 5;   // HtH, Hth, loss, 5 counters carried as doubles
+    long long visited_local = 0;
+    if (ctx->nranks > 1 && ctx->comm) {
+        // local visited count must be captured before the reduction overwrites nothing (it is not reduced)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));
+        NCCLCHK(ctx, ncclAllReduce(ctx->d_out, ctx->d_out, n_red, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        visited_local = ctx->h_out->last_visited + 1;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        visited_local = ctx->h_out->last_visited + 1;
+        if (ctx->nranks > 1) {
+            if (!ctx->cb_ar) { ctx->err = "nranks > 1 without communicator"; return SRL_ERR_COMM; }
+            if (ctx->cb_ar(reinterpret_cast<double *>(ctx->h_out), n_red, ctx->cb_user) != 0) { ctx->err = "allreduce callback failed"; return SRL_ERR_COMM; }
+        }
+    }
+    if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+
+    // total visited keypoints over all shards -> global index of the last visited keypoint
+    long long visited_total = visited_local;
+    if (ctx->nranks > 1) {
+        double v = (double)visited_local;
+        if (ctx->comm) {
+            // tiny second all-reduce kept off the hot path: only needed for the taps' status=3 marking
+            double *dv = reinterpret_cast<double *>(ctx->d_count);
+            HIPCHK(ctx, hipMemcpyAsync(dv, &v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            NCCLCHK(ctx, ncclAllReduce(dv, dv, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(&v, dv, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+            if (ctx->cb_ar(&v, 1, ctx->cb_user) != 0) { ctx->err = "allreduce callback failed"; return SRL_ERR_COMM; }
+        }
+        visited_total = (long long)(v + 0.5);
+    }
+
+    const SrlDevOut &r = *ctx->h_out;
+    std::memcpy(out->HtH, r.HtH, sizeof out->HtH);
+    std::memcpy(out->Hth, r.Hth, sizeof out->Hth);
+    out->loss_sum = r.loss;
+    out->num_residuals = (int32_t)(r.d_num_res + 0.5);
+    out->success = out->num_residuals >= o->min_number_neighbors ? 1 : 0;     // optimize.cpp:110
+    out->sum_candidates = (int64_t)(r.d_sum_pk + 0.5);
+    out->last_visited = visited_total - 1;
+    out->nan_error = r.d_nan > 0.5 ? 1 : 0;
+    out->num_fallback = (int32_t)(r.d_fallback + 0.5);
+
+    ctx->last_K = K;
+    ctx->last_nb = nb;
+    ctx->last_visited_local = visited_local - 1;
+    ctx->taps_valid = ctx->taps;
+
+    if (prof) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
+        hipEventElapsedTime(&ctx->timing.assoc_ms, ctx->ev[0], ctx->ev[1]);
+        hipEventElapsedTime(&ctx->timing.reduce_ms, ctx->ev[1], ctx->ev[2]);
+        hipEventElapsedTime(&ctx->timing.total_ms, ctx->ev[0], ctx->ev[3]);
+    }
+    {
+        // algorithmic bytes of this rank's association pass: 24 + 12*(2r+1)^3 + 12*P_k per keypoint.
+        // sum_pk in h_out is the all-reduced value; the per-rank value is recomputed from the ratio when sharded.
+        const long long side = 2 * nb + 1;
+        const long long per_kp = 24 + 12 * side * side * side;
+        const double pk_share = (ctx->nranks > 1 && ctx->total_n > 0) ? r.d_sum_pk * ((double)ctx->n / (double)ctx->total_n) : r.d_sum_pk;
+        ctx->timing.algorithmic_bytes = per_kp * (long long)ctx->n + (long long)(12.0 * pk_share);
+    }
+    if (out->nan_error) { ctx->err = "NaN planarity"; return SRL_ERR_NAN_PLANARITY; }
+    return SRL_OK;
+}
+
+int srl_fetch_neighbors(srl_ctx *ctx, int32_t *ids, uint8_t *status, int32_t *num_candidates) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (!ctx->taps_valid) { ctx->err = "taps were not enabled for the last srl_build_residuals"; return SRL_ERR_BAD_ARG; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n = ctx->n, K = ctx->last_K;
+    if (n == 0) return SRL_OK;
+    if (ids) HIPCHK(ctx, hipMemcpyAsync(ids, ctx->d_tap_ids, (size_t)n * K * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (status) HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (num_candidates) HIPCHK(ctx, hipMemcpyAsync(num_candidates, ctx->d_tap_ncand, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (status) for (long long k = ctx->last_visited_local + 1; k < n; k++) status[k] = 3;   // not visited (optimize.cpp:107)
+    return SRL_OK;
+}
+
+int srl_fetch_residuals(srl_ctx *ctx, double *normal, double *a2D, double *weight, double *norm_offset,
+                        double *distance, double *jacobian) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (!ctx->taps_valid) { ctx->err = "taps were not enabled for the last srl_build_residuals"; return SRL_ERR_BAD_ARG; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n = ctx->n;
+    if (n == 0) return SRL_OK;
+    std::vector<double> rec((size_t)n * 8);
+    HIPCHK(ctx, hipMemcpyAsync(rec.data(), ctx->d_rec, rec.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (normal) HIPCHK(ctx, hipMemcpyAsync(normal, ctx->d_tap_normal, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (a2D) HIPCHK(ctx, hipMemcpyAsync(a2D, ctx->d_tap_a2d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (norm_offset) HIPCHK(ctx, hipMemcpyAsync(norm_offset, ctx->d_tap_offset, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < n; k++) {
+        if (jacobian) for (int c = 0; c < 6; c++) jacobian[(size_t)k * 6 + c] = rec[(size_t)k * 8 + c];
+        if (distance) distance[k] = rec[(size_t)k * 8 + 6];
+        if (weight) weight[k] = rec[(size_t)k * 8 + 7];
+    }
+    return SRL_OK;
+}
+
+int srl_search_neighbors(srl_ctx *ctx, const double *world_xyz, int n, int nb_voxels_visited, double size_voxel_map,
+                         int max_num_neighbors, int threshold_voxel_capacity, int32_t *ids, float *nb_xyz,
+                         int32_t *num_found) {
+    if (!ctx || n < 0 || (n > 0 && (!world_xyz || !ids || !num_found))) return SRL_ERR_BAD_ARG;
+    if (!ctx->d_table) return SRL_ERR_NO_MAP;
+    if (nb_voxels_visited < 1 || nb_voxels_visited > 2 || max_num_neighbors < 1 || max_num_neighbors > SRL_MAX_NEIGHBORS)
+        return SRL_ERR_UNSUPPORTED;
+    if (n == 0) return SRL_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int K = max_num_neighbors;
+    double *d_q = nullptr;
+    int *d_ids = nullptr, *d_nf = nullptr;
+    float *d_xyz = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_q, (size_t)n * 3 * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&d_ids, (size_t)n * K * sizeof(int)));
+    HIPCHK(ctx, hipMalloc((void **)&d_nf, (size_t)n * sizeof(int)));
+    if (nb_xyz) HIPCHK(ctx, hipMalloc((void **)&d_xyz, (size_t)n * K * 3 * sizeof(float)));
+    HIPCHK(ctx, hipMemcpyAsync(d_q, world_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_ids, 0xFF, (size_t)n * K * sizeof(int), ctx->stream));
+    if (d_xyz) HIPCHK(ctx, hipMemsetAsync(d_xyz, 0, (size_t)n * K * 3 * sizeof(float), ctx->stream));
+    SrlSearchArgs a;
+    a.q = d_q; a.n = n; a.table = ctx->d_table; a.table_mask = ctx->table_cap - 1; a.slabs = ctx->d_slabs;
+    a.size_voxel = size_voxel_map; a.K = K; a.thr_cap = threshold_voxel_capacity; a.select_mode = 0;
+    a.ids = d_ids; a.nb_xyz = d_xyz; a.num_found = d_nf;
+    HIPCHK(ctx, srl_launch_search(a, nb_voxels_visited, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ids, d_ids, (size_t)n * K * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(num_found, d_nf, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (nb_xyz) HIPCHK(ctx, hipMemcpyAsync(nb_xyz, d_xyz, (size_t)n * K * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_q); hipFree(d_ids); hipFree(d_nf);
+    if (d_xyz) hipFree(d_xyz);
+    return SRL_OK;
+}
+
+int srl_transform_points(srl_ctx *ctx, const double *raw_xyz, int n, const double q[4], const double t[3],
+                         const double R_il[9], const double t_il[3], double *out_xyz) {
+    if (!ctx || n < 0 || (n > 0 && (!raw_xyz || !out_xyz)) || !q || !t || !R_il || !t_il) return SRL_ERR_BAD_ARG;
+    if (n == 0) return SRL_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *d_in = nullptr, *d_o = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_in, (size_t)n * 3 * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&d_o, (size_t)n * 3 * sizeof(double)));
+    HIPCHK(ctx, hipMemcpyAsync(d_in, raw_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SrlXform X;
+    const srl::Mat3 R = srl::Quat(q[0], q[1], q[2], q[3]).toRotationMatrix();   // utility.cpp:317: q_end.toRotationMatrix()
+    std::memcpy(X.R, R.a, sizeof X.R);
+    std::memcpy(X.t, t, sizeof X.t);
+    std::memcpy(X.R_il, R_il, sizeof X.R_il);
+    std::memcpy(X.t_il, t_il, sizeof X.t_il);
+    HIPCHK(ctx, srl_launch_transform(d_in, n, X, d_o, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out_xyz, d_o, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_in); hipFree(d_o);
+    return SRL_OK;
+}
+
+void srl_shard_range(int n, int nranks, int rank, int *begin, int *count) {
+    const long long b = (long long)rank * n / nranks;
+    const long long e = (long long)(rank + 1) * n / nranks;
+    if (begin) *begin = (int)b;
+    if (count) *count = (int)(e - b);
+}
+
+void srl_shard_budget(int max_num_residuals, const int64_t *accepted_per_rank, int nranks, int rank,
+                      int64_t *budget, int *mode) {
+    (void)nranks;
+    int64_t b = max_num_residuals;
+    int m = 0;
+    if (max_num_residuals <= 0) {
+        // optimize.cpp:107 with the class default -1: the loop is left after the first keypoint
+        m = (rank == 0) ? 1 : 2;
+    } else {
+        int64_t prior = 0;
+        for (int r = 0; r < rank; r++) prior += accepted_per_rank ? accepted_per_rank[r] : 0;
+        b = (int64_t)max_num_residuals - prior;
+        if (b <= 0) m = 2;      // an earlier shard already reached max_num_residuals
+    }
+    if (budget) *budget = b;
+    if (mode) *mode = m;
+}
+
+// ------------------------------------------------------------------------------------------ comm
+int srl_comm_unique_id(void *id) {
+    if (!id) return SRL_ERR_BAD_ARG;
+    static_assert(sizeof(ncclUniqueId) <= SRL_COMM_ID_BYTES, "unique id does not fit");
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return SRL_ERR_COMM;
+    std::memset(id, 0, SRL_COMM_ID_BYTES);
+    std::memcpy(id, &u, sizeof u);
+    return SRL_OK;
+}
+
+int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id) {
+    if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return SRL_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->comm) { ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    NCCLCHK(ctx, ncclCommInitRank(&ctx->comm, nranks, u, rank));
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    ctx->cb_ar = nullptr; ctx->cb_ag = nullptr; ctx->cb_user = nullptr;
+    int rc = ensure(ctx, ctx->d_gather, (size_t)nranks);
+    return rc;
+}
+
+int srl_comm_destroy(srl_ctx *ctx) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (ctx->comm) { ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
+    ctx->nranks = 1; ctx->rank = 0;
+    ctx->cb_ar = nullptr; ctx->cb_ag = nullptr; ctx->cb_user = nullptr;
+    return SRL_OK;
+}
+
+int srl_comm_set_host_callbacks(srl_ctx *ctx, int nranks, int rank, srl_allreduce_fn ar, srl_allgather_i64_fn ag, void *user) {
+    if (!ctx || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && (!ar || !ag))) return SRL_ERR_BAD_ARG;
+    if (ctx->comm) { ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
+    ctx->nranks = nranks; ctx->rank = rank;
+    ctx->cb_ar = ar; ctx->cb_ag = ag; ctx->cb_user = user;
+    return SRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// srl_ctx.h -- internal: the context object behind the opaque srl_ctx handle of include/srlivo_hip.h
+#pragma once
+#include "../../include/srlivo_hip.h"
+#include "srl_device.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <string>
+
+struct srl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // map
+    SrlMapSlot *d_table = nullptr;
+    unsigned table_cap = 0;            // slots (power of two)
+    unsigned char *d_slabs = nullptr;
+    unsigned slab_cap = 0;             // slabs allocated
+    int num_voxels = 0;
+    long long num_points = 0;
+
+    // sweep (this rank's shard)
+    double *d_raw = nullptr;           // SoA x|y|z, stride sweep_cap
+    int sweep_cap = 0;
+    int n = 0;                         // shard size
+    int shard_begin = 0;
+    int total_n = 0;
+
+    // work buffers
+    double *d_rec = nullptr;
+    unsigned char *d_status = nullptr;
+    double *d_partials = nullptr;
+    SrlBlockInfo *d_binfo = nullptr;
+    int work_cap = 0;                  // keypoints capacity of rec/status
+    int block_cap = 0;
+    SrlDevOut *d_out = nullptr;
+    SrlDevOut *h_out = nullptr;        // pinned
+    long long *d_count = nullptr;
+    long long *h_count = nullptr;      // pinned
+
+    // taps
+    bool taps = false;
+    int tap_cap = 0, tap_K = 0;
+    int *d_tap_ids = nullptr;
+    int *d_tap_ncand = nullptr;
+    double *d_tap_normal = nullptr, *d_tap_a2d = nullptr, *d_tap_offset = nullptr;
+    bool taps_valid = false;
+    int last_K = 0;
+    long long last_visited_local = -1;
+
+    // comm
+    int nranks = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+    srl_allreduce_fn cb_ar = nullptr;
+    srl_allgather_i64_fn cb_ag = nullptr;
+    void *cb_user = nullptr;
+    long long *d_gather = nullptr;     // nranks
+
+    // timing
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    srl_timing timing = {0, 0, 0, 0};
+    int last_nb = 1;
+};
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                   \
+            return SRL_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+#define NCCLCHK(ctx, call)                                                                     \
+    do {                                                                                       \
+        ncclResult_t r__ = (call);                                                             \
+        if (r__ != ncclSuccess) {                                                              \
+            (ctx)->err = std::string(#call) + ": " + ncclGetErrorString(r__);                  \
+            return SRL_ERR_COMM;                                                               \
+        }                                                                                      \
+    } while (0)
+
+template <class T>
+int ensure(srl_ctx *ctx, T *&p, size_t count) {
+    if (p) { HIPCHK(ctx, hipFree(p)); p = nullptr; }
+    if (count == 0) count = 1;
+    HIPCHK(ctx, hipMalloc((void **)&p, count * sizeof(T)));
+    return SRL_OK;
+}
+

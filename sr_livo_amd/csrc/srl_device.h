@@ -1,0 +1,134 @@
+// srl_device.h -- internal device-side data layout and kernel launch interface (gfx950 only).
+//
+// Data layout in HBM:
+//   * map slabs : one 256-byte, 256-byte-aligned record per voxel, in voxel CREATION order
+//                 (slab index == voxel index, so point id = slab*20 + slot matches the reference's
+//                 per-voxel push_back order, lioOptimization.cpp:413-443).  20 x (x,y,z) FP32 packed
+//                 AoS (240 B) + count + key.  One wave streams a slab as 60 consecutive dwords.
+//   * hash table: open addressing, power-of-two capacity >= 2 x voxels (load <= 0.5), 16-byte slots
+//                 {packed int16x3 key, slab, count}; replaces tsl::robin_map<voxel, voxelBlock>
+//                 (cloudMap.h:171) for find() only -- iteration order is never observed on the path.
+//   * sweep     : raw points SoA  x[N] | y[N] | z[N]  FP64 (coalesced per-thread loads in phase 0).
+//   * records   : per keypoint 8 doubles {J[6], distance, weight} + status byte (ordered cut-off path
+//                 and parity taps).
+//   * partials  : per workgroup 32 doubles (21 upper-tri HtH, 6 Hth, loss) + counts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SRL_CAP 20
+#define SRL_SLAB_BYTES 256
+#define SRL_KPB 64            // keypoints per workgroup
+#define SRL_BLOCK 256         // threads per workgroup (4 waves)
+#define SRL_SURV_CAP 128      // per-wave survivor scratch entries
+#define SRL_MAXK 32
+#define SRL_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define SRL_PART_STRIDE 32
+
+struct SrlMapSlot {
+    unsigned long long key;
+    unsigned slab;
+    unsigned count;
+};
+static_assert(sizeof(SrlMapSlot) == 16, "slot must be 16 bytes");
+
+struct SrlSlab {
+    float xyz[SRL_CAP][3];
+    unsigned count;
+    unsigned pad;
+    unsigned long long key;
+};
+static_assert(sizeof(SrlSlab) == SRL_SLAB_BYTES, "slab must be 256 bytes");
+
+struct SrlBlockInfo {          // per-workgroup integer results
+    int accepted;              // residuals accepted in this block
+    unsigned sum_pk;           // candidates visited
+    int nan_flag;
+    int num_fallback;
+};
+
+struct SrlDevOut {             // result of the reduce kernel (device, then copied to host)
+    double HtH[36];
+    double Hth[6];
+    double loss;
+    double d_num_res;          // counts carried as doubles so one all-reduce covers everything
+    double d_total_accepted;
+    double d_sum_pk;
+    double d_nan;
+    double d_fallback;
+    long long last_visited;    // local index of last visited keypoint (n-1 if no cut)
+    long long pad;
+};
+
+struct SrlAssocArgs {
+    // sweep
+    const double *raw_x, *raw_y, *raw_z;
+    int n;
+    // map
+    const SrlMapSlot *table;
+    unsigned table_mask;
+    const unsigned char *slabs;
+    // pose (computed on the host exactly like the reference: optimize.cpp:35 and :95)
+    double Rn[9];       // end_quat.normalized().toRotationMatrix()
+    double R[9];        // end_quat.toRotationMatrix()
+    double t[3];
+    double t_last[3];
+    double R_il[9];
+    double t_il[3];
+    // options
+    double size_voxel;
+    double max_dist;
+    double lambda_w, lambda_n;
+    double power_planarity;
+    double nbr_scale;   // max_dist * min_number_neighbors (optimize.cpp:88)
+    int K;              // max_number_neighbors
+    int min_nb;         // min_number_neighbors
+    int thr_cap;        // threshold_voxel_capacity
+    int select_mode;
+    // outputs
+    double *rec;            // n x 8
+    unsigned char *status;  // n
+    double *partials;       // nblocks x 32
+    SrlBlockInfo *binfo;    // nblocks
+    // parity taps (may be null)
+    int *tap_ids;           // n x K
+    int *tap_ncand;         // n
+    double *tap_normal;     // n x 3
+    double *tap_a2d;        // n
+    double *tap_offset;     // n
+};
+
+struct SrlReduceArgs {
+    const double *rec;
+    const unsigned char *status;
+    const double *partials;
+    const SrlBlockInfo *binfo;
+    int n;
+    int nblocks;
+    long long max_res;          // residual budget for THIS rank (already reduced by earlier ranks' counts)
+    SrlDevOut *out;
+};
+
+struct SrlSearchArgs {
+    const double *q;        // n x 3 world points (AoS, device)
+    int n;
+    const SrlMapSlot *table;
+    unsigned table_mask;
+    const unsigned char *slabs;
+    double size_voxel;
+    int K;
+    int thr_cap;
+    int select_mode;
+    int *ids;               // n x K
+    float *nb_xyz;          // n x K x 3 or null
+    int *num_found;         // n
+};
+
+// launchers (srl_kernels.hip)
+hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, hipStream_t s);
+hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s);
+hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, long long *out_total, hipStream_t s);
+hipError_t srl_launch_search(const SrlSearchArgs &a, int nb_voxels, hipStream_t s);
+struct SrlXform { double R[9], t[3], R_il[9], t_il[3]; };
+hipError_t srl_launch_transform(const double *raw_aos, int n, const SrlXform &X, double *out_aos, hipStream_t s);
+hipError_t srl_launch_aos_to_soa(const double *aos, int n, double *x, double *y, double *z, hipStream_t s);

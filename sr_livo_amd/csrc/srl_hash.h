@@ -1,0 +1,29 @@
+// srl_hash.h -- voxel key packing + hash shared by host (table build) and device (probe).
+// Replaces std::hash<voxel> (cloudMap.h:173-184) + tsl::robin_map's bucket_for_hash
+// (robin_growth_policy.h:107-109): only find() semantics are observable on the hot path, so the
+// device table is free to use its own (better mixed) hash.
+#pragma once
+#include <stdint.h>
+#ifdef __HIPCC__
+#define SRL_HD __host__ __device__
+#else
+#define SRL_HD
+#endif
+
+// voxel (cloudMap.h:124-145): three int16, packed into the low 48 bits
+SRL_HD inline unsigned long long srl_pack_key(short x, short y, short z) {
+    return (unsigned long long)(unsigned short)x | ((unsigned long long)(unsigned short)y << 16) |
+           ((unsigned long long)(unsigned short)z << 32);
+}
+SRL_HD inline void srl_unpack_key(unsigned long long k, short *x, short *y, short *z) {
+    *x = (short)(unsigned short)(k & 0xFFFFu);
+    *y = (short)(unsigned short)((k >> 16) & 0xFFFFu);
+    *z = (short)(unsigned short)((k >> 32) & 0xFFFFu);
+}
+// splitmix64 finaliser
+SRL_HD inline unsigned srl_hash_key(unsigned long long k) {
+    k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
+    k ^= k >> 27; k *= 0x94d049bb133111ebull;
+    k ^= k >> 31;
+    return (unsigned)k;
+}

@@ -1,0 +1,725 @@
+// srl_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, wave64) implementing the
+// SR-LIVO LIO scan-matching hot path.  Compiled with -ffp-contract=off: the FP64 distance /
+// transform arithmetic must round exactly like the reference's x86-64 (no FMA) build so that the
+// neighbour sets are bit-identical.
+//
+// Kernel map:
+//   srl_assoc_kernel<NB>   buildPlaneResiduals (optimize.cpp:18-131) for 64 keypoints per workgroup:
+//        phase 0  thread/keypoint : transformKeypoints (optimize.cpp:30-40, :83)
+//        phase 1  wave/keypoint   : searchNeighbors (optimize.cpp:365-426) -- (2r+1)^3 hash probes
+//                                   by lanes, occupied voxels compacted by ballot/mbcnt into LDS,
+//                                   candidates streamed 64 per round (coalesced 12-B loads from the
+//                                   256-B slabs), exact top-K by {f32 threshold from a 64-lane
+//                                   bitonic sort of per-lane minima -> ballot compaction of the
+//                                   survivors into LDS -> FP64 rank-by-counting}
+//        phase 2  thread/keypoint : computeNeighborhoodDistribution (optimize.cpp:316-353), weights,
+//                                   plane, signed distance gate, Jacobian (optimize.cpp:42-53,85-105),
+//                                   then an in-order H^T H / H^T h partial per workgroup.
+//   srl_reduce_kernel      the sequential early-exit (optimize.cpp:107) as an ordered prefix cut +
+//                          the deterministic final reduction of the partials (optimize.cpp:235,239).
+//   srl_search_kernel<NB>  searchNeighbors for a batch of world points (parity / API surface).
+#include "srl_device.h"
+#include "srl_hash.h"
+
+#include <math.h>
+
+namespace {
+
+struct VoxEnt { unsigned slab; unsigned count; };
+struct Surv { double d2; float x, y, z; unsigned id; };
+static_assert(sizeof(Surv) == 24, "survivor record is 24 bytes");
+
+__device__ __forceinline__ int lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+}
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+}
+
+struct Cand { bool valid; double d2; float x, y, z; unsigned id; };
+
+// candidate e = (compacted voxel e/20, slot e%20); d2 = ((dx*dx + dy*dy) + dz*dz) in FP64, no FMA
+__device__ __forceinline__ Cand eval_cand(int e, int nv, const VoxEnt *vox, const unsigned char *slabs,
+                                          double qx, double qy, double qz) {
+    Cand c;
+    c.valid = false;
+    c.d2 = __builtin_huge_val();
+    c.x = c.y = c.z = 0.0f;
+    c.id = 0;
+    const unsigned cv = (unsigned)e / SRL_CAP;
+    const unsigned slot = (unsigned)e - cv * SRL_CAP;
+    if ((int)cv < nv) {
+        const VoxEnt ve = vox[cv];
+        if (slot < ve.count) {
+            const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve.slab * SRL_SLAB_BYTES + slot * 12u);
+            c.x = p[0]; c.y = p[1]; c.z = p[2];
+            const double dx = (double)c.x - qx;
+            const double dy = (double)c.y - qy;
+            const double dz = (double)c.z - qz;
+            c.d2 = (dx * dx + dy * dy) + dz * dz;
+            c.valid = true;
+            c.id = ve.slab * SRL_CAP + slot;
+        }
+    }
+    return c;
+}
+
+// ---- (2r+1)^3 hash probes: lanes probe, occupied voxels are compacted (visit order kept) ----
+template <int NB>
+__device__ __forceinline__ int probe_voxels(double qx, double qy, double qz, double size_voxel, int thr_cap,
+                                            const SrlMapSlot *table, unsigned mask, VoxEnt *vox, int lane) {
+    constexpr int SIDE = 2 * NB + 1;
+    constexpr int NV = SIDE * SIDE * SIDE;
+    // static_cast<short>(point / size_voxel_map): truncation toward zero (optimize.cpp:372-374)
+    const short kx = (short)(int)(qx / size_voxel);
+    const short ky = (short)(int)(qy / size_voxel);
+    const short kz = (short)(int)(qz / size_voxel);
+    int nv = 0;
+#pragma unroll
+    for (int base = 0; base < NV; base += 64) {
+        const int i = base + lane;
+        bool found = false;
+        unsigned slab = 0, cnt = 0;
+        if (i < NV) {
+            // visit order: x outer, y, z inner (optimize.cpp:379-381)
+            const int ix = i / (SIDE * SIDE);
+            const int iy = (i / SIDE) % SIDE;
+            const int iz = i % SIDE;
+            const short vx = (short)(kx + (ix - NB));
+            const short vy = (short)(ky + (iy - NB));
+            const short vz = (short)(kz + (iz - NB));
+            const unsigned long long key = srl_pack_key(vx, vy, vz);
+            unsigned h = srl_hash_key(key) & mask;
+            for (unsigned probe = 0; probe <= mask; ++probe) {
+                const SrlMapSlot s = table[h];
+                if (s.key == key) {
+                    // NumPoints() < threshold_voxel_capacity -> skipped (optimize.cpp:389)
+                    found = (int)s.count >= thr_cap && s.count > 0;
+                    slab = s.slab;
+                    cnt = s.count;
+                    break;
+                }
+                if (s.key == SRL_EMPTY_KEY) break;
+                h = (h + 1) & mask;
+            }
+        }
+        const unsigned long long m = __ballot(found);
+        if (found) {
+            VoxEnt ve; ve.slab = slab; ve.count = cnt;
+            vox[nv + lanes_below(m)] = ve;
+        }
+        nv += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return nv;
+}
+
+// ---- exact top-K selection (ascending distance, ties by visit order) ----
+// Sink::put(rank, x, y, z, id) is called by exactly one lane per selected rank.
+template <class Sink>
+__device__ __forceinline__ void select_topk(double qx, double qy, double qz, int nv, const VoxEnt *vox,
+                                            const unsigned char *slabs, int K, int select_mode, Surv *surv,
+                                            int lane, Sink &sink, int &total_out, int &fallback_out) {
+    const int rounds = (nv * SRL_CAP + 63) >> 6;
+    const float kInfF = __builtin_huge_valf();
+
+    // pass 1: stream all candidates, per-lane minimum of (float)d2, count P_k
+    float lmin = kInfF;
+    int total = 0;
+    for (int j = 0; j < rounds; ++j) {
+        const Cand c = eval_cand(lane + 64 * j, nv, vox, slabs, qx, qy, qz);
+        const float key = c.valid ? (float)c.d2 : kInfF;
+        lmin = fminf(lmin, key);
+        total += __popcll(__ballot(c.valid));
+    }
+    total_out = total;
+    const int nsel = total < K ? total : K;
+    bool use_fallback = (select_mode == 1);
+    int c_surv = 0;
+
+    if (!use_fallback) {
+        // K-th smallest of the 64 per-lane minima = an upper bound of the K-th smallest distance
+        // (every lane's minimum is a distinct candidate): 64-lane bitonic sort of the f32 bit patterns.
+        unsigned v = __float_as_uint(lmin);
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const unsigned o = __shfl_xor(v, j);
+                const bool up = (lane & k) == 0;
+                const bool lo = (lane & j) == 0;
+                const unsigned mn = v < o ? v : o;
+                const unsigned mx = v < o ? o : v;
+                v = (lo == up) ? mn : mx;
+            }
+        }
+        const float tau = __uint_as_float(__shfl(v, K - 1));
+
+        // pass 2: survivors {(float)d2 <= tau} are a prefix of the true order that contains the top-K;
+        // compact them (visit order kept) into this wave's LDS scratch.
+        for (int j = 0; j < rounds; ++j) {
+            const Cand c = eval_cand(lane + 64 * j, nv, vox, slabs, qx, qy, qz);
+            const bool s = c.valid && ((float)c.d2 <= tau);
+            const unsigned long long m = __ballot(s);
+            const int pos = c_surv + lanes_below(m);
+            if (s && pos < SRL_SURV_CAP) {
+                Surv r; r.d2 = c.d2; r.x = c.x; r.y = c.y; r.z = c.z; r.id = c.id;
+                surv[pos] = r;
+            }
+            c_surv += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (c_surv > SRL_SURV_CAP) use_fallback = true;
+    }
+
+    if (!use_fallback) {
+        // exact FP64 rank by counting; equal distances keep visit order (j < i)
+        for (int i0 = 0; i0 < c_surv; i0 += 64) {
+            const int i = i0 + lane;
+            const bool act = i < c_surv;
+            Surv me;
+            if (act) me = surv[i];
+            else { me.d2 = __builtin_huge_val(); me.x = me.y = me.z = 0.0f; me.id = 0; }
+            int rank = 0;
+            for (int j = 0; j < c_surv; ++j) {
+                const double dj = surv[j].d2;
+                rank += ((dj < me.d2) || (dj == me.d2 && j < i)) ? 1 : 0;
+            }
+            if (act && rank < K) sink.put(rank, me.x, me.y, me.z, me.id);
+        }
+        fallback_out = 0;
+    } else {
+        // streaming extraction: nsel passes, each taking the lexicographic successor of (d2, e)
+        double last_d2 = -1.0;
+        int last_e = -1;
+        for (int r = 0; r < nsel; ++r) {
+            double bd2 = __builtin_huge_val();
+            int be = 0x7fffffff;
+            for (int j = 0; j < rounds; ++j) {
+                const int e = lane + 64 * j;
+                const Cand c = eval_cand(e, nv, vox, slabs, qx, qy, qz);
+                const bool gt = c.valid && (c.d2 > last_d2 || (c.d2 == last_d2 && e > last_e));
+                if (gt && (c.d2 < bd2 || (c.d2 == bd2 && e < be))) { bd2 = c.d2; be = e; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double od = __shfl_xor(bd2, off);
+                const int oe = __shfl_xor(be, off);
+                if (od < bd2 || (od == bd2 && oe < be)) { bd2 = od; be = oe; }
+            }
+            if ((be & 63) == lane) {
+                const Cand c = eval_cand(be, nv, vox, slabs, qx, qy, qz);
+                sink.put(r, c.x, c.y, c.z, c.id);
+            }
+            last_d2 = bd2;
+            last_e = be;
+        }
+        fallback_out = 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// small FP64 helpers (fixed evaluation order, mirrors the oracle / Eigen semantics)
+// ---------------------------------------------------------------------------------------------
+struct D3 { double x, y, z; };
+__device__ __forceinline__ D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ D3 sub(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ double dot3(D3 a, D3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ D3 matvec(const double *M, D3 v) {
+    return d3((M[0] * v.x + M[1] * v.y) + M[2] * v.z, (M[3] * v.x + M[4] * v.y) + M[5] * v.z,
+              (M[6] * v.x + M[7] * v.y) + M[8] * v.z);
+}
+__device__ __forceinline__ D3 add(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ D3 normalized3(D3 a) {
+    const double z = dot3(a, a);
+    if (z > 0.0) { const double n = sqrt(z); return d3(a.x / n, a.y / n, a.z / n); }
+    return a;
+}
+
+// FP64 cyclic Jacobi for a symmetric 3x3 (SelfAdjointEigenSolver<Matrix3d> restated, optimize.cpp:339):
+// eigenvalues ascending in ev[], eigenvector of the smallest eigenvalue in n0.
+__device__ void eig3_jacobi(const double Ain[3][3], double ev[3], D3 &n0) {
+    double a[3][3], V[3][3];
+    double scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) scale = fmax(scale, fabs(Ain[i][j]));
+    if (!(scale > 0.0)) scale = 1.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { a[i][j] = Ain[i][j] / scale; V[i][j] = (i == j) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 32; sweep++) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        if (off < 1e-40) break;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                const double apq = a[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+                if (theta < 0.0) t = -t;
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double s = t * c;
+                const int r = 3 - p - q;
+                const double app = a[p][p], aqq = a[q][q];
+                a[p][p] = app - t * apq;
+                a[q][q] = aqq + t * apq;
+                a[p][q] = a[q][p] = 0.0;
+                const double arp = a[r][p], arq = a[r][q];
+                a[r][p] = a[p][r] = c * arp - s * arq;
+                a[r][q] = a[q][r] = s * arp + c * arq;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+        }
+    }
+    const double d0 = a[0][0] * scale, d1 = a[1][1] * scale, d2 = a[2][2] * scale;
+    // stable ascending order of three values (same comparison sequence as the oracle)
+    int i0 = 0, i1 = 1, i2 = 2;
+    double e0 = d0, e1 = d1, e2 = d2;
+    if (e1 < e0) { double tdv = e0; e0 = e1; e1 = tdv; int ti = i0; i0 = i1; i1 = ti; }
+    if (e2 < e1) { double tdv = e1; e1 = e2; e2 = tdv; int ti = i1; i1 = i2; i2 = ti; }
+    if (e1 < e0) { double tdv = e0; e0 = e1; e1 = tdv; int ti = i0; i0 = i1; i1 = ti; }
+    ev[0] = e0; ev[1] = e1; ev[2] = e2;
+    // column i0 of V without runtime register indexing
+    n0.x = (i0 == 0) ? V[0][0] : ((i0 == 1) ? V[0][1] : V[0][2]);
+    n0.y = (i0 == 0) ? V[1][0] : ((i0 == 1) ? V[1][1] : V[1][2]);
+    n0.z = (i0 == 0) ? V[2][0] : ((i0 == 1) ? V[2][1] : V[2][2]);
+    (void)i2;
+}
+
+// dynamic LDS carve (all offsets multiples of 16; guide G17)
+#define NB_ROW (SRL_KPB + 1)   // row stride (entries) of the neighbour list: conflict-free phase-2 reads
+struct LdsLayout {
+    int off_nb, off_pw, off_nfound, off_ncand, off_vox, off_surv, off_misc, total;
+};
+__host__ __device__ inline LdsLayout lds_layout(int K) {
+    LdsLayout L;
+    int o = 0;
+    L.off_nb = o;     o += K * NB_ROW * 16;
+    L.off_pw = o;     o += SRL_KPB * 3 * 8;
+    L.off_nfound = o; o += SRL_KPB * 4;
+    L.off_ncand = o;  o += SRL_KPB * 4;
+    L.off_vox = o;    o += 4 * 128 * 8;
+    L.off_surv = o;   o += 4 * SRL_SURV_CAP * 24;     // aliased by the J records (64*8*8 = 4 KB) after the barrier
+    L.off_misc = o;   o += 64;
+    L.total = o;
+    return L;
+}
+
+struct LdsSink {
+    float4 *col;        // &nb[0][kl], row stride NB_ROW
+    int *tap_ids;       // global row or null
+    __device__ __forceinline__ void put(int rank, float x, float y, float z, unsigned id) {
+        col[rank * NB_ROW] = make_float4(x, y, z, __uint_as_float(id));
+        if (tap_ids) tap_ids[rank] = (int)id;
+    }
+};
+
+template <int NB>
+__global__ void __launch_bounds__(SRL_BLOCK) srl_assoc_kernel(const SrlAssocArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LdsLayout L = lds_layout(a.K);
+    float4 *s_nb = reinterpret_cast<float4 *>(smem + L.off_nb);
+    double *s_pw = reinterpret_cast<double *>(smem + L.off_pw);
+    int *s_nfound = reinterpret_cast<int *>(smem + L.off_nfound);
+    int *s_ncand = reinterpret_cast<int *>(smem + L.off_ncand);
+    VoxEnt *s_vox = reinterpret_cast<VoxEnt *>(smem + L.off_vox);
+    Surv *s_surv = reinterpret_cast<Surv *>(smem + L.off_surv);
+    double *s_jrec = reinterpret_cast<double *>(smem + L.off_surv);   // alias, used after the barrier
+    int *s_misc = reinterpret_cast<int *>(smem + L.off_misc);
+
+    const int tid = threadIdx.x;
+    const int lane = lane_id();
+    const int wave = tid >> 6;
+    const int base = blockIdx.x * SRL_KPB;
+
+    // ---------------- phase 0: transformKeypoints (optimize.cpp:30-40), location (optimize.cpp:83)
+    D3 p_imu = d3(0, 0, 0), p_w = d3(0, 0, 0);
+    if (tid < SRL_KPB) {
+        const int g = base + tid;
+        if (g < a.n) {
+            const D3 raw = d3(a.raw_x[g], a.raw_y[g], a.raw_z[g]);
+            p_imu = add(matvec(a.R_il, raw), d3(a.t_il[0], a.t_il[1], a.t_il[2]));
+            p_w = add(matvec(a.Rn, p_imu), d3(a.t[0], a.t[1], a.t[2]));
+        }
+        s_pw[tid * 3 + 0] = p_w.x;
+        s_pw[tid * 3 + 1] = p_w.y;
+        s_pw[tid * 3 + 2] = p_w.z;
+        s_nfound[tid] = 0;
+        s_ncand[tid] = 0;
+    }
+    if (tid == 0) s_misc[0] = 0;
+    __syncthreads();
+
+    // ---------------- phase 1: searchNeighbors, one wave per keypoint
+    {
+        VoxEnt *vox = s_vox + wave * 128;
+        Surv *surv = s_surv + wave * SRL_SURV_CAP;
+        int n_fallback = 0;
+        for (int i = 0; i < SRL_KPB / 4; ++i) {
+            const int kl = wave * (SRL_KPB / 4) + i;
+            const int g = base + kl;
+            if (g >= a.n) break;
+            const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
+            const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, vox, lane);
+            LdsSink sink;
+            sink.col = s_nb + kl;
+            sink.tap_ids = a.tap_ids ? (a.tap_ids + (size_t)g * a.K) : nullptr;
+            int total = 0, fb = 0;
+            select_topk(qx, qy, qz, nv, vox, a.slabs, a.K, a.select_mode, surv, lane, sink, total, fb);
+            n_fallback += fb;
+            if (lane == 0) {
+                s_nfound[kl] = total < a.K ? total : a.K;
+                s_ncand[kl] = total;
+            }
+        }
+        if (lane == 0 && n_fallback) atomicAdd(&s_misc[0], n_fallback);
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: plane fit + residual + Jacobian, one thread per keypoint (wave 0)
+    if (wave != 0) return;
+    const int g = base + tid;
+    int status = 3;
+    bool nan_bad = false;
+    double J[6] = {0, 0, 0, 0, 0, 0};
+    double dist = 0.0, weight = 0.0;
+    const int nf = s_nfound[tid];
+    if (g < a.n) {
+        status = 0;
+        if (nf >= a.min_nb) {
+            // barycenter, sequential in neighbour order (optimize.cpp:320-325)
+            D3 bc = d3(0, 0, 0);
+            for (int i = 0; i < nf; ++i) {
+                const float4 p = s_nb[i * NB_ROW + tid];
+                bc = add(bc, d3((double)p.x, (double)p.y, (double)p.z));
+            }
+            const double inv_n = (double)nf;
+            bc = d3(bc.x / inv_n, bc.y / inv_n, bc.z / inv_n);
+            double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            for (int i = 0; i < nf; ++i) {
+                const float4 p = s_nb[i * NB_ROW + tid];
+                const double ex = (double)p.x - bc.x, ey = (double)p.y - bc.y, ez = (double)p.z - bc.z;
+                C[0][0] += ex * ex; C[0][1] += ex * ey; C[0][2] += ex * ez;
+                C[1][1] += ey * ey; C[1][2] += ey * ez;
+                C[2][2] += ez * ez;
+            }
+            C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
+            double ev[3];
+            D3 nrm;
+            eig3_jacobi(C, ev, nrm);
+            nrm = normalized3(nrm);                                   // .col(0).normalized() (optimize.cpp:340)
+            const double sigma_1 = sqrt(fabs(ev[2]));
+            const double sigma_2 = sqrt(fabs(ev[1]));
+            const double sigma_3 = sqrt(fabs(ev[0]));
+            const double a2D = (sigma_2 - sigma_3) / sigma_1;          // optimize.cpp:343-346
+            if (a2D != a2D) nan_bad = true;                           // optimize.cpp:348-350
+            double w_plan = (a.power_planarity == 2.0) ? a2D * a2D : pow(a2D, a.power_planarity);
+            // normal flip: world-frame last translation minus body-frame location (optimize.cpp:49-51)
+            const D3 tl = d3(a.t_last[0], a.t_last[1], a.t_last[2]);
+            if (dot3(nrm, sub(tl, p_imu)) < 0.0) nrm = d3(-1.0 * nrm.x, -1.0 * nrm.y, -1.0 * nrm.z);
+            const float4 n0f = s_nb[tid];
+            const D3 nn0 = d3((double)n0f.x, (double)n0f.y, (double)n0f.z);
+            const D3 dq = sub(nn0, p_w);
+            weight = a.lambda_w * w_plan + a.lambda_n * exp(-sqrt(dot3(dq, dq)) / a.nbr_scale);   // optimize.cpp:87-88
+            const D3 nv = normalized3(nrm);                            // optimize.cpp:93
+            const double off = -dot3(nv, nn0);                         // optimize.cpp:94
+            const D3 pe = add(matvec(a.R, p_imu), d3(a.t[0], a.t[1], a.t[2]));
+            dist = dot3(nv, pe) + off;                                 // optimize.cpp:95
+            status = 1;
+            if (a.tap_normal) {
+                a.tap_normal[(size_t)g * 3 + 0] = nv.x; a.tap_normal[(size_t)g * 3 + 1] = nv.y; a.tap_normal[(size_t)g * 3 + 2] = nv.z;
+                a.tap_a2d[g] = a2D;
+                a.tap_offset[g] = off;
+            }
+            if (dist < a.max_dist) {                                   // signed gate (optimize.cpp:98)
+                status = 2;
+                J[0] = nv.x * weight; J[1] = nv.y * weight; J[2] = nv.z * weight;
+                // - n^T * R * skew(p_imu) * weight, left to right (optimize.cpp:101)
+                const double m0 = -nv.x, m1 = -nv.y, m2 = -nv.z;
+                const double r0 = (m0 * a.R[0] + m1 * a.R[3]) + m2 * a.R[6];
+                const double r1 = (m0 * a.R[1] + m1 * a.R[4]) + m2 * a.R[7];
+                const double r2 = (m0 * a.R[2] + m1 * a.R[5]) + m2 * a.R[8];
+                // skew(p) = [[0,-pz,py],[pz,0,-px],[-py,px,0]]
+                const double s0 = (r0 * 0.0 + r1 * p_imu.z) + r2 * (-p_imu.y);
+                const double s1 = (r0 * (-p_imu.z) + r1 * 0.0) + r2 * p_imu.x;
+                const double s2 = (r0 * p_imu.y + r1 * (-p_imu.x)) + r2 * 0.0;
+                J[3] = s0 * weight; J[4] = s1 * weight; J[5] = s2 * weight;
+            }
+        }
+        // per-keypoint record (ordered cut-off path + taps)
+        double *rec = a.rec + (size_t)g * 8;
+#pragma unroll
+        for (int c = 0; c < 6; c++) rec[c] = J[c];
+        rec[6] = dist;
+        rec[7] = weight;
+        a.status[g] = (unsigned char)status;
+        if (a.tap_ncand) a.tap_ncand[g] = s_ncand[tid];
+    }
+    // records to LDS for the in-order block partial
+#pragma unroll
+    for (int c = 0; c < 6; c++) s_jrec[tid * 8 + c] = J[c];
+    s_jrec[tid * 8 + 6] = dist;
+    s_jrec[tid * 8 + 7] = weight;
+    const unsigned long long acc_mask = __ballot(status == 2);
+    const unsigned long long nan_mask = __ballot(nan_bad);
+    int pk = (g < a.n) ? s_ncand[tid] : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
+    __builtin_amdgcn_wave_barrier();      // LDS is in-order per wave: the reads below see every lane's record
+
+    // component lane c: 0..20 upper-tri HtH (row-major a<=b), 21..26 Hth, 27 loss
+    if (tid < 28) {
+        int ia = 0, ib = 0;
+        if (tid < 21) {
+            int c = tid;
+            ia = 0;
+            int rowlen = 6;
+            while (c >= rowlen) { c -= rowlen; ia++; rowlen--; }
+            ib = ia + c;
+        } else if (tid < 27) {
+            ia = tid - 21;
+        }
+        double acc = 0.0;
+        for (int k = 0; k < SRL_KPB; ++k) {
+            if (!((acc_mask >> k) & 1ull)) continue;
+            const double *r = s_jrec + k * 8;
+            if (tid < 21) acc += r[ia] * r[ib];
+            else if (tid < 27) acc += r[ia] * (r[6] * r[7]);      // h = distance * weight (optimize.cpp:169)
+            else acc += r[6] * r[6];                              // loss (optimize.cpp:104)
+        }
+        a.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] = acc;
+    }
+    if (tid == 0) {
+        SrlBlockInfo bi;
+        bi.accepted = __popcll(acc_mask);
+        bi.sum_pk = (unsigned)pk;
+        bi.nan_flag = nan_mask ? 1 : 0;
+        bi.num_fallback = s_misc[0];
+        a.binfo[blockIdx.x] = bi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ordered cut-off + final reduction (single workgroup)
+// mode: 0 = budget max_res >= 1; 1 = visit only the first keypoint (max_num_residuals <= 0,
+// optimize.cpp:107 breaks after the first keypoint); 2 = visit nothing (budget spent by earlier shards)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) srl_reduce_kernel(const SrlReduceArgs a, int mode) {
+    __shared__ long long s_chunk[256];
+    __shared__ double s_part[8][SRL_PART_STRIDE];
+    __shared__ long long s_tot[4];          // total accepted, sum_pk, nan, fallback
+    __shared__ int s_cut[4];                // cut block, allowed in cut block, last visited local idx, num_res
+    const int tid = threadIdx.x;
+    const int nb = a.nblocks;
+
+    // integer totals
+    long long acc = 0, pk = 0, nanf = 0, fb = 0;
+    const int per = (nb + 255) / 256;
+    const int b0 = tid * per;
+    const int b1 = (b0 + per < nb) ? b0 + per : nb;
+    for (int b = b0; b < b1; ++b) {
+        const SrlBlockInfo bi = a.binfo[b];
+        acc += bi.accepted; pk += bi.sum_pk; nanf += bi.nan_flag; fb += bi.num_fallback;
+    }
+    s_chunk[tid] = acc;
+    if (tid < 4) s_tot[tid] = 0;
+    __syncthreads();
+    atomicAdd((unsigned long long *)&s_tot[1], (unsigned long long)pk);
+    atomicAdd((unsigned long long *)&s_tot[2], (unsigned long long)nanf);
+    atomicAdd((unsigned long long *)&s_tot[3], (unsigned long long)fb);
+    __syncthreads();
+
+    if (tid == 0) {
+        long long total = 0;
+        for (int i = 0; i < 256; ++i) total += s_chunk[i];
+        s_tot[0] = total;
+        int cut_block = nb, allowed = 0, last_visited = a.n - 1;
+        long long num_res = total;
+        if (mode == 2) {
+            cut_block = 0; allowed = 0; last_visited = -1; num_res = 0;
+        } else if (mode == 1) {
+            cut_block = 0; allowed = 0; last_visited = (a.n > 0) ? 0 : -1;
+            num_res = (a.n > 0 && a.status[0] == 2) ? 1 : 0;
+        } else if (total >= a.max_res) {
+            // find the keypoint holding the max_res-th accepted residual (optimize.cpp:107)
+            long long before = 0;
+            int c = 0;
+            while (c < 256 && before + s_chunk[c] < a.max_res) { before += s_chunk[c]; ++c; }
+            int b = c * per;
+            while (b < nb && before + a.binfo[b].accepted < a.max_res) { before += a.binfo[b].accepted; ++b; }
+            cut_block = b;
+            allowed = (int)(a.max_res - before);
+            int seen = 0;
+            int k = b * SRL_KPB;
+            const int kend = (k + SRL_KPB < a.n) ? k + SRL_KPB : a.n;
+            for (; k < kend; ++k) { if (a.status[k] == 2) { ++seen; if (seen == allowed) break; } }
+            last_visited = k;
+            num_res = a.max_res;
+        }
+        s_cut[0] = cut_block; s_cut[1] = allowed; s_cut[2] = last_visited; s_cut[3] = (int)num_res;
+    }
+    __syncthreads();
+    const int cut_block = s_cut[0];
+    const int last_visited = s_cut[2];
+
+    // deterministic sum of the partials of all blocks strictly before the cut block:
+    // part p sums blocks b == p (mod 8) ascending; parts are then added in order 0..7.
+    {
+        const int comp = tid & 31, part = tid >> 5;
+        double s = 0.0;
+        if (comp < 28)
+            for (int b = part; b < cut_block; b += 8) s += a.partials[(size_t)b * SRL_PART_STRIDE + comp];
+        s_part[part][comp] = s;
+    }
+    __syncthreads();
+    if (tid < 28) {
+        double s = s_part[0][tid];
+        for (int p = 1; p < 8; ++p) s += s_part[p][tid];
+        // cut block (or the single first keypoint in mode 1): re-accumulate from the records, in order
+        if (mode != 2 && cut_block < nb) {
+            int ia = 0, ib = 0;
+            if (tid < 21) { int c = tid; int rowlen = 6; while (c >= rowlen) { c -= rowlen; ia++; rowlen--; } ib = ia + c; }
+            else if (tid < 27) ia = tid - 21;
+            double accd = 0.0;
+            for (int k = cut_block * SRL_KPB; k <= last_visited; ++k) {
+                if (a.status[k] != 2) continue;
+                const double *r = a.rec + (size_t)k * 8;
+                if (tid < 21) accd += r[ia] * r[ib];
+                else if (tid < 27) accd += r[ia] * (r[6] * r[7]);
+                else accd += r[6] * r[6];
+            }
+            s += accd;
+        }
+        if (tid < 21) {
+            int ia = 0, c = tid, rowlen = 6;
+            while (c >= rowlen) { c -= rowlen; ia++; rowlen--; }
+            const int ib = ia + c;
+            a.out->HtH[ia * 6 + ib] = s;
+            a.out->HtH[ib * 6 + ia] = s;
+        } else if (tid < 27) {
+            a.out->Hth[tid - 21] = s;
+        } else {
+            a.out->loss = s;
+        }
+    }
+    if (tid == 0) {
+        a.out->d_num_res = (double)s_cut[3];
+        a.out->d_total_accepted = (double)s_tot[0];
+        a.out->d_sum_pk = (double)s_tot[1];
+        a.out->d_nan = (double)s_tot[2];
+        a.out->d_fallback = (double)s_tot[3];
+        a.out->last_visited = last_visited;
+        a.out->pad = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) srl_count_kernel(const SrlBlockInfo *binfo, int nblocks, long long *out_total) {
+    __shared__ long long s[256];
+    long long acc = 0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += binfo[b].accepted;
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { long long t = 0; for (int i = 0; i < 256; ++i) t += s[i]; *out_total = t; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// searchNeighbors for a batch of world points (one wave per query)
+// ---------------------------------------------------------------------------------------------
+struct GlobalSink {
+    int *ids;
+    float *xyz;
+    __device__ __forceinline__ void put(int rank, float x, float y, float z, unsigned id) {
+        ids[rank] = (int)id;
+        if (xyz) { xyz[rank * 3 + 0] = x; xyz[rank * 3 + 1] = y; xyz[rank * 3 + 2] = z; }
+    }
+};
+
+template <int NB>
+__global__ void __launch_bounds__(SRL_BLOCK) srl_search_kernel(const SrlSearchArgs a) {
+    __shared__ __attribute__((aligned(16))) VoxEnt s_vox[4][128];
+    __shared__ __attribute__((aligned(16))) Surv s_surv[4][SRL_SURV_CAP];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * 4;
+    for (int q = blockIdx.x * 4 + wave; q < a.n; q += nwaves) {
+        const double qx = a.q[(size_t)q * 3 + 0], qy = a.q[(size_t)q * 3 + 1], qz = a.q[(size_t)q * 3 + 2];
+        const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, s_vox[wave], lane);
+        GlobalSink sink;
+        sink.ids = a.ids + (size_t)q * a.K;
+        sink.xyz = a.nb_xyz ? a.nb_xyz + (size_t)q * a.K * 3 : nullptr;
+        int total = 0, fb = 0;
+        select_topk(qx, qy, qz, nv, s_vox[wave], a.slabs, a.K, a.select_mode, s_surv[wave], lane, sink, total, fb);
+        if (lane == 0) a.num_found[q] = total < a.K ? total : a.K;
+    }
+}
+
+// transformPoint (utility.cpp:314-318) for the post-solve loop (optimize.cpp:441-445)
+__global__ void srl_transform_kernel(const double *raw, int n, const SrlXform X, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const D3 r = d3(raw[(size_t)i * 3], raw[(size_t)i * 3 + 1], raw[(size_t)i * 3 + 2]);
+    const D3 pi = add(matvec(X.R_il, r), d3(X.t_il[0], X.t_il[1], X.t_il[2]));
+    const D3 pw = add(matvec(X.R, pi), d3(X.t[0], X.t[1], X.t[2]));
+    out[(size_t)i * 3] = pw.x; out[(size_t)i * 3 + 1] = pw.y; out[(size_t)i * 3 + 2] = pw.z;
+}
+
+__global__ void srl_aos_to_soa_kernel(const double *aos, int n, double *x, double *y, double *z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    x[i] = aos[(size_t)i * 3];
+    y[i] = aos[(size_t)i * 3 + 1];
+    z[i] = aos[(size_t)i * 3 + 2];
+}
+
+}  // namespace
+
+hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    const int nblocks = (a.n + SRL_KPB - 1) / SRL_KPB;
+    const LdsLayout L = lds_layout(a.K);
+    if (nb_voxels == 1) hipLaunchKernelGGL(srl_assoc_kernel<1>, dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+    else hipLaunchKernelGGL(srl_assoc_kernel<2>, dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+    return hipGetLastError();
+}
+
+hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(srl_reduce_kernel, dim3(1), dim3(256), 0, s, a, mode);
+    return hipGetLastError();
+}
+
+hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, long long *out_total, hipStream_t s) {
+    hipLaunchKernelGGL(srl_count_kernel, dim3(1), dim3(256), 0, s, binfo, nblocks, out_total);
+    return hipGetLastError();
+}
+
+hipError_t srl_launch_search(const SrlSearchArgs &a, int nb_voxels, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    int nblocks = (a.n + 3) / 4;
+    if (nblocks > 4096) nblocks = 4096;
+    if (nb_voxels == 1) hipLaunchKernelGGL(srl_search_kernel<1>, dim3(nblocks), dim3(SRL_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(srl_search_kernel<2>, dim3(nblocks), dim3(SRL_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t srl_launch_transform(const double *raw_aos, int n, const SrlXform &X, double *out_aos, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(srl_transform_kernel, dim3((n + 255) / 256), dim3(256), 0, s, raw_aos, n, X, out_aos);
+    return hipGetLastError();
+}
+
+hipError_t srl_launch_aos_to_soa(const double *aos, int n, double *x, double *y, double *z, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(srl_aos_to_soa_kernel, dim3((n + 255) / 256), dim3(256), 0, s, aos, n, x, y, z);
+    return hipGetLastError();
+}

@@ -1,0 +1,304 @@
+// srl_map_kernels.hip -- device-resident voxel map mutation for gfx950:
+// lioOptimization::addPointsToMap / addPointToMap (src/lioOptimization.cpp:520-554, 400-446).
+//
+// The reference inserts frame points one by one; the result depends on the order only WITHIN a voxel
+// (first come, first kept; min-distance test against residents incl. earlier points of the same
+// batch) and on the order in which new voxels are created (it defines slab ids = point ids).
+// Device formulation that reproduces both bit-for-bit:
+//   1. key[i]  = short(float(p_i) / voxel_size) per axis (insert keys come from the FP32-rounded
+//      position, lioOptimization.cpp:403-405 via cloudMap.cpp:7,28)
+//   2. stable radix sort of (key, i)  -> per-voxel segments in original point order
+//   3. run-length encode -> touched voxels; hash lookup; new voxels ranked by the index of their
+//      first point (= creation order) -> slab ids; CAS-insert into the open-addressing table
+//   4. one thread per touched voxel replays its segment sequentially (IsFull, min-distance, cap).
+#include "srl_ctx.h"
+#include "srl_hash.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+namespace {
+
+__global__ void k_point_keys(const double *xyz, int n, double voxel_size, unsigned long long *keys, unsigned *idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float fx = (float)xyz[(size_t)i * 3], fy = (float)xyz[(size_t)i * 3 + 1], fz = (float)xyz[(size_t)i * 3 + 2];
+    const short kx = (short)(int)((double)fx / voxel_size);
+    const short ky = (short)(int)((double)fy / voxel_size);
+    const short kz = (short)(int)((double)fz / voxel_size);
+    keys[i] = srl_pack_key(kx, ky, kz);
+    idx[i] = (unsigned)i;
+}
+
+// per touched voxel: table slot (or -1), flag new, first point index
+__global__ void k_lookup(const unsigned long long *ukeys, const int *seg_start, const unsigned *sorted_idx, int S,
+                         const SrlMapSlot *table, unsigned mask, int *seg_slot, unsigned char *is_new, unsigned *first_idx) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const unsigned long long key = ukeys[s];
+    unsigned h = srl_hash_key(key) & mask;
+    int slot = -1;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        const unsigned long long k = table[h].key;
+        if (k == key) { slot = (int)h; break; }
+        if (k == SRL_EMPTY_KEY) break;
+        h = (h + 1) & mask;
+    }
+    seg_slot[s] = slot;
+    is_new[s] = slot < 0 ? 1 : 0;
+    first_idx[s] = sorted_idx[seg_start[s]];
+}
+
+// new voxels in creation order r: slab = V + r; header written, key CAS-inserted into the table
+__global__ void k_create(const int *new_segs_sorted, int n_new, const unsigned long long *ukeys, int V,
+                         SrlMapSlot *table, unsigned mask, unsigned char *slabs, int *seg_slot) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_new) return;
+    const int s = new_segs_sorted[r];
+    const unsigned long long key = ukeys[s];
+    const unsigned slab = (unsigned)(V + r);
+    SrlSlab *sl = reinterpret_cast<SrlSlab *>(slabs + (size_t)slab * SRL_SLAB_BYTES);
+    sl->count = 0;
+    sl->pad = 0;
+    sl->key = key;
+    unsigned h = srl_hash_key(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        const unsigned long long prev = atomicCAS(&table[h].key, SRL_EMPTY_KEY, key);
+        if (prev == SRL_EMPTY_KEY) {
+            table[h].slab = slab;
+            table[h].count = 0;
+            seg_slot[s] = (int)h;
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+// sequential replay of one voxel's segment (lioOptimization.cpp:409-445)
+__global__ void k_replay(const int *seg_start, const int *seg_len, const unsigned *sorted_idx, int S, const double *xyz,
+                         const int *seg_slot, const unsigned char *is_new, SrlMapSlot *table, unsigned char *slabs,
+                         double voxel_size, double min_distance_points, int min_num_points, int *added_total) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int slot = seg_slot[s];
+    if (slot < 0) return;                       // voxel absent and min_num_points > 0: nothing is created
+    const unsigned slab = table[slot].slab;
+    SrlSlab *sl = reinterpret_cast<SrlSlab *>(slabs + (size_t)slab * SRL_SLAB_BYTES);
+    int count = (int)sl->count;
+    const bool fresh = is_new[s] != 0;
+    const int j0 = seg_start[s], j1 = j0 + seg_len[s];
+    int added = 0;
+    const double min_d2 = min_distance_points * min_distance_points;
+    for (int j = j0; j < j1; ++j) {
+        if (count == SRL_CAP) break;            // IsFull(): every later point of the batch is dropped too
+        const unsigned i = sorted_idx[j];
+        const float fx = (float)xyz[(size_t)i * 3], fy = (float)xyz[(size_t)i * 3 + 1], fz = (float)xyz[(size_t)i * 3 + 2];
+        bool add;
+        if (fresh && count == 0) {
+            add = true;                         // new voxel: first point is stored unconditionally (:437-443)
+        } else {
+            double sq_dist_min = 10 * voxel_size * voxel_size;
+            for (int k = 0; k < count; ++k) {
+                const double dx = (double)sl->xyz[k][0] - (double)fx;
+                const double dy = (double)sl->xyz[k][1] - (double)fy;
+                const double dz = (double)sl->xyz[k][2] - (double)fz;
+                const double sq = (dx * dx + dy * dy) + dz * dz;
+                if (sq < sq_dist_min) sq_dist_min = sq;
+            }
+            add = (sq_dist_min > min_d2) && (min_num_points <= 0 || count >= min_num_points);
+        }
+        if (add) {
+            sl->xyz[count][0] = fx; sl->xyz[count][1] = fy; sl->xyz[count][2] = fz;
+            ++count;
+            ++added;
+        }
+    }
+    sl->count = (unsigned)count;
+    table[slot].count = (unsigned)count;
+    if (added) atomicAdd(added_total, added);
+}
+
+__global__ void k_rebuild_table(const unsigned char *slabs, int V, SrlMapSlot *table, unsigned mask) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const SrlSlab *sl = reinterpret_cast<const SrlSlab *>(slabs + (size_t)v * SRL_SLAB_BYTES);
+    const unsigned long long key = sl->key;
+    unsigned h = srl_hash_key(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        const unsigned long long prev = atomicCAS(&table[h].key, SRL_EMPTY_KEY, key);
+        if (prev == SRL_EMPTY_KEY) { table[h].slab = (unsigned)v; table[h].count = sl->count; return; }
+        h = (h + 1) & mask;
+    }
+}
+
+__global__ void k_fill_empty(SrlMapSlot *table, unsigned cap) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    SrlMapSlot s; s.key = SRL_EMPTY_KEY; s.slab = 0; s.count = 0;
+    table[i] = s;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+unsigned next_pow2u(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+// grow slab storage / hash table so that `need_slabs` voxels fit with load <= 0.5
+int srl_ctx_grow_map(srl_ctx *ctx, unsigned need_slabs, unsigned need_slots) {
+    const unsigned new_slab_cap = ctx->slab_cap >= need_slabs ? ctx->slab_cap : std::max(need_slabs + need_slabs / 2u, 1024u);
+    unsigned new_table_cap = ctx->table_cap;
+    while (new_table_cap < need_slots || new_table_cap < 2u * new_slab_cap) new_table_cap = next_pow2u(new_table_cap ? new_table_cap * 2u : 2048u);
+    if (new_slab_cap != ctx->slab_cap) {
+        unsigned char *ns = nullptr;
+        HIPCHK(ctx, hipMalloc((void **)&ns, (size_t)new_slab_cap * SRL_SLAB_BYTES));
+        HIPCHK(ctx, hipMemsetAsync(ns, 0, (size_t)new_slab_cap * SRL_SLAB_BYTES, ctx->stream));
+        if (ctx->d_slabs && ctx->num_voxels > 0)
+            HIPCHK(ctx, hipMemcpyAsync(ns, ctx->d_slabs, (size_t)ctx->num_voxels * SRL_SLAB_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_slabs) HIPCHK(ctx, hipFree(ctx->d_slabs));
+        ctx->d_slabs = ns;
+        ctx->slab_cap = new_slab_cap;
+    }
+    if (new_table_cap != ctx->table_cap) {
+        SrlMapSlot *nt = nullptr;
+        HIPCHK(ctx, hipMalloc((void **)&nt, (size_t)new_table_cap * sizeof(SrlMapSlot)));
+        hipLaunchKernelGGL(k_fill_empty, dim3((new_table_cap + 255) / 256), dim3(256), 0, ctx->stream, nt, new_table_cap);
+        if (ctx->num_voxels > 0)
+            hipLaunchKernelGGL(k_rebuild_table, dim3((ctx->num_voxels + 255) / 256), dim3(256), 0, ctx->stream,
+                               ctx->d_slabs, ctx->num_voxels, nt, new_table_cap - 1);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_table) HIPCHK(ctx, hipFree(ctx->d_table));
+        ctx->d_table = nt;
+        ctx->table_cap = new_table_cap;
+    }
+    return SRL_OK;
+}
+
+int srl_map_insert_device(srl_ctx *ctx, const double *world_xyz, int n, double voxel_size, int cap,
+                          double min_distance_points, int min_num_points, int *num_added) {
+    (void)cap;
+    if (num_added) *num_added = 0;
+    if (n == 0) return SRL_OK;
+    if (!(voxel_size > 0.0)) return SRL_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (!ctx->d_table) {            // empty map: create storage
+        ctx->slab_cap = 0; ctx->table_cap = 0; ctx->num_voxels = 0; ctx->num_points = 0;
+        int rc = srl_ctx_grow_map(ctx, 4096u, 8192u);
+        if (rc) return rc;
+    }
+
+    DevBuf b_xyz, b_keys, b_keys2, b_idx, b_idx2, b_ukeys, b_len, b_start, b_nruns, b_tmp;
+    HIPCHK(ctx, b_xyz.alloc((size_t)n * 3 * sizeof(double)));
+    HIPCHK(ctx, b_keys.alloc((size_t)n * 8));
+    HIPCHK(ctx, b_keys2.alloc((size_t)n * 8));
+    HIPCHK(ctx, b_idx.alloc((size_t)n * 4));
+    HIPCHK(ctx, b_idx2.alloc((size_t)n * 4));
+    HIPCHK(ctx, b_ukeys.alloc((size_t)n * 8));
+    HIPCHK(ctx, b_len.alloc((size_t)n * 4));
+    HIPCHK(ctx, b_start.alloc((size_t)n * 4));
+    HIPCHK(ctx, b_nruns.alloc(16));
+    HIPCHK(ctx, hipMemcpyAsync(b_xyz.p, world_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_point_keys, dim3((n + 255) / 256), dim3(256), 0, st, b_xyz.as<double>(), n, voxel_size,
+                       b_keys.as<unsigned long long>(), b_idx.as<unsigned>());
+    HIPCHK(ctx, hipGetLastError());
+
+    // stable sort by key (48 significant bits): original order survives inside each voxel
+    size_t tmp_bytes = 0, need = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, need, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
+                                       b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st);
+    tmp_bytes = need;
+    hipcub::DeviceRunLengthEncode::Encode(nullptr, need, b_keys2.as<unsigned long long>(), b_ukeys.as<unsigned long long>(),
+                                          b_len.as<int>(), b_nruns.as<int>(), n, st);
+    tmp_bytes = std::max(tmp_bytes, need);
+    hipcub::DeviceScan::ExclusiveSum(nullptr, need, b_len.as<int>(), b_start.as<int>(), n, st);
+    tmp_bytes = std::max(tmp_bytes, need);
+    tmp_bytes += 4096;
+    HIPCHK(ctx, b_tmp.alloc(tmp_bytes));
+    size_t tb = tmp_bytes;
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
+                                                   b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st));
+    tb = tmp_bytes;
+    HIPCHK(ctx, hipcub::DeviceRunLengthEncode::Encode(b_tmp.p, tb, b_keys2.as<unsigned long long>(), b_ukeys.as<unsigned long long>(),
+                                                      b_len.as<int>(), b_nruns.as<int>(), n, st));
+    int S = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&S, b_nruns.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    tb = tmp_bytes;
+    HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, b_len.as<int>(), b_start.as<int>(), S, st));
+
+    // make room for the worst case (every touched voxel new) before slot indices are taken
+    {
+        const unsigned need_slabs = (unsigned)ctx->num_voxels + (unsigned)S;
+        if (need_slabs > ctx->slab_cap || 2u * need_slabs > ctx->table_cap) {
+            int rc = srl_ctx_grow_map(ctx, need_slabs, 2u * need_slabs);
+            if (rc) return rc;
+        }
+    }
+    const unsigned mask = ctx->table_cap - 1;
+
+    DevBuf b_slot, b_isnew, b_first, b_first2, b_seg, b_seg2, b_nsel, b_added;
+    HIPCHK(ctx, b_slot.alloc((size_t)S * 4));
+    HIPCHK(ctx, b_isnew.alloc((size_t)S));
+    HIPCHK(ctx, b_first.alloc((size_t)S * 4));
+    HIPCHK(ctx, b_first2.alloc((size_t)S * 4));
+    HIPCHK(ctx, b_seg.alloc((size_t)S * 4));
+    HIPCHK(ctx, b_seg2.alloc((size_t)S * 4));
+    HIPCHK(ctx, b_nsel.alloc(16));
+    HIPCHK(ctx, b_added.alloc(16));
+    HIPCHK(ctx, hipMemsetAsync(b_added.p, 0, 16, st));
+    hipLaunchKernelGGL(k_lookup, dim3((S + 255) / 256), dim3(256), 0, st, b_ukeys.as<unsigned long long>(), b_start.as<int>(),
+                       b_idx2.as<unsigned>(), S, ctx->d_table, mask, b_slot.as<int>(), b_isnew.as<unsigned char>(), b_first.as<unsigned>());
+    HIPCHK(ctx, hipGetLastError());
+
+    int n_new = 0;
+    if (min_num_points <= 0) {
+        // new voxels, ranked by the index of their first point = creation order of the sequential loop
+        DevBuf b_tmp2, b_newfirst;
+        HIPCHK(ctx, b_newfirst.alloc((size_t)S * 4));
+        hipcub::CountingInputIterator<int> seg_ids(0);
+        size_t need2 = 0, t2 = 0;
+        hipcub::DeviceSelect::Flagged(nullptr, need2, seg_ids, b_isnew.as<unsigned char>(), b_seg.as<int>(), b_nsel.as<int>(), S, st);
+        t2 = need2;
+        hipcub::DeviceSelect::Flagged(nullptr, need2, b_first.as<unsigned>(), b_isnew.as<unsigned char>(), b_newfirst.as<unsigned>(), b_nsel.as<int>(), S, st);
+        t2 = std::max(t2, need2);
+        hipcub::DeviceRadixSort::SortPairs(nullptr, need2, b_newfirst.as<unsigned>(), b_first2.as<unsigned>(), b_seg.as<int>(), b_seg2.as<int>(), S, 0, 32, st);
+        t2 = std::max(t2, need2) + 4096;
+        HIPCHK(ctx, b_tmp2.alloc(t2));
+        size_t tt = t2;
+        HIPCHK(ctx, hipcub::DeviceSelect::Flagged(b_tmp2.p, tt, seg_ids, b_isnew.as<unsigned char>(), b_seg.as<int>(), b_nsel.as<int>(), S, st));
+        tt = t2;
+        HIPCHK(ctx, hipcub::DeviceSelect::Flagged(b_tmp2.p, tt, b_first.as<unsigned>(), b_isnew.as<unsigned char>(), b_newfirst.as<unsigned>(), b_nsel.as<int>(), S, st));
+        HIPCHK(ctx, hipMemcpyAsync(&n_new, b_nsel.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (n_new > 0) {
+            tt = t2;
+            HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp2.p, tt, b_newfirst.as<unsigned>(), b_first2.as<unsigned>(),
+                                                           b_seg.as<int>(), b_seg2.as<int>(), n_new, 0, 32, st));
+            hipLaunchKernelGGL(k_create, dim3((n_new + 255) / 256), dim3(256), 0, st, b_seg2.as<int>(), n_new,
+                               b_ukeys.as<unsigned long long>(), ctx->num_voxels, ctx->d_table, mask, ctx->d_slabs, b_slot.as<int>());
+            HIPCHK(ctx, hipGetLastError());
+        }
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+
+    hipLaunchKernelGGL(k_replay, dim3((S + 127) / 128), dim3(128), 0, st, b_start.as<int>(), b_len.as<int>(), b_idx2.as<unsigned>(), S,
+                       b_xyz.as<double>(), b_slot.as<int>(), b_isnew.as<unsigned char>(), ctx->d_table, ctx->d_slabs, voxel_size,
+                       min_distance_points, min_num_points, b_added.as<int>());
+    HIPCHK(ctx, hipGetLastError());
+    int added = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&added, b_added.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    ctx->num_voxels += n_new;
+    ctx->num_points += added;
+    if (num_added) *num_added = added;
+    return SRL_OK;
+}

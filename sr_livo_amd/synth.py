@@ -1,0 +1,200 @@
+"""Seeded synthetic scenes / maps / sweeps for the parity tests and bench.py.
+
+Piecewise-planar world: ground plane z = -1.7 m plus 4 m x 4 m x 6 m boxes on a 10 m lattice (vertical
+faces x = const / y = const, so all six pose directions are observable).  Surface samples on a jittered 0.16 m grid with sigma = 0.02 m noise along the normal.
+The MAP is not produced here: callers push `map_candidates()` through addPointsToMap (the oracle's or
+the product's) so that it is a legal reference map (voxel 1.0 m, cap 20, min-distance 0.15 m, keys
+by truncation of the FP32 position).  No arithmetic of the hot path lives in this file.
+"""
+import math
+
+import numpy as np
+
+GROUND_Z = -1.7
+WALL_PITCH = 10.0
+WALL_HEIGHT = 6.0
+GRID = 0.16
+SIGMA = 0.02
+
+
+BOX_HALF = 2.0          # 4 m x 4 m x 6 m boxes centred on a 10 m lattice
+BOX_OFF = 5.37          # lattice offset: faces never sit on integer voxel faces
+
+
+def _box_centres(L):
+    ks = np.arange(math.floor((-L - BOX_OFF) / WALL_PITCH), math.ceil((L - BOX_OFF) / WALL_PITCH) + 1)
+    c = ks * WALL_PITCH + BOX_OFF
+    c = c[(c - BOX_HALF > -L) & (c + BOX_HALF < L)]
+    return c
+
+
+def _faces(L):
+    """(axis, plane coordinate, lo, hi) of every vertical box face inside [-L, L]^2."""
+    out = []
+    cs = _box_centres(L)
+    for cx in cs:
+        for cy in cs:
+            out.append((0, cx - BOX_HALF, cy - BOX_HALF, cy + BOX_HALF))
+            out.append((0, cx + BOX_HALF, cy - BOX_HALF, cy + BOX_HALF))
+            out.append((1, cy - BOX_HALF, cx - BOX_HALF, cx + BOX_HALF))
+            out.append((1, cy + BOX_HALF, cx - BOX_HALF, cx + BOX_HALF))
+    return out
+
+
+def _surface_samples(rng, half_extent):
+    """Jittered-grid samples of ground + box faces inside [-L, L]^2, with normal noise.  Returns (M,3)."""
+    L = float(half_extent)
+    n1 = int(2 * L / GRID)
+    gx, gy = np.meshgrid(np.arange(n1), np.arange(n1), indexing="ij")
+    g = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float64) * GRID - L
+    g += rng.uniform(0.0, GRID, g.shape)
+    ground = np.column_stack([g, GROUND_Z + rng.normal(0.0, SIGMA, len(g))])
+    parts = [ground]
+    nu = int(2 * BOX_HALF / GRID)
+    nz = int(WALL_HEIGHT / GRID)
+    su, sz = np.meshgrid(np.arange(nu), np.arange(nz), indexing="ij")
+    base = np.stack([su.ravel(), sz.ravel()], 1).astype(np.float64) * GRID
+    for axis, c, lo, _hi in _faces(L):
+        uz = base + rng.uniform(0.0, GRID, base.shape)
+        u = lo + uz[:, 0]
+        z = GROUND_Z + uz[:, 1]
+        off = c + rng.normal(0.0, SIGMA, len(u))
+        parts.append(np.column_stack([off, u, z]) if axis == 0 else np.column_stack([u, off, z]))
+    return np.concatenate(parts, 0)
+
+
+def map_candidates(seed, target_points):
+    """Shuffled candidate points for a map of about `target_points` points.  Insert ALL of them through
+    addPointsToMap: the extent is chosen so that the saturated map (cap 20 per 1 m voxel, as in a
+    long-running session) lands near the target."""
+    rng = np.random.default_rng(seed)
+    # saturated: ~18.4 kept points per voxel, ~0.9 voxel per m^2 of surface, ~1.96 m^2 surface per m^2 footprint
+    area = target_points / 20.0 / 1.65     # calibrated: saturated maps land within ~3 % of the target
+    L = max(16.0, 0.5 * math.sqrt(area))
+    pts = _surface_samples(rng, L)
+    rng.shuffle(pts, axis=0)
+    return pts, L
+
+
+def _raycast(o, d, L, max_range):
+    """Nearest hit of rays o + s d with the ground plane and the box faces.  Returns s (inf = miss)."""
+    n = len(d)
+    best = np.full(n, np.inf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = (GROUND_Z - o[2]) / d[:, 2]
+    ok = (d[:, 2] < 0) & (s > 0.5) & (np.abs(o[0] + s * d[:, 0]) < L) & (np.abs(o[1] + s * d[:, 1]) < L)
+    best = np.where(ok & (s < best), s, best)
+    z_lo, z_hi = GROUND_Z, GROUND_Z + WALL_HEIGHT
+    for axis, c, lo, hi in _faces(L):
+        if abs(c - o[axis]) > max_range:
+            continue
+        with np.errstate(divide="ignore", invalid="ignore"):
+            s = (c - o[axis]) / d[:, axis]
+        z = o[2] + s * d[:, 2]
+        u = o[1 - axis] + s * d[:, 1 - axis]
+        ok = np.isfinite(s) & (s > 0.5) & (z > z_lo) & (z < z_hi) & (u > lo) & (u < hi)
+        best = np.where(ok & (s < best), s, best)
+    best[best > max_range] = np.inf
+    return best
+
+
+def quat_from_rotvec(w):
+    w = np.asarray(w, dtype=np.float64)
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.array([1.0, 0.0, 0.0, 0.0])
+    a = w / th
+    return np.concatenate([[math.cos(th / 2)], a * math.sin(th / 2)])
+
+
+def quat_mul(a, b):
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz, aw * bz + az * bw + ax * by - ay * bx])
+
+
+def quat_to_rot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def make_sweep(seed, n, L, pattern="livox", max_range=50.0):
+    """N lidar-frame points (extrinsic identity) seen from a ground-truth pose, plus a perturbed
+    predicted pose.  pattern: 'livox' (70 deg forward cone, random) or 'ouster16' (16 rings x 360, ring-major).
+    Returns dict(raw (N,3), q_gt, t_gt, q_pred, t_pred, t_last)."""
+    rng = np.random.default_rng(seed)
+    rng_lim = min(max_range, 0.85 * L)
+    yaw = rng.uniform(-math.pi, math.pi)
+    q_gt = quat_mul(quat_from_rotvec([0, 0, yaw]), quat_from_rotvec(rng.normal(0, 0.02, 3)))
+    t_gt = np.array([rng.uniform(-3, 3) + 2.3, rng.uniform(-3, 3) + 1.7, rng.uniform(-0.1, 0.1)])
+    R = quat_to_rot(q_gt)
+    pts = np.zeros((0, 3))
+    while len(pts) < n:
+        m = int((n - len(pts)) * 1.6) + 1024
+        if pattern == "livox":
+            half = math.radians(35.0)
+            cosmin = math.cos(half)
+            cz = rng.uniform(cosmin, 1.0, m)
+            ph = rng.uniform(0, 2 * math.pi, m)
+            sz = np.sqrt(1 - cz * cz)
+            dl = np.column_stack([cz, sz * np.cos(ph), sz * np.sin(ph)])    # forward = +x of the lidar
+        else:
+            rings = np.radians(np.linspace(-15.0, 15.0, 16))
+            per = m // 16 + 1
+            az = rng.uniform(0, 2 * math.pi, (16, per))
+            el = np.repeat(rings[:, None], per, 1)
+            dl = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], -1).reshape(-1, 3)
+        dw = dl @ R.T
+        s = _raycast(t_gt, dw, L, rng_lim)
+        ok = np.isfinite(s)
+        p_l = dl[ok] * s[ok, None]
+        # noise along the ray (approximately along the normal for frontal hits), sigma 0.02
+        p_l = p_l + dl[ok] * rng.normal(0.0, SIGMA, (ok.sum(), 1))
+        pts = np.concatenate([pts, p_l], 0)
+    raw = pts[:n].copy()
+    if pattern != "livox":
+        # ring-major order: sort by elevation ring then azimuth
+        el = np.degrees(np.arcsin(raw[:, 2] / np.linalg.norm(raw, axis=1)))
+        ring = np.clip(np.round((el + 15.0) / 2.0), 0, 15).astype(int)
+        az = np.arctan2(raw[:, 1], raw[:, 0])
+        raw = raw[np.lexsort((az, ring))]
+    # predicted pose = gt (+) (0.05 m random direction, 0.5 deg random axis)
+    dv = rng.normal(size=3); dv *= 0.05 / np.linalg.norm(dv)
+    ax = rng.normal(size=3); ax *= math.radians(0.5) / np.linalg.norm(ax)
+    q_pred = quat_mul(q_gt, quat_from_rotvec(ax))
+    t_pred = t_gt + dv
+    vel = rng.normal(0, 0.5, 3)
+    t_last = t_pred - 0.1 * vel
+    return dict(raw=raw, q_gt=q_gt, t_gt=t_gt, q_pred=q_pred, t_pred=t_pred, t_last=t_last, vel=vel)
+
+
+def eskf_prior(eskf_like, q_pred, t_pred, vel):
+    """ESKF prior of SURVEY 8(d): ctor state (eskfEstimator.cpp:3-21), tryInit covariance scaling
+    (:74-76), noise of config/r3live.yaml:20-23, 10 stationary predict steps (dt 0.01), then the
+    predicted pose written into p, q, v.  `eskf_like` exposes set_noise / init_imu / scale_init_cov /
+    predict / get_state / set_state (oracle or product handle)."""
+    eskf_like.set_noise(0.1, 0.1, 0.0001, 0.0001)
+    eskf_like.scale_init_cov()
+    acc = np.array([0.0, 0.0, 9.81]); gyr = np.zeros(3)
+    eskf_like.init_imu(acc, gyr)
+    for _ in range(10):
+        eskf_like.predict(0.01, acc, gyr)
+    s = eskf_like.get_state()
+    s[0:3] = t_pred
+    s[3:7] = q_pred
+    s[7:10] = vel
+    eskf_like.set_state(s)
+    return s
+
+
+CONFIGS = {
+    # name: (n_keypoints, map_points, pattern, seed)   -- SURVEY.md 8(d)
+    "C1": (4096, 100_000, "livox", 20250304 + 1),
+    "C2": (24576, 1_000_000, "livox", 20250304 + 2),
+    "C3": (16384, 2_000_000, "ouster16", 20250304 + 3),
+    "C4": (262144, 10_000_000, "livox", 20250304 + 4),
+    "HEADLINE": (65536, 1_000_000, "livox", 20250304 + 5),
+}
