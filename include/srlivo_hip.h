@@ -166,13 +166,19 @@ void srl_shard_budget(int max_num_residuals, const int64_t *accepted_per_rank, i
 /* ------------------------------------------------------------------ measurement
  * HIP-event timings (ms) of the last srl_build_residuals on the context's own stream. */
 typedef struct srl_timing {
-    float assoc_ms;       /* association + plane fit + residual kernel */
-    float reduce_ms;      /* ordered cut-off + final reduction kernel(s) */
-    float total_ms;       /* first launch -> results on host */
-    int64_t algorithmic_bytes; /* sum_k (24 + 12*(2r+1)^3 + 12*P_k) for this rank's shard */
+    float   assoc_ms;          /* last call: association + plane fit + residual kernel */
+    float   reduce_ms;         /* last call: ordered cut-off + final reduction kernel(s) */
+    float   total_ms;          /* last call: first launch -> results on host */
+    int32_t calls;             /* srl_build_residuals calls since profiling was switched on */
+    int64_t algorithmic_bytes; /* last call: sum_k (24 + 12*(2r+1)^3 + 12*P_k) for this rank's shard */
+    double  sum_assoc_ms;      /* accumulated over `calls` */
+    double  sum_reduce_ms;
+    double  sum_total_ms;
+    int64_t sum_algorithmic_bytes;
+    int64_t sum_keypoints;
 } srl_timing;
 int srl_get_timing(srl_ctx *ctx, srl_timing *t);
-int srl_set_profiling(srl_ctx *ctx, int enable);   /* event timing on/off (off by default) */
+int srl_set_profiling(srl_ctx *ctx, int enable);   /* event timing on/off (off by default); switching on resets the sums */
 
 #ifdef __cplusplus
 }

@@ -271,6 +271,7 @@ int srl_set_taps(srl_ctx *ctx, int enable) {
 int srl_set_profiling(srl_ctx *ctx, int enable) {
     if (!ctx) return SRL_ERR_BAD_ARG;
     ctx->profiling = enable != 0;
+    if (ctx->profiling) std::memset(&ctx->timing, 0, sizeof ctx->timing);
     return SRL_OK;
 }
 
@@ -456,6 +457,11 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         hipEventElapsedTime(&ctx->timing.assoc_ms, ctx->ev[0], ctx->ev[1]);
         hipEventElapsedTime(&ctx->timing.reduce_ms, ctx->ev[1], ctx->ev[2]);
         hipEventElapsedTime(&ctx->timing.total_ms, ctx->ev[0], ctx->ev[3]);
+        ctx->timing.calls += 1;
+        ctx->timing.sum_assoc_ms += ctx->timing.assoc_ms;
+        ctx->timing.sum_reduce_ms += ctx->timing.reduce_ms;
+        ctx->timing.sum_total_ms += ctx->timing.total_ms;
+        ctx->timing.sum_keypoints += ctx->n;
     }
     {
         // algorithmic bytes of this rank's association pass: 24 + 12*(2r+1)^3 + 12*P_k per keypoint.
@@ -464,6 +470,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         const long long per_kp = 24 + 12 * side * side * side;
         const double pk_share = (ctx->nranks > 1 && ctx->total_n > 0) ? r.d_sum_pk * ((double)ctx->n / (double)ctx->total_n) : r.d_sum_pk;
         ctx->timing.algorithmic_bytes = per_kp * (long long)ctx->n + (long long)(12.0 * pk_share);
+        if (prof) ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes;
     }
     if (out->nan_error) { ctx->err = "NaN planarity"; return SRL_ERR_NAN_PLANARITY; }
     return SRL_OK;

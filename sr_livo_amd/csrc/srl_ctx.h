@@ -61,7 +61,7 @@ struct srl_ctx {
     // timing
     bool profiling = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    srl_timing timing = {0, 0, 0, 0};
+    srl_timing timing = {};
     int last_nb = 1;
 };
 

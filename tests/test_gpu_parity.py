@@ -1,0 +1,408 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle on the same
+seeded inputs and against the committed golden fixtures (tests/golden/).
+
+Bars (BASELINE.json north_star): neighbour indices bit-exact (on tie-free inputs; ties are counted by
+the oracle and must be zero here), residuals / normal equations / ESIKF state within 1e-5 RELATIVE.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import sr_livo_amd as srl
+from sr_livo_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5          # the tolerance north_star states for floating point
+TIGHT = 1e-9         # what we actually expect (same algorithm, FP64, different summation order only)
+INT_MAX = 2**31 - 1
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def state16(sw):
+    return np.concatenate([sw["q_pred"], sw["t_pred"], sw["vel"], np.zeros(6)])
+
+
+@pytest.fixture(scope="module")
+def ctx_small(golden):
+    ctx = srl.Context(0)
+    ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+    yield ctx
+    ctx.close()
+
+
+def gpu_pass(ctx, raw, q, t, t_last, frame_id=100, **optkw):
+    opts = srl.default_opts(**optkw)
+    ctx.sweep_upload(raw)
+    ctx.set_taps(1)
+    neq, rc = ctx.build_residuals(capi.make_frame(q, t, t_last, frame_id=frame_id), opts)
+    ids, status, ncand = ctx.fetch_neighbors(K=opts.max_number_neighbors)
+    res = ctx.fetch_residuals()
+    ctx.set_taps(0)
+    return dict(neq=neq, rc=rc, ids=ids, status=status, ncand=ncand, **res)
+
+
+def check_pass_against(g, ref, prefix, tol=TIGHT):
+    """ref: golden dict with keys prefix_one_*"""
+    st_ref = ref[f"{prefix}_one_status"]
+    assert np.array_equal(g["status"], st_ref), "status (accepted set / cut-off) differs"
+    visited = st_ref != 3
+    # neighbour indices: bit-exact
+    assert int(ref[f"{prefix}_one_num_ties"]) == 0
+    assert np.array_equal(g["ids"][visited], ref[f"{prefix}_one_ids"][visited]), "neighbour ids differ"
+    has_plane = (st_ref == 1) | (st_ref == 2)
+    acc = st_ref == 2
+    for key in ("normal", "a2D", "weight", "norm_offset", "distance"):
+        assert rel(g[key][has_plane], ref[f"{prefix}_one_{key}"][has_plane]) < tol, key
+    assert rel(g["jacobian"][acc], ref[f"{prefix}_one_jacobian"][acc]) < tol
+    assert g["neq"].num_residuals == int(ref[f"{prefix}_one_num_residuals"])
+    assert g["neq"].success == int(ref[f"{prefix}_one_success"])
+    assert rel(np.array(g["neq"].HtH).reshape(6, 6), ref[f"{prefix}_one_HtH"]) < tol
+    assert rel(np.array(g["neq"].Hth), ref[f"{prefix}_one_Hth"]) < tol
+    assert rel(g["neq"].loss_sum, ref[f"{prefix}_one_loss"]) < tol
+
+
+# ----------------------------------------------------------------------------- one pass vs golden
+@pytest.mark.parametrize("prefix,frame_id,max_res", [("full", 100, INT_MAX), ("cut600", 100, 600), ("init", 5, INT_MAX), ("neg1", 100, -1)])
+def test_one_pass_matches_golden(ctx_small, golden, prefix, frame_id, max_res):
+    g = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], frame_id=frame_id, max_num_residuals=max_res)
+    check_pass_against(g, golden, prefix)
+    assert TIGHT < RTOL
+    if prefix in ("full", "init"):
+        assert g["neq"].sum_candidates == int(golden[f"{prefix}_one_sum_candidates"])
+        assert g["neq"].last_visited == len(golden["raw"]) - 1
+    if prefix == "cut600":
+        assert g["neq"].last_visited == int(golden["cut600_one_num_visited"]) - 1
+
+
+def test_forced_extraction_selection_matches(ctx_small, golden):
+    """select_mode=1 forces the streaming-extraction selection (the overflow fallback) for every keypoint."""
+    g = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX, select_mode=1)
+    check_pass_against(g, golden, "full")
+    assert g["neq"].num_fallback == len(golden["raw"])
+
+
+def test_idempotent_bitwise(ctx_small, golden):
+    a = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX)
+    b = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX)
+    assert np.array_equal(np.array(a["neq"].HtH), np.array(b["neq"].HtH))
+    assert np.array_equal(np.array(a["neq"].Hth), np.array(b["neq"].Hth))
+    assert np.array_equal(a["ids"], b["ids"])
+
+
+# ----------------------------------------------------------------------------- full solve vs golden
+@pytest.mark.parametrize("prefix,frame_id,max_res", [("full", 100, INT_MAX), ("cut600", 100, 600), ("init", 5, INT_MAX)])
+def test_full_solve_matches_golden(golden, prefix, frame_id, max_res):
+    lio = srl.Lio(0)
+    try:
+        lio.ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        lio.eskf_set_state(golden[f"{prefix}_eskf_state0"])
+        lio.eskf_set_cov(golden[f"{prefix}_eskf_cov0"])
+        opts = srl.default_opts(max_num_residuals=max_res)
+        r = lio.update_iekf(opts, golden["raw"], golden[f"{prefix}_state0"], golden["t_last"], frame_id=frame_id, log_iters=20)
+        assert r["rc"] == 0
+        assert r["iters"] == int(golden[f"{prefix}_solve_rc"])            # iteration count equal
+        assert r["num_residuals"] == int(golden[f"{prefix}_solve_num_residuals"])
+        log_ref = golden[f"{prefix}_solve_log"]
+        assert rel(r["log"][:, :42], log_ref[:, :42]) < TIGHT             # HtH, Hth per iteration
+        assert rel(r["log"][:, 42:59], log_ref[:, 42:59]) < 1e-8           # d_x per iteration
+        assert np.array_equal(r["log"][:, 59], log_ref[:, 59])
+        assert rel(r["state"], golden[f"{prefix}_solve_state"]) < 1e-9     # p_state (q, t, v, ba, bg)
+        assert rel(lio.eskf_get_state(), golden[f"{prefix}_solve_eskf_state"]) < 1e-9
+        assert rel(lio.eskf_get_cov(), golden[f"{prefix}_solve_eskf_cov"]) < 1e-8
+    finally:
+        lio.close()
+
+
+def test_not_enough_residuals_is_reported(golden):
+    """max_num_residuals = -1 (class default): one keypoint visited, solve fails."""
+    lio = srl.Lio(0)
+    try:
+        lio.ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        lio.eskf_set_state(golden["neg1_eskf_state0"]); lio.eskf_set_cov(golden["neg1_eskf_cov0"])
+        r = lio.update_iekf(srl.default_opts(max_num_residuals=-1), golden["raw"], golden["neg1_state0"], golden["t_last"])
+        assert r["rc"] == capi.SRL_ERR_NOT_ENOUGH_RESIDUALS
+        assert r["num_residuals"] == int(golden["neg1_solve_num_residuals"])
+        assert int(golden["neg1_solve_rc"]) == -1
+        assert np.array_equal(r["state"], golden["neg1_state0"])          # pose untouched
+    finally:
+        lio.close()
+
+
+# ----------------------------------------------------------------------------- live oracle comparison
+@pytest.fixture(scope="module")
+def scene100k(oracle_lib, oracle_backend):
+    pts, L = synth.map_candidates(20250304 + 1, 100_000)
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(pts)
+    return dict(map=m, L=L, candidates=pts)
+
+
+@pytest.mark.parametrize("pattern,n,seed", [("livox", 4096, 11), ("ouster16", 3000, 12)])
+def test_config1_like_pass_vs_oracle(oracle_lib, scene100k, pattern, n, seed):
+    """C1: N = 4096 (and a ragged ring-indexed 3000), P = 100k: every output of one pass vs the live oracle."""
+    m = scene100k["map"]
+    sw = synth.make_sweep(seed, n, scene100k["L"], pattern=pattern)
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(*m.export())
+        g = gpu_pass(ctx, sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"], max_num_residuals=INT_MAX)
+        o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=INT_MAX), sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"])
+        ref = {f"x_one_{k}": v for k, v in o.items() if isinstance(v, np.ndarray)}
+        ref.update(x_one_num_ties=o["neq"].num_ties, x_one_num_residuals=o["neq"].num_residuals, x_one_success=o["neq"].success,
+                   x_one_loss=o["neq"].loss_sum)
+        check_pass_against(g, ref, "x")
+        assert g["neq"].sum_candidates == o["neq"].sum_candidates
+        assert np.array_equal(g["ncand"].sum(), o["neq"].sum_candidates)
+    finally:
+        ctx.close()
+
+
+def test_edge_cases_empty_far_and_ragged(oracle_lib, scene100k):
+    m = scene100k["map"]
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(*m.export())
+        L = scene100k["L"]
+        sw = synth.make_sweep(5, 70, L)          # ragged: 70 keypoints = 1 block + 6
+        raw = sw["raw"].copy()
+        raw[3] = [500.0, 500.0, 30.0]            # far outside the map: zero candidates
+        raw[10] = [1e-9, -1e-9, 0.0]             # at the sensor origin
+        g = gpu_pass(ctx, raw, sw["q_pred"], sw["t_pred"], sw["t_last"], max_num_residuals=INT_MAX)
+        o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=INT_MAX), raw, sw["q_pred"], sw["t_pred"], sw["t_last"])
+        assert np.array_equal(g["status"], o["status"])
+        assert g["status"][3] == 0 and g["ncand"][3] == 0
+        assert np.array_equal(g["ids"], o["ids"])
+        assert rel(np.array(g["neq"].HtH).reshape(6, 6), o["HtH"]) < TIGHT
+        # single keypoint
+        g1 = gpu_pass(ctx, raw[:1], sw["q_pred"], sw["t_pred"], sw["t_last"], max_num_residuals=INT_MAX)
+        assert g1["neq"].num_residuals in (0, 1) and g1["neq"].success == 0
+    finally:
+        ctx.close()
+
+
+def test_empty_map_and_missing_inputs_fail_loudly():
+    ctx = srl.Context(0)
+    try:
+        opts = srl.default_opts()
+        f = capi.make_frame([1, 0, 0, 0], [0, 0, 0], [0, 0, 0])
+        with pytest.raises(srl.SrlError):
+            ctx.build_residuals(f, opts)                       # no map
+        ctx.map_upload(np.zeros((0, 3), np.int16), np.zeros(0, np.int32), np.zeros((0, 20, 3), np.float32))
+        with pytest.raises(srl.SrlError):
+            ctx.build_residuals(f, opts)                       # no sweep
+        ctx.sweep_upload(np.random.default_rng(0).normal(size=(100, 3)))
+        neq, _ = ctx.build_residuals(f, opts)
+        assert neq.num_residuals == 0 and neq.success == 0 and neq.sum_candidates == 0
+        with pytest.raises(srl.SrlError):
+            ctx.build_residuals(f, srl.default_opts(max_number_neighbors=40))   # unsupported K
+    finally:
+        ctx.close()
+
+
+def test_search_neighbors_api_vs_oracle(oracle_lib, scene100k):
+    m = scene100k["map"]
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(*m.export())
+        rng = np.random.default_rng(3)
+        q = np.column_stack([rng.uniform(-20, 20, 300), rng.uniform(-20, 20, 300), rng.uniform(-2.0, 3.0, 300)])
+        for nb, K in ((1, 20), (2, 20), (1, 5), (2, 32)):
+            ids, xyz, nf = ctx.search_neighbors(q, nb=nb, K=K)
+            for i in range(len(q)):
+                r = m.search_neighbors(q[i], nb=nb, K=K)
+                assert nf[i] == r["n"]
+                if not r["tie"]:
+                    assert np.array_equal(ids[i, : r["n"]], r["ids"])
+                    assert np.array_equal(xyz[i, : r["n"]].astype(np.float64), r["xyz"])
+    finally:
+        ctx.close()
+
+
+def test_transform_points_matches_reference_formula(golden):
+    ctx = srl.Context(0)
+    try:
+        rng = np.random.default_rng(4)
+        raw = rng.normal(size=(1000, 3)) * 20
+        q = np.array([0.9, 0.1, -0.3, 0.2])      # deliberately NOT normalised (utility.cpp:317 uses q as is)
+        t = np.array([1.0, -2.0, 0.5])
+        R_il = synth.quat_to_rot(synth.quat_from_rotvec([0.1, 0.2, -0.1])); t_il = np.array([0.05, 0.02, -0.03])
+        out = ctx.transform_points(raw, q, t, R_il, t_il)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        ref = (raw @ R_il.T + t_il) @ R.T + t
+        assert rel(out, ref) < 1e-14
+    finally:
+        ctx.close()
+
+
+# ----------------------------------------------------------------------------- map insertion (next row f1)
+def test_map_insert_reproduces_the_sequential_map(oracle_lib, oracle_backend):
+    """addPointsToMap on the device must give the bit-identical map (keys, counts, slot order, FP32 xyz)
+    and therefore identical point ids -- in several batches, from empty, growing the table."""
+    pts, L = synth.map_candidates(99, 60_000)
+    m = oracle_lib.Map(oracle_backend)
+    ctx = srl.Context(0)
+    try:
+        cuts = [0, 7, 5000, 40000, len(pts)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            added_o = m.add_points(pts[a:b])
+            added_g = ctx.map_insert(pts[a:b])
+            assert added_g == added_o
+            assert ctx.map_size() == (m.size(), m.num_voxels())
+        ko, co, xo = m.export()
+        kg, cg, xg = ctx.map_download()
+        assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
+        # re-inserting the same points adds nothing (idempotence of the min-distance rule)
+        assert ctx.map_insert(pts[:20000]) == m.add_points(pts[:20000]) == 0
+        # min_num_points > 0 never creates voxels (lioOptimization.cpp:437)
+        far = pts[:100] + np.array([1000.0, 0, 0])
+        assert ctx.map_insert(far, min_num_points=3) == m.add_points(far, min_num_points=3)
+        assert ctx.map_size() == (m.size(), m.num_voxels())
+        # a pass on the inserted map gives the oracle's neighbour ids
+        sw = synth.make_sweep(100, 1024, L)
+        g = gpu_pass(ctx, sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"], max_num_residuals=INT_MAX)
+        o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=INT_MAX), sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"])
+        assert np.array_equal(g["ids"], o["ids"])
+    finally:
+        ctx.close()
+
+
+# ----------------------------------------------------------------------------- sharded path on one device
+@pytest.mark.parametrize("max_res", [INT_MAX, 600, 37, -1])
+def test_logical_shards_reproduce_single_rank(golden, max_res):
+    """G = 4 logical shards (threads, one context each, host callbacks standing in for RCCL): same
+    partition / ordered cut-off / reduction code as the multi-GPU path.  Result must equal the single
+    context result (bit-exact counts, 1e-12 on the sums: only the summation order differs)."""
+    G = 4
+    ref_ctx = srl.Context(0)
+    ref_ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+    ref = gpu_pass(ref_ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=max_res)
+    ref_ctx.close()
+
+    barrier = threading.Barrier(G)
+    lock = threading.Lock()
+    box = {"sum": None, "gather": [0] * G, "n": 0}
+    results = [None] * G
+    errors = []
+
+    def worker(rank):
+        try:
+            ctx = srl.Context(0)
+            ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+
+            def allreduce(buf):
+                with lock:
+                    box["sum"] = buf.copy() if box["n"] == 0 else box["sum"] + buf
+                    box["n"] += 1
+                barrier.wait()
+                buf[:] = box["sum"]
+                barrier.wait()
+                if rank == 0:
+                    box["n"] = 0
+                barrier.wait()
+
+            def allgather(v):
+                box["gather"][rank] = v
+                barrier.wait()
+                out = list(box["gather"])
+                barrier.wait()
+                return out
+
+            ctx.comm_set_host_callbacks(G, rank, allreduce, allgather)
+            results[rank] = gpu_pass(ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=max_res)
+            results[rank]["shard"] = ctx.sweep_shard()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    status = np.concatenate([results[r]["status"] for r in range(G)])
+    ids = np.concatenate([results[r]["ids"] for r in range(G)])
+    assert np.array_equal(status, ref["status"])
+    assert np.array_equal(ids[status != 3], ref["ids"][status != 3])
+    for r in range(G):
+        n = results[r]["neq"]
+        assert n.num_residuals == ref["neq"].num_residuals and n.success == ref["neq"].success
+        assert n.last_visited == ref["neq"].last_visited
+        assert rel(np.array(n.HtH), np.array(ref["neq"].HtH)) < 1e-12
+        assert rel(np.array(n.Hth), np.array(ref["neq"].Hth)) < 1e-12
+        assert np.array_equal(np.array(n.HtH), np.array(results[0]["neq"].HtH))   # identical on every rank
+
+
+def test_rccl_single_rank_communicator(golden):
+    """The RCCL path itself (ncclCommInitRank / AllReduce / AllGather) with a 1-rank communicator."""
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        base = gpu_pass(ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=600)
+        ctx.comm_init_rank(1, 0, srl.Context.comm_unique_id())
+        g = gpu_pass(ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=600)
+        assert np.array_equal(np.array(g["neq"].HtH), np.array(base["neq"].HtH))
+        assert g["neq"].num_residuals == base["neq"].num_residuals
+    finally:
+        ctx.close()
+
+
+# ----------------------------------------------------------------------------- class-surface forms
+def test_signature_compatible_build_plane_residuals(golden):
+    lio = srl.Lio(0)
+    try:
+        lio.ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        r = lio.build_plane_residuals(srl.default_opts(max_num_residuals=INT_MAX), golden["raw"], golden["full_state0"], golden["t_last"])
+        acc = golden["full_one_status"] == 2
+        assert r["success"] and len(r["rows"]) == acc.sum()
+        assert rel(r["rows"][:, 3:6], golden["full_one_normal"][acc]) < TIGHT
+        assert rel(r["rows"][:, 6:12], golden["full_one_jacobian"][acc]) < TIGHT
+        assert rel(r["rows"][:, 13], golden["full_one_distance"][acc]) < TIGHT
+        assert rel(r["loss_sum"], golden["full_one_loss"]) < TIGHT
+        assert rel(r["keypoint_world"], golden["full_one_point_world"]) < 1e-15
+    finally:
+        lio.close()
+
+
+def test_optimize_end_to_end_vs_oracle(oracle_lib, golden, oracle_backend):
+    """optimize(): gridSampling (host, tr1 order) -> updateIEKF -> re-transform, against the oracle fed
+    with the same keypoint selection."""
+    lio = srl.Lio(0)
+    try:
+        lio.ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        lio.eskf_set_state(golden["full_eskf_state0"]); lio.eskf_set_cov(golden["full_eskf_cov0"])
+        raw = golden["raw"]
+        world = golden["full_one_point_world"]
+        opts = srl.default_opts(max_num_residuals=600)
+        r = lio.optimize(opts, 1.0, raw, world, golden["full_state0"], golden["t_last"])
+        assert r["rc"] == 0
+        kidx = r["keypoint_index"]
+        assert len(kidx) >= 50 and len(np.unique(kidx)) == len(kidx)
+        # oracle on the same keypoints
+        m2 = oracle_lib.Map(oracle_backend)
+        pts, _ = synth.map_candidates(int(golden["map_seed"]), int(golden["map_target"]))
+        m2.add_points(pts)
+        assert np.array_equal(m2.export()[2], golden["map_xyz"])
+        e = oracle_lib.Eskf(oracle_backend)
+        e.set_state(golden["full_eskf_state0"]); e.set_cov(golden["full_eskf_cov0"])
+        u = oracle_lib.update_iekf(m2, e, oracle_lib.default_opts(max_num_residuals=600), raw[kidx], golden["full_state0"], golden["t_last"])
+        assert u["rc"] == r["iters"]
+        assert rel(r["state"], u["state"]) < 1e-9
+        # re-transformed frame points (optimize.cpp:441-445)
+        q = r["state"][0:4]; t = r["state"][4:7]
+        assert rel(r["world"], lio.ctx.transform_points(raw, q, t)) < 1e-15
+    finally:
+        lio.close()
