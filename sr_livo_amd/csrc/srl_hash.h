@@ -20,10 +20,12 @@ SRL_HD inline void srl_unpack_key(unsigned long long k, short *x, short *y, shor
     *y = (short)(unsigned short)((k >> 16) & 0xFFFFu);
     *z = (short)(unsigned short)((k >> 32) & 0xFFFFu);
 }
-// splitmix64 finaliser
+// 32-bit multiplicative mix of the three int16 coordinates (cheap on the device: 32-bit VALU only)
 SRL_HD inline unsigned srl_hash_key(unsigned long long k) {
-    k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
-    k ^= k >> 27; k *= 0x94d049bb133111ebull;
-    k ^= k >> 31;
-    return (unsigned)k;
+    const unsigned x = (unsigned)(k & 0xFFFFu), y = (unsigned)((k >> 16) & 0xFFFFu), z = (unsigned)((k >> 32) & 0xFFFFu);
+    unsigned h = (x * 0x9E3779B1u) ^ (y * 0x85EBCA77u) ^ (z * 0xC2B2AE3Du);
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 12;
+    return h;
 }

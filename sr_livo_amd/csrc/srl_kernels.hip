@@ -219,6 +219,87 @@ __device__ __forceinline__ void select_topk(double qx, double qy, double qz, int
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- fast exact top-K for r = 1 (<= 27 voxels, <= 9 rounds): candidates' d2 stay in registers ----
+//   pass 1  : 64 candidates per round (one coalesced 12-B load each), per-lane min of (float)d2
+//   tau     : 16-step bisection on the f32 bit pattern with ballot/popcount (1 VALU + SALU per step):
+//             an upper bound of the K-th smallest per-lane minimum, i.e. of the K-th smallest distance
+//   pass 2  : survivors {(float)d2 <= tau} (a prefix of the true order, >= K of them) compacted with
+//             ballot + mbcnt into LDS as (d2, e) in visit order
+//   rank    : strict FP64 rank by counting over the <= 64 survivors (2 keys per LDS broadcast read);
+//             any exact tie, or > 64 survivors, defers to the general path below (returns false).
+template <class Sink>
+__device__ __forceinline__ bool select_topk_fast(double qx, double qy, double qz, int nv, const VoxEnt *vox,
+                                                 const unsigned char *slabs, int K, void *scratch, int lane,
+                                                 Sink &sink, int &total_out) {
+    constexpr int MAXR = 9;
+    const int rounds = (nv * SRL_CAP + 63) >> 6;
+    const double kInf = __builtin_huge_val();
+    double d2r[MAXR];
+    float lmin = __builtin_huge_valf();
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < MAXR; ++j) {
+        d2r[j] = kInf;
+        if (j < rounds) {
+            const Cand c = eval_cand(lane + 64 * j, nv, vox, slabs, qx, qy, qz);
+            d2r[j] = c.d2;
+            lmin = fminf(lmin, (float)c.d2);
+            total += __popcll(__ballot(c.valid));
+        }
+    }
+    total_out = total;
+
+    const unsigned v = __float_as_uint(lmin);
+    unsigned lo = 0;
+#pragma unroll
+    for (int bit = 30; bit >= 15; --bit) {
+        const unsigned trial = lo | (1u << bit);
+        const int cnt = __popcll(__ballot(v < trial));
+        lo = (cnt < K) ? trial : lo;
+    }
+    const unsigned tau = lo | 0x7FFFu;
+
+    double *keys = reinterpret_cast<double *>(scratch);                       // [66], 16-B aligned
+    int *es = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scratch) + 66 * 8);   // [64]
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < MAXR; ++j) {
+        if (j < rounds) {
+            const bool sv = (d2r[j] < kInf) && (__float_as_uint((float)d2r[j]) <= tau);
+            const unsigned long long m = __ballot(sv);
+            const int pos = c + lanes_below(m);
+            if (sv && pos < 64) { keys[pos] = d2r[j]; es[pos] = lane + 64 * j; }
+            c += __popcll(m);
+        }
+    }
+    if (c > 64) return false;
+    if (lane < 2) keys[c + lane] = kInf;          // pad to an even count
+    __builtin_amdgcn_wave_barrier();
+
+    const bool act = lane < c;
+    const double my = act ? keys[lane] : kInf;
+    int rank = 0;
+    unsigned long long tie = 0;
+    for (int j = 0; j < c; j += 2) {
+        const double2 kk = *reinterpret_cast<const double2 *>(keys + j);
+        rank += (kk.x < my) ? 1 : 0;
+        rank += (kk.y < my) ? 1 : 0;
+        tie |= __ballot(kk.x == my) & ~(1ull << j);
+        tie |= __ballot(kk.y == my) & ~(2ull << j);
+    }
+    if (tie & __ballot(act)) return false;         // exact distance tie among survivors: general path decides
+    if (act && rank < K) {
+        const int e = es[lane];
+        const unsigned cv = (unsigned)e / SRL_CAP;
+        const unsigned slot = (unsigned)e - cv * SRL_CAP;
+        const VoxEnt ve = vox[cv];
+        const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve.slab * SRL_SLAB_BYTES + slot * 12u);
+        sink.put(rank, p[0], p[1], p[2], ve.slab * SRL_CAP + slot);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // small FP64 helpers (fixed evaluation order, mirrors the oracle / Eigen semantics)
 // ---------------------------------------------------------------------------------------------
@@ -376,7 +457,12 @@ __global__ void __launch_bounds__(SRL_BLOCK) srl_assoc_kernel(const SrlAssocArgs
             sink.col = s_nb + kl;
             sink.tap_ids = a.tap_ids ? (a.tap_ids + (size_t)g * a.K) : nullptr;
             int total = 0, fb = 0;
-            select_topk(qx, qy, qz, nv, vox, a.slabs, a.K, a.select_mode, surv, lane, sink, total, fb);
+            bool done = false;
+            if (NB == 1 && a.select_mode == 0) done = select_topk_fast(qx, qy, qz, nv, vox, a.slabs, a.K, surv, lane, sink, total);
+            if (!done) {
+                select_topk(qx, qy, qz, nv, vox, a.slabs, a.K, a.select_mode, surv, lane, sink, total, fb);
+                fb = (NB == 1) ? 1 : fb;       // r = 1: anything off the fast path counts as a fallback
+            }
             n_fallback += fb;
             if (lane == 0) {
                 s_nfound[kl] = total < a.K ? total : a.K;
@@ -515,9 +601,9 @@ __global__ void __launch_bounds__(SRL_BLOCK) srl_assoc_kernel(const SrlAssocArgs
 // mode: 0 = budget max_res >= 1; 1 = visit only the first keypoint (max_num_residuals <= 0,
 // optimize.cpp:107 breaks after the first keypoint); 2 = visit nothing (budget spent by earlier shards)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) srl_reduce_kernel(const SrlReduceArgs a, int mode) {
-    __shared__ long long s_chunk[256];
-    __shared__ double s_part[8][SRL_PART_STRIDE];
+__global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a, int mode) {
+    __shared__ long long s_chunk[1024];
+    __shared__ double s_part[32][SRL_PART_STRIDE];
     __shared__ long long s_tot[4];          // total accepted, sum_pk, nan, fallback
     __shared__ int s_cut[4];                // cut block, allowed in cut block, last visited local idx, num_res
     const int tid = threadIdx.x;
@@ -525,7 +611,7 @@ __global__ void __launch_bounds__(256) srl_reduce_kernel(const SrlReduceArgs a, 
 
     // integer totals
     long long acc = 0, pk = 0, nanf = 0, fb = 0;
-    const int per = (nb + 255) / 256;
+    const int per = (nb + 1023) / 1024;
     const int b0 = tid * per;
     const int b1 = (b0 + per < nb) ? b0 + per : nb;
     for (int b = b0; b < b1; ++b) {
@@ -535,15 +621,14 @@ __global__ void __launch_bounds__(256) srl_reduce_kernel(const SrlReduceArgs a, 
     s_chunk[tid] = acc;
     if (tid < 4) s_tot[tid] = 0;
     __syncthreads();
-    atomicAdd((unsigned long long *)&s_tot[1], (unsigned long long)pk);
-    atomicAdd((unsigned long long *)&s_tot[2], (unsigned long long)nanf);
-    atomicAdd((unsigned long long *)&s_tot[3], (unsigned long long)fb);
+    if (acc) atomicAdd((unsigned long long *)&s_tot[0], (unsigned long long)acc);
+    if (pk) atomicAdd((unsigned long long *)&s_tot[1], (unsigned long long)pk);
+    if (nanf) atomicAdd((unsigned long long *)&s_tot[2], (unsigned long long)nanf);
+    if (fb) atomicAdd((unsigned long long *)&s_tot[3], (unsigned long long)fb);
     __syncthreads();
 
     if (tid == 0) {
-        long long total = 0;
-        for (int i = 0; i < 256; ++i) total += s_chunk[i];
-        s_tot[0] = total;
+        const long long total = s_tot[0];
         int cut_block = nb, allowed = 0, last_visited = a.n - 1;
         long long num_res = total;
         if (mode == 2) {
@@ -555,7 +640,7 @@ __global__ void __launch_bounds__(256) srl_reduce_kernel(const SrlReduceArgs a, 
             // find the keypoint holding the max_res-th accepted residual (optimize.cpp:107)
             long long before = 0;
             int c = 0;
-            while (c < 256 && before + s_chunk[c] < a.max_res) { before += s_chunk[c]; ++c; }
+            while (c < 1024 && before + s_chunk[c] < a.max_res) { before += s_chunk[c]; ++c; }
             int b = c * per;
             while (b < nb && before + a.binfo[b].accepted < a.max_res) { before += a.binfo[b].accepted; ++b; }
             cut_block = b;
@@ -574,18 +659,20 @@ __global__ void __launch_bounds__(256) srl_reduce_kernel(const SrlReduceArgs a, 
     const int last_visited = s_cut[2];
 
     // deterministic sum of the partials of all blocks strictly before the cut block:
-    // part p sums blocks b == p (mod 8) ascending; parts are then added in order 0..7.
+    // part p sums blocks b == p (mod 32) ascending; parts are then added in order 0..31.
     {
         const int comp = tid & 31, part = tid >> 5;
-        double s = 0.0;
-        if (comp < 28)
-            for (int b = part; b < cut_block; b += 8) s += a.partials[(size_t)b * SRL_PART_STRIDE + comp];
-        s_part[part][comp] = s;
+        double s0 = 0.0;
+        if (comp < 28) {
+#pragma unroll 4
+            for (int b = part; b < cut_block; b += 32) s0 += a.partials[(size_t)b * SRL_PART_STRIDE + comp];
+        }
+        s_part[part][comp] = s0;
     }
     __syncthreads();
     if (tid < 28) {
         double s = s_part[0][tid];
-        for (int p = 1; p < 8; ++p) s += s_part[p][tid];
+        for (int p = 1; p < 32; ++p) s += s_part[p][tid];
         // cut block (or the single first keypoint in mode 1): re-accumulate from the records, in order
         if (mode != 2 && cut_block < nb) {
             int ia = 0, ib = 0;
@@ -659,7 +746,9 @@ __global__ void __launch_bounds__(SRL_BLOCK) srl_search_kernel(const SrlSearchAr
         sink.ids = a.ids + (size_t)q * a.K;
         sink.xyz = a.nb_xyz ? a.nb_xyz + (size_t)q * a.K * 3 : nullptr;
         int total = 0, fb = 0;
-        select_topk(qx, qy, qz, nv, s_vox[wave], a.slabs, a.K, a.select_mode, s_surv[wave], lane, sink, total, fb);
+        bool done = false;
+        if (NB == 1 && a.select_mode == 0) done = select_topk_fast(qx, qy, qz, nv, s_vox[wave], a.slabs, a.K, s_surv[wave], lane, sink, total);
+        if (!done) select_topk(qx, qy, qz, nv, s_vox[wave], a.slabs, a.K, a.select_mode, s_surv[wave], lane, sink, total, fb);
         if (lane == 0) a.num_found[q] = total < a.K ? total : a.K;
     }
 }
@@ -694,7 +783,7 @@ hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, hipStream_t s)
 }
 
 hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s) {
-    hipLaunchKernelGGL(srl_reduce_kernel, dim3(1), dim3(256), 0, s, a, mode);
+    hipLaunchKernelGGL(srl_reduce_kernel, dim3(1), dim3(1024), 0, s, a, mode);
     return hipGetLastError();
 }
 

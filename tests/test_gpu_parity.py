@@ -82,11 +82,16 @@ def test_one_pass_matches_golden(ctx_small, golden, prefix, frame_id, max_res):
         assert g["neq"].last_visited == int(golden["cut600_one_num_visited"]) - 1
 
 
-def test_forced_extraction_selection_matches(ctx_small, golden):
-    """select_mode=1 forces the streaming-extraction selection (the overflow fallback) for every keypoint."""
-    g = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX, select_mode=1)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_general_selection_paths_match(ctx_small, golden, mode):
+    """select_mode=1 forces the streaming-extraction selection (overflow fallback), select_mode=2 the general
+    two-pass threshold + tie-aware rank path, for every keypoint; both must equal the fast path's result."""
+    g = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX, select_mode=mode)
     check_pass_against(g, golden, "full")
     assert g["neq"].num_fallback == len(golden["raw"])
+    g0 = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX)
+    assert g0["neq"].num_fallback == 0
+    assert np.array_equal(np.array(g0["neq"].HtH), np.array(g["neq"].HtH))
 
 
 def test_idempotent_bitwise(ctx_small, golden):
