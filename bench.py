@@ -158,6 +158,9 @@ def main():
                      "kernel": "srl_assoc_kernel<1>", "avg_launch_ms": assoc_ms, "launches": tim.calls,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "reduce_kernel_avg_ms": tim.sum_reduce_ms / calls, "device_total_avg_ms": tim.sum_total_ms / calls},
+        "host_us_per_iter": {"enqueue": tim.sum_host_launch_us / calls, "wait_results": tim.sum_host_wait_us / calls,
+                             "build_residuals_call": tim.sum_host_total_us / calls,
+                             "whole_iteration": ms_per_step * 1e3 / max(iters, 1)},
         "setup_s": setup_s,
     }
 

@@ -176,6 +176,9 @@ typedef struct srl_timing {
     double  sum_total_ms;
     int64_t sum_algorithmic_bytes;
     int64_t sum_keypoints;
+    double  sum_host_launch_us; /* host wall: call entry -> both kernels enqueued */
+    double  sum_host_wait_us;   /* host wall: enqueue done -> results on the host (copy + stream sync [+ all-reduce]) */
+    double  sum_host_total_us;  /* host wall: whole srl_build_residuals call */
 } srl_timing;
 int srl_get_timing(srl_ctx *ctx, srl_timing *t);
 int srl_set_profiling(srl_ctx *ctx, int enable);   /* event timing on/off (off by default); switching on resets the sums */

@@ -53,7 +53,8 @@ class NormalEq(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("assoc_ms", C.c_float), ("reduce_ms", C.c_float), ("total_ms", C.c_float), ("calls", C.c_int32),
                 ("algorithmic_bytes", C.c_int64), ("sum_assoc_ms", C.c_double), ("sum_reduce_ms", C.c_double),
-                ("sum_total_ms", C.c_double), ("sum_algorithmic_bytes", C.c_int64), ("sum_keypoints", C.c_int64)]
+                ("sum_total_ms", C.c_double), ("sum_algorithmic_bytes", C.c_int64), ("sum_keypoints", C.c_int64),
+                ("sum_host_launch_us", C.c_double), ("sum_host_wait_us", C.c_double), ("sum_host_total_us", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)

@@ -171,9 +171,6 @@ optimizeSummary lioOptimization::buildPlaneResiduals(const icpOptions &cur_icp_o
 optimizeSummary lioOptimization::updateIEKF(const icpOptions &cur_icp_options, voxelHashMap &voxel_map_temp,
                                             std::vector<point3D> &keypoints, cloudFrame *p_frame) {
     (void)voxel_map_temp;
-    const int max_num_iter = p_frame->frame_id < cur_icp_options.init_num_frames
-                                 ? std::max(15, cur_icp_options.num_iters_icp) : cur_icp_options.num_iters_icp;
-
     if (!provider) {
         srl_ctx *ctx = voxel_map.ctx;
         if (!ctx) throw std::runtime_error("updateIEKF: no HIP context (the product has no CPU path)");
@@ -185,6 +182,14 @@ optimizeSummary lioOptimization::updateIEKF(const icpOptions &cur_icp_options, v
         }
         if (!sweep_pinned) resident_n = -1;
     }
+    return solveIEKF(cur_icp_options, p_frame);
+}
+
+// the ESIKF loop proper (optimize.cpp:135-313) on whatever sweep is resident in HBM
+optimizeSummary lioOptimization::solveIEKF(const icpOptions &cur_icp_options, cloudFrame *p_frame) {
+    const int max_num_iter = p_frame->frame_id < cur_icp_options.init_num_frames
+                                 ? std::max(15, cur_icp_options.num_iters_icp) : cur_icp_options.num_iters_icp;
+    if (!provider && !voxel_map.ctx) throw std::runtime_error("updateIEKF: no HIP context (the product has no CPU path)");
 
     const Vec3 p_predict = eskf_pro->getTranslation();
     const Quat q_predict = eskf_pro->getRotation();

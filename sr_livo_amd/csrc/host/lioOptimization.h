@@ -87,6 +87,9 @@ public:
     // pin a sweep in HBM: until releaseSweep(), updateIEKF calls with the same keypoint count skip their
     // own upload (bench: inputs resident before the timed region).
     int residentSweep(const double *raw_xyz, int n);
+    bool sweepPinned(int n) const { return sweep_pinned && resident_n == n; }
+    // updateIEKF on the sweep already resident in HBM (no keypoint vector needed)
+    optimizeSummary solveIEKF(const icpOptions &cur_icp_options, cloudFrame *p_frame);
     void releaseSweep() { sweep_pinned = false; resident_n = -1; }
     void setNormalEqProvider(normal_eq_provider fn, void *user) { provider = fn; provider_user = user; }
     srl_ctx *context() { return voxel_map.ctx; }

@@ -67,13 +67,14 @@ void write_log(const lioOptimization &L, double *log, int max_log_iters) {
 }
 
 int run_update(srl_lio *h, const srl_icp_opts *opts, std::vector<point3D> &keypoints, double state_io[16],
-               const double t_last[3], int frame_id, double *log, int max_log_iters, int *iters, int *num_res) {
+               const double t_last[3], int frame_id, double *log, int max_log_iters, int *iters, int *num_res,
+               bool resident = false) {
     FrameWindow w(h, state_io, t_last, frame_id, keypoints);
     h->lio->record_iterations = (log != nullptr);
     const icpOptions o = icpOptions::fromAbi(*opts);
     optimizeSummary s;
     try {
-        s = h->lio->updateIEKF(o, h->lio->voxel_map, keypoints, &w.cur);
+        s = resident ? h->lio->solveIEKF(o, &w.cur) : h->lio->updateIEKF(o, h->lio->voxel_map, keypoints, &w.cur);
     } catch (const std::exception &e) {
         h->lio->all_cloud_frame.clear();
         return status_from_exception(h, e);
@@ -214,25 +215,25 @@ int srl_lio_update_iekf(srl_lio *h, const srl_icp_opts *opts, const double *raw_
     if (!h || !opts || !state_io || !t_last || n < 0) return SRL_ERR_BAD_ARG;
     if (!h->lio->context()) { h->err = "host-only handle: use srl_lio_update_iekf_provided"; return SRL_ERR_NO_DEVICE; }
     h->lio->setNormalEqProvider(nullptr, nullptr);
-    std::vector<point3D> keypoints((size_t)n);
-    if (raw_xyz) h->lio->releaseSweep();
-    if (raw_xyz)
+    std::vector<point3D> keypoints;
+    if (raw_xyz) {
+        h->lio->releaseSweep();
+        keypoints.resize((size_t)n);
         for (int k = 0; k < n; k++) keypoints[k].raw_point = srl::vec3(raw_xyz[(size_t)k * 3], raw_xyz[(size_t)k * 3 + 1], raw_xyz[(size_t)k * 3 + 2]);
-    else {
-        int cnt = 0, total = 0;
-        srl_sweep_shard(h->lio->context(), nullptr, &cnt, &total);
-        if (total != n) { h->err = "no resident sweep of this size"; return SRL_ERR_NO_SWEEP; }
+        return run_update(h, opts, keypoints, state_io, t_last, frame_id, log, max_log_iters, iters, num_residuals_used);
     }
-    return run_update(h, opts, keypoints, state_io, t_last, frame_id, log, max_log_iters, iters, num_residuals_used);
+    if (!h->lio->sweepPinned(n)) { h->err = "no resident sweep of this size"; return SRL_ERR_NO_SWEEP; }
+    return run_update(h, opts, keypoints, state_io, t_last, frame_id, log, max_log_iters, iters, num_residuals_used, true);
 }
 
 int srl_lio_update_iekf_provided(srl_lio *h, const srl_icp_opts *opts, srl_normal_eq_provider provider, void *user, int n,
                                  double state_io[16], const double t_last[3], int frame_id, double *log, int max_log_iters,
                                  int *iters, int *num_residuals_used) {
     if (!h || !opts || !provider || !state_io || !t_last || n < 0) return SRL_ERR_BAD_ARG;
+    (void)n;
     h->lio->setNormalEqProvider(provider, user);
-    std::vector<point3D> keypoints((size_t)n);
-    int rc = run_update(h, opts, keypoints, state_io, t_last, frame_id, log, max_log_iters, iters, num_residuals_used);
+    std::vector<point3D> keypoints;
+    int rc = run_update(h, opts, keypoints, state_io, t_last, frame_id, log, max_log_iters, iters, num_residuals_used, true);
     h->lio->setNormalEqProvider(nullptr, nullptr);
     return rc;
 }

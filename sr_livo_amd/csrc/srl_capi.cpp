@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstring>
@@ -286,6 +287,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     if (!ctx || !f || !o || !out) return SRL_ERR_BAD_ARG;
     if (!ctx->d_table) return SRL_ERR_NO_MAP;
     if (ctx->total_n <= 0 && ctx->n <= 0) return SRL_ERR_NO_SWEEP;
+    const auto t_entry = std::chrono::steady_clock::now();
     HIPCHK(ctx, hipSetDevice(ctx->device));
 
     // init-mode switches (optimize.cpp:21-23)
@@ -396,6 +398,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     ra.out = ctx->d_out;
     HIPCHK(ctx, srl_launch_reduce(ra, mode, ctx->stream));
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    const auto t_enq = std::chrono::steady_clock::now();
 
     // the one exchange step: sum of the normal equations over the point-range shards
     const int n_red = 36 + 6 + 1 + 5;   // HtH, Hth, loss, 5 counters carried as doubles
@@ -418,6 +421,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         }
     }
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    const auto t_res = std::chrono::steady_clock::now();
 
     // total visited keypoints over all shards -> global index of the last visited keypoint
     long long visited_total = visited_local;
@@ -462,6 +466,10 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         ctx->timing.sum_reduce_ms += ctx->timing.reduce_ms;
         ctx->timing.sum_total_ms += ctx->timing.total_ms;
         ctx->timing.sum_keypoints += ctx->n;
+        const auto t_end = std::chrono::steady_clock::now();
+        ctx->timing.sum_host_launch_us += std::chrono::duration<double, std::micro>(t_enq - t_entry).count();
+        ctx->timing.sum_host_wait_us += std::chrono::duration<double, std::micro>(t_res - t_enq).count();
+        ctx->timing.sum_host_total_us += std::chrono::duration<double, std::micro>(t_end - t_entry).count();
     }
     {
         // algorithmic bytes of this rank's association pass: 24 + 12*(2r+1)^3 + 12*P_k per keypoint.

@@ -20,7 +20,7 @@
 #define SRL_SLAB_BYTES 256
 #define SRL_KPB 64            // keypoints per workgroup
 #define SRL_BLOCK 256         // threads per workgroup (4 waves)
-#define SRL_SURV_CAP 128      // per-wave survivor scratch entries
+#define SRL_SURV_CAP 64       // per-wave survivor scratch entries (general path; more survivors -> extraction)
 #define SRL_MAXK 32
 #define SRL_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define SRL_PART_STRIDE 32

@@ -219,32 +219,100 @@ __device__ __forceinline__ void select_topk(double qx, double qy, double qz, int
     __builtin_amdgcn_wave_barrier();
 }
 
-// ---- fast exact top-K for r = 1 (<= 27 voxels, <= 9 rounds): candidates' d2 stay in registers ----
-//   pass 1  : 64 candidates per round (one coalesced 12-B load each), per-lane min of (float)d2
-//   tau     : 16-step bisection on the f32 bit pattern with ballot/popcount (1 VALU + SALU per step):
-//             an upper bound of the K-th smallest per-lane minimum, i.e. of the K-th smallest distance
-//   pass 2  : survivors {(float)d2 <= tau} (a prefix of the true order, >= K of them) compacted with
-//             ballot + mbcnt into LDS as (d2, e) in visit order
-//   rank    : strict FP64 rank by counting over the <= 64 survivors (2 keys per LDS broadcast read);
-//             any exact tie, or > 64 survivors, defers to the general path below (returns false).
+// ---- fast exact top-K for r = 1 (<= 27 voxels): candidates' d2 stay in registers --------------------
+// Lane roles are fixed per wave (no integer division in the loop): lane l < 27 probes voxel offset
+// (l/9-1, l/3%3-1, l%3-1) [visit order x,y,z]; in candidate round j lane l evaluates slot l%20 of
+// compacted voxel 3j + l/20 (60 of 64 lanes busy, <= 9 rounds), so visit order = (round, lane).
+//   pass 1  : one coalesced 12-B load per candidate, d2 kept in registers, per-lane min of (float)d2
+//   tau     : bisection on the f32 bit pattern with ballot/popcount (1 VALU + SALU per step): an upper
+//             bound of the K-th smallest per-lane minimum, hence of the K-th smallest distance
+//   pass 2  : survivors {(float)d2 <= tau} (a prefix of the true order holding >= K candidates)
+//             compacted with ballot + mbcnt into LDS as (d2, voxel/slot code) in visit order
+//   rank    : strict FP64 rank by counting over the <= 64 survivors, 2 keys per LDS broadcast read;
+//             equal ranks among the first K (= an exact distance tie) or > 64 survivors defer to the
+//             general path (returns false).
+struct LaneRole {
+    int pdx, pdy, pdz;     // probe offset (lane < 27)
+    int c0, slot;          // candidate role: voxel-in-round (0..2, 3 = idle) and slot (0..19)
+};
+__device__ __forceinline__ LaneRole lane_role(int lane) {
+    LaneRole r;
+    const int ix = lane / 9, iy = (lane / 3) % 3, iz = lane % 3;
+    r.pdx = ix - 1; r.pdy = iy - 1; r.pdz = iz - 1;
+    r.c0 = lane / SRL_CAP;
+    r.slot = lane - r.c0 * SRL_CAP;
+    return r;
+}
+
+__device__ __forceinline__ int probe_voxels_r1(int kx, int ky, int kz, const LaneRole &role, int thr_cap,
+                                               const SrlMapSlot *table, unsigned mask, VoxEnt *vox, int lane) {
+    bool found = false;
+    unsigned slab = 0, cnt = 0;
+    if (lane < 27) {
+        const unsigned long long key = srl_pack_key((short)(kx + role.pdx), (short)(ky + role.pdy), (short)(kz + role.pdz));
+        unsigned h = srl_hash_key(key) & mask;
+        for (unsigned probe = 0; probe <= mask; ++probe) {
+            const SrlMapSlot sl = table[h];
+            if (sl.key == key) {
+                found = (int)sl.count >= thr_cap && sl.count > 0;   // optimize.cpp:389
+                slab = sl.slab;
+                cnt = sl.count;
+                break;
+            }
+            if (sl.key == SRL_EMPTY_KEY) break;
+            h = (h + 1) & mask;
+        }
+    }
+    const unsigned long long m = __ballot(found);
+    if (found) {
+        VoxEnt ve; ve.slab = slab; ve.count = cnt;
+        vox[lanes_below(m)] = ve;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return __popcll(m);
+}
+
 template <class Sink>
 __device__ __forceinline__ bool select_topk_fast(double qx, double qy, double qz, int nv, const VoxEnt *vox,
                                                  const unsigned char *slabs, int K, void *scratch, int lane,
-                                                 Sink &sink, int &total_out) {
+                                                 const LaneRole &role, Sink &sink, int &total_out) {
     constexpr int MAXR = 9;
-    const int rounds = (nv * SRL_CAP + 63) >> 6;
+    const int rounds = (nv + 2) / 3;
     const double kInf = __builtin_huge_val();
     double d2r[MAXR];
+    float px[MAXR], py[MAXR], pz[MAXR];
+    unsigned vmask = 0;
+    // issue every round's (LDS voxel entry ->) coalesced 12-B load first, consume afterwards: one L2
+    // round trip per keypoint instead of one per round
+#pragma unroll
+    for (int j = 0; j < MAXR; ++j) {
+        px[j] = py[j] = pz[j] = 0.0f;
+        if (j < rounds) {
+            const int cv = 3 * j + role.c0;
+            if (role.c0 < 3 && cv < nv) {
+                const VoxEnt ve = vox[cv];
+                if ((unsigned)role.slot < ve.count) {
+                    const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve.slab * SRL_SLAB_BYTES + role.slot * 12);
+                    px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
+                    vmask |= 1u << j;
+                }
+            }
+        }
+    }
     float lmin = __builtin_huge_valf();
     int total = 0;
 #pragma unroll
     for (int j = 0; j < MAXR; ++j) {
         d2r[j] = kInf;
         if (j < rounds) {
-            const Cand c = eval_cand(lane + 64 * j, nv, vox, slabs, qx, qy, qz);
-            d2r[j] = c.d2;
-            lmin = fminf(lmin, (float)c.d2);
-            total += __popcll(__ballot(c.valid));
+            const bool valid = (vmask >> j) & 1u;
+            const double dx = (double)px[j] - qx;
+            const double dy = (double)py[j] - qy;
+            const double dz = (double)pz[j] - qz;
+            const double d2 = valid ? (dx * dx + dy * dy) + dz * dz : kInf;
+            d2r[j] = d2;
+            lmin = fminf(lmin, (float)d2);
+            total += __popcll(__ballot(valid));
         }
     }
     total_out = total;
@@ -252,15 +320,16 @@ __device__ __forceinline__ bool select_topk_fast(double qx, double qy, double qz
     const unsigned v = __float_as_uint(lmin);
     unsigned lo = 0;
 #pragma unroll
-    for (int bit = 30; bit >= 15; --bit) {
+    for (int bit = 30; bit >= 18; --bit) {
         const unsigned trial = lo | (1u << bit);
         const int cnt = __popcll(__ballot(v < trial));
         lo = (cnt < K) ? trial : lo;
     }
-    const unsigned tau = lo | 0x7FFFu;
+    const unsigned tau = lo | 0x3FFFFu;
 
-    double *keys = reinterpret_cast<double *>(scratch);                       // [66], 16-B aligned
-    int *es = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scratch) + 66 * 8);   // [64]
+    double *keys = reinterpret_cast<double *>(scratch);                                        // [66], 16-B aligned
+    int *codes = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scratch) + 66 * 8); // [64] (voxel << 5) | slot
+    int *owner = codes + 64;                                                                   // [32] rank -> lane
     int c = 0;
 #pragma unroll
     for (int j = 0; j < MAXR; ++j) {
@@ -268,7 +337,7 @@ __device__ __forceinline__ bool select_topk_fast(double qx, double qy, double qz
             const bool sv = (d2r[j] < kInf) && (__float_as_uint((float)d2r[j]) <= tau);
             const unsigned long long m = __ballot(sv);
             const int pos = c + lanes_below(m);
-            if (sv && pos < 64) { keys[pos] = d2r[j]; es[pos] = lane + 64 * j; }
+            if (sv && pos < 64) { keys[pos] = d2r[j]; codes[pos] = ((3 * j + role.c0) << 5) | role.slot; }
             c += __popcll(m);
         }
     }
@@ -279,20 +348,22 @@ __device__ __forceinline__ bool select_topk_fast(double qx, double qy, double qz
     const bool act = lane < c;
     const double my = act ? keys[lane] : kInf;
     int rank = 0;
-    unsigned long long tie = 0;
+#pragma unroll 4
     for (int j = 0; j < c; j += 2) {
         const double2 kk = *reinterpret_cast<const double2 *>(keys + j);
         rank += (kk.x < my) ? 1 : 0;
         rank += (kk.y < my) ? 1 : 0;
-        tie |= __ballot(kk.x == my) & ~(1ull << j);
-        tie |= __ballot(kk.y == my) & ~(2ull << j);
     }
-    if (tie & __ballot(act)) return false;         // exact distance tie among survivors: general path decides
-    if (act && rank < K) {
-        const int e = es[lane];
-        const unsigned cv = (unsigned)e / SRL_CAP;
-        const unsigned slot = (unsigned)e - cv * SRL_CAP;
-        const VoxEnt ve = vox[cv];
+    // strict ranks are a permutation unless two survivors are exactly equal: detect a clash among the first K
+    const bool win = act && rank < K;
+    if (win) owner[rank] = lane;
+    __builtin_amdgcn_wave_barrier();
+    const bool clash = win && (owner[rank] != lane);
+    if (__ballot(clash)) return false;             // exact distance tie: the general path decides by visit order
+    if (win) {
+        const int code = codes[lane];
+        const VoxEnt ve = vox[code >> 5];
+        const unsigned slot = (unsigned)code & 31u;
         const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve.slab * SRL_SLAB_BYTES + slot * 12u);
         sink.put(rank, p[0], p[1], p[2], ve.slab * SRL_CAP + slot);
     }
@@ -381,13 +452,14 @@ __device__ void eig3_jacobi(const double Ain[3][3], double ev[3], D3 &n0) {
 // dynamic LDS carve (all offsets multiples of 16; guide G17)
 #define NB_ROW (SRL_KPB + 1)   // row stride (entries) of the neighbour list: conflict-free phase-2 reads
 struct LdsLayout {
-    int off_nb, off_pw, off_nfound, off_ncand, off_vox, off_surv, off_misc, total;
+    int off_nb, off_pw, off_kv, off_nfound, off_ncand, off_vox, off_surv, off_misc, total;
 };
 __host__ __device__ inline LdsLayout lds_layout(int K) {
     LdsLayout L;
     int o = 0;
-    L.off_nb = o;     o += K * NB_ROW * 16;
+    L.off_nb = o;     o += ((K * NB_ROW * 12 + 15) / 16) * 16;
     L.off_pw = o;     o += SRL_KPB * 3 * 8;
+    L.off_kv = o;     o += SRL_KPB * 4 * 4;
     L.off_nfound = o; o += SRL_KPB * 4;
     L.off_ncand = o;  o += SRL_KPB * 4;
     L.off_vox = o;    o += 4 * 128 * 8;
@@ -398,20 +470,26 @@ __host__ __device__ inline LdsLayout lds_layout(int K) {
 }
 
 struct LdsSink {
-    float4 *col;        // &nb[0][kl], row stride NB_ROW
+    float *col;         // &nbx[0][kl]; planes x | y | z, each K rows of NB_ROW floats
+    int plane;          // K * NB_ROW
     int *tap_ids;       // global row or null
     __device__ __forceinline__ void put(int rank, float x, float y, float z, unsigned id) {
-        col[rank * NB_ROW] = make_float4(x, y, z, __uint_as_float(id));
+        float *p = col + rank * NB_ROW;
+        p[0] = x;
+        p[plane] = y;
+        p[2 * plane] = z;
         if (tap_ids) tap_ids[rank] = (int)id;
     }
 };
 
 template <int NB>
-__global__ void __launch_bounds__(SRL_BLOCK) srl_assoc_kernel(const SrlAssocArgs a) {
+__global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout L = lds_layout(a.K);
-    float4 *s_nb = reinterpret_cast<float4 *>(smem + L.off_nb);
+    float *s_nb = reinterpret_cast<float *>(smem + L.off_nb);
+    const int nb_plane = a.K * NB_ROW;
     double *s_pw = reinterpret_cast<double *>(smem + L.off_pw);
+    int *s_kv = reinterpret_cast<int *>(smem + L.off_kv);
     int *s_nfound = reinterpret_cast<int *>(smem + L.off_nfound);
     int *s_ncand = reinterpret_cast<int *>(smem + L.off_ncand);
     VoxEnt *s_vox = reinterpret_cast<VoxEnt *>(smem + L.off_vox);
@@ -436,6 +514,10 @@ __global__ void __launch_bounds__(SRL_BLOCK) srl_assoc_kernel(const SrlAssocArgs
         s_pw[tid * 3 + 0] = p_w.x;
         s_pw[tid * 3 + 1] = p_w.y;
         s_pw[tid * 3 + 2] = p_w.z;
+        // static_cast<short>(point / size_voxel_map): truncation toward zero (optimize.cpp:372-374)
+        s_kv[tid * 4 + 0] = (int)(short)(int)(p_w.x / a.size_voxel);
+        s_kv[tid * 4 + 1] = (int)(short)(int)(p_w.y / a.size_voxel);
+        s_kv[tid * 4 + 2] = (int)(short)(int)(p_w.z / a.size_voxel);
         s_nfound[tid] = 0;
         s_ncand[tid] = 0;
     }
@@ -447,19 +529,24 @@ __global__ void __launch_bounds__(SRL_BLOCK) srl_assoc_kernel(const SrlAssocArgs
         VoxEnt *vox = s_vox + wave * 128;
         Surv *surv = s_surv + wave * SRL_SURV_CAP;
         int n_fallback = 0;
+        const LaneRole role = lane_role(lane);
         for (int i = 0; i < SRL_KPB / 4; ++i) {
             const int kl = wave * (SRL_KPB / 4) + i;
             const int g = base + kl;
             if (g >= a.n) break;
             const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
-            const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, vox, lane);
             LdsSink sink;
             sink.col = s_nb + kl;
+            sink.plane = nb_plane;
             sink.tap_ids = a.tap_ids ? (a.tap_ids + (size_t)g * a.K) : nullptr;
             int total = 0, fb = 0;
             bool done = false;
-            if (NB == 1 && a.select_mode == 0) done = select_topk_fast(qx, qy, qz, nv, vox, a.slabs, a.K, surv, lane, sink, total);
+            if (NB == 1 && a.select_mode == 0) {
+                const int nv = probe_voxels_r1(s_kv[kl * 4 + 0], s_kv[kl * 4 + 1], s_kv[kl * 4 + 2], role, a.thr_cap, a.table, a.table_mask, vox, lane);
+                done = select_topk_fast(qx, qy, qz, nv, vox, a.slabs, a.K, surv, lane, role, sink, total);
+            }
             if (!done) {
+                const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, vox, lane);
                 select_topk(qx, qy, qz, nv, vox, a.slabs, a.K, a.select_mode, surv, lane, sink, total, fb);
                 fb = (NB == 1) ? 1 : fb;       // r = 1: anything off the fast path counts as a fallback
             }
@@ -487,15 +574,15 @@ __global__ void __launch_bounds__(SRL_BLOCK) srl_assoc_kernel(const SrlAssocArgs
             // barycenter, sequential in neighbour order (optimize.cpp:320-325)
             D3 bc = d3(0, 0, 0);
             for (int i = 0; i < nf; ++i) {
-                const float4 p = s_nb[i * NB_ROW + tid];
-                bc = add(bc, d3((double)p.x, (double)p.y, (double)p.z));
+                const float *p = s_nb + i * NB_ROW + tid;
+                bc = add(bc, d3((double)p[0], (double)p[nb_plane], (double)p[2 * nb_plane]));
             }
             const double inv_n = (double)nf;
             bc = d3(bc.x / inv_n, bc.y / inv_n, bc.z / inv_n);
             double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
             for (int i = 0; i < nf; ++i) {
-                const float4 p = s_nb[i * NB_ROW + tid];
-                const double ex = (double)p.x - bc.x, ey = (double)p.y - bc.y, ez = (double)p.z - bc.z;
+                const float *p = s_nb + i * NB_ROW + tid;
+                const double ex = (double)p[0] - bc.x, ey = (double)p[nb_plane] - bc.y, ez = (double)p[2 * nb_plane] - bc.z;
                 C[0][0] += ex * ex; C[0][1] += ex * ey; C[0][2] += ex * ez;
                 C[1][1] += ey * ey; C[1][2] += ey * ez;
                 C[2][2] += ez * ez;
@@ -514,8 +601,7 @@ __global__ void __launch_bounds__(SRL_BLOCK) srl_assoc_kernel(const SrlAssocArgs
             // normal flip: world-frame last translation minus body-frame location (optimize.cpp:49-51)
             const D3 tl = d3(a.t_last[0], a.t_last[1], a.t_last[2]);
             if (dot3(nrm, sub(tl, p_imu)) < 0.0) nrm = d3(-1.0 * nrm.x, -1.0 * nrm.y, -1.0 * nrm.z);
-            const float4 n0f = s_nb[tid];
-            const D3 nn0 = d3((double)n0f.x, (double)n0f.y, (double)n0f.z);
+            const D3 nn0 = d3((double)s_nb[tid], (double)s_nb[nb_plane + tid], (double)s_nb[2 * nb_plane + tid]);
             const D3 dq = sub(nn0, p_w);
             weight = a.lambda_w * w_plan + a.lambda_n * exp(-sqrt(dot3(dq, dq)) / a.nbr_scale);   // optimize.cpp:87-88
             const D3 nv = normalized3(nrm);                            // optimize.cpp:93
@@ -746,9 +832,7 @@ __global__ void __launch_bounds__(SRL_BLOCK) srl_search_kernel(const SrlSearchAr
         sink.ids = a.ids + (size_t)q * a.K;
         sink.xyz = a.nb_xyz ? a.nb_xyz + (size_t)q * a.K * 3 : nullptr;
         int total = 0, fb = 0;
-        bool done = false;
-        if (NB == 1 && a.select_mode == 0) done = select_topk_fast(qx, qy, qz, nv, s_vox[wave], a.slabs, a.K, s_surv[wave], lane, sink, total);
-        if (!done) select_topk(qx, qy, qz, nv, s_vox[wave], a.slabs, a.K, a.select_mode, s_surv[wave], lane, sink, total, fb);
+        select_topk(qx, qy, qz, nv, s_vox[wave], a.slabs, a.K, a.select_mode, s_surv[wave], lane, sink, total, fb);
         if (lane == 0) a.num_found[q] = total < a.K ? total : a.K;
     }
 }
