@@ -13,6 +13,7 @@
 #include <chrono>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -335,6 +336,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     a.min_nb = o->min_number_neighbors;
     a.thr_cap = thr;
     a.select_mode = o->select_mode;
+    { const char *ab = std::getenv("SRL_ABLATE"); a.ablate = ab ? std::atoi(ab) : 0; }   // debug/profiling only
     a.rec = ctx->d_rec;
     a.status = ctx->d_status;
     a.partials = ctx->d_partials;

@@ -21,6 +21,7 @@
 #define SRL_KPB 64            // keypoints per workgroup
 #define SRL_BLOCK 256         // threads per workgroup (4 waves)
 #define SRL_SURV_CAP 64       // per-wave survivor scratch entries (general path; more survivors -> extraction)
+#define SRL_WAVE_SCRATCH 2048  // bytes of LDS scratch per wave (fast path: 64 x 16 B records + 66 keys + 32 owners = 1688 B)
 #define SRL_MAXK 32
 #define SRL_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define SRL_PART_STRIDE 32
@@ -85,6 +86,7 @@ struct SrlAssocArgs {
     int min_nb;         // min_number_neighbors
     int thr_cap;        // threshold_voxel_capacity
     int select_mode;
+    int ablate;             // debug only (env SRL_ABLATE): bit0 skip phase 2, bit1 stop after compaction, bit2 stop after probe, bit3 skip probe
     // outputs
     double *rec;            // n x 8
     unsigned char *status;  // n

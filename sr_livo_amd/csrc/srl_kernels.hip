@@ -28,6 +28,7 @@ namespace {
 struct VoxEnt { unsigned slab; unsigned count; };
 struct Surv { double d2; float x, y, z; unsigned id; };
 static_assert(sizeof(Surv) == 24, "survivor record is 24 bytes");
+static_assert(SRL_SURV_CAP * 24 <= SRL_WAVE_SCRATCH, "general-path scratch must fit");
 
 __device__ __forceinline__ int lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
@@ -70,6 +71,7 @@ __device__ __forceinline__ int probe_voxels(double qx, double qy, double qz, dou
                                             const SrlMapSlot *table, unsigned mask, VoxEnt *vox, int lane) {
     constexpr int SIDE = 2 * NB + 1;
     constexpr int NV = SIDE * SIDE * SIDE;
+    asm volatile("" : "+v"(lane));   // keep lane-derived constants of this rarely taken path out of the caller's loop preheader
     // static_cast<short>(point / size_voxel_map): truncation toward zero (optimize.cpp:372-374)
     const short kx = (short)(int)(qx / size_voxel);
     const short ky = (short)(int)(qy / size_voxel);
@@ -122,6 +124,7 @@ __device__ __forceinline__ void select_topk(double qx, double qy, double qz, int
                                             int lane, Sink &sink, int &total_out, int &fallback_out) {
     const int rounds = (nv * SRL_CAP + 63) >> 6;
     const float kInfF = __builtin_huge_valf();
+    asm volatile("" : "+v"(lane));   // see probe_voxels: no hoisting of the sort network's lane constants
 
     // pass 1: stream all candidates, per-lane minimum of (float)d2, count P_k
     float lmin = kInfF;
@@ -371,6 +374,143 @@ __device__ __forceinline__ bool select_topk_fast(double qx, double qy, double qz
     return true;
 }
 
+// ---- fast exact top-K, FP32 prefilter variant (default for r = 1) -----------------------------------
+// Only the ~25 survivors of a conservative FP32 threshold are ever evaluated in FP64:
+//   pass 1  : coalesced 12-B loads (all rounds in flight), d2f = |p - fl32(q)|^2 in FP32 (FMA allowed: it
+//             is a filter, never a result), per-lane minimum
+//   tau_f   : bisection (ballot/popcount) -> upper bound of the K-th smallest per-lane minimum
+//   margin  : |d2f - d2| <= M for every candidate with d2 <= 2 tau_f (M from the FP32 rounding model below),
+//             so the true K nearest all satisfy d2f <= tau_f + 2M: these survivors are compacted (visit
+//             order) into LDS as {x, y, z, voxel/slot code}
+//   exact   : lane i < c evaluates survivor i's d2 in FP64 with the reference's operation order
+//             ((dx*dx + dy*dy) + dz*dz, no FMA), strict rank by counting, clash check, emit from registers.
+struct SurvRec { float x, y, z; int code; };
+
+__device__ __forceinline__ float d2_f32(float px, float py, float pz, float qx, float qy, float qz) {
+#pragma clang fp contract(fast)
+    const float dx = px - qx, dy = py - qy, dz = pz - qz;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// R = compile-time number of candidate rounds (3 voxels each): straight-line code, arrays stay in registers
+template <int R, class Sink>
+__device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double qz, int nv, const VoxEnt *vox,
+                                                  const unsigned char *slabs, int K, void *scratch, int lane,
+                                                  const LaneRole &role, Sink &sink, int &total_out, int ablate) {
+    const float kInfF = __builtin_huge_valf();
+    const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
+    float px[R], py[R], pz[R];
+    bool val[R];
+    // every round's (LDS voxel entry ->) coalesced 12-B load is issued before any is consumed
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int cv = 3 * j + role.c0;
+        px[j] = 0.0f; py[j] = 0.0f; pz[j] = 0.0f;
+        val[j] = false;
+        if (role.c0 < 3 && cv < nv) {
+            const VoxEnt ve = vox[cv];
+            if ((unsigned)role.slot < ve.count) {
+                const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve.slab * SRL_SLAB_BYTES + role.slot * 12);
+                px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
+                val[j] = true;
+            }
+        }
+    }
+    float d2f[R];
+    float lmin = kInfF;
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const float d = d2_f32(px[j], py[j], pz[j], qxf, qyf, qzf);
+        d2f[j] = val[j] ? d : kInfF;
+        lmin = fminf(lmin, d2f[j]);
+        total += __popcll(__ballot(val[j]));
+    }
+    total_out = total;
+
+    const unsigned v = __float_as_uint(lmin);
+    unsigned lo = 0;
+#pragma unroll
+    for (int bit = 30; bit >= 18; --bit) {
+        const unsigned trial = lo | (1u << bit);
+        const int cnt = __popcll(__ballot(v < trial));
+        lo = (cnt < K) ? trial : lo;
+    }
+    const float tau_f = __uint_as_float(lo | 0x3FFFFu);   // >= K candidates have d2f <= tau_f (if that many exist)
+    // FP32 error model: a = abs error of fl32(q) per axis; per-axis difference error <= a + u*|d|; sum of
+    // squares (3 terms, FMA or not) adds <= 4u relative.  For d2, d2f <= T:  |d2f - d2| <= m(T) with
+    //   m(T) = 4 a sqrt(T) + 8 u T + 4 a^2   (u = 2^-24), evaluated at T = 2 tau_f + 1e-6 and doubled.
+    float thr = kInfF;
+    if (tau_f < kInfF) {
+        const float u = 5.9604645e-8f;
+        const float amax = fmaxf(fmaxf(fabsf(qxf), fabsf(qyf)), fabsf(qzf)) * u + 1e-30f;
+        const float T = 2.0f * tau_f + 1e-6f;
+        const float m = 4.0f * amax * sqrtf(T) + 8.0f * u * T + 4.0f * amax * amax;
+        thr = (tau_f + 2.0f * m) * 1.000001f;
+    }
+
+    SurvRec *recs = reinterpret_cast<SurvRec *>(scratch);                                          // [64], 16-B aligned
+    double *keys = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024);  // [66]
+    int *owner = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scratch) + 1024 + 66 * 8 + 8);  // [32]
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const bool sv = val[j] && d2f[j] <= thr;
+        const unsigned long long m = __ballot(sv);
+        const int pos = c + lanes_below(m);
+        if (sv && pos < 64) {
+            SurvRec r; r.x = px[j]; r.y = py[j]; r.z = pz[j]; r.code = ((3 * j + role.c0) << 5) | role.slot;
+            recs[pos] = r;
+        }
+        c += __popcll(m);
+    }
+    if (c > 64) return false;
+    if (ablate & 2) return true;
+    __builtin_amdgcn_wave_barrier();
+
+    const bool act = lane < c;
+    SurvRec me;
+    me.x = me.y = me.z = 0.0f; me.code = 0;
+    double my = __builtin_huge_val();
+    if (act) {
+        me = recs[lane];
+        const double dx = (double)me.x - qx;
+        const double dy = (double)me.y - qy;
+        const double dz = (double)me.z - qz;
+        my = (dx * dx + dy * dy) + dz * dz;          // the reference's evaluation order (optimize.cpp:394-395)
+    }
+    keys[lane] = my;                                  // lanes >= c write +inf: keys[c], keys[c+1] pad an odd count
+    if (lane < 2) keys[64 + lane] = __builtin_huge_val();
+    __builtin_amdgcn_wave_barrier();
+    int rank = 0;
+#pragma unroll 4
+    for (int j = 0; j < c; j += 2) {
+        const double2 kk = *reinterpret_cast<const double2 *>(keys + j);
+        rank += (kk.x < my) ? 1 : 0;
+        rank += (kk.y < my) ? 1 : 0;
+    }
+    const bool win = act && rank < K;
+    if (win) owner[rank] = lane;
+    __builtin_amdgcn_wave_barrier();
+    const bool clash = win && (owner[rank] != lane);
+    if (__ballot(clash)) return false;             // exact distance tie: the general path decides by visit order
+    if (win) {
+        const VoxEnt ve = vox[me.code >> 5];
+        sink.put(rank, me.x, me.y, me.z, ve.slab * SRL_CAP + ((unsigned)me.code & 31u));
+    }
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
+template <class Sink>
+__device__ __forceinline__ bool select_topk_f32(double qx, double qy, double qz, int nv, const VoxEnt *vox,
+                                                const unsigned char *slabs, int K, void *scratch, int lane,
+                                                const LaneRole &role, Sink &sink, int &total_out, int ablate) {
+    if (nv <= 9) return select_topk_f32_r<3>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
+    if (nv <= 15) return select_topk_f32_r<5>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
+    return select_topk_f32_r<9>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
+}
+
 // ---------------------------------------------------------------------------------------------
 // small FP64 helpers (fixed evaluation order, mirrors the oracle / Eigen semantics)
 // ---------------------------------------------------------------------------------------------
@@ -449,6 +589,47 @@ __device__ void eig3_jacobi(const double Ain[3][3], double ev[3], D3 &n0) {
     (void)i2;
 }
 
+// Closed-form symmetric 3x3 eigen-decomposition (trigonometric eigenvalues + cross-product eigenvector
+// of the smallest one): ~5x fewer FP64 instructions than the Jacobi sweeps above and no data-dependent
+// loop.  Same outputs (eigenvalues ascending, unit eigenvector of the smallest) to ~1e-13 relative for
+// the well-separated, near-planar neighbourhoods the path weights up; used by the fused kernel, the
+// Jacobi version stays as the reference form (selected with select_mode 4, and used by the oracle).
+__device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], D3 &n0) {
+    const double a00 = A[0][0], a11 = A[1][1], a22 = A[2][2], a01 = A[0][1], a02 = A[0][2], a12 = A[1][2];
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    const double q = (a00 + a11 + a22) / 3.0;
+    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+    if (!(p2 > 0.0)) {               // multiple of the identity (or zero)
+        ev[0] = ev[1] = ev[2] = q;
+        n0 = d3(1.0, 0.0, 0.0);
+        return;
+    }
+    const double p = sqrt(p2 / 6.0);
+    const double ip = 1.0 / p;
+    const double c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
+    double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+    r = fmin(1.0, fmax(-1.0, r));
+    const double phi = acos(r) / 3.0;
+    const double e2 = q + 2.0 * p * cos(phi);                                   // largest
+    const double e0 = q + 2.0 * p * cos(phi + 2.0943951023931954923084289221863);  // smallest (+ 2 pi / 3)
+    const double e1 = 3.0 * q - e0 - e2;
+    ev[0] = e0; ev[1] = e1; ev[2] = e2;
+    // null vector of (A - e0 I): the largest of the three row cross products
+    const D3 r0 = d3(a00 - e0, a01, a02), r1 = d3(a01, a11 - e0, a12), r2 = d3(a02, a12, a22 - e0);
+    const D3 x01 = d3(r0.y * r1.z - r0.z * r1.y, r0.z * r1.x - r0.x * r1.z, r0.x * r1.y - r0.y * r1.x);
+    const D3 x02 = d3(r0.y * r2.z - r0.z * r2.y, r0.z * r2.x - r0.x * r2.z, r0.x * r2.y - r0.y * r2.x);
+    const D3 x12 = d3(r1.y * r2.z - r1.z * r2.y, r1.z * r2.x - r1.x * r2.z, r1.x * r2.y - r1.y * r2.x);
+    const double n01 = dot3(x01, x01), n02 = dot3(x02, x02), n12 = dot3(x12, x12);
+    D3 best = x01;
+    double nb = n01;
+    if (n02 > nb) { best = x02; nb = n02; }
+    if (n12 > nb) { best = x12; nb = n12; }
+    if (!(nb > 0.0)) { n0 = d3(1.0, 0.0, 0.0); return; }
+    const double inv = 1.0 / sqrt(nb);
+    n0 = d3(best.x * inv, best.y * inv, best.z * inv);
+}
+
 // dynamic LDS carve (all offsets multiples of 16; guide G17)
 #define NB_ROW (SRL_KPB + 1)   // row stride (entries) of the neighbour list: conflict-free phase-2 reads
 struct LdsLayout {
@@ -463,7 +644,7 @@ __host__ __device__ inline LdsLayout lds_layout(int K) {
     L.off_nfound = o; o += SRL_KPB * 4;
     L.off_ncand = o;  o += SRL_KPB * 4;
     L.off_vox = o;    o += 4 * 128 * 8;
-    L.off_surv = o;   o += 4 * SRL_SURV_CAP * 24;     // aliased by the J records (64*8*8 = 4 KB) after the barrier
+    L.off_surv = o;   o += 4 * SRL_WAVE_SCRATCH;      // aliased by the J records (64*8*8 = 4 KB) after the barrier
     L.off_misc = o;   o += 64;
     L.total = o;
     return L;
@@ -482,7 +663,8 @@ struct LdsSink {
     }
 };
 
-template <int NB>
+// FAST: 0 = general path only, 1 = FP32-prefilter fast path, 2 = FP64-retained fast path (r = 1 only)
+template <int NB, int FAST>
 __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout L = lds_layout(a.K);
@@ -527,10 +709,12 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     // ---------------- phase 1: searchNeighbors, one wave per keypoint
     {
         VoxEnt *vox = s_vox + wave * 128;
-        Surv *surv = s_surv + wave * SRL_SURV_CAP;
+        Surv *surv = reinterpret_cast<Surv *>(smem + L.off_surv + wave * SRL_WAVE_SCRATCH);
         int n_fallback = 0;
-        const LaneRole role = lane_role(lane);
+        const LaneRole role0 = lane_role(lane);
         for (int i = 0; i < SRL_KPB / 4; ++i) {
+            LaneRole role = role0;
+            asm volatile("" : "+v"(role.c0), "+v"(role.slot));   // recompute the few role-derived values per keypoint instead of spilling them
             const int kl = wave * (SRL_KPB / 4) + i;
             const int g = base + kl;
             if (g >= a.n) break;
@@ -541,9 +725,12 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
             sink.tap_ids = a.tap_ids ? (a.tap_ids + (size_t)g * a.K) : nullptr;
             int total = 0, fb = 0;
             bool done = false;
-            if (NB == 1 && a.select_mode == 0) {
-                const int nv = probe_voxels_r1(s_kv[kl * 4 + 0], s_kv[kl * 4 + 1], s_kv[kl * 4 + 2], role, a.thr_cap, a.table, a.table_mask, vox, lane);
-                done = select_topk_fast(qx, qy, qz, nv, vox, a.slabs, a.K, surv, lane, role, sink, total);
+            if constexpr (NB == 1 && FAST != 0) {
+                int nv = 0;
+                if (!(a.ablate & 8)) nv = probe_voxels_r1(s_kv[kl * 4 + 0], s_kv[kl * 4 + 1], s_kv[kl * 4 + 2], role, a.thr_cap, a.table, a.table_mask, vox, lane);
+                if (a.ablate & 4) { done = true; total = nv; }
+                else if constexpr (FAST == 1) done = select_topk_f32(qx, qy, qz, nv, vox, a.slabs, a.K, surv, lane, role, sink, total, a.ablate);
+                else done = select_topk_fast(qx, qy, qz, nv, vox, a.slabs, a.K, surv, lane, role, sink, total);
             }
             if (!done) {
                 const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, vox, lane);
@@ -570,7 +757,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     const int nf = s_nfound[tid];
     if (g < a.n) {
         status = 0;
-        if (nf >= a.min_nb) {
+        if (nf >= a.min_nb && !(a.ablate & 1)) {
             // barycenter, sequential in neighbour order (optimize.cpp:320-325)
             D3 bc = d3(0, 0, 0);
             for (int i = 0; i < nf; ++i) {
@@ -590,7 +777,8 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
             C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
             double ev[3];
             D3 nrm;
-            eig3_jacobi(C, ev, nrm);
+            if (a.select_mode == 4) eig3_jacobi(C, ev, nrm);
+            else eig3_closed(C, ev, nrm);
             nrm = normalized3(nrm);                                   // .col(0).normalized() (optimize.cpp:340)
             const double sigma_1 = sqrt(fabs(ev[2]));
             const double sigma_2 = sqrt(fabs(ev[1]));
@@ -861,8 +1049,13 @@ hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, hipStream_t s)
     if (a.n <= 0) return hipSuccess;
     const int nblocks = (a.n + SRL_KPB - 1) / SRL_KPB;
     const LdsLayout L = lds_layout(a.K);
-    if (nb_voxels == 1) hipLaunchKernelGGL(srl_assoc_kernel<1>, dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
-    else hipLaunchKernelGGL(srl_assoc_kernel<2>, dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+    if (nb_voxels == 1) {
+        if (a.select_mode == 0 || a.select_mode == 4) hipLaunchKernelGGL((srl_assoc_kernel<1, 1>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+        else if (a.select_mode == 3) hipLaunchKernelGGL((srl_assoc_kernel<1, 2>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+        else hipLaunchKernelGGL((srl_assoc_kernel<1, 0>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+    } else {
+        hipLaunchKernelGGL((srl_assoc_kernel<2, 0>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+    }
     return hipGetLastError();
 }
 
