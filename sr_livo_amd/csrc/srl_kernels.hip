@@ -630,23 +630,30 @@ __device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], 
     n0 = d3(best.x * inv, best.y * inv, best.z * inv);
 }
 
-// dynamic LDS carve (all offsets multiples of 16; guide G17)
-#define NB_ROW (SRL_KPB + 1)   // row stride (entries) of the neighbour list: conflict-free phase-2 reads
+// dynamic LDS carve (all offsets multiples of 16; guide G17).  Every wave owns its 16 keypoints from
+// transform to partial normal equations, so all areas below are PER WAVE (no block barrier until the end).
+#define SRL_KPW (SRL_KPB / 4)      // keypoints per wave
+#define NB_ROW (SRL_KPW + 1)       // row stride (floats) of the neighbour planes
 struct LdsLayout {
-    int off_nb, off_pw, off_kv, off_nfound, off_ncand, off_vox, off_surv, off_misc, total;
+    int wave_bytes;                // per-wave region size
+    int off_nb, off_pw, off_pimu, off_kv, off_nfound, off_ncand, off_vox, off_scratch;   // offsets inside a wave region
+    int off_wpart, off_winfo, total;                                                      // block-level tail
 };
-__host__ __device__ inline LdsLayout lds_layout(int K) {
+__host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels) {
     LdsLayout L;
     int o = 0;
-    L.off_nb = o;     o += ((K * NB_ROW * 12 + 15) / 16) * 16;
-    L.off_pw = o;     o += SRL_KPB * 3 * 8;
-    L.off_kv = o;     o += SRL_KPB * 4 * 4;
-    L.off_nfound = o; o += SRL_KPB * 4;
-    L.off_ncand = o;  o += SRL_KPB * 4;
-    L.off_vox = o;    o += 4 * 128 * 8;
-    L.off_surv = o;   o += 4 * SRL_WAVE_SCRATCH;      // aliased by the J records (64*8*8 = 4 KB) after the barrier
-    L.off_misc = o;   o += 64;
-    L.total = o;
+    L.off_nb = o;      o += ((3 * K * NB_ROW * 4 + 15) / 16) * 16;   // planes x | y | z, K rows of NB_ROW floats
+    L.off_pw = o;      o += SRL_KPW * 3 * 8;
+    L.off_pimu = o;    o += SRL_KPW * 3 * 8;
+    L.off_kv = o;      o += SRL_KPW * 4 * 4;
+    L.off_nfound = o;  o += SRL_KPW * 4;
+    L.off_ncand = o;   o += SRL_KPW * 4;
+    L.off_vox = o;     o += (nb_voxels == 1 ? 32 : 128) * 8;
+    L.off_scratch = o; o += SRL_WAVE_SCRATCH;
+    L.wave_bytes = o;
+    L.off_wpart = 4 * o;
+    L.off_winfo = L.off_wpart + 4 * 32 * 8;
+    L.total = L.off_winfo + 4 * 4 * 4;
     return L;
 }
 
@@ -663,60 +670,72 @@ struct LdsSink {
     }
 };
 
+// butterfly add inside groups of 4 lanes (sub-lanes of one keypoint): all 4 lanes end with the same bits
+__device__ __forceinline__ double quad_sum(double v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+// sum over the 16 keypoints of a wave for a value held per (keypoint, sub-lane): lanes with equal sub-lane
+__device__ __forceinline__ double kp_sum(double v) {
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
 // FAST: 0 = general path only, 1 = FP32-prefilter fast path, 2 = FP64-retained fast path (r = 1 only)
 template <int NB, int FAST>
 __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayout L = lds_layout(a.K);
-    float *s_nb = reinterpret_cast<float *>(smem + L.off_nb);
-    const int nb_plane = a.K * NB_ROW;
-    double *s_pw = reinterpret_cast<double *>(smem + L.off_pw);
-    int *s_kv = reinterpret_cast<int *>(smem + L.off_kv);
-    int *s_nfound = reinterpret_cast<int *>(smem + L.off_nfound);
-    int *s_ncand = reinterpret_cast<int *>(smem + L.off_ncand);
-    VoxEnt *s_vox = reinterpret_cast<VoxEnt *>(smem + L.off_vox);
-    Surv *s_surv = reinterpret_cast<Surv *>(smem + L.off_surv);
-    double *s_jrec = reinterpret_cast<double *>(smem + L.off_surv);   // alias, used after the barrier
-    int *s_misc = reinterpret_cast<int *>(smem + L.off_misc);
-
+    const LdsLayout L = lds_layout(a.K, NB);
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wave = tid >> 6;
-    const int base = blockIdx.x * SRL_KPB;
+    unsigned char *wbase = smem + wave * L.wave_bytes;
+    float *s_nb = reinterpret_cast<float *>(wbase + L.off_nb);
+    const int nb_plane = a.K * NB_ROW;
+    double *s_pw = reinterpret_cast<double *>(wbase + L.off_pw);
+    double *s_pimu = reinterpret_cast<double *>(wbase + L.off_pimu);
+    int *s_kv = reinterpret_cast<int *>(wbase + L.off_kv);
+    int *s_nfound = reinterpret_cast<int *>(wbase + L.off_nfound);
+    int *s_ncand = reinterpret_cast<int *>(wbase + L.off_ncand);
+    VoxEnt *vox = reinterpret_cast<VoxEnt *>(wbase + L.off_vox);
+    Surv *surv = reinterpret_cast<Surv *>(wbase + L.off_scratch);
+    double *s_wpart = reinterpret_cast<double *>(smem + L.off_wpart);     // [4][32]
+    int *s_winfo = reinterpret_cast<int *>(smem + L.off_winfo);           // [4][4]: accepted, sum_pk, nan, fallback
 
-    // ---------------- phase 0: transformKeypoints (optimize.cpp:30-40), location (optimize.cpp:83)
-    D3 p_imu = d3(0, 0, 0), p_w = d3(0, 0, 0);
-    if (tid < SRL_KPB) {
-        const int g = base + tid;
+    const int wbase_kp = blockIdx.x * SRL_KPB + wave * SRL_KPW;           // first keypoint of this wave
+
+    // ---------------- phase 0: transformKeypoints (optimize.cpp:30-40), location (optimize.cpp:83), voxel key
+    if (lane < SRL_KPW) {
+        const int g = wbase_kp + lane;
+        D3 p_imu = d3(0, 0, 0), p_w = d3(0, 0, 0);
         if (g < a.n) {
             const D3 raw = d3(a.raw_x[g], a.raw_y[g], a.raw_z[g]);
             p_imu = add(matvec(a.R_il, raw), d3(a.t_il[0], a.t_il[1], a.t_il[2]));
             p_w = add(matvec(a.Rn, p_imu), d3(a.t[0], a.t[1], a.t[2]));
         }
-        s_pw[tid * 3 + 0] = p_w.x;
-        s_pw[tid * 3 + 1] = p_w.y;
-        s_pw[tid * 3 + 2] = p_w.z;
+        s_pw[lane * 3 + 0] = p_w.x; s_pw[lane * 3 + 1] = p_w.y; s_pw[lane * 3 + 2] = p_w.z;
+        s_pimu[lane * 3 + 0] = p_imu.x; s_pimu[lane * 3 + 1] = p_imu.y; s_pimu[lane * 3 + 2] = p_imu.z;
         // static_cast<short>(point / size_voxel_map): truncation toward zero (optimize.cpp:372-374)
-        s_kv[tid * 4 + 0] = (int)(short)(int)(p_w.x / a.size_voxel);
-        s_kv[tid * 4 + 1] = (int)(short)(int)(p_w.y / a.size_voxel);
-        s_kv[tid * 4 + 2] = (int)(short)(int)(p_w.z / a.size_voxel);
-        s_nfound[tid] = 0;
-        s_ncand[tid] = 0;
+        s_kv[lane * 4 + 0] = (int)(short)(int)(p_w.x / a.size_voxel);
+        s_kv[lane * 4 + 1] = (int)(short)(int)(p_w.y / a.size_voxel);
+        s_kv[lane * 4 + 2] = (int)(short)(int)(p_w.z / a.size_voxel);
+        s_nfound[lane] = 0;
+        s_ncand[lane] = 0;
     }
-    if (tid == 0) s_misc[0] = 0;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 
-    // ---------------- phase 1: searchNeighbors, one wave per keypoint
+    // ---------------- phase 1: searchNeighbors, the whole wave on one keypoint at a time
+    int n_fallback = 0;
     {
-        VoxEnt *vox = s_vox + wave * 128;
-        Surv *surv = reinterpret_cast<Surv *>(smem + L.off_surv + wave * SRL_WAVE_SCRATCH);
-        int n_fallback = 0;
         const LaneRole role0 = lane_role(lane);
-        for (int i = 0; i < SRL_KPB / 4; ++i) {
+        for (int kl = 0; kl < SRL_KPW; ++kl) {
             LaneRole role = role0;
             asm volatile("" : "+v"(role.c0), "+v"(role.slot));   // recompute the few role-derived values per keypoint instead of spilling them
-            const int kl = wave * (SRL_KPB / 4) + i;
-            const int g = base + kl;
+            const int g = wbase_kp + kl;
             if (g >= a.n) break;
             const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
             LdsSink sink;
@@ -743,80 +762,91 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
                 s_ncand[kl] = total;
             }
         }
-        if (lane == 0 && n_fallback) atomicAdd(&s_misc[0], n_fallback);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 
-    // ---------------- phase 2: plane fit + residual + Jacobian, one thread per keypoint (wave 0)
-    if (wave != 0) return;
-    const int g = base + tid;
+    // ---------------- phase 2: plane fit + residual + Jacobian for this wave's 16 keypoints, 4 lanes each.
+    // Sub-lane s accumulates neighbours s, s+4, ...; quad butterflies make the sums identical in the 4 lanes,
+    // which then run the (scalar) eigen-solve / weights redundantly and split the 28 H^T H / H^T h / loss
+    // products between them (7 each) before the sum over keypoints.
+    const int kl = lane >> 2, sl = lane & 3;
+    const int g = wbase_kp + kl;
     int status = 3;
     bool nan_bad = false;
     double J[6] = {0, 0, 0, 0, 0, 0};
     double dist = 0.0, weight = 0.0;
-    const int nf = s_nfound[tid];
-    if (g < a.n) {
-        status = 0;
-        if (nf >= a.min_nb && !(a.ablate & 1)) {
-            // barycenter, sequential in neighbour order (optimize.cpp:320-325)
-            D3 bc = d3(0, 0, 0);
-            for (int i = 0; i < nf; ++i) {
-                const float *p = s_nb + i * NB_ROW + tid;
-                bc = add(bc, d3((double)p[0], (double)p[nb_plane], (double)p[2 * nb_plane]));
-            }
-            const double inv_n = (double)nf;
-            bc = d3(bc.x / inv_n, bc.y / inv_n, bc.z / inv_n);
-            double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-            for (int i = 0; i < nf; ++i) {
-                const float *p = s_nb + i * NB_ROW + tid;
-                const double ex = (double)p[0] - bc.x, ey = (double)p[nb_plane] - bc.y, ez = (double)p[2 * nb_plane] - bc.z;
-                C[0][0] += ex * ex; C[0][1] += ex * ey; C[0][2] += ex * ez;
-                C[1][1] += ey * ey; C[1][2] += ey * ez;
-                C[2][2] += ez * ez;
-            }
-            C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
-            double ev[3];
-            D3 nrm;
-            if (a.select_mode == 4) eig3_jacobi(C, ev, nrm);
-            else eig3_closed(C, ev, nrm);
-            nrm = normalized3(nrm);                                   // .col(0).normalized() (optimize.cpp:340)
-            const double sigma_1 = sqrt(fabs(ev[2]));
-            const double sigma_2 = sqrt(fabs(ev[1]));
-            const double sigma_3 = sqrt(fabs(ev[0]));
-            const double a2D = (sigma_2 - sigma_3) / sigma_1;          // optimize.cpp:343-346
-            if (a2D != a2D) nan_bad = true;                           // optimize.cpp:348-350
-            double w_plan = (a.power_planarity == 2.0) ? a2D * a2D : pow(a2D, a.power_planarity);
-            // normal flip: world-frame last translation minus body-frame location (optimize.cpp:49-51)
-            const D3 tl = d3(a.t_last[0], a.t_last[1], a.t_last[2]);
-            if (dot3(nrm, sub(tl, p_imu)) < 0.0) nrm = d3(-1.0 * nrm.x, -1.0 * nrm.y, -1.0 * nrm.z);
-            const D3 nn0 = d3((double)s_nb[tid], (double)s_nb[nb_plane + tid], (double)s_nb[2 * nb_plane + tid]);
-            const D3 dq = sub(nn0, p_w);
-            weight = a.lambda_w * w_plan + a.lambda_n * exp(-sqrt(dot3(dq, dq)) / a.nbr_scale);   // optimize.cpp:87-88
-            const D3 nv = normalized3(nrm);                            // optimize.cpp:93
-            const double off = -dot3(nv, nn0);                         // optimize.cpp:94
-            const D3 pe = add(matvec(a.R, p_imu), d3(a.t[0], a.t[1], a.t[2]));
-            dist = dot3(nv, pe) + off;                                 // optimize.cpp:95
-            status = 1;
-            if (a.tap_normal) {
-                a.tap_normal[(size_t)g * 3 + 0] = nv.x; a.tap_normal[(size_t)g * 3 + 1] = nv.y; a.tap_normal[(size_t)g * 3 + 2] = nv.z;
-                a.tap_a2d[g] = a2D;
-                a.tap_offset[g] = off;
-            }
-            if (dist < a.max_dist) {                                   // signed gate (optimize.cpp:98)
-                status = 2;
-                J[0] = nv.x * weight; J[1] = nv.y * weight; J[2] = nv.z * weight;
-                // - n^T * R * skew(p_imu) * weight, left to right (optimize.cpp:101)
-                const double m0 = -nv.x, m1 = -nv.y, m2 = -nv.z;
-                const double r0 = (m0 * a.R[0] + m1 * a.R[3]) + m2 * a.R[6];
-                const double r1 = (m0 * a.R[1] + m1 * a.R[4]) + m2 * a.R[7];
-                const double r2 = (m0 * a.R[2] + m1 * a.R[5]) + m2 * a.R[8];
-                // skew(p) = [[0,-pz,py],[pz,0,-px],[-py,px,0]]
-                const double s0 = (r0 * 0.0 + r1 * p_imu.z) + r2 * (-p_imu.y);
-                const double s1 = (r0 * (-p_imu.z) + r1 * 0.0) + r2 * p_imu.x;
-                const double s2 = (r0 * p_imu.y + r1 * (-p_imu.x)) + r2 * 0.0;
-                J[3] = s0 * weight; J[4] = s1 * weight; J[5] = s2 * weight;
-            }
+    const int nf = s_nfound[kl];
+    if (g < a.n) status = 0;
+    const bool fit = (g < a.n) && (nf >= a.min_nb) && !(a.ablate & 1);
+    // the butterflies need all four sub-lanes of a quad active together: `fit` is uniform inside a quad
+    if (fit) {
+        const D3 p_imu = d3(s_pimu[kl * 3 + 0], s_pimu[kl * 3 + 1], s_pimu[kl * 3 + 2]);
+        const D3 p_w = d3(s_pw[kl * 3 + 0], s_pw[kl * 3 + 1], s_pw[kl * 3 + 2]);
+        // barycenter (optimize.cpp:320-325)
+        D3 bc = d3(0, 0, 0);
+        for (int i = sl; i < nf; i += 4) {
+            const float *p = s_nb + i * NB_ROW + kl;
+            bc = add(bc, d3((double)p[0], (double)p[nb_plane], (double)p[2 * nb_plane]));
         }
+        bc = d3(quad_sum(bc.x), quad_sum(bc.y), quad_sum(bc.z));
+        const double cnt = (double)nf;
+        bc = d3(bc.x / cnt, bc.y / cnt, bc.z / cnt);
+        // scatter matrix, upper triangle (optimize.cpp:328-337)
+        double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+        for (int i = sl; i < nf; i += 4) {
+            const float *p = s_nb + i * NB_ROW + kl;
+            const double ex = (double)p[0] - bc.x, ey = (double)p[nb_plane] - bc.y, ez = (double)p[2 * nb_plane] - bc.z;
+            c00 += ex * ex; c01 += ex * ey; c02 += ex * ez;
+            c11 += ey * ey; c12 += ey * ez;
+            c22 += ez * ez;
+        }
+        double C[3][3];
+        C[0][0] = quad_sum(c00); C[0][1] = quad_sum(c01); C[0][2] = quad_sum(c02);
+        C[1][1] = quad_sum(c11); C[1][2] = quad_sum(c12); C[2][2] = quad_sum(c22);
+        C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
+        double ev[3];
+        D3 nrm;
+        if (a.select_mode == 4) eig3_jacobi(C, ev, nrm);
+        else eig3_closed(C, ev, nrm);
+        nrm = normalized3(nrm);                                   // .col(0).normalized() (optimize.cpp:340)
+        const double sigma_1 = sqrt(fabs(ev[2]));
+        const double sigma_2 = sqrt(fabs(ev[1]));
+        const double sigma_3 = sqrt(fabs(ev[0]));
+        const double a2D = (sigma_2 - sigma_3) / sigma_1;          // optimize.cpp:343-346
+        if (a2D != a2D) nan_bad = true;                           // optimize.cpp:348-350
+        const double w_plan = (a.power_planarity == 2.0) ? a2D * a2D : pow(a2D, a.power_planarity);
+        // normal flip: world-frame last translation minus body-frame location (optimize.cpp:49-51)
+        const D3 tl = d3(a.t_last[0], a.t_last[1], a.t_last[2]);
+        if (dot3(nrm, sub(tl, p_imu)) < 0.0) nrm = d3(-1.0 * nrm.x, -1.0 * nrm.y, -1.0 * nrm.z);
+        const D3 nn0 = d3((double)s_nb[kl], (double)s_nb[nb_plane + kl], (double)s_nb[2 * nb_plane + kl]);
+        const D3 dq = sub(nn0, p_w);
+        weight = a.lambda_w * w_plan + a.lambda_n * exp(-sqrt(dot3(dq, dq)) / a.nbr_scale);   // optimize.cpp:87-88
+        const D3 nv = normalized3(nrm);                            // optimize.cpp:93
+        const double off = -dot3(nv, nn0);                         // optimize.cpp:94
+        const D3 pe = add(matvec(a.R, p_imu), d3(a.t[0], a.t[1], a.t[2]));
+        dist = dot3(nv, pe) + off;                                 // optimize.cpp:95
+        status = 1;
+        if (a.tap_normal && sl == 0) {
+            a.tap_normal[(size_t)g * 3 + 0] = nv.x; a.tap_normal[(size_t)g * 3 + 1] = nv.y; a.tap_normal[(size_t)g * 3 + 2] = nv.z;
+            a.tap_a2d[g] = a2D;
+            a.tap_offset[g] = off;
+        }
+        if (dist < a.max_dist) {                                   // signed gate (optimize.cpp:98)
+            status = 2;
+            J[0] = nv.x * weight; J[1] = nv.y * weight; J[2] = nv.z * weight;
+            // - n^T * R * skew(p_imu) * weight, left to right (optimize.cpp:101)
+            const double m0 = -nv.x, m1 = -nv.y, m2 = -nv.z;
+            const double r0 = (m0 * a.R[0] + m1 * a.R[3]) + m2 * a.R[6];
+            const double r1 = (m0 * a.R[1] + m1 * a.R[4]) + m2 * a.R[7];
+            const double r2 = (m0 * a.R[2] + m1 * a.R[5]) + m2 * a.R[8];
+            // skew(p) = [[0,-pz,py],[pz,0,-px],[-py,px,0]]
+            const double s0 = (r0 * 0.0 + r1 * p_imu.z) + r2 * (-p_imu.y);
+            const double s1 = (r0 * (-p_imu.z) + r1 * 0.0) + r2 * p_imu.x;
+            const double s2 = (r0 * p_imu.y + r1 * (-p_imu.x)) + r2 * 0.0;
+            J[3] = s0 * weight; J[4] = s1 * weight; J[5] = s2 * weight;
+        }
+    }
+    if (g < a.n && sl == 0) {
         // per-keypoint record (ordered cut-off path + taps)
         double *rec = a.rec + (size_t)g * 8;
 #pragma unroll
@@ -824,48 +854,67 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
         rec[6] = dist;
         rec[7] = weight;
         a.status[g] = (unsigned char)status;
-        if (a.tap_ncand) a.tap_ncand[g] = s_ncand[tid];
+        if (a.tap_ncand) a.tap_ncand[g] = s_ncand[kl];
     }
-    // records to LDS for the in-order block partial
-#pragma unroll
-    for (int c = 0; c < 6; c++) s_jrec[tid * 8 + c] = J[c];
-    s_jrec[tid * 8 + 6] = dist;
-    s_jrec[tid * 8 + 7] = weight;
-    const unsigned long long acc_mask = __ballot(status == 2);
-    const unsigned long long nan_mask = __ballot(nan_bad);
-    int pk = (g < a.n) ? s_ncand[tid] : 0;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
-    __builtin_amdgcn_wave_barrier();      // LDS is in-order per wave: the reads below see every lane's record
 
-    // component lane c: 0..20 upper-tri HtH (row-major a<=b), 21..26 Hth, 27 loss
+    // ---- wave partial of H^T H (21 upper-tri), H^T h (6), loss (1): component c = 4 m + sub, m = 0..6
+    {
+        const double h = dist * weight;                           // optimize.cpp:169
+        const bool accd = status == 2;
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            const int c = 4 * m + sl;
+            double v = 0.0;
+            if (accd) {
+                if (c < 21) {
+                    int ia = 0, cc = c, rowlen = 6;
+                    while (cc >= rowlen) { cc -= rowlen; ia++; rowlen--; }
+                    const int ib = ia + cc;
+                    // select J[ia], J[ib] without runtime register indexing
+                    double ja = J[0], jb = J[0];
+#pragma unroll
+                    for (int t = 1; t < 6; ++t) { ja = (ia == t) ? J[t] : ja; jb = (ib == t) ? J[t] : jb; }
+                    v = ja * jb;
+                } else if (c < 27) {
+                    const int ia = c - 21;
+                    double ja = J[0];
+#pragma unroll
+                    for (int t = 1; t < 6; ++t) ja = (ia == t) ? J[t] : ja;
+                    v = ja * h;
+                } else {
+                    v = dist * dist;                              // loss (optimize.cpp:104)
+                }
+            }
+            v = kp_sum(v);
+            if (lane < 4) s_wpart[wave * 32 + c] = v;
+        }
+    }
+    {
+        const unsigned long long acc_mask = __ballot(status == 2 && sl == 0);
+        const unsigned long long nan_mask = __ballot(nan_bad);
+        int pk = (lane < SRL_KPW && wbase_kp + lane < a.n) ? s_ncand[lane] : 0;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
+        if (lane == 0) {
+            s_winfo[wave * 4 + 0] = __popcll(acc_mask);
+            s_winfo[wave * 4 + 1] = pk;
+            s_winfo[wave * 4 + 2] = nan_mask ? 1 : 0;
+            s_winfo[wave * 4 + 3] = n_fallback;
+        }
+    }
+    __syncthreads();
+
+    // ---- block partial = wave partials added in wave order (deterministic)
     if (tid < 28) {
-        int ia = 0, ib = 0;
-        if (tid < 21) {
-            int c = tid;
-            ia = 0;
-            int rowlen = 6;
-            while (c >= rowlen) { c -= rowlen; ia++; rowlen--; }
-            ib = ia + c;
-        } else if (tid < 27) {
-            ia = tid - 21;
-        }
-        double acc = 0.0;
-        for (int k = 0; k < SRL_KPB; ++k) {
-            if (!((acc_mask >> k) & 1ull)) continue;
-            const double *r = s_jrec + k * 8;
-            if (tid < 21) acc += r[ia] * r[ib];
-            else if (tid < 27) acc += r[ia] * (r[6] * r[7]);      // h = distance * weight (optimize.cpp:169)
-            else acc += r[6] * r[6];                              // loss (optimize.cpp:104)
-        }
-        a.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] = acc;
+        const double v = ((s_wpart[tid] + s_wpart[32 + tid]) + s_wpart[64 + tid]) + s_wpart[96 + tid];
+        a.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] = v;
     }
     if (tid == 0) {
         SrlBlockInfo bi;
-        bi.accepted = __popcll(acc_mask);
-        bi.sum_pk = (unsigned)pk;
-        bi.nan_flag = nan_mask ? 1 : 0;
-        bi.num_fallback = s_misc[0];
+        bi.accepted = s_winfo[0] + s_winfo[4] + s_winfo[8] + s_winfo[12];
+        bi.sum_pk = (unsigned)(s_winfo[1] + s_winfo[5] + s_winfo[9] + s_winfo[13]);
+        bi.nan_flag = (s_winfo[2] | s_winfo[6] | s_winfo[10] | s_winfo[14]) ? 1 : 0;
+        bi.num_fallback = s_winfo[3] + s_winfo[7] + s_winfo[11] + s_winfo[15];
         a.binfo[blockIdx.x] = bi;
     }
 }
@@ -1048,7 +1097,7 @@ __global__ void srl_aos_to_soa_kernel(const double *aos, int n, double *x, doubl
 hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
     const int nblocks = (a.n + SRL_KPB - 1) / SRL_KPB;
-    const LdsLayout L = lds_layout(a.K);
+    const LdsLayout L = lds_layout(a.K, nb_voxels);
     if (nb_voxels == 1) {
         if (a.select_mode == 0 || a.select_mode == 4) hipLaunchKernelGGL((srl_assoc_kernel<1, 1>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
         else if (a.select_mode == 3) hipLaunchKernelGGL((srl_assoc_kernel<1, 2>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
