@@ -121,6 +121,11 @@ int srl_ctx_create(int device, srl_ctx **out) {
         delete ctx;
         return SRL_ERR_HIP;
     }
+    if (hipHostMalloc((void **)&ctx->h_mail, sizeof(SrlMailbox), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+        delete ctx;
+        return SRL_ERR_HIP;
+    }
+    std::memset(ctx->h_mail, 0, sizeof(SrlMailbox));
     for (int i = 0; i < 4; i++) hipEventCreate(&ctx->ev[i]);
     *out = ctx;
     return SRL_OK;
@@ -137,6 +142,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     for (void *b : bufs) if (b) hipFree(b);
     if (ctx->h_out) hipHostFree(ctx->h_out);
     if (ctx->h_count) hipHostFree(ctx->h_count);
+    if (ctx->h_mail) hipHostFree(ctx->h_mail);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -398,6 +404,11 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     ra.nblocks = nblocks;
     ra.max_res = budget;
     ra.out = ctx->d_out;
+    // single rank: the reduce kernel publishes straight into host-mapped memory and the host spins on the
+    // sequence word -- no D2H copy, no stream synchronisation on the per-iteration critical path
+    const bool mailbox = (ctx->nranks == 1);
+    ra.mailbox = mailbox ? ctx->h_mail : nullptr;
+    ra.seq = ++ctx->seq;
     HIPCHK(ctx, srl_launch_reduce(ra, mode, ctx->stream));
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     const auto t_enq = std::chrono::steady_clock::now();
@@ -413,6 +424,18 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         visited_local = ctx->h_out->last_visited + 1;
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    } else if (mailbox) {
+        volatile unsigned long long *seqp = &ctx->h_mail->seq;
+        unsigned long long spins = 0;
+        while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != ra.seq) {
+            if ((++spins & 0xFFFFF) == 0) {           // every ~1M polls: make sure the stream has not faulted
+                const hipError_t qe = hipStreamQuery(ctx->stream);
+                if (qe != hipSuccess && qe != hipErrorNotReady) { ctx->err = std::string("reduce kernel: ") + hipGetErrorString(qe); return SRL_ERR_HIP; }
+                if (qe == hipSuccess && __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != ra.seq) { ctx->err = "reduce kernel finished without publishing"; return SRL_ERR_HIP; }
+            }
+        }
+        std::memcpy(ctx->h_out, &ctx->h_mail->out, sizeof(SrlDevOut));
+        visited_local = ctx->h_out->last_visited + 1;
     } else {
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

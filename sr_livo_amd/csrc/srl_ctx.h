@@ -39,6 +39,8 @@ struct srl_ctx {
     SrlDevOut *h_out = nullptr;        // pinned
     long long *d_count = nullptr;
     long long *h_count = nullptr;      // pinned
+    SrlMailbox *h_mail = nullptr;      // host-mapped fine-grained mailbox the reduce kernel publishes into
+    unsigned long long seq = 0;
 
     // taps
     bool taps = false;

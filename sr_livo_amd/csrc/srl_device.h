@@ -61,6 +61,12 @@ struct SrlDevOut {             // result of the reduce kernel (device, then copi
     long long pad;
 };
 
+struct SrlMailbox {            // host-mapped (fine-grained) memory the reduce kernel publishes into (single rank)
+    SrlDevOut out;
+    unsigned long long seq;    // = launch sequence number once `out` is complete
+    unsigned long long pad[7];
+};
+
 struct SrlAssocArgs {
     // sweep
     const double *raw_x, *raw_y, *raw_z;
@@ -108,7 +114,9 @@ struct SrlReduceArgs {
     int n;
     int nblocks;
     long long max_res;          // residual budget for THIS rank (already reduced by earlier ranks' counts)
-    SrlDevOut *out;
+    SrlDevOut *out;             // device result (multi-rank: all-reduced afterwards) ...
+    SrlMailbox *mailbox;        // ... or, single rank: host-mapped mailbox written with system-scope stores (no memcpy)
+    unsigned long long seq;
 };
 
 struct SrlSearchArgs {

@@ -944,10 +944,19 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
     s_chunk[tid] = acc;
     if (tid < 4) s_tot[tid] = 0;
     __syncthreads();
-    if (acc) atomicAdd((unsigned long long *)&s_tot[0], (unsigned long long)acc);
-    if (pk) atomicAdd((unsigned long long *)&s_tot[1], (unsigned long long)pk);
-    if (nanf) atomicAdd((unsigned long long *)&s_tot[2], (unsigned long long)nanf);
-    if (fb) atomicAdd((unsigned long long *)&s_tot[3], (unsigned long long)fb);
+    {   // wave-level sums first (integers: order irrelevant), then one LDS atomic per wave and counter
+        long long w0 = acc, w1 = pk, w2 = nanf, w3 = fb;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            w0 += __shfl_xor(w0, off); w1 += __shfl_xor(w1, off); w2 += __shfl_xor(w2, off); w3 += __shfl_xor(w3, off);
+        }
+        if ((tid & 63) == 0) {
+            if (w0) atomicAdd((unsigned long long *)&s_tot[0], (unsigned long long)w0);
+            if (w1) atomicAdd((unsigned long long *)&s_tot[1], (unsigned long long)w1);
+            if (w2) atomicAdd((unsigned long long *)&s_tot[2], (unsigned long long)w2);
+            if (w3) atomicAdd((unsigned long long *)&s_tot[3], (unsigned long long)w3);
+        }
+    }
     __syncthreads();
 
     if (tid == 0) {
@@ -983,16 +992,32 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
 
     // deterministic sum of the partials of all blocks strictly before the cut block:
     // part p sums blocks b == p (mod 32) ascending; parts are then added in order 0..31.
+    // 32 independent coalesced loads are in flight per thread before the first add (one memory round trip).
     {
         const int comp = tid & 31, part = tid >> 5;
         double s0 = 0.0;
-        if (comp < 28) {
-#pragma unroll 4
-            for (int b = part; b < cut_block; b += 32) s0 += a.partials[(size_t)b * SRL_PART_STRIDE + comp];
+        for (int b0 = part; b0 < cut_block; b0 += 32 * 32) {
+            double v[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const int b = b0 + 32 * k;
+                v[k] = (b < cut_block) ? a.partials[(size_t)b * SRL_PART_STRIDE + comp] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) s0 += v[k];
         }
         s_part[part][comp] = s0;
     }
     __syncthreads();
+    // results: to the host-mapped mailbox with system-scope (write-through) stores when given, else to device memory
+    SrlDevOut *out = a.mailbox ? &a.mailbox->out : a.out;
+    const bool to_host = a.mailbox != nullptr;
+    auto put_f = [to_host](double *p, double x) {
+        if (to_host) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else *p = x;
+    };
+    auto put_i = [to_host](long long *p, long long x) {
+        if (to_host) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else *p = x;
+    };
     if (tid < 28) {
         double s = s_part[0][tid];
         for (int p = 1; p < 32; ++p) s += s_part[p][tid];
@@ -1015,22 +1040,27 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
             int ia = 0, c = tid, rowlen = 6;
             while (c >= rowlen) { c -= rowlen; ia++; rowlen--; }
             const int ib = ia + c;
-            a.out->HtH[ia * 6 + ib] = s;
-            a.out->HtH[ib * 6 + ia] = s;
+            put_f(&out->HtH[ia * 6 + ib], s);
+            if (ib != ia) put_f(&out->HtH[ib * 6 + ia], s);
         } else if (tid < 27) {
-            a.out->Hth[tid - 21] = s;
+            put_f(&out->Hth[tid - 21], s);
         } else {
-            a.out->loss = s;
+            put_f(&out->loss, s);
         }
     }
-    if (tid == 0) {
-        a.out->d_num_res = (double)s_cut[3];
-        a.out->d_total_accepted = (double)s_tot[0];
-        a.out->d_sum_pk = (double)s_tot[1];
-        a.out->d_nan = (double)s_tot[2];
-        a.out->d_fallback = (double)s_tot[3];
-        a.out->last_visited = last_visited;
-        a.out->pad = 0;
+    if (tid == 32) {
+        put_f(&out->d_num_res, (double)s_cut[3]);
+        put_f(&out->d_total_accepted, (double)s_tot[0]);
+        put_f(&out->d_sum_pk, (double)s_tot[1]);
+        put_f(&out->d_nan, (double)s_tot[2]);
+        put_f(&out->d_fallback, (double)s_tot[3]);
+        put_i(&out->last_visited, (long long)last_visited);
+        put_i(&out->pad, 0);
+    }
+    if (to_host && tid < 64) {
+        // every writer sits in wave 0: drain the write-through stores, then publish the sequence word
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) __hip_atomic_store(&a.mailbox->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
