@@ -130,6 +130,17 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    # PCIe-inclusive rate (never `value`): the sweep crosses the host boundary on every solve
+    # (srl_sweep_upload: 24 B/keypoint H2D + SoA transpose), the map stays resident.
+    n_pcie = max(3, min(10, args.steps))
+    barrier()
+    t2 = time.perf_counter()
+    for _ in range(n_pcie):
+        lio.resident_sweep(sweep["raw"])
+        solve()
+    barrier()
+    pcie_elapsed = time.perf_counter() - t2
+
     iters = r["iters"]
     sweeps_per_step = world if (world > 1 and not sharded) else 1
     value = sweeps_per_step * args.steps / elapsed
@@ -161,6 +172,7 @@ def main():
         "host_us_per_iter": {"enqueue": tim.sum_host_launch_us / calls, "wait_results": tim.sum_host_wait_us / calls,
                              "build_residuals_call": tim.sum_host_total_us / calls,
                              "whole_iteration": ms_per_step * 1e3 / max(iters, 1)},
+        "pcie_inclusive_sweeps_per_s": (world if (world > 1 and not sharded) else 1) * n_pcie / pcie_elapsed,
         "setup_s": setup_s,
     }
 
