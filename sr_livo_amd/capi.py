@@ -10,7 +10,7 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrlivo_hip.so")
+LIB_PATH = os.environ.get("SRL_LIB_PATH") or os.path.join(_HERE, "libsrlivo_hip.so")   # env override: A/B builds only
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 SRL_OK = 0

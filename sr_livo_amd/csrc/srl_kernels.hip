@@ -769,8 +769,9 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     // Sub-lane s accumulates neighbours s, s+4, ...; quad butterflies make the sums identical in the 4 lanes,
     // which then run the (scalar) eigen-solve / weights redundantly and split the 28 H^T H / H^T h / loss
     // products between them (7 each) before the sum over keypoints.
-    const int kl = lane >> 2, sl = lane & 3;
-    const int g = wbase_kp + kl;
+    const int kl = (lane >> 2) < SRL_KPW ? (lane >> 2) : (SRL_KPW - 1), sl = lane & 3;
+    const bool owner_lane = (lane >> 2) < SRL_KPW;          // KPW < 16: the upper quads idle through phase 2
+    const int g = owner_lane ? wbase_kp + kl : a.n;
     int status = 3;
     bool nan_bad = false;
     double J[6] = {0, 0, 0, 0, 0, 0};
@@ -894,7 +895,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
         const unsigned long long nan_mask = __ballot(nan_bad);
         int pk = (lane < SRL_KPW && wbase_kp + lane < a.n) ? s_ncand[lane] : 0;
 #pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
+        for (int off = 32; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
         if (lane == 0) {
             s_winfo[wave * 4 + 0] = __popcll(acc_mask);
             s_winfo[wave * 4 + 1] = pk;

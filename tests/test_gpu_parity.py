@@ -411,3 +411,110 @@ def test_optimize_end_to_end_vs_oracle(oracle_lib, golden, oracle_backend):
         assert rel(r["world"], lio.ctx.transform_points(raw, q, t)) < 1e-15
     finally:
         lio.close()
+
+
+# ----------------------------------------------------------------------------- BASELINE.json configs at full size
+def _full_size_case(oracle_lib, oracle_backend, n_kp, map_pts, pattern, seed, check_oracle_pass=True):
+    """Build the map twice (oracle sequential insert, device insert), compare them bit for bit, then one pass
+    and one full solve against the oracle, plus size-independent properties."""
+    pts, L = synth.map_candidates(seed, map_pts)
+    sw = synth.make_sweep(seed + 1000, n_kp, L, pattern=pattern)
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(pts)
+    lio = srl.Lio(0)
+    try:
+        lio.add_points_to_map(pts)
+        assert lio.map_size() == m.size()
+        kg, cg, xg = lio.ctx.map_download()
+        ko, co, xo = m.export()
+        assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
+
+        g = gpu_pass(lio.ctx, sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"], max_num_residuals=INT_MAX)
+        # properties that need no oracle: idempotence (bitwise), every id points at a stored point,
+        # neighbours sorted by distance, checksum of per-keypoint candidates = kernel's own total
+        g2 = gpu_pass(lio.ctx, sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"], max_num_residuals=INT_MAX)
+        assert np.array_equal(np.array(g["neq"].HtH), np.array(g2["neq"].HtH)) and np.array_equal(g["ids"], g2["ids"])
+        assert int(g["ncand"].sum()) == g["neq"].sum_candidates
+        ids = g["ids"]; ok = ids >= 0
+        assert np.all(cg[ids[ok] // 20] > ids[ok] % 20)
+        R = synth.quat_to_rot(sw["q_pred"] / np.linalg.norm(sw["q_pred"]))
+        pw = sw["raw"] @ R.T + sw["t_pred"]
+        full = ok.all(1)
+        nbp = xg.reshape(-1, 3)[ids[full]].astype(np.float64)
+        d = np.linalg.norm(nbp - pw[full][:, None, :], axis=2)
+        assert np.all(np.diff(d, axis=1) >= 0)
+        if check_oracle_pass:
+            o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=INT_MAX), sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"])
+            ref = {f"x_one_{k}": v for k, v in o.items() if isinstance(v, np.ndarray)}
+            ref.update(x_one_num_ties=o["neq"].num_ties, x_one_num_residuals=o["neq"].num_residuals, x_one_success=o["neq"].success,
+                       x_one_loss=o["neq"].loss_sum)
+            check_pass_against(g, ref, "x")
+            assert g["neq"].sum_candidates == o["neq"].sum_candidates
+        # full solve: both the throughput setting and the shipped max_num_residuals = 600
+        for max_res in (INT_MAX, 600):
+            e = oracle_lib.Eskf(oracle_backend)
+            synth.eskf_prior(e, sw["q_pred"], sw["t_pred"], sw["vel"])
+            lio.eskf_set_state(e.get_state()); lio.eskf_set_cov(e.get_cov())
+            st = state16(sw)
+            opts = srl.default_opts(max_num_residuals=max_res)
+            r = lio.update_iekf(opts, sw["raw"], st, sw["t_last"])
+            u = oracle_lib.update_iekf(m, e, oracle_lib.opts_from_product(opts), sw["raw"], st, sw["t_last"])
+            assert r["rc"] == 0 and r["iters"] == u["rc"] and r["num_residuals"] == u["num_residuals"]
+            assert rel(r["state"], u["state"]) < 1e-9
+            assert rel(lio.eskf_get_cov(), e.get_cov()) < 1e-8
+    finally:
+        lio.close()
+
+
+def test_config2_r3live_24k_on_1M(oracle_lib, oracle_backend):
+    """BASELINE configs[1]: Livox-like sweep (24 576 keypoints), 1 M-point map, full ESIKF solve."""
+    _full_size_case(oracle_lib, oracle_backend, *synth.CONFIGS["C2"])
+
+
+def test_config3_ouster16_16k_on_2M(oracle_lib, oracle_backend):
+    """BASELINE configs[2]: ring-indexed Ouster-16-like sweep (16 384 keypoints), 2 M-point map."""
+    _full_size_case(oracle_lib, oracle_backend, *synth.CONFIGS["C3"])
+
+
+def test_headline_64k_on_1M(oracle_lib, oracle_backend):
+    """The metric's own configuration: 65 536-keypoint Livox-like sweep, 1 M-point map."""
+    _full_size_case(oracle_lib, oracle_backend, *synth.CONFIGS["HEADLINE"])
+
+
+def test_config4_dense_256k_on_10M_logical_shards(oracle_lib, oracle_backend):
+    """BASELINE configs[3] on one device: 262 144 keypoints, 10 M-point / ~500 k-voxel map.  Map equality
+    with the sequential insert, kernel properties, the oracle on a 16 384-keypoint sample (ids bit-exact),
+    and additivity over 8 point-range shards (the sum the RCCL all-reduce performs)."""
+    n_kp, map_pts, pattern, seed = synth.CONFIGS["C4"]
+    pts, L = synth.map_candidates(seed, map_pts)
+    sw = synth.make_sweep(seed + 1000, n_kp, L, pattern=pattern)
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(pts)
+    ctx = srl.Context(0)
+    try:
+        assert ctx.map_insert(pts) == m.size()
+        kg, cg, xg = ctx.map_download()
+        ko, co, xo = m.export()
+        assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
+        assert len(cg) > 400_000 and m.size() > 9_000_000
+        g = gpu_pass(ctx, sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"], max_num_residuals=INT_MAX)
+        assert int(g["ncand"].sum()) == g["neq"].sum_candidates and g["neq"].num_fallback == 0
+        # oracle on a sample of keypoints
+        rng = np.random.default_rng(0)
+        sel = np.sort(rng.choice(n_kp, 16384, replace=False))
+        o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=INT_MAX), sw["raw"][sel], sw["q_pred"], sw["t_pred"], sw["t_last"])
+        assert o["neq"].num_ties == 0
+        assert np.array_equal(g["status"][sel], o["status"]) and np.array_equal(g["ids"][sel], o["ids"])
+        acc = o["status"] == 2
+        assert rel(g["jacobian"][sel][acc], o["jacobian"][acc]) < TIGHT and rel(g["distance"][sel][acc], o["distance"][acc]) < TIGHT
+        # additivity over 8 contiguous shards
+        HtH = np.zeros(36); Hth = np.zeros(6); nres = 0
+        for r in range(8):
+            b, c = srl.shard_range(n_kp, 8, r)
+            gs = gpu_pass(ctx, sw["raw"][b:b + c], sw["q_pred"], sw["t_pred"], sw["t_last"], max_num_residuals=INT_MAX)
+            HtH += np.array(gs["neq"].HtH); Hth += np.array(gs["neq"].Hth); nres += gs["neq"].num_residuals
+            assert np.array_equal(gs["ids"], g["ids"][b:b + c])
+        assert nres == g["neq"].num_residuals
+        assert rel(HtH, np.array(g["neq"].HtH)) < 1e-12 and rel(Hth, np.array(g["neq"].Hth)) < 1e-11
+    finally:
+        ctx.close()
