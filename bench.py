@@ -151,6 +151,20 @@ def main():
     bytes_per_launch = tim.sum_algorithmic_bytes / calls
     achieved = bytes_per_launch / (assoc_ms * 1e-3) / 1e9 if assoc_ms > 0 else 0.0
 
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (bench.py cannot
+    # profile itself): (2 x FETCH_SIZE + WRITE_SIZE) KB, the x2 being the gfx950 FETCH_SIZE correction for wide
+    # coalesced reads (MI355X_MICROARCH.md, HBM section).  null when no matching profile is committed.
+    traffic, traffic_src = None, None
+    try:
+        prof_path = os.path.join(ROOT, "profiles", "r01_final_rocprofv3_summary.json")
+        pm = json.load(open(prof_path))["pmc_per_dispatch"]
+        k = [v for n, v in pm.items() if "assoc" in n][0]
+        if args.workload == "HEADLINE" and world == 1:
+            traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+            traffic_src = "profiles/r01_final_rocprofv3_summary.json (separate --pmc passes of this command)"
+    except Exception:
+        pass
+
     out = {
         "metric": "sweeps/s (full ESIKF solve of a 64k-pt Livox sweep vs 1M-pt voxel map)",
         "value": value, "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +179,7 @@ def main():
                    "esikf_iterations_per_solve": iters, "residuals_used": r["num_residuals"]},
         "ms_per_esikf_iter": ms_per_step / max(iters, 1),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "srl_assoc_kernel<1>", "avg_launch_ms": assoc_ms, "launches": tim.calls,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "reduce_kernel_avg_ms": tim.sum_reduce_ms / calls, "device_total_avg_ms": tim.sum_total_ms / calls},
