@@ -158,7 +158,7 @@ int srl_map_upload(srl_ctx *ctx, const int16_t *keys_xyz, const int32_t *counts,
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // capacity with headroom so that srl_map_insert can add voxels without an immediate rebuild
     const unsigned slab_cap = std::max<unsigned>(1024u, (unsigned)V + (unsigned)V / 2u + 4096u);
-    const unsigned table_cap = next_pow2(std::max<unsigned>(2048u, 2u * slab_cap));
+    const unsigned table_cap = next_pow2(std::max<unsigned>(2048u, SRL_TABLE_FACTOR * slab_cap));
     std::vector<SrlSlab> slabs((size_t)V);
     std::vector<SrlMapSlot> table((size_t)table_cap);
     for (auto &s : table) { s.key = SRL_EMPTY_KEY; s.slab = 0; s.count = 0; }

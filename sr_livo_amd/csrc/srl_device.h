@@ -24,6 +24,7 @@
 #define SRL_WAVE_SCRATCH 2048  // bytes of LDS scratch per wave (fast path: 64 x 16 B records + 66 keys + 32 owners = 1688 B)
 #define SRL_MAXK 32
 #define SRL_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define SRL_TABLE_FACTOR 4u   // hash slots per voxel capacity (load <= 0.25: a 2-slot probe almost always resolves)
 #define SRL_PART_STRIDE 32
 
 struct SrlMapSlot {

@@ -247,32 +247,59 @@ __device__ __forceinline__ LaneRole lane_role(int lane) {
     return r;
 }
 
-__device__ __forceinline__ int probe_voxels_r1(int kx, int ky, int kz, const LaneRole &role, int thr_cap,
-                                               const SrlMapSlot *table, unsigned mask, VoxEnt *vox, int lane) {
+// Probe state of one keypoint: key, home slot and the first two table slots (a 2-slot window resolves
+// > 99 % of the probes at load <= 0.25).  Issued one keypoint ahead so the L2 round trip of the hash
+// lookup overlaps the previous keypoint's selection.
+struct ProbeReq {
+    unsigned long long key;
+    unsigned h;
+    SrlMapSlot s0, s1;
+};
+__device__ __forceinline__ ProbeReq probe_issue(int kx, int ky, int kz, const LaneRole &role, const SrlMapSlot *table,
+                                                unsigned mask, int lane) {
+    ProbeReq r;
+    r.key = SRL_EMPTY_KEY; r.h = 0;
+    r.s0.key = SRL_EMPTY_KEY; r.s0.slab = 0; r.s0.count = 0;
+    r.s1 = r.s0;
+    if (lane < 27) {
+        r.key = srl_pack_key((short)(kx + role.pdx), (short)(ky + role.pdy), (short)(kz + role.pdz));
+        r.h = srl_hash_key(r.key) & mask;
+        r.s0 = table[r.h];
+        r.s1 = table[(r.h + 1) & mask];
+    }
+    return r;
+}
+__device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, const SrlMapSlot *table, unsigned mask,
+                                            VoxEnt *vox, int lane) {
     bool found = false;
     unsigned slab = 0, cnt = 0;
     if (lane < 27) {
-        const unsigned long long key = srl_pack_key((short)(kx + role.pdx), (short)(ky + role.pdy), (short)(kz + role.pdz));
-        unsigned h = srl_hash_key(key) & mask;
-        for (unsigned probe = 0; probe <= mask; ++probe) {
-            const SrlMapSlot sl = table[h];
-            if (sl.key == key) {
-                found = (int)sl.count >= thr_cap && sl.count > 0;   // optimize.cpp:389
-                slab = sl.slab;
-                cnt = sl.count;
-                break;
+        if (r.s0.key == r.key) { slab = r.s0.slab; cnt = r.s0.count; found = true; }
+        else if (r.s0.key != SRL_EMPTY_KEY) {
+            if (r.s1.key == r.key) { slab = r.s1.slab; cnt = r.s1.count; found = true; }
+            else if (r.s1.key != SRL_EMPTY_KEY) {
+                unsigned h = (r.h + 2) & mask;                 // rare: continue the linear probe
+                for (unsigned probe = 2; probe <= mask; ++probe) {
+                    const SrlMapSlot sl = table[h];
+                    if (sl.key == r.key) { slab = sl.slab; cnt = sl.count; found = true; break; }
+                    if (sl.key == SRL_EMPTY_KEY) break;
+                    h = (h + 1) & mask;
+                }
             }
-            if (sl.key == SRL_EMPTY_KEY) break;
-            h = (h + 1) & mask;
         }
+        found = found && (int)cnt >= thr_cap && cnt > 0;        // NumPoints() < threshold -> skipped (optimize.cpp:389)
     }
     const unsigned long long m = __ballot(found);
-    if (found) {
-        VoxEnt ve; ve.slab = slab; ve.count = cnt;
-        vox[lanes_below(m)] = ve;
+    const int nv = __popcll(m);
+    if (lane < 27) {
+        // found voxels first (visit order kept), the other probe lanes zero-fill the tail: entries [nv, 27)
+        // read as "count 0", so the candidate rounds need no bounds branch
+        VoxEnt ve; ve.slab = found ? slab : 0u; ve.count = found ? cnt : 0u;
+        const int pos = found ? lanes_below(m) : nv + lanes_below(~m & 0x7FFFFFFull);
+        vox[pos] = ve;
     }
     __builtin_amdgcn_wave_barrier();
-    return __popcll(m);
+    return nv;
 }
 
 template <class Sink>
@@ -401,19 +428,20 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
     float px[R], py[R], pz[R];
     bool val[R];
-    // every round's (LDS voxel entry ->) coalesced 12-B load is issued before any is consumed
+    // all voxel entries (branch-free LDS reads; the list is zero-filled up to 27 entries, idle lanes read
+    // entry 26 + ... clamped), then every round's coalesced 12-B load, all in flight before the first use
+    (void)nv;
+    VoxEnt ve[R];
+    const int cbase = role.c0 < 3 ? role.c0 : 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) ve[j] = vox[3 * j + cbase];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const int cv = 3 * j + role.c0;
         px[j] = 0.0f; py[j] = 0.0f; pz[j] = 0.0f;
-        val[j] = false;
-        if (role.c0 < 3 && cv < nv) {
-            const VoxEnt ve = vox[cv];
-            if ((unsigned)role.slot < ve.count) {
-                const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve.slab * SRL_SLAB_BYTES + role.slot * 12);
-                px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
-                val[j] = true;
-            }
+        val[j] = role.c0 < 3 && (unsigned)role.slot < ve[j].count;
+        if (val[j]) {
+            const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve[j].slab * SRL_SLAB_BYTES + role.slot * 12);
+            px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
         }
     }
     float d2f[R];
@@ -732,6 +760,8 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     int n_fallback = 0;
     {
         const LaneRole role0 = lane_role(lane);
+        ProbeReq preq;
+        if constexpr (NB == 1 && FAST != 0) preq = probe_issue(s_kv[0], s_kv[1], s_kv[2], role0, a.table, a.table_mask, lane);
         for (int kl = 0; kl < SRL_KPW; ++kl) {
             LaneRole role = role0;
             asm volatile("" : "+v"(role.c0), "+v"(role.slot));   // recompute the few role-derived values per keypoint instead of spilling them
@@ -746,7 +776,10 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
             bool done = false;
             if constexpr (NB == 1 && FAST != 0) {
                 int nv = 0;
-                if (!(a.ablate & 8)) nv = probe_voxels_r1(s_kv[kl * 4 + 0], s_kv[kl * 4 + 1], s_kv[kl * 4 + 2], role, a.thr_cap, a.table, a.table_mask, vox, lane);
+                const ProbeReq cur = preq;
+                if (kl + 1 < SRL_KPW)      // hash lookup of the NEXT keypoint goes out before this one is consumed
+                    preq = probe_issue(s_kv[kl * 4 + 4], s_kv[kl * 4 + 5], s_kv[kl * 4 + 6], role, a.table, a.table_mask, lane);
+                if (!(a.ablate & 8)) nv = probe_finish(cur, a.thr_cap, a.table, a.table_mask, vox, lane);
                 if (a.ablate & 4) { done = true; total = nv; }
                 else if constexpr (FAST == 1) done = select_topk_f32(qx, qy, qz, nv, vox, a.slabs, a.K, surv, lane, role, sink, total, a.ablate);
                 else done = select_topk_fast(qx, qy, qz, nv, vox, a.slabs, a.K, surv, lane, role, sink, total);

@@ -154,7 +154,7 @@ unsigned next_pow2u(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return 
 int srl_ctx_grow_map(srl_ctx *ctx, unsigned need_slabs, unsigned need_slots) {
     const unsigned new_slab_cap = ctx->slab_cap >= need_slabs ? ctx->slab_cap : std::max(need_slabs + need_slabs / 2u, 1024u);
     unsigned new_table_cap = ctx->table_cap;
-    while (new_table_cap < need_slots || new_table_cap < 2u * new_slab_cap) new_table_cap = next_pow2u(new_table_cap ? new_table_cap * 2u : 2048u);
+    while (new_table_cap < need_slots || new_table_cap < SRL_TABLE_FACTOR * new_slab_cap) new_table_cap = next_pow2u(new_table_cap ? new_table_cap * 2u : 2048u);
     if (new_slab_cap != ctx->slab_cap) {
         unsigned char *ns = nullptr;
         HIPCHK(ctx, hipMalloc((void **)&ns, (size_t)new_slab_cap * SRL_SLAB_BYTES));
@@ -238,8 +238,8 @@ int srl_map_insert_device(srl_ctx *ctx, const double *world_xyz, int n, double v
     // make room for the worst case (every touched voxel new) before slot indices are taken
     {
         const unsigned need_slabs = (unsigned)ctx->num_voxels + (unsigned)S;
-        if (need_slabs > ctx->slab_cap || 2u * need_slabs > ctx->table_cap) {
-            int rc = srl_ctx_grow_map(ctx, need_slabs, 2u * need_slabs);
+        if (need_slabs > ctx->slab_cap || SRL_TABLE_FACTOR * need_slabs > ctx->table_cap) {
+            int rc = srl_ctx_grow_map(ctx, need_slabs, SRL_TABLE_FACTOR * need_slabs);
             if (rc) return rc;
         }
     }
