@@ -64,6 +64,8 @@ def main():
                     help="2^31-1 = throughput headline (every keypoint contributes); 600 = shipped yaml value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--select-mode", type=int, default=0)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="attach an RCCL communicator even at world size 1 (exercises the sharded code path on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,7 +78,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -93,7 +95,7 @@ def main():
     lio = srl.Lio(local_rank)
     lio.add_points_to_map(cands)
     n_map = lio.map_size()
-    if sharded:
+    if sharded or (args.force_comm and dist is not None):
         uid = [srl.Context.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         lio.ctx.comm_init_rank(world, rank, uid[0])

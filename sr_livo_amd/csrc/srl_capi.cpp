@@ -373,7 +373,10 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     // residual budget of this rank (sequential early exit, optimize.cpp:107, across ordered shards)
     int64_t budget = o->max_num_residuals;
     int mode = 0;
-    if (o->max_num_residuals <= 0 || ctx->nranks == 1) {
+    const bool coll = ctx->comm && (ctx->nranks > 1 || ctx->force_coll);
+    // the ordered cut can only trigger when max_num_residuals <= number of keypoints: otherwise no exchange of counts
+    const bool cut_possible = (long long)o->max_num_residuals <= (long long)ctx->total_n;
+    if (o->max_num_residuals <= 0 || (ctx->nranks == 1 && !coll) || !cut_possible) {
         srl_shard_budget(o->max_num_residuals, nullptr, ctx->nranks, ctx->rank, &budget, &mode);
     } else {
         HIPCHK(ctx, srl_launch_count(ctx->d_binfo, nblocks, ctx->d_count, ctx->stream));
@@ -406,7 +409,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     ra.out = ctx->d_out;
     // single rank: the reduce kernel publishes straight into host-mapped memory and the host spins on the
     // sequence word -- no D2H copy, no stream synchronisation on the per-iteration critical path
-    const bool mailbox = (ctx->nranks == 1);
+    const bool mailbox = (ctx->nranks == 1) && !coll;
     ra.mailbox = mailbox ? ctx->h_mail : nullptr;
     ra.seq = ++ctx->seq;
     HIPCHK(ctx, srl_launch_reduce(ra, mode, ctx->stream));
@@ -414,16 +417,14 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     const auto t_enq = std::chrono::steady_clock::now();
 
     // the one exchange step: sum of the normal equations over the point-range shards
-    const int n_red = 36 + 6 + 1 + 5;   // HtH, Hth, loss, 5 counters carried as doubles
+    const int n_red = 36 + 6 + 1 + 6;   // HtH, Hth, loss, 6 counters carried as doubles (incl. visited keypoints)
     long long visited_local = 0;
-    if (ctx->nranks > 1 && ctx->comm) {
-        // local visited count must be captured before the reduction overwrites nothing (it is not reduced)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));
+    if (coll) {
+        // one ncclAllReduce of 49 doubles on the context's stream; last_visited sits behind the reduced range
         NCCLCHK(ctx, ncclAllReduce(ctx->d_out, ctx->d_out, n_red, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         visited_local = ctx->h_out->last_visited + 1;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     } else if (mailbox) {
         volatile unsigned long long *seqp = &ctx->h_mail->seq;
         unsigned long long spins = 0;
@@ -448,22 +449,8 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     const auto t_res = std::chrono::steady_clock::now();
 
-    // total visited keypoints over all shards -> global index of the last visited keypoint
-    long long visited_total = visited_local;
-    if (ctx->nranks > 1) {
-        double v = (double)visited_local;
-        if (ctx->comm) {
-            // tiny second all-reduce kept off the hot path: only needed for the taps' status=3 marking
-            double *dv = reinterpret_cast<double *>(ctx->d_count);
-            HIPCHK(ctx, hipMemcpyAsync(dv, &v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-            NCCLCHK(ctx, ncclAllReduce(dv, dv, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(&v, dv, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        } else {
-            if (ctx->cb_ar(&v, 1, ctx->cb_user) != 0) { ctx->err = "allreduce callback failed"; return SRL_ERR_COMM; }
-        }
-        visited_total = (long long)(v + 0.5);
-    }
+    // total visited keypoints over all shards (part of the reduced range) -> global index of the last visited one
+    const long long visited_total = (long long)(ctx->h_out->d_visited + 0.5);
 
     const SrlDevOut &r = *ctx->h_out;
     std::memcpy(out->HtH, r.HtH, sizeof out->HtH);
@@ -646,6 +633,7 @@ int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id) {
     ctx->nranks = nranks;
     ctx->rank = rank;
     ctx->cb_ar = nullptr; ctx->cb_ag = nullptr; ctx->cb_user = nullptr;
+    { const char *fc = std::getenv("SRL_FORCE_COLLECTIVES"); ctx->force_coll = fc && std::atoi(fc) != 0; }
     int rc = ensure(ctx, ctx->d_gather, (size_t)nranks);
     return rc;
 }

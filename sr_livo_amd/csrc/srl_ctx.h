@@ -55,6 +55,7 @@ struct srl_ctx {
     // comm
     int nranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
+    bool force_coll = false;           // env SRL_FORCE_COLLECTIVES=1: run the RCCL calls even with one rank (test hook)
     srl_allreduce_fn cb_ar = nullptr;
     srl_allgather_i64_fn cb_ag = nullptr;
     void *cb_user = nullptr;

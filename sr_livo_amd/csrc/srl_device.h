@@ -58,6 +58,7 @@ struct SrlDevOut {             // result of the reduce kernel (device, then copi
     double d_sum_pk;
     double d_nan;
     double d_fallback;
+    double d_visited;          // keypoints visited by the sequential loop in this shard (summed by the all-reduce)
     long long last_visited;    // local index of last visited keypoint (n-1 if no cut)
     long long pad;
 };

@@ -1088,6 +1088,7 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
         put_f(&out->d_sum_pk, (double)s_tot[1]);
         put_f(&out->d_nan, (double)s_tot[2]);
         put_f(&out->d_fallback, (double)s_tot[3]);
+        put_f(&out->d_visited, (double)(last_visited + 1));
         put_i(&out->last_visited, (long long)last_visited);
         put_i(&out->pad, 0);
     }

@@ -351,16 +351,24 @@ def test_logical_shards_reproduce_single_rank(golden, max_res):
         assert np.array_equal(np.array(n.HtH), np.array(results[0]["neq"].HtH))   # identical on every rank
 
 
-def test_rccl_single_rank_communicator(golden):
-    """The RCCL path itself (ncclCommInitRank / AllReduce / AllGather) with a 1-rank communicator."""
+def test_rccl_single_rank_communicator(golden, monkeypatch):
+    """The RCCL path itself -- ncclCommInitRank, ncclAllGather of the accepted counts, ncclAllReduce of the 48
+    doubles on the context's stream -- with a 1-rank communicator (SRL_FORCE_COLLECTIVES runs the collectives
+    even though one rank needs none).  Results must equal the communicator-free path bit for bit."""
     ctx = srl.Context(0)
     try:
         ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
-        base = gpu_pass(ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=600)
-        ctx.comm_init_rank(1, 0, srl.Context.comm_unique_id())
-        g = gpu_pass(ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=600)
-        assert np.array_equal(np.array(g["neq"].HtH), np.array(base["neq"].HtH))
-        assert g["neq"].num_residuals == base["neq"].num_residuals
+        for max_res in (600, INT_MAX):
+            ctx.comm_set_host_callbacks(1, 0, lambda b: None, lambda v: [v])      # detach any communicator
+            base = gpu_pass(ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=max_res)
+            monkeypatch.setenv("SRL_FORCE_COLLECTIVES", "1")
+            ctx.comm_init_rank(1, 0, srl.Context.comm_unique_id())
+            g = gpu_pass(ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=max_res)
+            monkeypatch.delenv("SRL_FORCE_COLLECTIVES")
+            assert np.array_equal(np.array(g["neq"].HtH), np.array(base["neq"].HtH))
+            assert np.array_equal(np.array(g["neq"].Hth), np.array(base["neq"].Hth))
+            assert g["neq"].num_residuals == base["neq"].num_residuals and g["neq"].last_visited == base["neq"].last_visited
+            assert np.array_equal(g["status"], base["status"])
     finally:
         ctx.close()
 
