@@ -411,7 +411,7 @@ __device__ __forceinline__ bool select_topk_fast(double qx, double qy, double qz
 //             order) into LDS as {x, y, z, voxel/slot code}
 //   exact   : lane i < c evaluates survivor i's d2 in FP64 with the reference's operation order
 //             ((dx*dx + dy*dy) + dz*dz, no FMA), strict rank by counting, clash check, emit from registers.
-struct SurvRec { float x, y, z; int code; };
+struct alignas(16) SurvRec { float x, y, z; int code; };
 
 __device__ __forceinline__ float d2_f32(float px, float py, float pz, float qx, float qy, float qz) {
 #pragma clang fp contract(fast)
@@ -427,9 +427,9 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     const float kInfF = __builtin_huge_valf();
     const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
     float px[R], py[R], pz[R];
-    bool val[R];
-    // all voxel entries (branch-free LDS reads; the list is zero-filled up to 27 entries, idle lanes read
-    // entry 26 + ... clamped), then every round's coalesced 12-B load, all in flight before the first use
+    // all voxel entries (branch-free LDS reads; the list is zero-filled up to 27 entries), then every round's
+    // coalesced 12-B load, all in flight before the first use.  Lanes without a candidate keep +inf
+    // coordinates, so their FP32 distance is +inf with no validity flag to carry around.
     (void)nv;
     VoxEnt ve[R];
     const int cbase = role.c0 < 3 ? role.c0 : 0;
@@ -437,9 +437,8 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     for (int j = 0; j < R; ++j) ve[j] = vox[3 * j + cbase];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        px[j] = 0.0f; py[j] = 0.0f; pz[j] = 0.0f;
-        val[j] = role.c0 < 3 && (unsigned)role.slot < ve[j].count;
-        if (val[j]) {
+        px[j] = kInfF; py[j] = kInfF; pz[j] = kInfF;
+        if (role.c0 < 3 && (unsigned)role.slot < ve[j].count) {
             const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve[j].slab * SRL_SLAB_BYTES + role.slot * 12);
             px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
         }
@@ -449,10 +448,9 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     int total = 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const float d = d2_f32(px[j], py[j], pz[j], qxf, qyf, qzf);
-        d2f[j] = val[j] ? d : kInfF;
+        d2f[j] = d2_f32(px[j], py[j], pz[j], qxf, qyf, qzf);
         lmin = fminf(lmin, d2f[j]);
-        total += __popcll(__ballot(val[j]));
+        total += __popcll(__ballot(d2f[j] < kInfF));
     }
     total_out = total;
 
@@ -467,26 +465,28 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     const float tau_f = __uint_as_float(lo | 0x3FFFFu);   // >= K candidates have d2f <= tau_f (if that many exist)
     // FP32 error model: a = abs error of fl32(q) per axis; per-axis difference error <= a + u*|d|; sum of
     // squares (3 terms, FMA or not) adds <= 4u relative.  For d2, d2f <= T:  |d2f - d2| <= m(T) with
-    //   m(T) = 4 a sqrt(T) + 8 u T + 4 a^2   (u = 2^-24), evaluated at T = 2 tau_f + 1e-6 and doubled.
+    //   m(T) = 4 a sqrt(T) + 8 u T + 4 a^2   (u = 2^-24), evaluated at T = 2 tau_f + 1e-6 and doubled
+    //   (raw v_sqrt_f32, 1 ulp, inflated by 1e-4: this is a bound, not a result).
     float thr = kInfF;
     if (tau_f < kInfF) {
         const float u = 5.9604645e-8f;
         const float amax = fmaxf(fmaxf(fabsf(qxf), fabsf(qyf)), fabsf(qzf)) * u + 1e-30f;
         const float T = 2.0f * tau_f + 1e-6f;
-        const float m = 4.0f * amax * sqrtf(T) + 8.0f * u * T + 4.0f * amax * amax;
+        const float m = 4.0f * amax * (__builtin_amdgcn_sqrtf(T) * 1.0001f) + 8.0f * u * T + 4.0f * amax * amax;
         thr = (tau_f + 2.0f * m) * 1.000001f;
     }
 
-    SurvRec *recs = reinterpret_cast<SurvRec *>(scratch);                                          // [64], 16-B aligned
+    SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));            // [64], 16-B aligned
     double *keys = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024);  // [66]
     int *owner = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scratch) + 1024 + 66 * 8 + 8);  // [32]
     int c = 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const bool sv = val[j] && d2f[j] <= thr;
+        const bool sv = d2f[j] <= thr && d2f[j] < kInfF;
         const unsigned long long m = __ballot(sv);
-        const int pos = c + lanes_below(m);
-        if (sv && pos < 64) {
+        int pos = c + lanes_below(m);
+        pos = pos < 63 ? pos : 63;          // > 64 survivors bail out below; the clamp only keeps the stores in bounds
+        if (sv) {
             SurvRec r; r.x = px[j]; r.y = py[j]; r.z = pz[j]; r.code = ((3 * j + role.c0) << 5) | role.slot;
             recs[pos] = r;
         }
