@@ -534,9 +534,16 @@ template <class Sink>
 __device__ __forceinline__ bool select_topk_f32(double qx, double qy, double qz, int nv, const VoxEnt *vox,
                                                 const unsigned char *slabs, int K, void *scratch, int lane,
                                                 const LaneRole &role, Sink &sink, int &total_out, int ablate) {
-    if (nv <= 9) return select_topk_f32_r<3>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
-    if (nv <= 15) return select_topk_f32_r<5>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
-    return select_topk_f32_r<9>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
+    // straight-line instantiation per number of candidate rounds (3 voxels per round)
+    switch ((nv + 2) / 3) {
+        case 0: case 1: case 2: case 3:
+            return select_topk_f32_r<3>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
+        case 4: return select_topk_f32_r<4>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
+        case 5: return select_topk_f32_r<5>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
+        case 6: return select_topk_f32_r<6>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
+        case 7: return select_topk_f32_r<7>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
+        default: return select_topk_f32_r<9>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
