@@ -20,10 +20,15 @@ SRL_HD inline void srl_unpack_key(unsigned long long k, short *x, short *y, shor
     *y = (short)(unsigned short)((k >> 16) & 0xFFFFu);
     *z = (short)(unsigned short)((k >> 32) & 0xFFFFu);
 }
-// 32-bit multiplicative mix of the three int16 coordinates (cheap on the device: 32-bit VALU only)
+// Multiplicative mix of the three int16 coordinates.  The per-coordinate products use 24-bit constants so
+// the device can take the full-rate 24-bit multiplier (v_mul_u32_u24); one 32-bit multiply finalises.
 SRL_HD inline unsigned srl_hash_key(unsigned long long k) {
     const unsigned x = (unsigned)(k & 0xFFFFu), y = (unsigned)((k >> 16) & 0xFFFFu), z = (unsigned)((k >> 32) & 0xFFFFu);
-    unsigned h = (x * 0x9E3779B1u) ^ (y * 0x85EBCA77u) ^ (z * 0xC2B2AE3Du);
+#ifdef __HIP_DEVICE_COMPILE__
+    unsigned h = __umul24(x, 0x9E3779u) ^ __umul24(y, 0x85EBCBu) ^ __umul24(z, 0xC2B2AFu);
+#else
+    unsigned h = (x * 0x9E3779u) ^ (y * 0x85EBCBu) ^ (z * 0xC2B2AFu);   // 16-bit x 24-bit: no overflow, same value
+#endif
     h ^= h >> 15;
     h *= 0x2C1B3C6Du;
     h ^= h >> 12;

@@ -898,36 +898,27 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
         if (a.tap_ncand) a.tap_ncand[g] = s_ncand[kl];
     }
 
-    // ---- wave partial of H^T H (21 upper-tri), H^T h (6), loss (1): component c = 4 m + sub, m = 0..6
+    // ---- wave partial of H^T H (21 upper-tri), H^T h (6), loss (1): component c = 4 m + sub-lane, m = 0..6.
+    // The four candidates of every m are compile-time index pairs; the sub-lane picks one (no per-lane index math).
     {
         const double h = dist * weight;                           // optimize.cpp:169
         const bool accd = status == 2;
+        auto comp = [&](int c) -> double {                        // c is a compile-time constant after unrolling
+            if (c < 21) {
+                int ia = 0, cc = c, rowlen = 6;
+                while (cc >= rowlen) { cc -= rowlen; ia++; rowlen--; }
+                return J[ia] * J[ia + cc];
+            }
+            if (c < 27) return J[c - 21] * h;
+            return dist * dist;                                   // loss (optimize.cpp:104)
+        };
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
-            const int c = 4 * m + sl;
-            double v = 0.0;
-            if (accd) {
-                if (c < 21) {
-                    int ia = 0, cc = c, rowlen = 6;
-                    while (cc >= rowlen) { cc -= rowlen; ia++; rowlen--; }
-                    const int ib = ia + cc;
-                    // select J[ia], J[ib] without runtime register indexing
-                    double ja = J[0], jb = J[0];
-#pragma unroll
-                    for (int t = 1; t < 6; ++t) { ja = (ia == t) ? J[t] : ja; jb = (ib == t) ? J[t] : jb; }
-                    v = ja * jb;
-                } else if (c < 27) {
-                    const int ia = c - 21;
-                    double ja = J[0];
-#pragma unroll
-                    for (int t = 1; t < 6; ++t) ja = (ia == t) ? J[t] : ja;
-                    v = ja * h;
-                } else {
-                    v = dist * dist;                              // loss (optimize.cpp:104)
-                }
-            }
+            const double v0 = comp(4 * m), v1 = comp(4 * m + 1), v2 = comp(4 * m + 2), v3 = comp(4 * m + 3);
+            double v = (sl == 0) ? v0 : ((sl == 1) ? v1 : ((sl == 2) ? v2 : v3));
+            v = accd ? v : 0.0;
             v = kp_sum(v);
-            if (lane < 4) s_wpart[wave * 32 + c] = v;
+            if (lane < 4) s_wpart[wave * 32 + 4 * m + sl] = v;
         }
     }
     {
