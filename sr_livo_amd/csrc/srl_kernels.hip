@@ -742,6 +742,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     int *s_winfo = reinterpret_cast<int *>(smem + L.off_winfo);           // [4][4]: accepted, sum_pk, nan, fallback
 
     const int wbase_kp = blockIdx.x * SRL_KPB + wave * SRL_KPW;           // first keypoint of this wave
+    if (a.ablate & 16) return;                                            // debug: launch/drain floor
 
     // ---------------- phase 0: transformKeypoints (optimize.cpp:30-40), location (optimize.cpp:83), voxel key
     if (lane < SRL_KPW) {
@@ -755,9 +756,11 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
         s_pw[lane * 3 + 0] = p_w.x; s_pw[lane * 3 + 1] = p_w.y; s_pw[lane * 3 + 2] = p_w.z;
         s_pimu[lane * 3 + 0] = p_imu.x; s_pimu[lane * 3 + 1] = p_imu.y; s_pimu[lane * 3 + 2] = p_imu.z;
         // static_cast<short>(point / size_voxel_map): truncation toward zero (optimize.cpp:372-374)
-        s_kv[lane * 4 + 0] = (int)(short)(int)(p_w.x / a.size_voxel);
-        s_kv[lane * 4 + 1] = (int)(short)(int)(p_w.y / a.size_voxel);
-        s_kv[lane * 4 + 2] = (int)(short)(int)(p_w.z / a.size_voxel);
+        // (x / 1.0 == x exactly: the shipped size_voxel_map = 1.0 skips three FP64 divisions)
+        const bool unit = a.size_voxel == 1.0;
+        s_kv[lane * 4 + 0] = (int)(short)(int)(unit ? p_w.x : p_w.x / a.size_voxel);
+        s_kv[lane * 4 + 1] = (int)(short)(int)(unit ? p_w.y : p_w.y / a.size_voxel);
+        s_kv[lane * 4 + 2] = (int)(short)(int)(unit ? p_w.z : p_w.z / a.size_voxel);
         s_nfound[lane] = 0;
         s_ncand[lane] = 0;
     }
@@ -768,7 +771,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     {
         const LaneRole role0 = lane_role(lane);
         ProbeReq preq;
-        if constexpr (NB == 1 && FAST != 0) preq = probe_issue(s_kv[0], s_kv[1], s_kv[2], role0, a.table, a.table_mask, lane);
+        if constexpr (NB == 1 && FAST != 0) { if (!(a.ablate & 32)) preq = probe_issue(s_kv[0], s_kv[1], s_kv[2], role0, a.table, a.table_mask, lane); }
         for (int kl = 0; kl < SRL_KPW; ++kl) {
             LaneRole role = role0;
             asm volatile("" : "+v"(role.c0), "+v"(role.slot));   // recompute the few role-derived values per keypoint instead of spilling them
@@ -784,7 +787,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
             if constexpr (NB == 1 && FAST != 0) {
                 int nv = 0;
                 const ProbeReq cur = preq;
-                if (kl + 1 < SRL_KPW)      // hash lookup of the NEXT keypoint goes out before this one is consumed
+                if (kl + 1 < SRL_KPW && !(a.ablate & 32))      // hash lookup of the NEXT keypoint goes out before this one is consumed
                     preq = probe_issue(s_kv[kl * 4 + 4], s_kv[kl * 4 + 5], s_kv[kl * 4 + 6], role, a.table, a.table_mask, lane);
                 if (!(a.ablate & 8)) nv = probe_finish(cur, a.thr_cap, a.table, a.table_mask, vox, lane);
                 if (a.ablate & 4) { done = true; total = nv; }
@@ -805,6 +808,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     }
     __builtin_amdgcn_wave_barrier();
 
+    if (a.ablate & 64) return;                                            // debug: phase 0 + loop skeleton only
     // ---------------- phase 2: plane fit + residual + Jacobian for this wave's 16 keypoints, 4 lanes each.
     // Sub-lane s accumulates neighbours s, s+4, ...; quad butterflies make the sums identical in the 4 lanes,
     // which then run the (scalar) eigen-solve / weights redundantly and split the 28 H^T H / H^T h / loss
@@ -887,15 +891,18 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
             J[3] = s0 * weight; J[4] = s1 * weight; J[5] = s2 * weight;
         }
     }
-    if (g < a.n && sl == 0) {
-        // per-keypoint record (ordered cut-off path + taps)
-        double *rec = a.rec + (size_t)g * 8;
-#pragma unroll
-        for (int c = 0; c < 6; c++) rec[c] = J[c];
-        rec[6] = dist;
-        rec[7] = weight;
-        a.status[g] = (unsigned char)status;
-        if (a.tap_ncand) a.tap_ncand[g] = s_ncand[kl];
+    if (g < a.n) {
+        // per-keypoint record {J[6], distance, weight} (ordered cut-off path + taps): the four lanes of a quad hold
+        // identical values, so sub-lane s stores doubles 2s, 2s+1 -- one fully coalesced 16-B store per lane
+        // (1 KB per wave) instead of eight scattered 8-B stores.
+        double2 v;
+        v.x = (sl == 0) ? J[0] : ((sl == 1) ? J[2] : ((sl == 2) ? J[4] : dist));
+        v.y = (sl == 0) ? J[1] : ((sl == 1) ? J[3] : ((sl == 2) ? J[5] : weight));
+        *reinterpret_cast<double2 *>(a.rec + (size_t)g * 8 + 2 * sl) = v;
+        if (sl == 0) {
+            a.status[g] = (unsigned char)status;
+            if (a.tap_ncand) a.tap_ncand[g] = s_ncand[kl];
+        }
     }
 
     // ---- wave partial of H^T H (21 upper-tri), H^T h (6), loss (1): component c = 4 m + sub-lane, m = 0..6.
