@@ -910,12 +910,11 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     {
         const double h = dist * weight;                           // optimize.cpp:169
         const bool accd = status == 2;
-        auto comp = [&](int c) -> double {                        // c is a compile-time constant after unrolling
-            if (c < 21) {
-                int ia = 0, cc = c, rowlen = 6;
-                while (cc >= rowlen) { cc -= rowlen; ia++; rowlen--; }
-                return J[ia] * J[ia + cc];
-            }
+        // upper-triangular (row, column) of component c < 21; indices fold to constants after unrolling
+        constexpr int IA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+        constexpr int IB[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+        auto comp = [&](int c) -> double {
+            if (c < 21) return J[IA[c]] * J[IB[c]];
             if (c < 27) return J[c - 21] * h;
             return dist * dist;                                   // loss (optimize.cpp:104)
         };
