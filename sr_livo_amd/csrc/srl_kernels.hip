@@ -851,9 +851,8 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
         C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
         double ev[3];
         D3 nrm;
-        if (a.select_mode == 4) eig3_jacobi(C, ev, nrm);
-        else eig3_closed(C, ev, nrm);
-        nrm = normalized3(nrm);                                   // .col(0).normalized() (optimize.cpp:340)
+        if (a.select_mode == 4) { eig3_jacobi(C, ev, nrm); nrm = normalized3(nrm); }   // .col(0).normalized() (optimize.cpp:340)
+        else eig3_closed(C, ev, nrm);                              // already unit length (re-normalised once more at :93 below)
         const double sigma_1 = sqrt(fabs(ev[2]));
         const double sigma_2 = sqrt(fabs(ev[1]));
         const double sigma_3 = sqrt(fabs(ev[0]));
