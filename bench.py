@@ -56,7 +56,7 @@ class _EskfAdapter:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="HEADLINE", choices=sorted(synth.CONFIGS))
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replay"])
