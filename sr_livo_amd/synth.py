@@ -129,7 +129,14 @@ def make_sweep(seed, n, L, pattern="livox", max_range=50.0):
     rng_lim = min(max_range, 0.85 * L)
     yaw = rng.uniform(-math.pi, math.pi)
     q_gt = quat_mul(quat_from_rotvec([0, 0, yaw]), quat_from_rotvec(rng.normal(0, 0.02, 3)))
-    t_gt = np.array([rng.uniform(-3, 3) + 2.3, rng.uniform(-3, 3) + 1.7, rng.uniform(-0.1, 0.1)])
+    while True:
+        t_gt = np.array([rng.uniform(-3, 3) + 2.3, rng.uniform(-3, 3) + 1.7, rng.uniform(-0.1, 0.1)])
+        # keep the sensor out of (and 0.8 m away from) the boxes; re-draw otherwise (seeds that were fine are unchanged)
+        cs = _box_centres(L)
+        dx = np.maximum(np.abs(t_gt[0] - cs) - BOX_HALF, 0.0)
+        dy = np.maximum(np.abs(t_gt[1] - cs) - BOX_HALF, 0.0)
+        if np.min(np.hypot(dx[:, None], dy[None, :])) > 0.8:
+            break
     R = quat_to_rot(q_gt)
     pts = np.zeros((0, 3))
     while len(pts) < n:

@@ -526,3 +526,103 @@ def test_config4_dense_256k_on_10M_logical_shards(oracle_lib, oracle_backend):
         assert rel(HtH, np.array(g["neq"].HtH)) < 1e-12 and rel(Hth, np.array(g["neq"].Hth)) < 1e-11
     finally:
         ctx.close()
+
+
+# ----------------------------------------------------------------------------- multi-sweep replay (path + map insertion chained)
+def test_multi_sweep_replay_matches_oracle(oracle_lib, oracle_backend):
+    """Six consecutive sweeps along a trajectory: IMU predict -> optimize (gridSampling + updateIEKF +
+    re-transform) -> addPointsToMap, on the device-resident map, against the oracle doing the same sequence.
+    Poses, covariances and the final maps must agree (the maps bit for bit)."""
+    rng = np.random.default_rng(2024)
+    pts, L = synth.map_candidates(555, 120_000)
+    # initial map: only part of the scene, the sweeps fill in the rest
+    init = pts[: len(pts) // 3]
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(init)
+    lio = srl.Lio(0)
+    try:
+        lio.add_points_to_map(init)
+        e = oracle_lib.Eskf(oracle_backend)
+        sw0 = synth.make_sweep(600, 6000, L)
+        synth.eskf_prior(e, sw0["q_gt"], sw0["t_gt"], np.zeros(3))
+        lio.eskf_set_noise(0.1, 0.1, 0.0001, 0.0001)          # same IMU noise model / last IMU sample as the oracle filter
+        lio.eskf_init_imu(np.array([0.0, 0.0, 9.81]), np.zeros(3))
+        lio.eskf_set_state(e.get_state()); lio.eskf_set_cov(e.get_cov())
+        opts_p = srl.default_opts(max_num_residuals=600)
+        opts_o = oracle_lib.opts_from_product(opts_p)
+        t_last = sw0["t_gt"].copy()
+        acc = np.array([0.0, 0.0, 9.81]); gyr = np.zeros(3)
+        for k in range(6):
+            sw = synth.make_sweep(600 + k, 6000, L)          # new viewpoint each sweep
+            # "IMU": a few predict steps, then teleport the prior near the sweep's true pose (both filters alike)
+            for _ in range(3):
+                e.predict(0.01, acc, gyr); lio.eskf_predict(0.01, acc, gyr)
+            s = e.get_state(); s[0:3] = sw["t_pred"]; s[3:7] = sw["q_pred"]; s[7:10] = 0.0
+            e.set_state(s); lio.eskf_set_state(s)
+            st = np.concatenate([sw["q_pred"], sw["t_pred"], np.zeros(9)])
+            R0 = synth.quat_to_rot(sw["q_pred"])
+            world0 = sw["raw"] @ R0.T + sw["t_pred"]       # buildFrame's point field (pose prior)
+            frame_id = 100 + k
+            g = lio.optimize(opts_p, 1.5, sw["raw"], world0, st, t_last, frame_id=frame_id)
+            assert g["rc"] == 0
+            kidx = g["keypoint_index"]
+            u = oracle_lib.update_iekf(m, e, opts_o, sw["raw"][kidx], st, t_last, frame_id=frame_id)
+            assert u["rc"] == g["iters"] and u["num_residuals"] == g["num_residuals"]
+            assert rel(g["state"], u["state"]) < 1e-9
+            assert rel(lio.eskf_get_cov(), e.get_cov()) < 1e-8
+            # re-transformed frame -> map (optimize.cpp:441-445, lioOptimization.cpp:1027)
+            q, t = u["state"][0:4], u["state"][4:7]
+            w, x, y, z = q
+            Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                           [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                           [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+            assert rel(g["world"], sw["raw"] @ Rq.T + t) < 1e-12
+            # both maps receive the SAME world points (the product's), so the comparison stays bit-exact
+            m.add_points(g["world"])
+            lio.add_points_to_map(g["world"])
+            assert lio.map_size() == m.size()
+            t_last = u["state"][4:7].copy()
+        kg, cg, xg = lio.ctx.map_download()
+        ko, co, xo = m.export()
+        assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
+        assert m.size() > len(init) * 0.5
+    finally:
+        lio.close()
+
+
+# ----------------------------------------------------------------------------- non-default frames and options
+def test_extrinsics_unnormalised_quaternion_and_voxel_size(oracle_lib, oracle_backend):
+    """Non-identity R_imu_lidar / t_imu_lidar, an un-normalised state quaternion (optimize.cpp:35 normalises for the
+    association but :95/:101 do not -- SURVEY Appendix B.10), and a 0.5 m voxel map (exercises the FP64 division
+    in the voxel key and denser candidate sets), K = 12 / min 10, power_planarity 3, other weights."""
+    pts, L = synth.map_candidates(901, 60_000)
+    sw = synth.make_sweep(902, 3000, L)
+    R_il = synth.quat_to_rot(synth.quat_from_rotvec([0.03, -0.02, 0.05])); t_il = np.array([0.08, -0.03, 0.02])
+    raw = (sw["raw"] - t_il) @ R_il            # so that R_il raw + t_il reproduces the sweep in the IMU frame
+    q = sw["q_pred"] * 1.0007
+    for voxel, cap_min_dist in ((0.5, 0.1), (1.0, 0.15)):
+        m = oracle_lib.Map(oracle_backend)
+        m.add_points(pts, voxel_size=voxel, min_dist=cap_min_dist)
+        ctx = srl.Context(0)
+        try:
+            assert ctx.map_insert(pts, voxel_size=voxel, min_dist=cap_min_dist) == m.size()
+            kg, cg, xg = ctx.map_download(); ko, co, xo = m.export()
+            assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
+            kw = dict(size_voxel_map=voxel, max_number_neighbors=12, min_number_neighbors=10, power_planarity=3.0,
+                      weight_alpha=0.7, weight_neighborhood=0.3, max_dist_to_plane_icp=0.2, max_num_residuals=INT_MAX)
+            opts = srl.default_opts(**kw)
+            ctx.sweep_upload(raw); ctx.set_taps(1)
+            f = capi.make_frame(q, sw["t_pred"], sw["t_last"], R_il=R_il, t_il=t_il)
+            neq, rc = ctx.build_residuals(f, opts)
+            ids, status, ncand = ctx.fetch_neighbors(K=12); res = ctx.fetch_residuals(); ctx.set_taps(0)
+            o = m.build_plane_residuals(oracle_lib.default_opts(**kw), raw, q, sw["t_pred"], sw["t_last"], R_il=R_il, t_il=t_il)
+            assert o["neq"].num_ties == 0
+            assert np.array_equal(status, o["status"]) and np.array_equal(ids, o["ids"])
+            hp = o["status"] >= 1; acc = o["status"] == 2
+            assert acc.sum() > 1000
+            for k in ("normal", "a2D", "weight", "norm_offset", "distance"):
+                assert rel(res[k][hp], o[k][hp]) < TIGHT, k
+            assert rel(res["jacobian"][acc], o["jacobian"][acc]) < TIGHT
+            assert rel(np.array(neq.HtH).reshape(6, 6), o["HtH"]) < TIGHT and rel(np.array(neq.Hth), o["Hth"]) < TIGHT
+        finally:
+            ctx.close()
