@@ -113,6 +113,22 @@ int srl_map_download(srl_ctx *ctx, int16_t *keys_xyz, int32_t *counts, float *xy
 int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n);
 int srl_sweep_shard(srl_ctx *ctx, int *begin, int *count, int *total);
 
+/* ------------------------------------------------------------------ frame-resident pipeline (optional)
+ * Keeps the whole reconstructed sweep in HBM from keypoint selection to map insertion.
+ * srl_frame_upload            replaces handing p_frame->point_frame (raw points) to optimize() (optimize.cpp:428)
+ * srl_frame_select_keypoints  replaces gridSampling / subSampleFrame (utility.cpp:167-201) applied to
+ *                             point = R(q) (R_il raw + t_il) + t (utility.cpp:314-318): same keypoints in the same
+ *                             (std::tr1::unordered_map iteration) order; they become the resident sweep.
+ * srl_frame_commit            replaces the re-transform loop (optimize.cpp:441-445) + addPointsToMap
+ *                             (lioOptimization.cpp:520-554) with the final pose, without leaving the device. */
+int srl_frame_upload(srl_ctx *ctx, const double *raw_xyz, int n);
+int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3], const double R_il[9],
+                               const double t_il[3], double sample_voxel_size,
+                               int32_t *keypoint_index /* capacity n, or NULL */, int *num_keypoints);
+int srl_frame_commit(srl_ctx *ctx, const double q[4], const double t[3], const double R_il[9], const double t_il[3],
+                     double voxel_size, int cap, double min_distance_points, int min_num_points,
+                     double *world_out /* n x 3 or NULL */, int *num_added);
+
 /* ------------------------------------------------------------------ hot path
  * replaces: lioOptimization::buildPlaneResiduals (optimize.cpp:18-131) incl. searchNeighbors
  * (:365-426), computeNeighborhoodDistribution (:316-353), and the H_x^T H_x / H_x^T h contraction

@@ -69,6 +69,19 @@ int srl_lio_optimize(srl_lio *lio, const srl_icp_opts *opts, double sample_voxel
                      double *frame_world, int n, double state_io[16], const double t_last[3], int frame_id,
                      int32_t *keypoint_index, int *num_keypoints, int *iters, int *num_residuals_used);
 
+/* Frame-resident form of optimize() + the map update that follows it in stateEstimation
+ * (lioOptimization.cpp:1027,1051): the raw frame (n x 3) is uploaded once; keypoints are selected on the device
+ * from point = R(q)(R_il raw + t_il) + t with the PRIOR pose in state_io (what point3D::point holds when
+ * optimize() is entered, lioOptimization.cpp:981-1001 -> utility.cpp:314-318) -- same keypoints, same order as
+ * gridSampling -- and the ESIKF runs on them in place.  srl_lio_commit_frame then re-transforms the frame with
+ * `state` (optimize.cpp:441-445) and inserts it (addPointsToMap) without the points leaving HBM;
+ * world_out (n x 3, optional) receives point3D::point. */
+int srl_lio_optimize_resident(srl_lio *lio, const srl_icp_opts *opts, double sample_voxel_size, const double *frame_raw,
+                              int n, double state_io[16], const double t_last[3], int frame_id, int32_t *keypoint_index,
+                              int *num_keypoints, int *iters, int *num_residuals_used);
+int srl_lio_commit_frame(srl_lio *lio, const double state[16], double voxel_size, int max_num_points_in_voxel,
+                         double min_distance_points, int min_num_points, double *world_out, int *num_added);
+
 /* lioOptimization::searchNeighbors / computeNeighborhoodDistribution single-call forms */
 int srl_lio_search_neighbors(srl_lio *lio, const double point[3], int nb_voxels_visited, double size_voxel_map,
                              int max_num_neighbors, int threshold_voxel_capacity, double *out_xyz /* K x 3 */,

@@ -82,6 +82,8 @@ def load(backend="plain"):
     lib.orc_derivative_s2.argtypes = [dp, dp]
     lib.orc_inverse17.argtypes = [dp, dp]; lib.orc_inverse17.restype = C.c_int
     lib.orc_eig3.argtypes = [dp, dp, dp]
+    lib.orc_transform_points.argtypes = [p, C.c_int, dp, dp, dp, dp, p]
+    lib.orc_grid_sampling.argtypes = [p, C.c_int, C.c_double, p]; lib.orc_grid_sampling.restype = C.c_int
     _libs[path] = lib
     return lib
 
@@ -218,3 +220,23 @@ def update_iekf(m, e, opts, raw, state, t_last, R_il=None, t_il=None, frame_id=1
     rc = m.lib.orc_update_iekf(m.h, e.h, C.byref(opts), _vp(raw), len(raw), _dp(st), _dp(_f64(t_last)), _dp(R_il), _dp(t_il),
                                frame_id, cap, laser_point_cov, _vp(log) if log is not None else None, log_iters, C.byref(nres))
     return dict(rc=rc, state=st, num_residuals=nres.value, log=None if log is None else log[: max(rc, 0)])
+
+
+def transform_points(raw, q, t, R_il=None, t_il=None, backend="plain"):
+    """transformPoint over a frame (utility.cpp:314-318)."""
+    lib = load(backend)
+    r = _f64(raw, (-1, 3))
+    out = np.empty_like(r)
+    R_il = _f64(np.eye(3) if R_il is None else R_il).ravel()
+    t_il = _f64(np.zeros(3) if t_il is None else t_il)
+    lib.orc_transform_points(_vp(r), len(r), _dp(_f64(q)), _dp(_f64(t)), _dp(R_il), _dp(t_il), _vp(out))
+    return out
+
+
+def grid_sampling(world, size_voxel, backend="plain"):
+    """gridSampling (utility.cpp:188-201): frame indices of the keypoints, in keypoint order."""
+    lib = load(backend)
+    w = _f64(world, (-1, 3))
+    idx = np.empty(max(len(w), 1), dtype=np.int32)
+    m = lib.orc_grid_sampling(_vp(w), len(w), float(size_voxel), _vp(idx))
+    return idx[:m].copy()

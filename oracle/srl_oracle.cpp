@@ -23,6 +23,7 @@
 #include <queue>
 #include <tuple>
 #include <unordered_map>
+#include <tr1/unordered_map>
 #include <vector>
 
 #ifdef ORC_USE_TSL
@@ -1194,6 +1195,34 @@ int orc_update_iekf(orc_map *m, orc_eskf *e, const orc_icp_opts *o, const double
 
 void orc_quat_to_rot(const double q[4], double R[9]) { m3_to(quat_to_rot(Q4{q[0], q[1], q[2], q[3]}), R); }
 void orc_rot_to_quat(const double R[9], double q[4]) { Q4 r = rot_to_quat(m3_from(R)); q[0] = r.w; q[1] = r.x; q[2] = r.y; q[3] = r.z; }
+void orc_transform_points(const double *raw_xyz, int n, const double q[4], const double t[3], const double R_il[9],
+                          const double t_il[3], double *world_xyz) {
+    const M3 R = quat_to_rot(Q4{q[0], q[1], q[2], q[3]});       // utility.cpp:317: q_end.toRotationMatrix()
+    const M3 Ril = m3_from(R_il);
+    const V3 til = v3(t_il[0], t_il[1], t_il[2]), te = v3(t[0], t[1], t[2]);
+    for (int i = 0; i < n; i++) {
+        const V3 raw = v3(raw_xyz[3 * (size_t)i], raw_xyz[3 * (size_t)i + 1], raw_xyz[3 * (size_t)i + 2]);
+        const V3 w = R * (Ril * raw + til) + te;
+        world_xyz[3 * (size_t)i] = w.x; world_xyz[3 * (size_t)i + 1] = w.y; world_xyz[3 * (size_t)i + 2] = w.z;
+    }
+}
+
+int orc_grid_sampling(const double *world_xyz, int n, double size_voxel, int32_t *idx_out) {
+    // subSampleFrame (utility.cpp:167-186): every point is pushed into its voxel's vector, then the first
+    // element of each vector is taken while iterating the tr1 container.
+    std::tr1::unordered_map<voxel, std::vector<int>, voxel_hash> grid;
+    for (int i = 0; i < n; i++) {
+        const short kx = static_cast<short>(world_xyz[3 * (size_t)i] / size_voxel);
+        const short ky = static_cast<short>(world_xyz[3 * (size_t)i + 1] / size_voxel);
+        const short kz = static_cast<short>(world_xyz[3 * (size_t)i + 2] / size_voxel);
+        grid[voxel(kx, ky, kz)].push_back(i);
+    }
+    int m = 0;
+    for (const auto &kv : grid)
+        if (kv.second.size() > 0) idx_out[m++] = kv.second[0];
+    return m;
+}
+
 void orc_so3_to_rot(const double w[3], double R[9]) { m3_to(so3_to_rotation(v3(w[0], w[1], w[2])), R); }
 void orc_so3_to_quat(const double w[3], double q[4]) { Q4 r = so3_to_quat(v3(w[0], w[1], w[2])); q[0] = r.w; q[1] = r.x; q[2] = r.y; q[3] = r.z; }
 void orc_rot_to_so3(const double R[9], double w[3]) { V3 r = rotation_to_so3(m3_from(R)); w[0] = r.x; w[1] = r.y; w[2] = r.z; }

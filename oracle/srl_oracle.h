@@ -137,6 +137,16 @@ int orc_update_iekf(orc_map *m, orc_eskf *e, const orc_icp_opts *o, const double
                     const double t_il[3], int frame_id, int cap, double laser_point_cov,
                     double *log, int max_log_iters, int *num_residuals_used);
 
+/* ---- frame side of optimize() (rows f1/f2) ----
+ * orc_transform_points: transformPoint (utility.cpp:314-318) over n raw points:
+ *     point = q.toRotationMatrix() * (R_il * raw + t_il) + t   (q used as is, not normalised)
+ * orc_grid_sampling: gridSampling -> subSampleFrame (utility.cpp:167-201): key = short(point / size), first point
+ *     of every voxel, emitted in std::tr1::unordered_map iteration order.  idx_out (capacity n) receives the
+ *     frame indices of the keypoints, in keypoint order; returns their number. */
+void orc_transform_points(const double *raw_xyz, int n, const double q_wxyz[4], const double t[3], const double R_il[9],
+                          const double t_il[3], double *world_xyz);
+int  orc_grid_sampling(const double *world_xyz, int n, double size_voxel, int32_t *idx_out);
+
 /* small numeric helpers exported for unit tests (utility.h numType, utility.cpp:146-153) */
 void   orc_quat_to_rot(const double q_wxyz[4], double R[9]);
 void   orc_rot_to_quat(const double R[9], double q_wxyz[4]);

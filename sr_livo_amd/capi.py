@@ -94,6 +94,9 @@ def load_library():
         "srl_fetch_residuals": ([p, p, p, p, p, p, p], C.c_int),
         "srl_search_neighbors": ([p, p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, p, p, p], C.c_int),
         "srl_transform_points": ([p, p, C.c_int, dp, dp, dp, dp, p], C.c_int),
+        "srl_frame_upload": ([p, p, C.c_int], C.c_int),
+        "srl_frame_select_keypoints": ([p, dp, dp, dp, dp, C.c_double, p, C.POINTER(C.c_int)], C.c_int),
+        "srl_frame_commit": ([p, dp, dp, dp, dp, C.c_double, C.c_int, C.c_double, C.c_int, p, C.POINTER(C.c_int)], C.c_int),
         "srl_comm_unique_id": ([p], C.c_int),
         "srl_comm_init_rank": ([p, C.c_int, C.c_int, p], C.c_int),
         "srl_comm_destroy": ([p], C.c_int),
@@ -127,6 +130,9 @@ def load_library():
                                           C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_lio_optimize": ([p, C.POINTER(IcpOpts), C.c_double, p, p, C.c_int, dp, dp, C.c_int, p,
                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "srl_lio_optimize_resident": ([p, C.POINTER(IcpOpts), C.c_double, p, C.c_int, dp, dp, C.c_int, p,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "srl_lio_commit_frame": ([p, dp, C.c_double, C.c_int, C.c_double, C.c_int, p, C.POINTER(C.c_int)], C.c_int),
         "srl_lio_search_neighbors": ([p, dp, C.c_int, C.c_double, C.c_int, C.c_int, p, p, C.POINTER(C.c_int)], C.c_int),
         "srl_lio_neighborhood": ([p, p, C.c_int, dp, dp, dp, dp], C.c_int),
         "srl_lio_build_plane_residuals": ([p, C.POINTER(IcpOpts), p, C.c_int, dp, dp, C.c_int, p, C.c_int,
@@ -326,6 +332,31 @@ class Context:
         self._chk(self.lib.srl_transform_points(self.h, _ptr(r), len(r), _dptr(_f64(q)), _dptr(_f64(t)), _dptr(R_il), _dptr(t_il), _ptr(out)), "srl_transform_points")
         return out
 
+    # --- frame-resident pipeline
+    def frame_upload(self, raw_xyz):
+        r = _f64(raw_xyz, (-1, 3))
+        self._frame_n = len(r)
+        self._chk(self.lib.srl_frame_upload(self.h, _ptr(r), len(r)), "srl_frame_upload")
+
+    def frame_select_keypoints(self, q, t, sample_voxel_size, R_il=None, t_il=None):
+        R_il = _f64(np.eye(3) if R_il is None else R_il).ravel()
+        t_il = _f64(np.zeros(3) if t_il is None else t_il)
+        idx = np.empty(max(self._frame_n, 1), dtype=np.int32)
+        m = C.c_int()
+        self._chk(self.lib.srl_frame_select_keypoints(self.h, _dptr(_f64(q)), _dptr(_f64(t)), _dptr(R_il), _dptr(t_il),
+                                                      float(sample_voxel_size), _ptr(idx), C.byref(m)), "srl_frame_select_keypoints")
+        return idx[: m.value].copy()
+
+    def frame_commit(self, q, t, voxel_size=1.0, cap=20, min_dist=0.15, min_num_points=0, R_il=None, t_il=None, want_world=True):
+        R_il = _f64(np.eye(3) if R_il is None else R_il).ravel()
+        t_il = _f64(np.zeros(3) if t_il is None else t_il)
+        world = np.empty((self._frame_n, 3)) if want_world else None
+        added = C.c_int()
+        self._chk(self.lib.srl_frame_commit(self.h, _dptr(_f64(q)), _dptr(_f64(t)), _dptr(R_il), _dptr(t_il), float(voxel_size), cap,
+                                            float(min_dist), min_num_points, _ptr(world) if want_world else None, C.byref(added)),
+                  "srl_frame_commit")
+        return world, added.value
+
     # --- multi-GPU
     @staticmethod
     def comm_unique_id():
@@ -477,6 +508,25 @@ class Lio:
                                                  _dptr(_f64(t_last)), int(frame_id), _ptr(kidx), C.byref(nk), C.byref(iters), C.byref(nres)),
                        "optimize", ok=allow)
         return dict(rc=rc, state=st, world=world, keypoint_index=kidx[: nk.value].copy(), iters=iters.value, num_residuals=nres.value)
+
+    def optimize_resident(self, opts, sample_voxel_size, frame_raw, state, t_last, frame_id=100,
+                          allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):
+        raw = _f64(frame_raw, (-1, 3))
+        st = _f64(state).copy()
+        kidx = np.empty(max(len(raw), 1), dtype=np.int32)
+        nk, iters, nres = C.c_int(), C.c_int(), C.c_int()
+        rc = self._chk(self.lib.srl_lio_optimize_resident(self.h, C.byref(opts), float(sample_voxel_size), _ptr(raw), len(raw), _dptr(st),
+                                                          _dptr(_f64(t_last)), int(frame_id), _ptr(kidx), C.byref(nk), C.byref(iters),
+                                                          C.byref(nres)), "optimize_resident", ok=allow)
+        self._frame_n = len(raw)
+        return dict(rc=rc, state=st, keypoint_index=kidx[: nk.value].copy(), iters=iters.value, num_residuals=nres.value)
+
+    def commit_frame(self, state, voxel_size=1.0, cap=20, min_dist=0.15, min_num_points=0, want_world=True):
+        world = np.empty((self._frame_n, 3)) if want_world else None
+        added = C.c_int()
+        self._chk(self.lib.srl_lio_commit_frame(self.h, _dptr(_f64(state)), float(voxel_size), cap, float(min_dist), min_num_points,
+                                                _ptr(world) if want_world else None, C.byref(added)), "commit_frame")
+        return world, added.value
 
     def search_neighbors(self, point, nb=1, size=1.0, K=20, thr=1):
         out = np.zeros((K, 3)); vox = np.zeros((K, 3), dtype=np.int16); nf = C.c_int()

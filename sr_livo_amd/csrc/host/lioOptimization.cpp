@@ -490,4 +490,36 @@ optimizeSummary lioOptimization::optimize(cloudFrame *p_frame, const icpOptions 
     return optimize_summary;
 }
 
+// ---------------------------------------------------------------- frame-resident optimize() (optimize.cpp:428-448)
+optimizeSummary lioOptimization::optimizeResident(cloudFrame *p_frame, const double *frame_raw, int n, const icpOptions &cur_icp_options,
+                                                  double sample_voxel_size, std::vector<int> *keypoint_index) {
+    srl_ctx *ctx = voxel_map.ctx;
+    if (!ctx) throw std::runtime_error("optimize: no HIP context (the product has no CPU path)");
+    releaseSweep();
+    check(ctx, srl_frame_upload(ctx, frame_raw, n), "srl_frame_upload");
+    const Quat &q = p_frame->p_state->rotation;
+    const double qv[4] = {q.w, q.x, q.y, q.z};
+    std::vector<int32_t> idx((size_t)std::max(n, 1));
+    int m = 0;
+    check(ctx, srl_frame_select_keypoints(ctx, qv, p_frame->p_state->translation.a, R_imu_lidar.a, t_imu_lidar.a, sample_voxel_size,
+                                          idx.data(), &m), "srl_frame_select_keypoints");
+    if (keypoint_index) keypoint_index->assign(idx.begin(), idx.begin() + m);
+    resident_n = m;
+    sweep_pinned = true;
+    optimizeSummary s = solveIEKF(cur_icp_options, p_frame);
+    releaseSweep();
+    return s;
+}
+
+int lioOptimization::commitFrame(const state *p_state, double voxel_size, int max_num_points_in_voxel, double min_distance_points,
+                                 int min_num_points, double *world_out) {
+    srl_ctx *ctx = voxel_map.ctx;
+    if (!ctx) throw std::runtime_error("addPointsToMap: no HIP context (the product has no CPU path)");
+    const double qv[4] = {p_state->rotation.w, p_state->rotation.x, p_state->rotation.y, p_state->rotation.z};
+    int added = 0;
+    check(ctx, srl_frame_commit(ctx, qv, p_state->translation.a, R_imu_lidar.a, t_imu_lidar.a, voxel_size, max_num_points_in_voxel,
+                                min_distance_points, min_num_points, world_out, &added), "srl_frame_commit");
+    return added;
+}
+
 }  // namespace srlivo

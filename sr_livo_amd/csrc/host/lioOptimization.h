@@ -91,6 +91,14 @@ public:
     // updateIEKF on the sweep already resident in HBM (no keypoint vector needed)
     optimizeSummary solveIEKF(const icpOptions &cur_icp_options, cloudFrame *p_frame);
     void releaseSweep() { sweep_pinned = false; resident_n = -1; }
+    // frame-resident form of optimize(): the raw frame is uploaded once, keypoints are selected on the device with
+    // the prior pose of p_frame->p_state (same set and order as gridSampling on transformPoint-ed points), the
+    // ESIKF runs on them in place.  Returns the keypoints' frame indices through keypoint_index (optional).
+    optimizeSummary optimizeResident(cloudFrame *p_frame, const double *frame_raw, int n, const icpOptions &cur_icp_options,
+                                     double sample_voxel_size, std::vector<int> *keypoint_index = nullptr);
+    // transformPoint over the uploaded frame with p_state's pose + addPointsToMap, all on the device
+    int commitFrame(const state *p_state, double voxel_size, int max_num_points_in_voxel, double min_distance_points,
+                    int min_num_points, double *world_out = nullptr);
     void setNormalEqProvider(normal_eq_provider fn, void *user) { provider = fn; provider_user = user; }
     srl_ctx *context() { return voxel_map.ctx; }
 

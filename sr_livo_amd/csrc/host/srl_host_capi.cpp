@@ -274,6 +274,46 @@ int srl_lio_optimize(srl_lio *h, const srl_icp_opts *opts, double sample_voxel_s
     return SRL_OK;
 }
 
+int srl_lio_optimize_resident(srl_lio *h, const srl_icp_opts *opts, double sample_voxel_size, const double *frame_raw, int n,
+                              double state_io[16], const double t_last[3], int frame_id, int32_t *keypoint_index,
+                              int *num_keypoints, int *iters, int *num_residuals_used) {
+    if (!h || !opts || (n > 0 && !frame_raw) || !state_io || !t_last || n < 0) return SRL_ERR_BAD_ARG;
+    if (!h->lio->context()) return SRL_ERR_NO_DEVICE;
+    h->lio->setNormalEqProvider(nullptr, nullptr);
+    std::vector<point3D> none;
+    FrameWindow w(h, state_io, t_last, frame_id, none);
+    const icpOptions o = icpOptions::fromAbi(*opts);
+    optimizeSummary s;
+    std::vector<int> kidx;
+    try {
+        s = h->lio->optimizeResident(&w.cur, frame_raw, n, o, sample_voxel_size, &kidx);
+    } catch (const std::exception &e) {
+        h->lio->all_cloud_frame.clear();
+        return status_from_exception(h, e);
+    }
+    h->lio->all_cloud_frame.clear();
+    if (num_keypoints) *num_keypoints = (int)kidx.size();
+    if (keypoint_index) for (size_t i = 0; i < kidx.size(); i++) keypoint_index[i] = kidx[i];
+    state_to(h->cur_state, state_io);
+    if (iters) *iters = h->lio->last_num_iterations;
+    if (num_residuals_used) *num_residuals_used = s.num_residuals_used;
+    if (!s.success) { h->err = s.error_log; return SRL_ERR_NOT_ENOUGH_RESIDUALS; }
+    return SRL_OK;
+}
+
+int srl_lio_commit_frame(srl_lio *h, const double state[16], double voxel_size, int max_num_points_in_voxel,
+                         double min_distance_points, int min_num_points, double *world_out, int *num_added) {
+    if (!h || !state) return SRL_ERR_BAD_ARG;
+    if (!h->lio->context()) return SRL_ERR_NO_DEVICE;
+    srlivo::state st;
+    state_from(state, st);
+    try {
+        const int added = h->lio->commitFrame(&st, voxel_size, max_num_points_in_voxel, min_distance_points, min_num_points, world_out);
+        if (num_added) *num_added = added;
+    } catch (const std::exception &e) { return status_from_exception(h, e); }
+    return SRL_OK;
+}
+
 int srl_lio_search_neighbors(srl_lio *h, const double point[3], int nb_voxels_visited, double size_voxel_map,
                              int max_num_neighbors, int threshold_voxel_capacity, double *out_xyz, int16_t *out_voxels,
                              int *num_found) {

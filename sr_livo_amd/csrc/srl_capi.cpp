@@ -59,6 +59,8 @@ int ensure_taps(srl_ctx *ctx, int n, int K) {
 
 }  // namespace
 
+int srl_ctx_ensure_work(srl_ctx *ctx, int n) { return ensure_work(ctx, n); }   // used by srl_frame_kernels.hip
+
 // shared with srl_map_kernels.hip
 int srl_ctx_grow_map(srl_ctx *ctx, unsigned need_slabs, unsigned need_slots);
 
@@ -136,7 +138,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
-    void *bufs[] = {ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
+    void *bufs[] = {ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
                     ctx->d_out, ctx->d_count, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
                     ctx->d_tap_offset, ctx->d_gather};
     for (void *b : bufs) if (b) hipFree(b);

@@ -28,6 +28,12 @@ struct srl_ctx {
     int shard_begin = 0;
     int total_n = 0;
 
+    // frame-resident pipeline (srl_frame_*)
+    double *d_frame_raw = nullptr;     // AoS n x 3
+    double *d_frame_world = nullptr;   // AoS n x 3
+    int frame_cap = 0;
+    int frame_n = -1;
+
     // work buffers
     double *d_rec = nullptr;
     unsigned char *d_status = nullptr;

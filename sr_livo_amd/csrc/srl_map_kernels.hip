@@ -182,9 +182,18 @@ int srl_ctx_grow_map(srl_ctx *ctx, unsigned need_slabs, unsigned need_slots) {
     return SRL_OK;
 }
 
+int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, int n, double voxel_size,
+                        double min_distance_points, int min_num_points, int *num_added);
+
 int srl_map_insert_device(srl_ctx *ctx, const double *world_xyz, int n, double voxel_size, int cap,
                           double min_distance_points, int min_num_points, int *num_added) {
     (void)cap;
+    return srl_map_insert_impl(ctx, world_xyz, false, n, voxel_size, min_distance_points, min_num_points, num_added);
+}
+
+// world_xyz: host pointer, or (on_device) a device pointer that stays valid for the duration of the call
+int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, int n, double voxel_size,
+                        double min_distance_points, int min_num_points, int *num_added) {
     if (num_added) *num_added = 0;
     if (n == 0) return SRL_OK;
     if (!(voxel_size > 0.0)) return SRL_ERR_BAD_ARG;
@@ -197,7 +206,12 @@ int srl_map_insert_device(srl_ctx *ctx, const double *world_xyz, int n, double v
     }
 
     DevBuf b_xyz, b_keys, b_keys2, b_idx, b_idx2, b_ukeys, b_len, b_start, b_nruns, b_tmp;
-    HIPCHK(ctx, b_xyz.alloc((size_t)n * 3 * sizeof(double)));
+    const double *d_xyz = world_xyz;
+    if (!on_device) {
+        HIPCHK(ctx, b_xyz.alloc((size_t)n * 3 * sizeof(double)));
+        HIPCHK(ctx, hipMemcpyAsync(b_xyz.p, world_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+        d_xyz = b_xyz.as<double>();
+    }
     HIPCHK(ctx, b_keys.alloc((size_t)n * 8));
     HIPCHK(ctx, b_keys2.alloc((size_t)n * 8));
     HIPCHK(ctx, b_idx.alloc((size_t)n * 4));
@@ -206,8 +220,7 @@ int srl_map_insert_device(srl_ctx *ctx, const double *world_xyz, int n, double v
     HIPCHK(ctx, b_len.alloc((size_t)n * 4));
     HIPCHK(ctx, b_start.alloc((size_t)n * 4));
     HIPCHK(ctx, b_nruns.alloc(16));
-    HIPCHK(ctx, hipMemcpyAsync(b_xyz.p, world_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_point_keys, dim3((n + 255) / 256), dim3(256), 0, st, b_xyz.as<double>(), n, voxel_size,
+    hipLaunchKernelGGL(k_point_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, voxel_size,
                        b_keys.as<unsigned long long>(), b_idx.as<unsigned>());
     HIPCHK(ctx, hipGetLastError());
 
@@ -291,7 +304,7 @@ int srl_map_insert_device(srl_ctx *ctx, const double *world_xyz, int n, double v
     }
 
     hipLaunchKernelGGL(k_replay, dim3((S + 127) / 128), dim3(128), 0, st, b_start.as<int>(), b_len.as<int>(), b_idx2.as<unsigned>(), S,
-                       b_xyz.as<double>(), b_slot.as<int>(), b_isnew.as<unsigned char>(), ctx->d_table, ctx->d_slabs, voxel_size,
+                       d_xyz, b_slot.as<int>(), b_isnew.as<unsigned char>(), ctx->d_table, ctx->d_slabs, voxel_size,
                        min_distance_points, min_num_points, b_added.as<int>());
     HIPCHK(ctx, hipGetLastError());
     int added = 0;

@@ -626,3 +626,106 @@ def test_extrinsics_unnormalised_quaternion_and_voxel_size(oracle_lib, oracle_ba
             assert rel(np.array(neq.HtH).reshape(6, 6), o["HtH"]) < TIGHT and rel(np.array(neq.Hth), o["Hth"]) < TIGHT
         finally:
             ctx.close()
+
+
+# ----------------------------------------------------------------------------- frame-resident pipeline (rows f1/f2)
+def test_frame_pipeline_selects_reference_keypoints_and_commits(oracle_lib, oracle_backend):
+    """srl_frame_upload -> srl_frame_select_keypoints -> srl_build_residuals -> srl_frame_commit against
+    transformPoint + gridSampling + buildPlaneResiduals + addPointsToMap of the oracle: same keypoints in the
+    same (tr1 iteration) order, bit-identical normal equations to the upload-the-keypoints path, bit-identical map."""
+    pts, L = synth.map_candidates(1201, 80_000)
+    sw = synth.make_sweep(1202, 30_000, L)
+    R_il = synth.quat_to_rot(synth.quat_from_rotvec([0.02, 0.01, -0.04])); t_il = np.array([0.05, 0.02, -0.03])
+    raw = (sw["raw"] - t_il) @ R_il
+    q = sw["q_pred"] * 0.9996           # un-normalised: transformPoint uses q as is
+    t = sw["t_pred"]
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(pts[: len(pts) // 2])
+    ctx = srl.Context(0); ctx2 = srl.Context(0)
+    try:
+        for c in (ctx, ctx2):
+            assert c.map_insert(pts[: len(pts) // 2]) == m.size()
+        for size in (1.5, 0.4):
+            world = oracle_lib.transform_points(raw, q, t, R_il, t_il, backend=oracle_backend)
+            want = oracle_lib.grid_sampling(world, size, backend=oracle_backend)
+            ctx.frame_upload(raw)
+            got = ctx.frame_select_keypoints(q, t, size, R_il, t_il)
+            assert np.array_equal(got, want), "keypoint set/order differs from gridSampling"
+            assert ctx.sweep_shard() == (0, len(want), len(want))
+        # the selection is the resident sweep: same normal equations as uploading those keypoints
+        opts = srl.default_opts(max_num_residuals=INT_MAX)
+        f = capi.make_frame(q, t, sw["t_last"], R_il=R_il, t_il=t_il)
+        n1, _ = ctx.build_residuals(f, opts)
+        ctx2.sweep_upload(raw[want])
+        n2, _ = ctx2.build_residuals(f, opts)
+        assert n1.num_residuals == n2.num_residuals > 500
+        assert np.array_equal(np.array(n1.HtH), np.array(n2.HtH)) and np.array_equal(np.array(n1.Hth), np.array(n2.Hth))
+        o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=INT_MAX), raw[want], q, t, sw["t_last"], R_il=R_il, t_il=t_il)
+        assert rel(np.array(n1.HtH).reshape(6, 6), o["HtH"]) < TIGHT and n1.num_residuals == o["neq"].num_residuals
+        # commit with another pose: transform + insert on the device
+        q2 = sw["q_gt"]; t2 = sw["t_gt"]
+        world2, added = ctx.frame_commit(q2, t2, R_il=R_il, t_il=t_il)
+        want2 = oracle_lib.transform_points(raw, q2, t2, R_il, t_il, backend=oracle_backend)
+        assert np.array_equal(world2, want2), "device transformPoint is not bit-identical"
+        before = m.size()
+        m.add_points(want2)
+        assert added == m.size() - before and added > 300
+        kg, cg, xg = ctx.map_download(); ko, co, xo = m.export()
+        assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
+        # empty frame
+        ctx.frame_upload(np.zeros((0, 3)))
+        assert len(ctx.frame_select_keypoints(q, t, 1.0)) == 0
+        assert ctx.frame_commit(q2, t2)[1] == 0
+    finally:
+        ctx.close(); ctx2.close()
+
+
+def test_resident_replay_matches_oracle(oracle_lib, oracle_backend):
+    """The multi-sweep replay with the frame kept in HBM: optimize_resident (device keypoint selection + ESIKF)
+    and commit_frame (device re-transform + addPointsToMap) against the oracle running
+    transformPoint -> gridSampling -> updateIEKF -> transformPoint -> addPointsToMap."""
+    pts, L = synth.map_candidates(555, 120_000)
+    init = pts[: len(pts) // 3]
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(init)
+    lio = srl.Lio(0)
+    try:
+        lio.add_points_to_map(init)
+        e = oracle_lib.Eskf(oracle_backend)
+        sw0 = synth.make_sweep(600, 6000, L)
+        synth.eskf_prior(e, sw0["q_gt"], sw0["t_gt"], np.zeros(3))
+        lio.eskf_set_noise(0.1, 0.1, 0.0001, 0.0001)
+        lio.eskf_init_imu(np.array([0.0, 0.0, 9.81]), np.zeros(3))
+        lio.eskf_set_state(e.get_state()); lio.eskf_set_cov(e.get_cov())
+        opts_p = srl.default_opts(max_num_residuals=600)
+        opts_o = oracle_lib.opts_from_product(opts_p)
+        t_last = sw0["t_gt"].copy()
+        acc = np.array([0.0, 0.0, 9.81]); gyr = np.zeros(3)
+        for k in range(5):
+            sw = synth.make_sweep(600 + k, 8000, L)
+            for _ in range(2):
+                e.predict(0.01, acc, gyr); lio.eskf_predict(0.01, acc, gyr)
+            s = e.get_state(); s[0:3] = sw["t_pred"]; s[3:7] = sw["q_pred"]; s[7:10] = 0.0
+            e.set_state(s); lio.eskf_set_state(s)
+            st = np.concatenate([sw["q_pred"], sw["t_pred"], np.zeros(9)])
+            frame_id = 100 + k
+            g = lio.optimize_resident(opts_p, 1.5, sw["raw"], st, t_last, frame_id=frame_id)
+            assert g["rc"] == 0
+            world0 = oracle_lib.transform_points(sw["raw"], sw["q_pred"], sw["t_pred"], backend=oracle_backend)
+            kidx = oracle_lib.grid_sampling(world0, 1.5, backend=oracle_backend)
+            assert np.array_equal(g["keypoint_index"], kidx)
+            u = oracle_lib.update_iekf(m, e, opts_o, sw["raw"][kidx], st, t_last, frame_id=frame_id)
+            assert u["rc"] == g["iters"] and u["num_residuals"] == g["num_residuals"]
+            assert rel(g["state"], u["state"]) < 1e-9
+            assert rel(lio.eskf_get_cov(), e.get_cov()) < 1e-8
+            world, added = lio.commit_frame(g["state"])
+            assert np.array_equal(world, oracle_lib.transform_points(sw["raw"], g["state"][0:4], g["state"][4:7], backend=oracle_backend))
+            assert rel(world, oracle_lib.transform_points(sw["raw"], u["state"][0:4], u["state"][4:7], backend=oracle_backend)) < 1e-9
+            before = m.size()
+            m.add_points(world)                 # same world points into both maps: the comparison stays bit-exact
+            assert added == m.size() - before and lio.map_size() == m.size()
+            t_last = u["state"][4:7].copy()
+        kg, cg, xg = lio.ctx.map_download(); ko, co, xo = m.export()
+        assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
+    finally:
+        lio.close()

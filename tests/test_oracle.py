@@ -12,6 +12,7 @@ import pytest
 from scipy.spatial.transform import Rotation
 
 from oracle import pyoracle as po
+import sr_livo_amd as srl
 from sr_livo_amd import synth
 
 import np_reference as npr
@@ -238,3 +239,28 @@ def test_oracle_reproduces_golden_vectors(golden, small_scene, oracle_backend, p
     assert u["rc"] == int(golden[f"{prefix}_solve_rc"])
     assert np.array_equal(u["state"], golden[f"{prefix}_solve_state"])
     assert np.array_equal(e.get_cov(), golden[f"{prefix}_solve_eskf_cov"])
+
+
+# ----------------------------------------------------------------------------- frame side (utility.cpp:167-201,314-318)
+def test_transform_points_and_grid_sampling(oracle_lib):
+    rng = np.random.default_rng(77)
+    raw = rng.uniform(-30, 30, (20000, 3))
+    q = np.array([0.9, 0.1, -0.2, 0.3]) * 1.01                # un-normalised on purpose
+    t = np.array([1.0, -2.0, 0.5]); t_il = np.array([0.1, 0.2, -0.05])
+    a = 0.3; R_il = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    world = oracle_lib.transform_points(raw, q, t, R_il, t_il)
+    w, x, y, z = q                                             # Eigen's toRotationMatrix on the raw coefficients
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    assert np.allclose(world, (raw @ R_il.T + t_il) @ R.T + t, rtol=0, atol=1e-12)
+    for size in (0.5, 1.5):
+        idx = oracle_lib.grid_sampling(world, size)
+        keys = np.trunc(world / size).astype(np.int64)         # static_cast<short> truncates toward zero
+        first = {}
+        for i, k in enumerate(map(tuple, keys)):
+            first.setdefault(k, i)
+        assert sorted(idx.tolist()) == sorted(first.values())  # first point of every voxel, nothing else
+        assert np.array_equal(idx, oracle_lib.grid_sampling(world, size))
+        assert np.array_equal(idx, srl.grid_sampling(world, size))      # host mirror uses the same container type
+    assert len(oracle_lib.grid_sampling(np.zeros((0, 3)), 1.0)) == 0
