@@ -122,6 +122,30 @@ int srl_sweep_shard(srl_ctx *ctx, int *begin, int *count, int *total);
  * srl_frame_commit            replaces the re-transform loop (optimize.cpp:441-445) + addPointsToMap
  *                             (lioOptimization.cpp:520-554) with the final pose, without leaving the device. */
 int srl_frame_upload(srl_ctx *ctx, const double *raw_xyz, int n);
+
+/* Sweep reconstruction: the per-point stages of buildFrame (lioOptimization.cpp:833-850).
+ * srl_imu_state mirrors imuState (cloudMap.h:110-122), quat as w x y z.
+ * srl_frame_undistort replaces distortFrameByConstant / distortFrameByImu (utility.cpp:203-306) followed by
+ *   transformAllImuPoint (utility.cpp:320-332) over ALL n points of the cut sweep: relative_time_ms is
+ *   point3D::relative_time (makePointTimestamp, lioOptimization.cpp:786-819), motion_compensation the enum of
+ *   include/utility.h:82-86 (SRL_MC_NONE = neither branch of lioOptimization.cpp:833-836 runs).  imu_point_in (or NULL
+ *   = zeros) is what imu_point holds before: distortFrameByImu leaves points its interval walk does not reach untouched.
+ *   Outputs (optional): point3D::imu_point and the corrected point3D::raw_point, n x 3 each.  The corrected sweep
+ *   stays in HBM.
+ * srl_frame_take makes the points index[0..m) of the corrected sweep the resident frame (what srl_frame_upload
+ *   would upload) -- the order buildFrame's shuffle / subSampleFrame / shuffle leaves (a host decision). */
+typedef struct srl_imu_state {
+    double timestamp;
+    double un_acc[3], un_gyr[3], trans[3];
+    double quat[4];
+    double vel[3];
+} srl_imu_state;
+enum { SRL_MC_IMU = 0, SRL_MC_CONSTANT_VELOCITY = 1, SRL_MC_NONE = 2 };
+int srl_frame_undistort(srl_ctx *ctx, const double *raw_xyz, const double *relative_time_ms, const double *imu_point_in,
+                        int n, const srl_imu_state *imu_states, int n_states, double time_frame_begin,
+                        int motion_compensation, const double R_il[9], const double t_il[3], double *imu_point_out,
+                        double *raw_out);
+int srl_frame_take(srl_ctx *ctx, const int32_t *index, int m);
 int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3], const double R_il[9],
                                const double t_il[3], double sample_voxel_size,
                                int32_t *keypoint_index /* capacity n, or NULL */, int *num_keypoints);

@@ -69,6 +69,52 @@ int srl_lio_optimize(srl_lio *lio, const srl_icp_opts *opts, double sample_voxel
                      double *frame_world, int n, double state_io[16], const double t_last[3], int frame_id,
                      int32_t *keypoint_index, int *num_keypoints, int *iters, int *num_residuals_used);
 
+/* eskfEstimator::tryInit (eskfEstimator.cpp:43-118): imu_meas as t (n), gyr (n x 3), acc (n x 3).
+ * *initialized: 1 initialised by this call (initial_flag set), 0 wait for more, -1 / -2 gyro / accel variance too large.
+ * get_init_stats: mean_gyr, mean_acc, gyr_cov, acc_cov, num_init_meas, initial_flag (14 doubles).
+ * initial_flag is process-global, as in the reference (utility.cpp:11). */
+int srl_lio_eskf_try_init(srl_lio *lio, const double *t, const double *gyr, const double *acc, int n, int *initialized);
+int srl_lio_eskf_get_init_stats(srl_lio *lio, double out[14]);
+int srl_lio_set_initial_flag(srl_lio *lio, int flag);
+/* lioOptimization::stateInitialization (lioOptimization.cpp:895-990): pose prior (q wxyz, t) of frame index_frame from
+ * prev2 / prev1 = poses of all_cloud_frame[size-2] / [size-1]; initialization: 0 INIT_IMU, 1 INIT_CONSTANT_VELOCITY. */
+int srl_lio_state_initialization(srl_lio *lio, int index_frame, int initialization, const double prev2[7],
+                                 const double prev1[7], double out[7]);
+
+/* ---- ROS-free replay driver: the LIO part of lioOptimization::run()'s loop body (lioOptimization.cpp:1427-1584):
+ * tryInit while the filter is uninitialised; afterwards IMU propagation (predict per sample, imu_states), then
+ * process() = stateInitialization -> buildFrame (device undistortion) -> stateEstimation (device keypoints, ESIKF,
+ * device map insert) and the sliding window.  One call = one `Measurements` element: time_frame = time_image,
+ * IMU samples (time, linear_acceleration, angular_velocity), the cut sweep (sensor-frame points + absolute point
+ * timestamps) and time_sweep = (begin, offset).  srl_odometry_opts carries the odometryOptions fields the path
+ * reads (parameters.h:58-88) plus the IMU noise parameters (setAccCov ...) and isPointTimeEnable(). */
+typedef struct srl_odometry_opts {
+    double init_voxel_size, init_sample_voxel_size;
+    int init_num_frames, num_for_initialization;
+    double voxel_size, sample_voxel_size;
+    int max_num_points_in_voxel;
+    double min_distance_points;
+    int motion_compensation;          /* include/utility.h:82-86: 0 IMU, 1 CONSTANT_VELOCITY */
+    int initialization;               /* include/utility.h:88-92: 0 INIT_IMU, 1 INIT_CONSTANT_VELOCITY */
+    int point_time_enable;
+    double acc_cov, gyr_cov, b_acc_cov, b_gyr_cov;
+    srl_icp_opts icp;
+} srl_odometry_opts;
+typedef struct srl_replay_result {
+    int processed;                    /* 0: the call only fed tryInit */
+    int initialized;                  /* initial_flag after the call */
+    int index_frame;                  /* after the call */
+    int success, num_residuals_used, iterations;
+    int frame_points, keypoints, points_added;
+    double state[16];                 /* p_state of the frame: q wxyz, t, v, ba, bg */
+} srl_replay_result;
+int srl_lio_set_odometry_options(srl_lio *lio, const srl_odometry_opts *opts);
+int srl_lio_run_measurement(srl_lio *lio, double time_frame, const double *imu_t, const double *imu_acc,
+                            const double *imu_gyr, int n_imu, const double *pts_raw, const double *pts_timestamp,
+                            int n_pts, double time_sweep_begin, double time_sweep_offset, srl_replay_result *out);
+/* point3D::raw_point / ::point / ::imu_point of the newest frame in all_cloud_frame (any pointer may be NULL) */
+int srl_lio_last_frame(srl_lio *lio, int capacity, double *raw_point, double *point, double *imu_point, int *n);
+
 /* Frame-resident form of optimize() + the map update that follows it in stateEstimation
  * (lioOptimization.cpp:1027,1051): the raw frame (n x 3) is uploaded once; keypoints are selected on the device
  * from point = R(q)(R_il raw + t_il) + t with the PRIOR pose in state_io (what point3D::point holds when

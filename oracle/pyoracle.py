@@ -73,6 +73,10 @@ def load(backend="plain"):
     lib.orc_eskf_init_imu.argtypes = [p, dp, dp]
     lib.orc_eskf_scale_init_cov.argtypes = [p]
     lib.orc_eskf_predict.argtypes = [p, C.c_double, dp, dp]
+    lib.orc_eskf_try_init.argtypes = [p, dp, dp, dp, C.c_int]; lib.orc_eskf_try_init.restype = C.c_int
+    lib.orc_eskf_get_init_stats.argtypes = [p, dp]
+    lib.orc_eskf_set_g_norm.argtypes = [p, C.c_double]
+    lib.orc_state_initialization.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp]
     lib.orc_update_iekf.argtypes = [p, p, C.POINTER(OrcOpts), p, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, C.c_double,
                                     p, C.c_int, C.POINTER(C.c_int)]
     lib.orc_update_iekf.restype = C.c_int
@@ -82,6 +86,14 @@ def load(backend="plain"):
     lib.orc_derivative_s2.argtypes = [dp, dp]
     lib.orc_inverse17.argtypes = [dp, dp]; lib.orc_inverse17.restype = C.c_int
     lib.orc_eig3.argtypes = [dp, dp, dp]
+    lib.orc_distort_frame_by_constant.argtypes = [p, p, C.c_int, p, C.c_int, C.c_double, dp, dp, p]
+    lib.orc_distort_frame_by_imu.argtypes = [p, p, C.c_int, p, C.c_int, C.c_double, dp, dp, p]
+    lib.orc_distort_frame_by_imu.restype = C.c_int
+    lib.orc_transform_all_imu_point.argtypes = [p, C.c_int, p, C.c_int, dp, dp, p]
+    lib.orc_build_frame_order.argtypes = [p, C.c_int, C.c_double, C.c_int, p]; lib.orc_build_frame_order.restype = C.c_int
+    lib.orc_make_point_timestamp.argtypes = [p, C.c_int, C.c_double, C.c_double, C.c_int, p, p, p]
+    lib.orc_make_point_timestamp.restype = C.c_int
+    lib.orc_mt19937_64_nth.argtypes = [C.c_int]; lib.orc_mt19937_64_nth.restype = C.c_uint64
     lib.orc_transform_points.argtypes = [p, C.c_int, dp, dp, dp, dp, p]
     lib.orc_grid_sampling.argtypes = [p, C.c_int, C.c_double, p]; lib.orc_grid_sampling.restype = C.c_int
     _libs[path] = lib
@@ -205,6 +217,16 @@ class Eskf:
     def scale_init_cov(self):
         self.lib.orc_eskf_scale_init_cov(self.h)
 
+    def try_init(self, t, gyr, acc):
+        t = _f64(t); g = _f64(gyr, (-1, 3)); a = _f64(acc, (-1, 3))
+        return self.lib.orc_eskf_try_init(self.h, _dp(t), _dp(g), _dp(a), len(t))
+
+    def init_stats(self):
+        o = np.zeros(14)
+        self.lib.orc_eskf_get_init_stats(self.h, _dp(o))
+        return dict(mean_gyr=o[0:3].copy(), mean_acc=o[3:6].copy(), gyr_cov=o[6:9].copy(), acc_cov=o[9:12].copy(),
+                    num_init_meas=int(o[12]), initial_flag=bool(o[13]))
+
     def predict(self, dt, acc1, gyr1):
         self.lib.orc_eskf_predict(self.h, dt, _dp(_f64(acc1)), _dp(_f64(gyr1)))
 
@@ -240,3 +262,60 @@ def grid_sampling(world, size_voxel, backend="plain"):
     idx = np.empty(max(len(w), 1), dtype=np.int32)
     m = lib.orc_grid_sampling(_vp(w), len(w), float(size_voxel), _vp(idx))
     return idx[:m].copy()
+
+
+def state_initialization(index_frame, initialization, initial_flag, prev2, prev1, eskf_q=(1, 0, 0, 0), eskf_t=(0, 0, 0), backend="plain"):
+    """stateInitialization (lioOptimization.cpp:895-990) -> (q wxyz, t)."""
+    lib = load(backend)
+    out = np.zeros(7)
+    lib.orc_state_initialization(int(index_frame), int(initialization), int(bool(initial_flag)), _dp(_f64(prev2)), _dp(_f64(prev1)),
+                                 _dp(_f64(eskf_q)), _dp(_f64(eskf_t)), _dp(out))
+    return out[0:4].copy(), out[4:7].copy()
+
+
+def _ext(R_il, t_il):
+    return _f64(np.eye(3) if R_il is None else R_il).ravel(), _f64(np.zeros(3) if t_il is None else t_il)
+
+
+def distort_frame(raw, relative_time_ms, imu_states, time_frame_begin, mode, R_il=None, t_il=None, imu_point_in=None, backend="plain"):
+    """distortFrameByConstant (mode 1) / distortFrameByImu (mode 0) (utility.cpp:203-306) -> imu_point, number written."""
+    lib = load(backend)
+    r = _f64(raw, (-1, 3)); rel = _f64(relative_time_ms); st = _f64(imu_states, (-1, 17))
+    R, t = _ext(R_il, t_il)
+    imu = np.zeros_like(r) if imu_point_in is None else _f64(imu_point_in, (-1, 3)).copy()
+    if mode == 1:
+        lib.orc_distort_frame_by_constant(_vp(r), _vp(rel), len(r), _vp(st), len(st), float(time_frame_begin), _dp(R), _dp(t), _vp(imu))
+        return imu, len(r)
+    if mode == 0:
+        k = lib.orc_distort_frame_by_imu(_vp(r), _vp(rel), len(r), _vp(st), len(st), float(time_frame_begin), _dp(R), _dp(t), _vp(imu))
+        return imu, k
+    return imu, 0
+
+
+def transform_all_imu_point(imu_point, imu_states, R_il=None, t_il=None, backend="plain"):
+    lib = load(backend)
+    p = _f64(imu_point, (-1, 3)); st = _f64(imu_states, (-1, 17))
+    R, t = _ext(R_il, t_il)
+    out = np.empty_like(p)
+    lib.orc_transform_all_imu_point(_vp(p), len(p), _vp(st), len(st), _dp(R), _dp(t), _vp(out))
+    return out
+
+
+def build_frame_order(point_xyz, sample_size, do_subsample=True, backend="plain"):
+    lib = load(backend)
+    p = _f64(point_xyz, (-1, 3))
+    order = np.empty(max(len(p), 1), dtype=np.int32)
+    m = lib.orc_build_frame_order(_vp(p), len(p), float(sample_size), int(bool(do_subsample)), _vp(order))
+    return order[:m].copy()
+
+
+def make_point_timestamp(timestamp, time_begin, time_end, point_time_enable=True, backend="plain"):
+    lib = load(backend)
+    ts = _f64(timestamp)
+    rel = np.zeros_like(ts); alpha = np.zeros_like(ts); keep = np.zeros(len(ts), dtype=np.uint8)
+    lib.orc_make_point_timestamp(_vp(ts), len(ts), float(time_begin), float(time_end), int(bool(point_time_enable)), _vp(rel), _vp(alpha), _vp(keep))
+    return rel, alpha, keep.astype(bool)
+
+
+def mt19937_64_nth(n, backend="plain"):
+    return int(load(backend).orc_mt19937_64_nth(int(n)))

@@ -23,6 +23,7 @@
 #include <queue>
 #include <tuple>
 #include <unordered_map>
+#include <random>
 #include <tr1/unordered_map>
 #include <vector>
 
@@ -144,6 +145,14 @@ inline Q4 q_inverse(const Q4 &q) {
     double n2 = q_sqnorm(q);
     if (n2 > 0.0) return Q4{q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2};
     return Q4{0, 0, 0, 0};
+}
+
+// Eigen::QuaternionBase::_transformVector (Quaternion * Vector3, Eigen 3.3 Geometry/Quaternion.h): NOT via a matrix
+inline V3 q_rotate(const Q4 &q, const V3 &v) {
+    const V3 qv = v3(q.x, q.y, q.z);
+    V3 uv = cross(qv, v);
+    uv = uv + uv;
+    return (v + q.w * uv) + cross(qv, uv);
 }
 
 // numType::normalizeR (utility.h:194-202)
@@ -687,6 +696,10 @@ struct orc_eskf {
     V3 p; Q4 q; V3 v, ba, bg, g;
     double noise[12][12];
     double covariance[17][17];
+    // tryInit bookkeeping (eskfEstimator.h:26-45, utility.cpp:11,14)
+    V3 acc_cov_scale, gyr_cov_scale, mean_gyr, mean_acc;
+    bool is_first_imu_meas; double time_first_imu; int num_init_meas;
+    bool initial_flag; double G_norm;
 };
 
 namespace {
@@ -697,6 +710,34 @@ void eskf_init(orc_eskf *e) {                   // eskfEstimator.cpp:3-21
     e->q = Q4{1, 0, 0, 0};
     e->v = e->ba = e->bg = v3(0, 0, 0);
     e->g = v3(0.0, 0.0, 9.81);
+    e->mean_gyr = v3(0, 0, 0);
+    e->mean_acc = v3(0, 0, 9.81);
+    e->is_first_imu_meas = true;
+    e->num_init_meas = 1;
+    e->initial_flag = false;
+    e->G_norm = 9.81;                           // lioOptimization.cpp:366-367 with the shipped G = (0,0,9.81)
+}
+inline V3 cwise_sq(const V3 &a) { return v3(a.x * a.x, a.y * a.y, a.z * a.z); }
+void eskf_initialization(orc_eskf *e, const double *t, const double *gyr, const double *acc, int n) {   // eskfEstimator.cpp:93-118
+    if (e->is_first_imu_meas) {
+        e->num_init_meas = 1;
+        e->is_first_imu_meas = false;
+        e->time_first_imu = t[0];
+        e->mean_gyr = v3(gyr[0], gyr[1], gyr[2]);
+        e->mean_acc = v3(acc[0], acc[1], acc[2]);
+    }
+    for (int i = 0; i < n; i++) {
+        const V3 w = v3(gyr[3 * i], gyr[3 * i + 1], gyr[3 * i + 2]), a = v3(acc[3 * i], acc[3 * i + 1], acc[3 * i + 2]);
+        const int N = e->num_init_meas;         // int: "/ num_init_meas" divides by the converted double
+        e->mean_gyr = e->mean_gyr + (w - e->mean_gyr) / (double)N;
+        e->mean_acc = e->mean_acc + (a - e->mean_acc) / (double)N;
+        // a * (N - 1.0) / N  parses as (a * (N - 1.0)) / N;  (N * N) is an int product
+        e->gyr_cov = (e->gyr_cov * (N - 1.0)) / (double)N + (cwise_sq(w - e->mean_gyr) * (N - 1.0)) / (double)(N * N);
+        e->acc_cov = (e->acc_cov * (N - 1.0)) / (double)N + (cwise_sq(a - e->mean_acc) * (N - 1.0)) / (double)(N * N);
+        e->num_init_meas++;
+    }
+    e->gyr_0 = v3(gyr[3 * (n - 1)], gyr[3 * (n - 1) + 1], gyr[3 * (n - 1) + 2]);
+    e->acc_0 = v3(acc[3 * (n - 1)], acc[3 * (n - 1) + 1], acc[3 * (n - 1) + 2]);
 }
 void eskf_observe(orc_eskf *e, const double d[17]) {   // eskfEstimator.cpp:219-230
     e->p = e->p + v3(d[0], d[1], d[2]);
@@ -1143,7 +1184,64 @@ void orc_eskf_set_state(orc_eskf *e, const double s[19]) {
 void orc_eskf_get_cov(const orc_eskf *e, double P[289]) { std::memcpy(P, e->covariance, 289 * sizeof(double)); }
 void orc_eskf_set_cov(orc_eskf *e, const double P[289]) { std::memcpy(e->covariance, P, 289 * sizeof(double)); }
 // setAccCov.. + initializeNoise (eskfEstimator.cpp:23-41,120-126): after tryInit gyr_cov=gyr_cov_scale etc.
+int orc_eskf_try_init(orc_eskf *e, const double *t, const double *gyr, const double *acc, int n) {     // eskfEstimator.cpp:43-91
+    if (n <= 0) return e->initial_flag ? 1 : 0;     // imu_meas.front()/back() on an empty vector is UB upstream
+    eskf_initialization(e, t, gyr, acc, n);
+    if (e->num_init_meas > 10 /*MIN_INI_COUNT*/ && t[n - 1] - e->time_first_imu > 3.0 /*MIN_INI_TIME*/) {
+        const double r = e->G_norm / norm(e->mean_acc);
+        e->acc_cov = e->acc_cov * std::pow(r, 2);
+        if (norm(e->gyr_cov) > 0.5 /*MAX_GYR_VAR*/) return -1;
+        if (norm(e->acc_cov) > 0.6 /*MAX_ACC_VAR*/) return -2;
+        e->initial_flag = true;
+        e->gyr_cov = e->gyr_cov_scale;
+        e->acc_cov = e->acc_cov_scale;
+        e->bg = e->mean_gyr;
+        e->g = (e->mean_acc / norm(e->mean_acc)) * e->G_norm;
+        orc_eskf_scale_init_cov(e);
+        std::memset(e->noise, 0, sizeof e->noise);                                                    // initializeNoise :120-126
+        for (int i = 0; i < 3; i++) {
+            const double a[3] = {e->acc_cov.x, e->acc_cov.y, e->acc_cov.z}, g[3] = {e->gyr_cov.x, e->gyr_cov.y, e->gyr_cov.z};
+            const double ba[3] = {e->b_acc_cov.x, e->b_acc_cov.y, e->b_acc_cov.z}, bg[3] = {e->b_gyr_cov.x, e->b_gyr_cov.y, e->b_gyr_cov.z};
+            e->noise[i][i] = a[i]; e->noise[3 + i][3 + i] = g[i]; e->noise[6 + i][6 + i] = ba[i]; e->noise[9 + i][9 + i] = bg[i];
+        }
+        return 1;
+    }
+    return 0;
+}
+void orc_eskf_get_init_stats(const orc_eskf *e, double out[14]) {
+    const V3 *v[4] = {&e->mean_gyr, &e->mean_acc, &e->gyr_cov, &e->acc_cov};
+    for (int k = 0; k < 4; k++) { out[3 * k] = v[k]->x; out[3 * k + 1] = v[k]->y; out[3 * k + 2] = v[k]->z; }
+    out[12] = (double)e->num_init_meas;
+    out[13] = e->initial_flag ? 1.0 : 0.0;
+}
+void orc_eskf_set_g_norm(orc_eskf *e, double g_norm) { e->G_norm = g_norm; }
+
+// stateInitialization (lioOptimization.cpp:895-990).  prev2/prev1: (q wxyz, t) of all_cloud_frame[size-2] / [size-1].
+// initialization (utility.h:88-92): 0 INIT_IMU, 1 INIT_CONSTANT_VELOCITY, anything else -> copy the last pose
+void orc_state_initialization(int index_frame, int initialization, int initial_flag, const double prev2[7], const double prev1[7],
+                              const double eskf_q[4], const double eskf_t[3], double out[7]) {
+    Q4 q = Q4{1, 0, 0, 0}; V3 t = v3(0, 0, 0);
+    if (index_frame > 2) {
+        const Q4 q1 = Q4{prev1[0], prev1[1], prev1[2], prev1[3]}, q2 = Q4{prev2[0], prev2[1], prev2[2], prev2[3]};
+        const V3 t1 = v3(prev1[4], prev1[5], prev1[6]), t2 = v3(prev2[4], prev2[5], prev2[6]);
+        const bool const_vel = initialization == 1 || (initialization == 0 && !initial_flag);
+        if (const_vel) {
+            const Q4 d = q_mul(q1, q_inverse(q2));                // (q1 * q2^-1) * q1: operator* is left-associative
+            q = q_mul(d, q1);
+            t = t1 + q_rotate(d, t1 - t2);                        // Quaternion * Vector3 = rotate by the (q1 q2^-1) product
+        } else if (initialization == 0) {
+            q = Q4{eskf_q[0], eskf_q[1], eskf_q[2], eskf_q[3]};
+            t = v3(eskf_t[0], eskf_t[1], eskf_t[2]);
+        } else {
+            q = q1; t = t1;
+        }
+    }
+    out[0] = q.w; out[1] = q.x; out[2] = q.y; out[3] = q.z; out[4] = t.x; out[5] = t.y; out[6] = t.z;
+}
+
 void orc_eskf_set_noise(orc_eskf *e, double acc_cov, double gyr_cov, double b_acc_cov, double b_gyr_cov) {
+    e->acc_cov_scale = v3(acc_cov, acc_cov, acc_cov);
+    e->gyr_cov_scale = v3(gyr_cov, gyr_cov, gyr_cov);
     e->acc_cov = v3(acc_cov, acc_cov, acc_cov);
     e->gyr_cov = v3(gyr_cov, gyr_cov, gyr_cov);
     e->b_acc_cov = v3(b_acc_cov, b_acc_cov, b_acc_cov);
@@ -1221,6 +1319,135 @@ int orc_grid_sampling(const double *world_xyz, int n, double size_voxel, int32_t
     for (const auto &kv : grid)
         if (kv.second.size() > 0) idx_out[m++] = kv.second[0];
     return m;
+}
+
+namespace {
+struct ImuState { double timestamp; V3 un_acc, un_gyr, trans; Q4 quat; V3 vel; };
+inline ImuState imu_state_at(const double *s, int i) {
+    const double *p = s + 17 * (size_t)i;
+    ImuState r;
+    r.timestamp = p[0];
+    r.un_acc = v3(p[1], p[2], p[3]); r.un_gyr = v3(p[4], p[5], p[6]); r.trans = v3(p[7], p[8], p[9]);
+    r.quat = Q4{p[10], p[11], p[12], p[13]}; r.vel = v3(p[14], p[15], p[16]);
+    return r;
+}
+// Eigen::QuaternionBase::slerp (Eigen 3.3 Geometry/Quaternion.h)
+inline Q4 q_slerp(const Q4 &a, double t, const Q4 &b) {
+    const double one = 1.0 - 2.220446049250313e-16;
+    const double d = ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w;
+    const double absD = std::fabs(d);
+    double scale0, scale1;
+    if (absD >= one) { scale0 = 1.0 - t; scale1 = t; }
+    else {
+        const double theta = std::acos(absD), sinTheta = std::sin(theta);
+        scale0 = std::sin((1.0 - t) * theta) / sinTheta;
+        scale1 = std::sin(t * theta) / sinTheta;
+    }
+    if (d < 0.0) scale1 = -scale1;
+    return Q4{scale0 * a.w + scale1 * b.w, scale0 * a.x + scale1 * b.x, scale0 * a.y + scale1 * b.y, scale0 * a.z + scale1 * b.z};
+}
+inline V3 p3(const double *a, int i) { return v3(a[3 * (size_t)i], a[3 * (size_t)i + 1], a[3 * (size_t)i + 2]); }
+inline void s3(double *a, int i, const V3 &v) { a[3 * (size_t)i] = v.x; a[3 * (size_t)i + 1] = v.y; a[3 * (size_t)i + 2] = v.z; }
+}  // namespace
+
+void orc_distort_frame_by_constant(const double *raw_xyz, const double *relative_time, int n, const double *imu_states,
+                                   int n_states, double time_frame_begin, const double R_il[9], const double t_il[3],
+                                   double *imu_point) {                                     // utility.cpp:203-236
+    const ImuState first = imu_state_at(imu_states, 0), last = imu_state_at(imu_states, n_states - 1);
+    const double time_frame_end = last.timestamp;
+    const M3 Ril = m3_from(R_il);
+    const V3 til = v3(t_il[0], t_il[1], t_il[2]);
+    for (int i = 0; i < n; i++) {
+        double time_point = time_frame_begin + relative_time[i] / 1000.0;
+        if (std::fabs(time_point - time_frame_begin) < 1e-6) time_point = time_frame_begin + 1e-6;
+        if (std::fabs(time_point - time_frame_end) < 1e-6) time_point = time_frame_end - 1e-6;
+        double alpha_time = (time_point - time_frame_begin) / (time_frame_end - time_frame_begin);
+        if (alpha_time > 1) alpha_time = 1;
+        if (alpha_time < 0) alpha_time = 0;
+        const Q4 quat_alpha = q_slerp(first.quat, alpha_time, last.quat);
+        const V3 trans_alpha = (1.0 - alpha_time) * first.trans + alpha_time * last.trans;
+        s3(imu_point, i, quat_to_rot(quat_alpha) * (Ril * p3(raw_xyz, i) + til) + trans_alpha);
+    }
+}
+
+int orc_distort_frame_by_imu(const double *raw_xyz, const double *relative_time, int n, const double *imu_states,
+                             int n_states, double time_frame_begin, const double R_il[9], const double t_il[3],
+                             double *imu_point) {                                           // utility.cpp:238-306
+    const M3 Ril = m3_from(R_il);
+    const V3 til = v3(t_il[0], t_il[1], t_il[2]);
+    int iter = 0;
+    for (int k = 0; k + 1 < n_states; k++) {
+        const ImuState a = imu_state_at(imu_states, k), b = imu_state_at(imu_states, k + 1);
+        const double time_imu_begin = a.timestamp, time_imu_end = b.timestamp;
+        while (iter != n) {
+            double time_point = time_frame_begin + relative_time[iter] / 1000.0;
+            if (time_point > time_imu_begin - 1e-6 && time_point < time_imu_end + 1e-6) {
+                if (std::fabs(time_point - time_imu_begin) < 1e-6) time_point = time_imu_begin + 1e-6;
+                if (std::fabs(time_point - time_imu_end) < 1e-6) time_point = time_imu_end - 1e-6;
+                const double dt = time_point - time_imu_begin;
+                const Q4 quat_point = q_normalized(q_mul(a.quat, so3_to_quat(b.un_gyr * dt)));
+                const V3 trans_point = (a.trans + a.vel * dt) + ((0.5 * b.un_acc) * dt) * dt;
+                s3(imu_point, iter, quat_to_rot(quat_point) * (Ril * p3(raw_xyz, iter) + til) + trans_point);
+                iter++;
+            } else {
+                break;
+            }
+        }
+    }
+    return iter;
+}
+
+void orc_transform_all_imu_point(const double *imu_point, int n, const double *imu_states, int n_states,
+                                 const double R_il[9], const double t_il[3], double *raw_xyz) {   // utility.cpp:320-332
+    const ImuState last = imu_state_at(imu_states, n_states - 1);
+    const M3 Rinv = quat_to_rot(q_inverse(last.quat));
+    const V3 trans_end_inv = (Rinv * -1.0) * last.trans;
+    const M3 RilT = transpose(m3_from(R_il));
+    const V3 til = v3(t_il[0], t_il[1], t_il[2]);
+    for (int i = 0; i < n; i++) s3(raw_xyz, i, RilT * (Rinv * p3(imu_point, i) + trans_end_inv) - RilT * til);
+}
+
+int orc_build_frame_order(const double *point_xyz, int n, double sample_size, int do_subsample, int32_t *order_out) {
+    std::vector<int> frame((size_t)n);
+    for (int i = 0; i < n; i++) frame[i] = i;
+    std::mt19937_64 seed;                                          // boost::mt19937_64 seed; (lioOptimization.cpp:840)
+    std::shuffle(frame.begin(), frame.end(), seed);
+    if (do_subsample) {                                            // odometry_options.voxel_size > 0
+        std::tr1::unordered_map<voxel, std::vector<int>, voxel_hash> grid;      // subSampleFrame, utility.cpp:167-186
+        for (int i = 0; i < (int)frame.size(); i++) {
+            const double *p = point_xyz + 3 * (size_t)frame[i];
+            grid[voxel(static_cast<short>(p[0] / sample_size), static_cast<short>(p[1] / sample_size),
+                       static_cast<short>(p[2] / sample_size))].push_back(frame[i]);
+        }
+        frame.resize(0);
+        for (const auto &kv : grid)
+            if (kv.second.size() > 0) frame.push_back(kv.second[0]);
+        std::shuffle(frame.begin(), frame.end(), seed);
+    }
+    for (size_t i = 0; i < frame.size(); i++) order_out[i] = frame[i];
+    return (int)frame.size();
+}
+
+int orc_make_point_timestamp(const double *timestamp, int n, double time_begin, double time_end, int point_time_enable,
+                             double *relative_time, double *alpha_time, uint8_t *keep_out) {      // lioOptimization.cpp:786-819
+    const double delta_t = time_end - time_begin;
+    int kept = 0;
+    for (int i = 0; i < n; i++) {
+        if (!point_time_enable && (timestamp[i] > time_end || timestamp[i] < time_begin)) { keep_out[i] = 0; continue; }
+        keep_out[i] = 1; kept++;
+        relative_time[i] = timestamp[i] - time_begin;
+        alpha_time[i] = relative_time[i] / delta_t;
+        relative_time[i] = relative_time[i] * 1000.0;
+        if (point_time_enable && alpha_time[i] > 1.0) alpha_time[i] = 1.0 - 1e-5;
+    }
+    return kept;
+}
+
+uint64_t orc_mt19937_64_nth(int nth) {
+    std::mt19937_64 e;
+    uint64_t v = 0;
+    for (int i = 0; i < nth; i++) v = e();
+    return v;
 }
 
 void orc_so3_to_rot(const double w[3], double R[9]) { m3_to(so3_to_rotation(v3(w[0], w[1], w[2])), R); }

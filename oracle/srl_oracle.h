@@ -124,6 +124,17 @@ void orc_eskf_set_cov(orc_eskf *e, const double P[289]);
 void orc_eskf_set_noise(orc_eskf *e, double acc_cov, double gyr_cov, double b_acc_cov, double b_gyr_cov);
 void orc_eskf_init_imu(orc_eskf *e, const double acc0[3], const double gyr0[3]);
 void orc_eskf_scale_init_cov(orc_eskf *e);         /* tryInit covariance scaling, eskfEstimator.cpp:74-76 */
+/* tryInit (eskfEstimator.cpp:43-118): t (n), gyr / acc (n x 3) = imu_meas {time, {gyr, acc}}.  Returns 1 when the
+ * filter became initialised in this call (initial_flag = true), 0 "wait more", -1 / -2 gyro / accelerometer
+ * variance too large.  acc_cov / gyr_cov start at zero here (uninitialised Eigen members upstream; the first
+ * sample multiplies them by 0).  get_init_stats: mean_gyr, mean_acc, gyr_cov, acc_cov, num_init_meas, initial_flag. */
+int  orc_eskf_try_init(orc_eskf *e, const double *t, const double *gyr, const double *acc, int n);
+void orc_eskf_get_init_stats(const orc_eskf *e, double out[14]);
+void orc_eskf_set_g_norm(orc_eskf *e, double g_norm);
+/* stateInitialization (lioOptimization.cpp:895-990): prev2 / prev1 = (q wxyz, t) of all_cloud_frame[size-2] / [size-1];
+ * initialization: 0 INIT_IMU, 1 INIT_CONSTANT_VELOCITY (utility.h:88-92), other = copy the last pose. */
+void orc_state_initialization(int index_frame, int initialization, int initial_flag, const double prev2[7],
+                              const double prev1[7], const double eskf_q[4], const double eskf_t[3], double out[7]);
 void orc_eskf_predict(orc_eskf *e, double dt, const double acc1[3], const double gyr1[3]);
 void orc_eskf_observe(orc_eskf *e, const double dx[17]);
 
@@ -146,6 +157,31 @@ int orc_update_iekf(orc_map *m, orc_eskf *e, const orc_icp_opts *o, const double
 void orc_transform_points(const double *raw_xyz, int n, const double q_wxyz[4], const double t[3], const double R_il[9],
                           const double t_il[3], double *world_xyz);
 int  orc_grid_sampling(const double *world_xyz, int n, double size_voxel, int32_t *idx_out);
+
+/* ---- sweep reconstruction (row f4): buildFrame's per-point stages (lioOptimization.cpp:821-850) ----
+ * imu_states: n_states x 17 doubles = timestamp, un_acc(3), un_gyr(3), trans(3), quat wxyz(4), vel(3) (cloudMap.h:110-122).
+ * relative_time in milliseconds (makePointTimestamp, lioOptimization.cpp:786-819).
+ * orc_distort_frame_by_constant / _by_imu (utility.cpp:203-306): write imu_point (n x 3); _by_imu leaves the points
+ *   the sequential interval walk never reaches untouched (imu_point is in/out) and returns how many it wrote.
+ * orc_transform_all_imu_point (utility.cpp:320-332): raw_point <- lidar frame at the sweep end.
+ * orc_build_frame_order (lioOptimization.cpp:840-848): the index order buildFrame leaves the frame in:
+ *   std::shuffle with a default-seeded 64-bit Mersenne twister (boost::mt19937_64 == std::mt19937_64, seed 5489),
+ *   subSampleFrame on point3D::point (= the sensor-frame point, cloudProcessing.cpp:143), the same engine shuffles again.
+ *   Returns the number of kept points; order_out has capacity n.
+ * orc_make_point_timestamp (lioOptimization.cpp:786-819): point_time_enable != 0 keeps every point (alpha clamp
+ *   1 - 1e-5), == 0 erases points outside [time_begin, time_end]; keep_out (n) flags the survivors. */
+void orc_distort_frame_by_constant(const double *raw_xyz, const double *relative_time, int n, const double *imu_states,
+                                   int n_states, double time_frame_begin, const double R_il[9], const double t_il[3],
+                                   double *imu_point);
+int  orc_distort_frame_by_imu(const double *raw_xyz, const double *relative_time, int n, const double *imu_states,
+                              int n_states, double time_frame_begin, const double R_il[9], const double t_il[3],
+                              double *imu_point);
+void orc_transform_all_imu_point(const double *imu_point, int n, const double *imu_states, int n_states,
+                                 const double R_il[9], const double t_il[3], double *raw_xyz);
+int  orc_build_frame_order(const double *point_xyz, int n, double sample_size, int do_subsample, int32_t *order_out);
+int  orc_make_point_timestamp(const double *timestamp, int n, double time_begin, double time_end, int point_time_enable,
+                              double *relative_time, double *alpha_time, uint8_t *keep_out);
+uint64_t orc_mt19937_64_nth(int nth);            /* KAT: the 10000th output of a default-seeded engine */
 
 /* small numeric helpers exported for unit tests (utility.h numType, utility.cpp:146-153) */
 void   orc_quat_to_rot(const double q_wxyz[4], double R[9]);

@@ -57,6 +57,27 @@ class Timing(C.Structure):
                 ("sum_host_launch_us", C.c_double), ("sum_host_wait_us", C.c_double), ("sum_host_total_us", C.c_double)]
 
 
+class ImuState(C.Structure):
+    _fields_ = [("timestamp", C.c_double), ("un_acc", C.c_double * 3), ("un_gyr", C.c_double * 3), ("trans", C.c_double * 3),
+                ("quat", C.c_double * 4), ("vel", C.c_double * 3)]
+
+
+class OdometryOpts(C.Structure):
+    _fields_ = [("init_voxel_size", C.c_double), ("init_sample_voxel_size", C.c_double), ("init_num_frames", C.c_int),
+                ("num_for_initialization", C.c_int), ("voxel_size", C.c_double), ("sample_voxel_size", C.c_double),
+                ("max_num_points_in_voxel", C.c_int), ("min_distance_points", C.c_double), ("motion_compensation", C.c_int),
+                ("initialization", C.c_int), ("point_time_enable", C.c_int), ("acc_cov", C.c_double), ("gyr_cov", C.c_double),
+                ("b_acc_cov", C.c_double), ("b_gyr_cov", C.c_double), ("icp", IcpOpts)]
+
+
+class ReplayResult(C.Structure):
+    _fields_ = [("processed", C.c_int), ("initialized", C.c_int), ("index_frame", C.c_int), ("success", C.c_int),
+                ("num_residuals_used", C.c_int), ("iterations", C.c_int), ("frame_points", C.c_int), ("keypoints", C.c_int),
+                ("points_added", C.c_int), ("state", C.c_double * 16)]
+
+
+MC_IMU, MC_CONSTANT_VELOCITY, MC_NONE = 0, 1, 2
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p)
 PROVIDER_FN = C.CFUNCTYPE(C.c_int, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq), C.c_void_p)
@@ -95,6 +116,8 @@ def load_library():
         "srl_search_neighbors": ([p, p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, p, p, p], C.c_int),
         "srl_transform_points": ([p, p, C.c_int, dp, dp, dp, dp, p], C.c_int),
         "srl_frame_upload": ([p, p, C.c_int], C.c_int),
+        "srl_frame_undistort": ([p, p, p, p, C.c_int, p, C.c_int, C.c_double, C.c_int, dp, dp, p, p], C.c_int),
+        "srl_frame_take": ([p, p, C.c_int], C.c_int),
         "srl_frame_select_keypoints": ([p, dp, dp, dp, dp, C.c_double, p, C.POINTER(C.c_int)], C.c_int),
         "srl_frame_commit": ([p, dp, dp, dp, dp, C.c_double, C.c_int, C.c_double, C.c_int, p, C.POINTER(C.c_int)], C.c_int),
         "srl_comm_unique_id": ([p], C.c_int),
@@ -130,6 +153,14 @@ def load_library():
                                           C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_lio_optimize": ([p, C.POINTER(IcpOpts), C.c_double, p, p, C.c_int, dp, dp, C.c_int, p,
                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "srl_lio_eskf_try_init": ([p, dp, dp, dp, C.c_int, C.POINTER(C.c_int)], C.c_int),
+        "srl_lio_eskf_get_init_stats": ([p, dp], C.c_int),
+        "srl_lio_set_initial_flag": ([p, C.c_int], C.c_int),
+        "srl_lio_state_initialization": ([p, C.c_int, C.c_int, dp, dp, dp], C.c_int),
+        "srl_lio_set_odometry_options": ([p, C.POINTER(OdometryOpts)], C.c_int),
+        "srl_lio_run_measurement": ([p, C.c_double, p, p, p, C.c_int, p, p, C.c_int, C.c_double, C.c_double,
+                                     C.POINTER(ReplayResult)], C.c_int),
+        "srl_lio_last_frame": ([p, C.c_int, p, p, p, C.POINTER(C.c_int)], C.c_int),
         "srl_lio_optimize_resident": ([p, C.POINTER(IcpOpts), C.c_double, p, C.c_int, dp, dp, C.c_int, p,
                                        C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_lio_commit_frame": ([p, dp, C.c_double, C.c_int, C.c_double, C.c_int, p, C.POINTER(C.c_int)], C.c_int),
@@ -338,6 +369,24 @@ class Context:
         self._frame_n = len(r)
         self._chk(self.lib.srl_frame_upload(self.h, _ptr(r), len(r)), "srl_frame_upload")
 
+    def frame_undistort(self, raw_xyz, relative_time_ms, imu_states, time_frame_begin, mode, R_il=None, t_il=None, imu_point_in=None):
+        """imu_states: (S, 17) array = timestamp, un_acc, un_gyr, trans, quat wxyz, vel.  Returns (imu_point, raw_point)."""
+        r = _f64(raw_xyz, (-1, 3)); rel = _f64(relative_time_ms)
+        st = _f64(imu_states, (-1, 17))
+        R_il = _f64(np.eye(3) if R_il is None else R_il).ravel()
+        t_il = _f64(np.zeros(3) if t_il is None else t_il)
+        pin = None if imu_point_in is None else _f64(imu_point_in, (-1, 3))
+        imu = np.empty_like(r); out = np.empty_like(r)
+        self._chk(self.lib.srl_frame_undistort(self.h, _ptr(r), _ptr(rel), None if pin is None else _ptr(pin), len(r), _ptr(st), len(st),
+                                               float(time_frame_begin), int(mode), _dptr(R_il), _dptr(t_il), _ptr(imu), _ptr(out)),
+                  "srl_frame_undistort")
+        return imu, out
+
+    def frame_take(self, index):
+        idx = np.ascontiguousarray(index, dtype=np.int32)
+        self._frame_n = len(idx)
+        self._chk(self.lib.srl_frame_take(self.h, _ptr(idx), len(idx)), "srl_frame_take")
+
     def frame_select_keypoints(self, q, t, sample_voxel_size, R_il=None, t_il=None):
         R_il = _f64(np.eye(3) if R_il is None else R_il).ravel()
         t_il = _f64(np.zeros(3) if t_il is None else t_il)
@@ -444,6 +493,27 @@ class Lio:
     def eskf_init_imu(self, acc0, gyr0):
         self._chk(self.lib.srl_lio_eskf_init_imu(self.h, _dptr(_f64(acc0)), _dptr(_f64(gyr0))), "eskf_init_imu")
 
+    def eskf_try_init(self, t, gyr, acc):
+        t = _f64(t); g = _f64(gyr, (-1, 3)); a = _f64(acc, (-1, 3))
+        r = C.c_int()
+        self._chk(self.lib.srl_lio_eskf_try_init(self.h, _dptr(t), _dptr(g), _dptr(a), len(t), C.byref(r)), "eskf_try_init")
+        return r.value
+
+    def eskf_init_stats(self):
+        o = np.zeros(14)
+        self._chk(self.lib.srl_lio_eskf_get_init_stats(self.h, _dptr(o)), "eskf_get_init_stats")
+        return dict(mean_gyr=o[0:3].copy(), mean_acc=o[3:6].copy(), gyr_cov=o[6:9].copy(), acc_cov=o[9:12].copy(),
+                    num_init_meas=int(o[12]), initial_flag=bool(o[13]))
+
+    def set_initial_flag(self, flag):
+        self._chk(self.lib.srl_lio_set_initial_flag(self.h, int(bool(flag))), "set_initial_flag")
+
+    def state_initialization(self, index_frame, initialization, prev2, prev1):
+        out = np.zeros(7)
+        self._chk(self.lib.srl_lio_state_initialization(self.h, int(index_frame), int(initialization), _dptr(_f64(prev2)),
+                                                        _dptr(_f64(prev1)), _dptr(out)), "state_initialization")
+        return out[0:4].copy(), out[4:7].copy()
+
     def eskf_scale_init_cov(self):
         self._chk(self.lib.srl_lio_eskf_scale_init_cov(self.h), "eskf_scale_init_cov")
 
@@ -508,6 +578,38 @@ class Lio:
                                                  _dptr(_f64(t_last)), int(frame_id), _ptr(kidx), C.byref(nk), C.byref(iters), C.byref(nres)),
                        "optimize", ok=allow)
         return dict(rc=rc, state=st, world=world, keypoint_index=kidx[: nk.value].copy(), iters=iters.value, num_residuals=nres.value)
+
+    def set_odometry_options(self, **kw):
+        o = OdometryOpts()
+        d = dict(init_voxel_size=0.2, init_sample_voxel_size=1.0, init_num_frames=20, num_for_initialization=10, voxel_size=0.5,
+                 sample_voxel_size=1.5, max_num_points_in_voxel=20, min_distance_points=0.1, motion_compensation=MC_CONSTANT_VELOCITY,
+                 initialization=0, point_time_enable=1, acc_cov=0.1, gyr_cov=0.1, b_acc_cov=0.0001, b_gyr_cov=0.0001)
+        icp = kw.pop("icp", None) or default_opts()
+        d.update(kw)
+        for k, v in d.items():
+            setattr(o, k, v)
+        o.icp = icp
+        self._chk(self.lib.srl_lio_set_odometry_options(self.h, C.byref(o)), "set_odometry_options")
+        return o
+
+    def run_measurement(self, time_frame, imu_t, imu_acc, imu_gyr, pts_raw, pts_timestamp, time_sweep_begin, time_sweep_offset,
+                        allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):
+        it = _f64(imu_t); ia = _f64(imu_acc, (-1, 3)); ig = _f64(imu_gyr, (-1, 3))
+        pr = _f64(pts_raw, (-1, 3)); pt = _f64(pts_timestamp)
+        out = ReplayResult()
+        rc = self._chk(self.lib.srl_lio_run_measurement(self.h, float(time_frame), _ptr(it), _ptr(ia), _ptr(ig), len(it), _ptr(pr), _ptr(pt),
+                                                        len(pr), float(time_sweep_begin), float(time_sweep_offset), C.byref(out)),
+                       "run_measurement", ok=allow)
+        return dict(rc=rc, processed=bool(out.processed), initialized=bool(out.initialized), index_frame=out.index_frame,
+                    success=bool(out.success), num_residuals=out.num_residuals_used, iters=out.iterations, frame_points=out.frame_points,
+                    keypoints=out.keypoints, points_added=out.points_added, state=np.array(out.state))
+
+    def last_frame(self):
+        n = C.c_int()
+        self._chk(self.lib.srl_lio_last_frame(self.h, 0, None, None, None, C.byref(n)), "last_frame")
+        raw = np.empty((n.value, 3)); pt = np.empty((n.value, 3)); imu = np.empty((n.value, 3))
+        self._chk(self.lib.srl_lio_last_frame(self.h, n.value, _ptr(raw), _ptr(pt), _ptr(imu), C.byref(n)), "last_frame")
+        return dict(raw_point=raw, point=pt, imu_point=imu)
 
     def optimize_resident(self, opts, sample_voxel_size, frame_raw, state, t_last, frame_id=100,
                           allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):

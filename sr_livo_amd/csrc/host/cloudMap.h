@@ -40,6 +40,15 @@ struct voxel {                       // cloudMap.h:124-145
     short x = 0, y = 0, z = 0;
 };
 
+struct imuState {                    // cloudMap.h:110-122
+    double timestamp = 0.0;
+    srl::Vec3 un_acc = srl::Vec3::Zero();
+    srl::Vec3 un_gyr = srl::Vec3::Zero();
+    srl::Vec3 trans = srl::Vec3::Zero();
+    srl::Quat quat;
+    srl::Vec3 vel = srl::Vec3::Zero();
+};
+
 // handle onto the device-resident map (slabs + open-addressing table in HBM)
 struct voxelHashMap {
     srl_ctx *ctx = nullptr;

@@ -2,7 +2,12 @@
 // :120-126 (initializeNoise), :134-164 (accessors), :166-217 (predict), :219-230 (observe).
 #include "eskfEstimator.h"
 
+#include <cmath>
+
 namespace srlivo {
+
+bool initial_flag = false;       // src/utility.cpp:11
+extern double G_norm;            // src/utility.cpp:14 (defined in lioOptimization.cpp)
 
 using srl::Mat3;
 using srl::Vec3;
@@ -16,6 +21,60 @@ eskfEstimator::eskfEstimator() {
     ba = Vec3::Zero();
     bg = Vec3::Zero();
     g = srl::vec3(0.0, 0.0, 9.81);
+}
+
+// include/utility.h:28-31
+#define MIN_INI_COUNT 10
+#define MIN_INI_TIME 3.0
+#define MAX_GYR_VAR 0.5
+#define MAX_ACC_VAR 0.6
+
+int eskfEstimator::tryInit(const std::vector<imuMeas> &imu_meas) {
+    if (imu_meas.empty()) return initial_flag ? 1 : 0;      // front()/back() of an empty vector upstream: undefined
+    initialization(imu_meas);
+
+    if (num_init_meas > MIN_INI_COUNT && imu_meas.back().first - time_first_imu > MIN_INI_TIME) {
+        acc_cov = acc_cov * std::pow(G_norm / mean_acc.norm(), 2);
+        if (gyr_cov.norm() > MAX_GYR_VAR) return -1;
+        if (acc_cov.norm() > MAX_ACC_VAR) return -2;
+
+        initial_flag = true;
+
+        gyr_cov = gyr_cov_scale;
+        acc_cov = acc_cov_scale;
+
+        const Vec3 init_bg = mean_gyr;
+        const Vec3 init_gravity = (mean_acc / mean_acc.norm()) * G_norm;
+        setBg(init_bg);
+        setGravity(init_gravity);
+
+        scaleInitialCovariance();
+        initializeNoise();
+        return 1;
+    }
+    return 0;
+}
+
+void eskfEstimator::initialization(const std::vector<imuMeas> &imu_meas) {
+    if (is_first_imu_meas) {
+        num_init_meas = 1;
+        is_first_imu_meas = false;
+        time_first_imu = imu_meas.front().first;
+        mean_gyr = imu_meas.front().second.first;
+        mean_acc = imu_meas.front().second.second;
+    }
+    for (const auto &imu : imu_meas) {
+        const double N = (double)num_init_meas;
+        mean_gyr = mean_gyr + (imu.second.first - mean_gyr) / N;
+        mean_acc = mean_acc + (imu.second.second - mean_acc) / N;
+        const Vec3 dg = imu.second.first - mean_gyr, da = imu.second.second - mean_acc;
+        const double NN = (double)(num_init_meas * num_init_meas);
+        gyr_cov = (gyr_cov * (N - 1.0)) / N + (srl::vec3(dg[0] * dg[0], dg[1] * dg[1], dg[2] * dg[2]) * (N - 1.0)) / NN;
+        acc_cov = (acc_cov * (N - 1.0)) / N + (srl::vec3(da[0] * da[0], da[1] * da[1], da[2] * da[2]) * (N - 1.0)) / NN;
+        num_init_meas++;
+    }
+    gyr_0 = imu_meas.back().second.first;
+    acc_0 = imu_meas.back().second.second;
 }
 
 void eskfEstimator::setAccCov(double para) { acc_cov_scale = srl::vec3(para, para, para); }

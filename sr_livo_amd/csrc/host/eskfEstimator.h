@@ -1,12 +1,21 @@
 // eskfEstimator.h (host mirror) -- class surface of the reference's 17-dim error-state Kalman filter
 // (include/eskfEstimator.h:19-112).  The 17-dim algebra stays on the host exactly as in the reference
-// (SURVEY.md 8(a) rows a2/a6); only the per-point sums move to the GPU.  tryInit / observePose /
-// updateAndReset are not on the hot path (observePose etc. are dead code in the reference).
+// (SURVEY.md 8(a) rows a2/a6); only the per-point sums move to the GPU.  observePose / updateAndReset /
+// projectCovariance / calculateLxly have no caller anywhere in the reference (dead code) and are not mirrored.
 #pragma once
 #include "srl_la.h"
 #include "utility.h"
 
+#include <utility>
+#include <vector>
+
 namespace srlivo {
+
+// src/utility.cpp:11,14 (globals in the reference)
+extern bool initial_flag;
+
+// imu_meas element: {time, {gyr, acc}} (lioOptimization.cpp:1453)
+typedef std::pair<double, std::pair<srl::Vec3, srl::Vec3>> imuMeas;
 
 class eskfEstimator {
 private:
@@ -23,8 +32,25 @@ private:
     srl::Mat<12, 12> noise;
     srl::Mat17 covariance;
 
+    srl::Vec3 mean_gyr = srl::vec3(0, 0, 0), mean_acc = srl::vec3(0, 0, 9.81);
+    bool is_first_imu_meas = true;
+    double time_first_imu = 0.0;
+    int num_init_meas = 1;
+
+    void initialization(const std::vector<imuMeas> &imu_meas);       // eskfEstimator.cpp:93-118
+
 public:
     eskfEstimator();
+
+    // eskfEstimator.cpp:43-91.  acc_cov / gyr_cov start at zero (uninitialised members upstream, multiplied by
+    // (1 - 1.0) on the first sample).  The outcome is in srlivo::initial_flag, like upstream; the return value
+    // adds the reason: 1 initialised now, 0 wait, -1 / -2 gyroscope / accelerometer variance above MAX_*_VAR.
+    int tryInit(const std::vector<imuMeas> &imu_meas);
+    srl::Vec3 getMeanGyr() const { return mean_gyr; }
+    srl::Vec3 getMeanAcc() const { return mean_acc; }
+    srl::Vec3 getGyrCov() const { return gyr_cov; }
+    srl::Vec3 getAccCov() const { return acc_cov; }
+    int getNumInitMeas() const { return num_init_meas; }
 
     void setAccCov(double para);
     void setGyrCov(double para);

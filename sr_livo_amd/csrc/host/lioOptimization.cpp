@@ -9,6 +9,7 @@
 #include <cstring>
 #include <sstream>
 #include <stdexcept>
+#include <random>
 #include <tr1/unordered_map>
 
 namespace srlivo {
@@ -72,6 +73,7 @@ lioOptimization::lioOptimization(int device) {
 }
 
 lioOptimization::~lioOptimization() {
+    releaseFrames();
     if (voxel_map.ctx) srl_ctx_destroy(voxel_map.ctx);
     delete eskf_pro;
 }
@@ -490,16 +492,152 @@ optimizeSummary lioOptimization::optimize(cloudFrame *p_frame, const icpOptions 
     return optimize_summary;
 }
 
-// ---------------------------------------------------------------- frame-resident optimize() (optimize.cpp:428-448)
-optimizeSummary lioOptimization::optimizeResident(cloudFrame *p_frame, const double *frame_raw, int n, const icpOptions &cur_icp_options,
-                                                  double sample_voxel_size, std::vector<int> *keypoint_index) {
+// ---------------------------------------------------------------- lioOptimization.cpp:895-990
+void lioOptimization::stateInitialization(state *cur_state) {
+    if (index_frame <= 2) {
+        cur_state->rotation = Quat::Identity();
+        cur_state->translation = Vec3::Zero();
+        return;
+    }
+    // index_frame == 3 and index_frame > 3 run the same code upstream
+    const state *s1 = all_cloud_frame[all_cloud_frame.size() - 1]->p_state;
+    const state *s2 = all_cloud_frame[all_cloud_frame.size() - 2]->p_state;
+    const bool constant_velocity = initialization == INIT_CONSTANT_VELOCITY || (initialization == INIT_IMU && !initial_flag);
+    if (constant_velocity) {
+        const Quat d = s1->rotation * s2->rotation.inverse();
+        cur_state->rotation = d * s1->rotation;
+        cur_state->translation = s1->translation + d * (s1->translation - s2->translation);
+    } else if (initialization == INIT_IMU) {
+        cur_state->rotation = eskf_pro->getRotation();
+        cur_state->translation = eskf_pro->getTranslation();
+    } else {
+        cur_state->rotation = s1->rotation;
+        cur_state->translation = s1->translation;
+    }
+}
+
+// ---------------------------------------------------------------- lioOptimization.cpp:786-819
+void lioOptimization::makePointTimestamp(std::vector<point3D> &sweep, double time_begin, double time_end) {
+    const double delta_t = time_end - time_begin;
+    if (point_time_enable) {
+        for (size_t i = 0; i < sweep.size(); i++) {
+            sweep[i].relative_time = sweep[i].timestamp - time_begin;
+            sweep[i].alpha_time = sweep[i].relative_time / delta_t;
+            sweep[i].relative_time = sweep[i].relative_time * 1000.0;
+            if (sweep[i].alpha_time > 1.0) sweep[i].alpha_time = 1.0 - 1e-5;
+        }
+        return;
+    }
+    size_t kept = 0;                     // erase-in-loop upstream; one stable compaction here
+    for (size_t i = 0; i < sweep.size(); i++) {
+        if (sweep[i].timestamp > time_end || sweep[i].timestamp < time_begin) continue;
+        point3D p = sweep[i];
+        p.relative_time = p.timestamp - time_begin;
+        p.alpha_time = p.relative_time / delta_t;
+        p.relative_time = p.relative_time * 1000.0;
+        sweep[kept++] = p;
+    }
+    sweep.resize(kept);
+}
+
+// ---------------------------------------------------------------- lioOptimization.cpp:821-893
+cloudFrame *lioOptimization::buildFrame(std::vector<point3D> &cut_sweep, state *cur_state, double timestamp_begin, double timestamp_offset) {
+    srl_ctx *ctx = voxel_map.ctx;
+    if (!ctx) throw std::runtime_error("buildFrame: no HIP context (the product has no CPU path)");
+    std::vector<point3D> sweep(cut_sweep);
+
+    const double time_sweep_begin = timestamp_begin;
+    const double time_frame_begin = timestamp_begin;
+    makePointTimestamp(sweep, time_frame_begin, timestamp_begin + timestamp_offset);
+
+    // device: distortFrameBy* + transformAllImuPoint over the whole sweep
+    const int n = (int)sweep.size();
+    std::vector<double> raw((size_t)n * 3), rel((size_t)n), imu_in((size_t)n * 3), imu_out((size_t)n * 3), raw_out((size_t)n * 3);
+    for (int i = 0; i < n; i++) {
+        for (int d = 0; d < 3; d++) { raw[(size_t)i * 3 + d] = sweep[i].raw_point[d]; imu_in[(size_t)i * 3 + d] = sweep[i].imu_point[d]; }
+        rel[i] = sweep[i].relative_time;
+    }
+    std::vector<srl_imu_state> st(imu_states.size());
+    for (size_t k = 0; k < imu_states.size(); k++) {
+        st[k].timestamp = imu_states[k].timestamp;
+        for (int d = 0; d < 3; d++) {
+            st[k].un_acc[d] = imu_states[k].un_acc[d]; st[k].un_gyr[d] = imu_states[k].un_gyr[d];
+            st[k].trans[d] = imu_states[k].trans[d]; st[k].vel[d] = imu_states[k].vel[d];
+        }
+        st[k].quat[0] = imu_states[k].quat.w; st[k].quat[1] = imu_states[k].quat.x; st[k].quat[2] = imu_states[k].quat.y; st[k].quat[3] = imu_states[k].quat.z;
+    }
+    const int mode = motion_compensation == CONSTANT_VELOCITY ? SRL_MC_CONSTANT_VELOCITY : motion_compensation == IMU ? SRL_MC_IMU : SRL_MC_NONE;
+    check(ctx, srl_frame_undistort(ctx, raw.data(), rel.data(), imu_in.data(), n, st.data(), (int)st.size(), time_frame_begin, mode,
+                                   R_imu_lidar.a, t_imu_lidar.a, imu_out.data(), raw_out.data()), "srl_frame_undistort");
+
+    // host: the order (indices only).  subSampleFrame keys on point3D::point, which still holds the sensor-frame
+    // point here (cloudProcessing.cpp:143); the engine is shared by both shuffles.
+    const double sample_size = index_frame < init_num_frames ? init_voxel_size : voxel_size;
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::mt19937_64 seed;                                                // boost::mt19937_64 seed;
+    std::shuffle(order.begin(), order.end(), seed);
+    if (voxel_size > 0) {
+        std::tr1::unordered_map<voxel, std::vector<int>, std::hash<voxel>> grid;
+        for (int i : order) {
+            const srl::Vec3 &p = sweep[i].point;
+            grid[voxel(static_cast<short>(p[0] / sample_size), static_cast<short>(p[1] / sample_size), static_cast<short>(p[2] / sample_size))].push_back(i);
+        }
+        order.resize(0);
+        for (const auto &kv : grid)
+            if (kv.second.size() > 0) order.push_back(kv.second[0]);
+        std::shuffle(order.begin(), order.end(), seed);
+    }
+    std::vector<int32_t> take(order.begin(), order.end());
+    check(ctx, srl_frame_take(ctx, take.data(), (int)take.size()), "srl_frame_take");
+    releaseSweep();
+
+    std::vector<point3D> frame(order.size());
+    for (size_t k = 0; k < order.size(); k++) {
+        const int i = order[k];
+        frame[k] = sweep[i];
+        for (int d = 0; d < 3; d++) { frame[k].imu_point[d] = imu_out[(size_t)i * 3 + d]; frame[k].raw_point[d] = raw_out[(size_t)i * 3 + d]; }
+    }
+
+    double dt_offset = 0;
+    if (index_frame > 1) dt_offset -= time_frame_begin - all_cloud_frame.back()->time_sweep_end;
+    if (index_frame <= 2)
+        for (auto &p : frame) p.alpha_time = 1.0;
+
+    // transformPoint (lioOptimization.cpp:864-876): prior pose for index_frame > 2, identity before
+    const Quat q_t = index_frame > 2 ? cur_state->rotation : Quat::Identity();
+    const Vec3 t_t = index_frame > 2 ? cur_state->translation : Vec3::Zero();
+    if (!frame.empty()) {
+        std::vector<double> fr(frame.size() * 3), world(frame.size() * 3);
+        for (size_t k = 0; k < frame.size(); k++) for (int d = 0; d < 3; d++) fr[k * 3 + d] = frame[k].raw_point[d];
+        const double qv[4] = {q_t.w, q_t.x, q_t.y, q_t.z};
+        check(ctx, srl_transform_points(ctx, fr.data(), (int)frame.size(), qv, t_t.a, R_imu_lidar.a, t_imu_lidar.a, world.data()), "srl_transform_points");
+        for (size_t k = 0; k < frame.size(); k++) frame[k].point = srl::vec3(world[k * 3], world[k * 3 + 1], world[k * 3 + 2]);
+    }
+
+    cloudFrame *p_frame = new cloudFrame(frame, cur_state);
+    p_frame->time_sweep_begin = time_sweep_begin;
+    p_frame->time_sweep_end = timestamp_begin + timestamp_offset;
+    p_frame->time_frame_begin = time_frame_begin;
+    p_frame->time_frame_end = p_frame->time_sweep_end;
+    p_frame->offset_begin = 0;
+    p_frame->offset_end = timestamp_offset;
+    p_frame->dt_offset = dt_offset;
+    p_frame->id = (int)all_cloud_frame.size();
+    p_frame->sub_id = 0;
+    p_frame->frame_id = index_frame;
+    all_cloud_frame.push_back(p_frame);
+    return p_frame;
+}
+
+optimizeSummary lioOptimization::optimizeBuiltFrame(cloudFrame *p_frame, const icpOptions &cur_icp_options, double sample_voxel_size,
+                                                    std::vector<int> *keypoint_index) {
     srl_ctx *ctx = voxel_map.ctx;
     if (!ctx) throw std::runtime_error("optimize: no HIP context (the product has no CPU path)");
     releaseSweep();
-    check(ctx, srl_frame_upload(ctx, frame_raw, n), "srl_frame_upload");
     const Quat &q = p_frame->p_state->rotation;
     const double qv[4] = {q.w, q.x, q.y, q.z};
-    std::vector<int32_t> idx((size_t)std::max(n, 1));
+    std::vector<int32_t> idx(std::max<size_t>(p_frame->point_frame.size(), 1));
     int m = 0;
     check(ctx, srl_frame_select_keypoints(ctx, qv, p_frame->p_state->translation.a, R_imu_lidar.a, t_imu_lidar.a, sample_voxel_size,
                                           idx.data(), &m), "srl_frame_select_keypoints");
@@ -509,6 +647,159 @@ optimizeSummary lioOptimization::optimizeResident(cloudFrame *p_frame, const dou
     optimizeSummary s = solveIEKF(cur_icp_options, p_frame);
     releaseSweep();
     return s;
+}
+
+// ---------------------------------------------------------------- lioOptimization.cpp:991-1034 (LIO part)
+optimizeSummary lioOptimization::stateEstimation(cloudFrame *p_frame) {
+    optimizeSummary optimize_summary;
+    const double kSizeVoxelMap = optimize_options.size_voxel_map;
+    state commit_pose;                                   // identity: what buildFrame gave point3D::point for index_frame <= 2
+    if (p_frame->frame_id > 1) {
+        const double svs = p_frame->frame_id < init_num_frames ? init_sample_voxel_size : sample_voxel_size;
+        std::vector<int> kidx;
+        optimize_summary = optimizeBuiltFrame(p_frame, optimize_options, svs, &kidx);
+        last_frame_keypoints = (int)kidx.size();
+        if (!optimize_summary.success) return optimize_summary;
+        commit_pose = *p_frame->p_state;                 // optimize() re-transformed the frame with the final pose
+    } else {
+        p_frame->p_state->translation = eskf_pro->getTranslation();
+        p_frame->p_state->rotation = eskf_pro->getRotation();
+        p_frame->p_state->velocity = eskf_pro->getVelocity();
+        p_frame->p_state->ba = eskf_pro->getBa();
+        p_frame->p_state->bg = eskf_pro->getBg();
+        G = eskf_pro->getGravity();
+        G_norm = G.norm();
+        optimize_summary.success = true;
+    }
+    // addPointsToMap(voxel_map, p_frame, ...) on the frame resident in HBM
+    const int n = (int)p_frame->point_frame.size();
+    std::vector<double> world(download_frame_points ? (size_t)n * 3 : 0);
+    last_points_added = commitFrame(&commit_pose, kSizeVoxelMap, max_num_points_in_voxel, min_distance_points, 0,
+                                    download_frame_points && n > 0 ? world.data() : nullptr);
+    if (download_frame_points && p_frame->frame_id > 1)
+        for (int k = 0; k < n; k++) p_frame->point_frame[k].point = srl::vec3(world[(size_t)k * 3], world[(size_t)k * 3 + 1], world[(size_t)k * 3 + 2]);
+    return optimize_summary;
+}
+
+// ---------------------------------------------------------------- lioOptimization.cpp:1036-1133 (LIO part)
+void lioOptimization::process(std::vector<point3D> &cut_sweep, double timestamp_begin, double timestamp_offset, optimizeSummary *summary_out) {
+    state *cur_state = new state();
+    stateInitialization(cur_state);
+    std::vector<point3D> const_frame(cut_sweep.begin(), cut_sweep.end());
+    cloudFrame *p_frame = buildFrame(const_frame, cur_state, timestamp_begin, timestamp_offset);
+    last_frame_points = (int)p_frame->point_frame.size();
+    optimizeSummary summary = stateEstimation(p_frame);
+    if (summary_out) *summary_out = summary;
+    dt_sum = 0;
+
+    int num_remove = 0;
+    auto drop_front = [&]() {
+        cloudFrame *f = all_cloud_frame[0];
+        trajectory.push_back(poseRecord{f->time_sweep_end, f->p_state->translation, f->p_state->rotation});   // recordSinglePose
+        delete f->p_state;                                                                              // cloudFrame::release
+        delete f;
+        all_cloud_frame.erase(all_cloud_frame.begin());
+        num_remove++;
+    };
+    if (initial_flag) {
+        if (index_frame > 1)
+            while (all_cloud_frame.size() > 2) drop_front();
+    } else {
+        while ((int)all_cloud_frame.size() > num_for_initialization) drop_front();
+    }
+    for (size_t i = 0; i < all_cloud_frame.size(); i++) all_cloud_frame[i]->id = all_cloud_frame[i]->id - num_remove;
+}
+
+void lioOptimization::releaseFrames() {
+    for (cloudFrame *f : all_cloud_frame) { delete f->p_state; delete f; }
+    all_cloud_frame.clear();
+}
+
+// ---------------------------------------------------------------- lioOptimization.cpp:1427-1584 (loop body of run())
+bool lioOptimization::runMeasurement(Measurement &measurement, optimizeSummary *summary) {
+    const double time_frame = measurement.time_frame;
+    double dx = 0, dy = 0, dz = 0, rx = 0, ry = 0, rz = 0;
+
+    if (!initial_flag) {
+        for (const imuSample &imu_msg : measurement.imu) {
+            const double time_imu = imu_msg.time;
+            if (time_imu <= time_frame) {
+                current_time = time_imu;
+                dx = imu_msg.acc[0]; dy = imu_msg.acc[1]; dz = imu_msg.acc[2];
+                rx = imu_msg.gyr[0]; ry = imu_msg.gyr[1]; rz = imu_msg.gyr[2];
+            } else {
+                const double dt_1 = time_frame - current_time;
+                const double dt_2 = time_imu - time_frame;
+                current_time = time_frame;
+                const double w1 = dt_2 / (dt_1 + dt_2);
+                const double w2 = dt_1 / (dt_1 + dt_2);
+                dx = w1 * dx + w2 * imu_msg.acc[0]; dy = w1 * dy + w2 * imu_msg.acc[1]; dz = w1 * dz + w2 * imu_msg.acc[2];
+                rx = w1 * rx + w2 * imu_msg.gyr[0]; ry = w1 * ry + w2 * imu_msg.gyr[1]; rz = w1 * rz + w2 * imu_msg.gyr[2];
+            }
+            imu_meas.emplace_back(current_time, std::make_pair(srl::vec3(rx, ry, rz), srl::vec3(dx, dy, dz)));
+        }
+        eskf_pro->tryInit(imu_meas);
+        imu_meas.clear();
+        last_time_frame = time_frame;
+        return false;
+    }
+
+    auto push_state = [&](const Vec3 &un_acc, const Vec3 &un_gyr, bool before_predict) {
+        (void)before_predict;
+        imuState s;
+        s.timestamp = current_time;
+        s.un_acc = un_acc;
+        s.un_gyr = un_gyr;
+        s.trans = eskf_pro->getTranslation();
+        s.quat = eskf_pro->getRotation();
+        s.vel = eskf_pro->getVelocity();
+        imu_states.push_back(s);
+    };
+    push_state(eskf_pro->getRotation().toRotationMatrix() * (eskf_pro->getLastAcc() - eskf_pro->getBa()),
+               eskf_pro->getLastGyr() - eskf_pro->getBg(), true);
+
+    for (const imuSample &imu_msg : measurement.imu) {
+        const double time_imu = imu_msg.time;
+        double dt;
+        if (time_imu <= time_frame) {
+            dt = time_imu - current_time;
+            if (dt < -1e-6) continue;
+            current_time = time_imu;
+            dx = imu_msg.acc[0]; dy = imu_msg.acc[1]; dz = imu_msg.acc[2];
+            rx = imu_msg.gyr[0]; ry = imu_msg.gyr[1]; rz = imu_msg.gyr[2];
+        } else {
+            const double dt_1 = time_frame - current_time;
+            const double dt_2 = time_imu - time_frame;
+            current_time = time_frame;
+            const double w1 = dt_2 / (dt_1 + dt_2);
+            const double w2 = dt_1 / (dt_1 + dt_2);
+            dx = w1 * dx + w2 * imu_msg.acc[0]; dy = w1 * dy + w2 * imu_msg.acc[1]; dz = w1 * dz + w2 * imu_msg.acc[2];
+            rx = w1 * rx + w2 * imu_msg.gyr[0]; ry = w1 * ry + w2 * imu_msg.gyr[1]; rz = w1 * rz + w2 * imu_msg.gyr[2];
+            dt = dt_1;
+        }
+        // un_acc / un_gyr use the filter state BEFORE the predict, trans / quat / vel the state after it
+        const Vec3 un_acc = eskf_pro->getRotation().toRotationMatrix() * (0.5 * (eskf_pro->getLastAcc() + srl::vec3(dx, dy, dz)) - eskf_pro->getBa());
+        const Vec3 un_gyr = 0.5 * (eskf_pro->getLastGyr() + srl::vec3(rx, ry, rz)) - eskf_pro->getBg();
+        dt_sum = dt_sum + dt;
+        eskf_pro->predict(dt, srl::vec3(dx, dy, dz), srl::vec3(rx, ry, rz));
+        push_state(un_acc, un_gyr, false);
+    }
+
+    process(measurement.lidar_points, measurement.time_sweep_begin, measurement.time_sweep_offset, summary);
+
+    imu_states.clear();
+    last_time_frame = time_frame;
+    index_frame++;
+    return true;
+}
+
+// ---------------------------------------------------------------- frame-resident optimize() (optimize.cpp:428-448)
+optimizeSummary lioOptimization::optimizeResident(cloudFrame *p_frame, const double *frame_raw, int n, const icpOptions &cur_icp_options,
+                                                  double sample_voxel_size, std::vector<int> *keypoint_index) {
+    srl_ctx *ctx = voxel_map.ctx;
+    if (!ctx) throw std::runtime_error("optimize: no HIP context (the product has no CPU path)");
+    check(ctx, srl_frame_upload(ctx, frame_raw, n), "srl_frame_upload");
+    return optimizeBuiltFrame(p_frame, cur_icp_options, sample_voxel_size, keypoint_index);
 }
 
 int lioOptimization::commitFrame(const state *p_state, double voxel_size, int max_num_points_in_voxel, double min_distance_points,

@@ -26,6 +26,7 @@ public:
     int id = 0;            // the index in all_cloud_frame
     int sub_id = 0;
     int frame_id = 0;
+    double offset_begin = 0, offset_end = 0, dt_offset = 0;
     state *p_state = nullptr;
     std::vector<point3D> point_frame;
     bool success = true;
@@ -82,6 +83,57 @@ public:
     void addPointsToMap(voxelHashMap &map, cloudFrame *p_frame, double voxel_size, int max_num_points_in_voxel,
                         double min_distance_points, int min_num_points = 0, bool to_rendering = false);
     size_t mapSize(const voxelHashMap &map);
+
+    // stateInitialization (lioOptimization.cpp:895-990): pose prior of the next frame from the last two frames of
+    // all_cloud_frame (constant velocity), the filter (INIT_IMU once initial_flag is set) or the last pose.
+    void stateInitialization(state *cur_state);
+    int index_frame = 1;                                                 // lioOptimization.cpp:355
+    enum StateInitialization { INIT_IMU = 0, INIT_CONSTANT_VELOCITY = 1 };   // include/utility.h:88-92
+    int initialization = INIT_IMU;                                      // odometry_options.initialization (both yaml: "imu")
+
+    // sweep reconstruction (lioOptimization.cpp:786-893).  The per-point math of distortFrameByConstant/-ByImu and
+    // transformAllImuPoint runs on the device over the whole cut sweep (srl_frame_undistort); the order decisions
+    // (two std::shuffle with one default-seeded mt19937_64, subSampleFrame's tr1 iteration order) stay on the host;
+    // the surviving points become the resident frame (srl_frame_take), so optimizeResident(p_frame, ...) and
+    // commitFrame() need no further upload.  point_frame of the returned frame is filled from the device results.
+    void makePointTimestamp(std::vector<point3D> &sweep, double time_begin, double time_end);
+    cloudFrame *buildFrame(std::vector<point3D> &cut_sweep, state *cur_state, double timestamp_begin, double timestamp_offset);
+    // optimize() on the frame buildFrame left resident in HBM
+    optimizeSummary optimizeBuiltFrame(cloudFrame *p_frame, const icpOptions &cur_icp_options, double sample_voxel_size,
+                                       std::vector<int> *keypoint_index = nullptr);
+    std::vector<imuState> imu_states;                                    // lioOptimization.h:263
+    bool point_time_enable = true;                                       // cloud_pro->isPointTimeEnable()
+    enum MotionCompensation { IMU = 0, CONSTANT_VELOCITY = 1 };          // include/utility.h:82-86
+    int motion_compensation = CONSTANT_VELOCITY;                         // odometry_options (parameters.h:84)
+    double init_voxel_size = 0.2, voxel_size = 0.5;                      // parameters.h:62,70
+    int init_num_frames = 20;                                            // parameters.h:66
+
+    // ---- ROS-free replay driver: the LIO part of run() / process() / stateEstimation() ----
+    // (lioOptimization.cpp:1427-1584, :1036-1133, :991-1034).  Image / rendering / publishing / file output are out
+    // of scope; recordSinglePose's rows are kept in `trajectory` instead of pose.txt.
+    struct imuSample { double time; srl::Vec3 acc, gyr; };
+    struct Measurement {
+        double time_frame = 0;                         // measurement.time_image
+        std::vector<imuSample> imu;                    // measurement.imu_measurements
+        std::vector<point3D> lidar_points;             // raw_point, point (= raw_point), timestamp
+        double time_sweep_begin = 0, time_sweep_offset = 0;   // measurement.time_sweep
+    };
+    struct poseRecord { double time; srl::Vec3 translation; srl::Quat rotation; };
+    // returns false while the filter is still initialising (no frame processed)
+    bool runMeasurement(Measurement &measurement, optimizeSummary *summary = nullptr);
+    void process(std::vector<point3D> &cut_sweep, double timestamp_begin, double timestamp_offset, optimizeSummary *summary = nullptr);
+    optimizeSummary stateEstimation(cloudFrame *p_frame);
+    void releaseFrames();
+    icpOptions optimize_options;                                         // odometry_options.optimize_options
+    double init_sample_voxel_size = 1.0, sample_voxel_size = 1.5;        // parameters.h:64,72
+    int num_for_initialization = 10;                                     // parameters.h:68
+    int max_num_points_in_voxel = 20;                                    // parameters.h:76
+    double min_distance_points = 0.1;                                    // parameters.h:78
+    bool download_frame_points = true;       // fill point3D::point of the frame after the device commit
+    std::vector<poseRecord> trajectory;
+    std::vector<imuMeas> imu_meas;
+    double current_time = -1, last_time_frame = -1, dt_sum = 0;         // lioOptimization.cpp:353-357
+    int last_frame_keypoints = 0, last_frame_points = 0, last_points_added = 0;
 
     // ---- ours ----
     // pin a sweep in HBM: until releaseSweep(), updateIEKF calls with the same keypoint count skip their

@@ -40,8 +40,12 @@ void state_to(const state &st, double s[16]) {
 struct FrameWindow {
     std::vector<point3D> no_points;
     cloudFrame prev, cur;
+    srl_lio *owner;
+    std::vector<cloudFrame *> saved;          // the replay driver's own window, put back on exit
+    ~FrameWindow() { owner->lio->all_cloud_frame.swap(saved); }
     FrameWindow(srl_lio *h, const double state_io[16], const double t_last[3], int frame_id, std::vector<point3D> &pts)
-        : prev(no_points, &h->prev_state), cur(pts, &h->cur_state) {
+        : prev(no_points, &h->prev_state), cur(pts, &h->cur_state), owner(h) {
+        saved.swap(h->lio->all_cloud_frame);
         h->prev_state = state();
         h->prev_state.translation = srl::vec3(t_last[0], t_last[1], t_last[2]);
         state_from(state_io, h->cur_state);
@@ -271,6 +275,136 @@ int srl_lio_optimize(srl_lio *h, const srl_icp_opts *opts, double sample_voxel_s
     if (num_residuals_used) *num_residuals_used = s.num_residuals_used;
     if (!s.success) { h->err = s.error_log; return SRL_ERR_NOT_ENOUGH_RESIDUALS; }
     for (int k = 0; k < n; k++) for (int d = 0; d < 3; d++) frame_world[(size_t)k * 3 + d] = w.cur.point_frame[k].point[d];
+    return SRL_OK;
+}
+
+int srl_lio_eskf_try_init(srl_lio *h, const double *t, const double *gyr, const double *acc, int n, int *initialized) {
+    if (!h || n < 0 || (n > 0 && (!t || !gyr || !acc))) return SRL_ERR_BAD_ARG;
+    std::vector<imuMeas> meas((size_t)n);
+    for (int i = 0; i < n; i++) {
+        meas[i].first = t[i];
+        meas[i].second.first = srl::vec3(gyr[3 * i], gyr[3 * i + 1], gyr[3 * i + 2]);
+        meas[i].second.second = srl::vec3(acc[3 * i], acc[3 * i + 1], acc[3 * i + 2]);
+    }
+    const int r = h->lio->eskf_pro->tryInit(meas);
+    if (initialized) *initialized = r;
+    return SRL_OK;
+}
+int srl_lio_eskf_get_init_stats(srl_lio *h, double out[14]) {
+    if (!h || !out) return SRL_ERR_BAD_ARG;
+    const eskfEstimator *e = h->lio->eskf_pro;
+    const srl::Vec3 v[4] = {e->getMeanGyr(), e->getMeanAcc(), e->getGyrCov(), e->getAccCov()};
+    for (int k = 0; k < 4; k++) for (int d = 0; d < 3; d++) out[3 * k + d] = v[k][d];
+    out[12] = (double)e->getNumInitMeas();
+    out[13] = initial_flag ? 1.0 : 0.0;
+    return SRL_OK;
+}
+int srl_lio_set_initial_flag(srl_lio *h, int flag) {
+    if (!h) return SRL_ERR_BAD_ARG;
+    initial_flag = flag != 0;
+    return SRL_OK;
+}
+int srl_lio_state_initialization(srl_lio *h, int index_frame, int initialization, const double prev2[7], const double prev1[7],
+                                 double out[7]) {
+    if (!h || !out || (index_frame > 2 && (!prev2 || !prev1))) return SRL_ERR_BAD_ARG;
+    state s2, s1, cur;
+    if (index_frame > 2) {
+        s2.rotation = srl::Quat(prev2[0], prev2[1], prev2[2], prev2[3]); s2.translation = srl::vec3(prev2[4], prev2[5], prev2[6]);
+        s1.rotation = srl::Quat(prev1[0], prev1[1], prev1[2], prev1[3]); s1.translation = srl::vec3(prev1[4], prev1[5], prev1[6]);
+    }
+    std::vector<point3D> none;
+    cloudFrame f2(none, &s2), f1(none, &s1);
+    std::vector<cloudFrame *> saved;
+    saved.swap(h->lio->all_cloud_frame);
+    h->lio->all_cloud_frame.push_back(&f2);
+    h->lio->all_cloud_frame.push_back(&f1);
+    const int saved_index = h->lio->index_frame, saved_init = h->lio->initialization;
+    h->lio->index_frame = index_frame;
+    h->lio->initialization = initialization;
+    h->lio->stateInitialization(&cur);
+    h->lio->all_cloud_frame.swap(saved);
+    h->lio->index_frame = saved_index;
+    h->lio->initialization = saved_init;
+    out[0] = cur.rotation.w; out[1] = cur.rotation.x; out[2] = cur.rotation.y; out[3] = cur.rotation.z;
+    for (int d = 0; d < 3; d++) out[4 + d] = cur.translation[d];
+    return SRL_OK;
+}
+
+// ---- ROS-free replay driver
+int srl_lio_set_odometry_options(srl_lio *h, const srl_odometry_opts *o) {
+    if (!h || !o) return SRL_ERR_BAD_ARG;
+    lioOptimization &L = *h->lio;
+    L.init_voxel_size = o->init_voxel_size; L.init_sample_voxel_size = o->init_sample_voxel_size;
+    L.init_num_frames = o->init_num_frames; L.num_for_initialization = o->num_for_initialization;
+    L.voxel_size = o->voxel_size; L.sample_voxel_size = o->sample_voxel_size;
+    L.max_num_points_in_voxel = o->max_num_points_in_voxel; L.min_distance_points = o->min_distance_points;
+    L.motion_compensation = o->motion_compensation; L.initialization = o->initialization;
+    L.point_time_enable = o->point_time_enable != 0;
+    L.optimize_options = icpOptions::fromAbi(o->icp);
+    L.eskf_pro->setAccCov(o->acc_cov); L.eskf_pro->setGyrCov(o->gyr_cov);
+    L.eskf_pro->setBiasAccCov(o->b_acc_cov); L.eskf_pro->setBiasGyrCov(o->b_gyr_cov);
+    return SRL_OK;
+}
+
+int srl_lio_run_measurement(srl_lio *h, double time_frame, const double *imu_t, const double *imu_acc, const double *imu_gyr,
+                            int n_imu, const double *pts_raw, const double *pts_timestamp, int n_pts, double time_sweep_begin,
+                            double time_sweep_offset, srl_replay_result *out) {
+    if (!h || n_imu < 0 || n_pts < 0 || (n_imu > 0 && (!imu_t || !imu_acc || !imu_gyr)) || (n_pts > 0 && (!pts_raw || !pts_timestamp)))
+        return SRL_ERR_BAD_ARG;
+    lioOptimization &L = *h->lio;
+    lioOptimization::Measurement m;
+    m.time_frame = time_frame; m.time_sweep_begin = time_sweep_begin; m.time_sweep_offset = time_sweep_offset;
+    m.imu.resize((size_t)n_imu);
+    for (int i = 0; i < n_imu; i++) {
+        m.imu[i].time = imu_t[i];
+        m.imu[i].acc = srl::vec3(imu_acc[3 * i], imu_acc[3 * i + 1], imu_acc[3 * i + 2]);
+        m.imu[i].gyr = srl::vec3(imu_gyr[3 * i], imu_gyr[3 * i + 1], imu_gyr[3 * i + 2]);
+    }
+    m.lidar_points.resize((size_t)n_pts);
+    for (int i = 0; i < n_pts; i++) {
+        point3D &p = m.lidar_points[i];
+        p.raw_point = srl::vec3(pts_raw[3 * (size_t)i], pts_raw[3 * (size_t)i + 1], pts_raw[3 * (size_t)i + 2]);
+        p.point = p.raw_point;                                   // cloudProcessing.cpp:143
+        p.timestamp = pts_timestamp[i];
+    }
+    optimizeSummary s;
+    bool processed = false;
+    if (out) std::memset(out, 0, sizeof *out);
+    try {
+        if (initial_flag && !L.context()) return SRL_ERR_NO_DEVICE;
+        processed = L.runMeasurement(m, &s);
+    } catch (const std::exception &e) { return status_from_exception(h, e); }
+    if (out) {
+        out->processed = processed ? 1 : 0;
+        out->initialized = initial_flag ? 1 : 0;
+        out->index_frame = L.index_frame;
+        if (processed) {
+            out->success = s.success ? 1 : 0;
+            out->num_residuals_used = s.num_residuals_used;
+            out->iterations = L.last_num_iterations;
+            out->frame_points = L.last_frame_points;
+            out->keypoints = L.last_frame_keypoints;
+            out->points_added = L.last_points_added;
+            const state *st = L.all_cloud_frame.back()->p_state;
+            state_to(*st, out->state);
+        }
+    }
+    if (processed && !s.success) { h->err = s.error_log; return SRL_ERR_NOT_ENOUGH_RESIDUALS; }
+    return SRL_OK;
+}
+
+int srl_lio_last_frame(srl_lio *h, int capacity, double *raw_point, double *point, double *imu_point, int *n) {
+    if (!h || !n) return SRL_ERR_BAD_ARG;
+    if (h->lio->all_cloud_frame.empty()) { *n = 0; return SRL_OK; }
+    const std::vector<point3D> &f = h->lio->all_cloud_frame.back()->point_frame;
+    *n = (int)f.size();
+    const int m = std::min(capacity, *n);
+    for (int k = 0; k < m; k++)
+        for (int d = 0; d < 3; d++) {
+            if (raw_point) raw_point[(size_t)k * 3 + d] = f[k].raw_point[d];
+            if (point) point[(size_t)k * 3 + d] = f[k].point[d];
+            if (imu_point) imu_point[(size_t)k * 3 + d] = f[k].imu_point[d];
+        }
     return SRL_OK;
 }
 

@@ -87,6 +87,8 @@ struct Quat {
         return Quat(w * b.w - x * b.x - y * b.y - z * b.z, w * b.x + x * b.w + y * b.z - z * b.y,
                     w * b.y + y * b.w + z * b.x - x * b.z, w * b.z + z * b.w + x * b.y - y * b.x);
     }
+    // Quaternion * Vector3 (Eigen's _transformVector: two cross products, not a matrix product)
+    Vec3 operator*(const Vec3 &v) const;
     Mat3 toRotationMatrix() const {
         const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
         const double twx = tx * w, twy = ty * w, twz = tz * w;
@@ -125,6 +127,13 @@ struct Quat {
         return q;
     }
 };
+
+inline Vec3 Quat::operator*(const Vec3 &v) const {
+    const Vec3 qv = vec3(x, y, z);
+    Vec3 uv = cross(qv, v);
+    uv = uv + uv;
+    return (v + w * uv) + cross(qv, uv);
+}
 
 // Matrix<double,N,N>::inverse() for N > 4: PartialPivLU, then solve against the identity
 template <int N>

@@ -33,6 +33,11 @@ struct srl_ctx {
     double *d_frame_world = nullptr;   // AoS n x 3
     int frame_cap = 0;
     int frame_n = -1;
+    // undistorted sweep (srl_frame_undistort): inputs, imu_point, corrected raw_point
+    double *d_corr_in = nullptr, *d_corr_rel = nullptr, *d_corr_imu = nullptr, *d_corr_raw = nullptr;
+    int *d_corr_seg = nullptr;
+    int corr_cap = 0;
+    int corr_n = -1;
 
     // work buffers
     double *d_rec = nullptr;

@@ -91,20 +91,252 @@ void fill_xf(Xf &X, const double q[4], const double t[3], const double R_il[9], 
 
 int srl_ctx_ensure_work(srl_ctx *ctx, int n);   // srl_capi.cpp
 
-extern "C" {
+namespace {
 
-int srl_frame_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
-    if (!ctx || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+int ensure_frame(srl_ctx *ctx, int n) {
     if (n > ctx->frame_cap) {
         if (ctx->d_frame_raw) HIPCHK(ctx, hipFree(ctx->d_frame_raw));
         if (ctx->d_frame_world) HIPCHK(ctx, hipFree(ctx->d_frame_world));
         ctx->d_frame_raw = ctx->d_frame_world = nullptr;
+        ctx->frame_cap = 0;
         const int cap = std::max(n, 4096);
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_frame_raw, (size_t)cap * 3 * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_frame_world, (size_t)cap * 3 * sizeof(double)));
         ctx->frame_cap = cap;
     }
+    return SRL_OK;
+}
+
+// ---------------------------------------------------------------------------- sweep reconstruction (row f4)
+// Per-point stages of buildFrame (lioOptimization.cpp:833-850): distortFrameByConstant / distortFrameByImu
+// (utility.cpp:203-306) then transformAllImuPoint (:320-332), one thread per point, FP64, the reference's
+// operation order.  sin / cos / acos come from the device math library, so results agree with the CPU to a few
+// ulp, not bit for bit.
+struct Q4d { double w, x, y, z; };
+
+__device__ inline void d_quat_to_rot(const Q4d &q, double R[9]) {             // Eigen toRotationMatrix
+    const double tx = 2.0 * q.x, ty = 2.0 * q.y, tz = 2.0 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0 - (txx + tyy);
+}
+__device__ inline Q4d d_q_normalized(const Q4d &q) {
+    const double z = ((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w;
+    if (z > 0.0) { const double n = sqrt(z); return Q4d{q.w / n, q.x / n, q.y / n, q.z / n}; }
+    return q;
+}
+__device__ inline Q4d d_q_mul(const Q4d &a, const Q4d &b) {
+    return Q4d{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+               a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+__device__ inline Q4d d_so3_to_quat(double x, double y, double z) {            // numType::so3ToQuat, utility.h:299-324
+    const double theta = sqrt((x * x + y * y) + z * z);
+    if (theta < 0.0001) return d_q_normalized(Q4d{1.0, x / 2.0, y / 2.0, z / 2.0});
+    const double ux = x / theta, uy = y / theta, uz = z / theta;
+    const double s = sin(0.5 * theta);
+    return d_q_normalized(Q4d{cos(0.5 * theta), ux * s, uy * s, uz * s});
+}
+__device__ inline Q4d d_q_slerp(const Q4d &a, double t, const Q4d &b) {       // Eigen QuaternionBase::slerp
+    const double one = 1.0 - 2.220446049250313e-16;
+    const double d = ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w;
+    const double absD = fabs(d);
+    double scale0, scale1;
+    if (absD >= one) { scale0 = 1.0 - t; scale1 = t; }
+    else {
+        const double theta = acos(absD), sinTheta = sin(theta);
+        scale0 = sin((1.0 - t) * theta) / sinTheta;
+        scale1 = sin(t * theta) / sinTheta;
+    }
+    if (d < 0.0) scale1 = -scale1;
+    return Q4d{scale0 * a.w + scale1 * b.w, scale0 * a.x + scale1 * b.x, scale0 * a.y + scale1 * b.y, scale0 * a.z + scale1 * b.z};
+}
+__device__ inline void d_mv(const double R[9], double x, double y, double z, double &ox, double &oy, double &oz) {
+    ox = (R[0] * x + R[1] * y) + R[2] * z;
+    oy = (R[3] * x + R[4] * y) + R[5] * z;
+    oz = (R[6] * x + R[7] * y) + R[8] * z;
+}
+
+struct UndistortArgs {
+    const double *raw, *rel, *states;      // n x 3, n, n_states x 17
+    const int *seg;                        // IMU mode: interval per point, -1 = never reached
+    double *imu, *raw_out;                 // n x 3 each; imu is in/out
+    int n, mode;
+    double tfb, tfe;
+    double q0[4], q1[4], tr0[3], tr1[3];
+    double R_il[9], t_il[3];
+    double Rinv[9], tinv[3], RilT[9], RilT_til[3];
+};
+
+__global__ void k_undistort(const UndistortArgs A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const double rx = A.raw[(size_t)i * 3], ry = A.raw[(size_t)i * 3 + 1], rz = A.raw[(size_t)i * 3 + 2];
+    double lx, ly, lz;
+    d_mv(A.R_il, rx, ry, rz, lx, ly, lz);
+    lx += A.t_il[0]; ly += A.t_il[1]; lz += A.t_il[2];
+    double px = A.imu[(size_t)i * 3], py = A.imu[(size_t)i * 3 + 1], pz = A.imu[(size_t)i * 3 + 2];
+    if (A.mode == SRL_MC_CONSTANT_VELOCITY) {
+        double time_point = A.tfb + A.rel[i] / 1000.0;
+        if (fabs(time_point - A.tfb) < 1e-6) time_point = A.tfb + 1e-6;
+        if (fabs(time_point - A.tfe) < 1e-6) time_point = A.tfe - 1e-6;
+        double alpha = (time_point - A.tfb) / (A.tfe - A.tfb);
+        if (alpha > 1) alpha = 1;
+        if (alpha < 0) alpha = 0;
+        const Q4d qa = d_q_slerp(Q4d{A.q0[0], A.q0[1], A.q0[2], A.q0[3]}, alpha, Q4d{A.q1[0], A.q1[1], A.q1[2], A.q1[3]});
+        double R[9];
+        d_quat_to_rot(qa, R);
+        d_mv(R, lx, ly, lz, px, py, pz);
+        px += (1.0 - alpha) * A.tr0[0] + alpha * A.tr1[0];
+        py += (1.0 - alpha) * A.tr0[1] + alpha * A.tr1[1];
+        pz += (1.0 - alpha) * A.tr0[2] + alpha * A.tr1[2];
+    } else if (A.mode == SRL_MC_IMU) {
+        const int k = A.seg[i];
+        if (k >= 0) {
+            const double *a = A.states + 17 * (size_t)k, *b = a + 17;
+            const double tb = a[0], te = b[0];
+            double time_point = A.tfb + A.rel[i] / 1000.0;
+            if (fabs(time_point - tb) < 1e-6) time_point = tb + 1e-6;
+            if (fabs(time_point - te) < 1e-6) time_point = te - 1e-6;
+            const double dt = time_point - tb;
+            const Q4d qp = d_q_normalized(d_q_mul(Q4d{a[10], a[11], a[12], a[13]}, d_so3_to_quat(b[4] * dt, b[5] * dt, b[6] * dt)));
+            double R[9];
+            d_quat_to_rot(qp, R);
+            d_mv(R, lx, ly, lz, px, py, pz);
+            px += (a[7] + a[14] * dt) + ((0.5 * b[1]) * dt) * dt;
+            py += (a[8] + a[15] * dt) + ((0.5 * b[2]) * dt) * dt;
+            pz += (a[9] + a[16] * dt) + ((0.5 * b[3]) * dt) * dt;
+        }
+    }
+    A.imu[(size_t)i * 3] = px; A.imu[(size_t)i * 3 + 1] = py; A.imu[(size_t)i * 3 + 2] = pz;
+    // transformAllImuPoint
+    double ex, ey, ez, ox, oy, oz;
+    d_mv(A.Rinv, px, py, pz, ex, ey, ez);
+    ex += A.tinv[0]; ey += A.tinv[1]; ez += A.tinv[2];
+    d_mv(A.RilT, ex, ey, ez, ox, oy, oz);
+    A.raw_out[(size_t)i * 3] = ox - A.RilT_til[0];
+    A.raw_out[(size_t)i * 3 + 1] = oy - A.RilT_til[1];
+    A.raw_out[(size_t)i * 3 + 2] = oz - A.RilT_til[2];
+}
+
+__global__ void k_gather_aos(const double *src, const int *sel, int m, double *dst) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const int i = sel[k];
+    dst[(size_t)k * 3] = src[(size_t)i * 3];
+    dst[(size_t)k * 3 + 1] = src[(size_t)i * 3 + 1];
+    dst[(size_t)k * 3 + 2] = src[(size_t)i * 3 + 2];
+}
+
+}  // namespace
+
+extern "C" {
+
+int srl_frame_undistort(srl_ctx *ctx, const double *raw_xyz, const double *relative_time_ms, const double *imu_point_in, int n,
+                        const srl_imu_state *imu_states, int n_states, double time_frame_begin, int motion_compensation,
+                        const double R_il[9], const double t_il[3], double *imu_point_out, double *raw_out) {
+    if (!ctx || n < 0 || (n > 0 && (!raw_xyz || !relative_time_ms)) || !imu_states || n_states < 1 || !R_il || !t_il)
+        return SRL_ERR_BAD_ARG;
+    if (motion_compensation != SRL_MC_IMU && motion_compensation != SRL_MC_CONSTANT_VELOCITY && motion_compensation != SRL_MC_NONE)
+        return SRL_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->corr_n = -1;
+    if (n > ctx->corr_cap) {
+        void *bufs[] = {ctx->d_corr_raw, ctx->d_corr_imu, ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_seg};
+        for (void *b : bufs) if (b) HIPCHK(ctx, hipFree(b));
+        ctx->d_corr_raw = ctx->d_corr_imu = ctx->d_corr_in = ctx->d_corr_rel = nullptr; ctx->d_corr_seg = nullptr;
+        ctx->corr_cap = 0;
+        const int cap = std::max(n, 4096);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_corr_raw, (size_t)cap * 24));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_corr_imu, (size_t)cap * 24));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_corr_in, (size_t)cap * 24));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_corr_rel, (size_t)cap * 8));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_corr_seg, (size_t)cap * 4));
+        ctx->corr_cap = cap;
+    }
+    if (n == 0) { ctx->corr_n = 0; return SRL_OK; }
+    hipStream_t st = ctx->stream;
+    DevBuf b_states;
+    HIPCHK(ctx, b_states.alloc((size_t)n_states * sizeof(srl_imu_state)));
+    static_assert(sizeof(srl_imu_state) == 17 * sizeof(double), "srl_imu_state is 17 packed doubles");
+    HIPCHK(ctx, hipMemcpyAsync(b_states.p, imu_states, (size_t)n_states * sizeof(srl_imu_state), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_corr_in, raw_xyz, (size_t)n * 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_corr_rel, relative_time_ms, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    if (imu_point_in) HIPCHK(ctx, hipMemcpyAsync(ctx->d_corr_imu, imu_point_in, (size_t)n * 24, hipMemcpyHostToDevice, st));
+    else HIPCHK(ctx, hipMemsetAsync(ctx->d_corr_imu, 0, (size_t)n * 24, st));
+
+    std::vector<int> seg;
+    if (motion_compensation == SRL_MC_IMU) {
+        // the interval walk of distortFrameByImu (utility.cpp:247-305) is sequential in the point order: a point that
+        // fits the current interval advances the point cursor, one that does not advances the interval -- and a point
+        // no later interval fits stops everything behind it.  Integer control flow on N timestamps: replayed on the
+        // host; the per-point math runs on the device.
+        seg.assign((size_t)n, -1);
+        int iter = 0;
+        for (int k = 0; k + 1 < n_states; k++) {
+            const double tb = imu_states[k].timestamp, te = imu_states[k + 1].timestamp;
+            while (iter != n) {
+                const double time_point = time_frame_begin + relative_time_ms[iter] / 1000.0;
+                if (time_point > tb - 1e-6 && time_point < te + 1e-6) seg[iter++] = k;
+                else break;
+            }
+        }
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_corr_seg, seg.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    }
+
+    UndistortArgs A;
+    A.raw = ctx->d_corr_in; A.rel = ctx->d_corr_rel; A.states = b_states.as<double>(); A.seg = ctx->d_corr_seg;
+    A.imu = ctx->d_corr_imu; A.raw_out = ctx->d_corr_raw; A.n = n; A.mode = motion_compensation;
+    A.tfb = time_frame_begin; A.tfe = imu_states[n_states - 1].timestamp;
+    const srl_imu_state &s0 = imu_states[0], &s1 = imu_states[n_states - 1];
+    for (int d = 0; d < 4; d++) { A.q0[d] = s0.quat[d]; A.q1[d] = s1.quat[d]; }
+    for (int d = 0; d < 3; d++) { A.tr0[d] = s0.trans[d]; A.tr1[d] = s1.trans[d]; A.t_il[d] = t_il[d]; }
+    std::memcpy(A.R_il, R_il, sizeof A.R_il);
+    const srl::Mat3 Rinv = srl::Quat(s1.quat[0], s1.quat[1], s1.quat[2], s1.quat[3]).inverse().toRotationMatrix();
+    srl::Mat3 Ril;
+    std::memcpy(Ril.a, R_il, sizeof Ril.a);
+    const srl::Mat3 RilT = Ril.transpose();
+    const srl::Vec3 tinv = (-1.0 * Rinv) * srl::vec3(s1.trans[0], s1.trans[1], s1.trans[2]);
+    const srl::Vec3 rt = RilT * srl::vec3(t_il[0], t_il[1], t_il[2]);
+    std::memcpy(A.Rinv, Rinv.a, sizeof A.Rinv);
+    std::memcpy(A.RilT, RilT.a, sizeof A.RilT);
+    for (int d = 0; d < 3; d++) { A.tinv[d] = tinv[d]; A.RilT_til[d] = rt[d]; }
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, A);
+    HIPCHK(ctx, hipGetLastError());
+    if (imu_point_out) HIPCHK(ctx, hipMemcpyAsync(imu_point_out, ctx->d_corr_imu, (size_t)n * 24, hipMemcpyDeviceToHost, st));
+    if (raw_out) HIPCHK(ctx, hipMemcpyAsync(raw_out, ctx->d_corr_raw, (size_t)n * 24, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    ctx->corr_n = n;
+    return SRL_OK;
+}
+
+int srl_frame_take(srl_ctx *ctx, const int32_t *index, int m) {
+    if (!ctx || m < 0 || (m > 0 && !index)) return SRL_ERR_BAD_ARG;
+    if (ctx->corr_n < 0) { ctx->err = "no undistorted sweep (srl_frame_undistort first)"; return SRL_ERR_NO_SWEEP; }
+    for (int k = 0; k < m; k++)
+        if (index[k] < 0 || index[k] >= ctx->corr_n) { ctx->err = "frame index out of range"; return SRL_ERR_BAD_ARG; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_frame(ctx, m);
+    if (rc) return rc;
+    ctx->frame_n = m;
+    if (m > 0) {
+        DevBuf b_sel;
+        HIPCHK(ctx, b_sel.alloc((size_t)m * 4));
+        HIPCHK(ctx, hipMemcpyAsync(b_sel.p, index, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_gather_aos, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_corr_raw, b_sel.as<int>(), m, ctx->d_frame_raw);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SRL_OK;
+}
+
+int srl_frame_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
+    if (!ctx || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc0 = ensure_frame(ctx, n);
+    if (rc0) return rc0;
     ctx->frame_n = n;
     if (n > 0) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_raw, raw_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));

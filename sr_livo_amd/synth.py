@@ -205,3 +205,71 @@ CONFIGS = {
     "C4": (262144, 10_000_000, "livox", 20250304 + 4),
     "HEADLINE": (65536, 1_000_000, "livox", 20250304 + 5),
 }
+
+
+def sweep_from_pose(rng, n, L, q, t, max_range=50.0):
+    """n lidar-frame points (livox cone) ray-cast from the scene pose (q, t); same noise model as make_sweep."""
+    rng_lim = min(max_range, 0.85 * L)
+    R = quat_to_rot(q)
+    pts = np.zeros((0, 3))
+    while len(pts) < n:
+        m = int((n - len(pts)) * 1.6) + 1024
+        cosmin = math.cos(math.radians(35.0))
+        cz = rng.uniform(cosmin, 1.0, m)
+        ph = rng.uniform(0, 2 * math.pi, m)
+        sz = np.sqrt(1 - cz * cz)
+        dl = np.column_stack([cz, sz * np.cos(ph), sz * np.sin(ph)])
+        s = _raycast(np.asarray(t, float), dl @ R.T, L, rng_lim)
+        ok = np.isfinite(s)
+        pts = np.concatenate([pts, dl[ok] * s[ok, None] + dl[ok] * rng.normal(0.0, SIGMA, (ok.sum(), 1))], 0)
+    return pts[:n].copy()
+
+
+def make_sequence(seed, n_moving, n_pts, L, imu_rate=200.0, sweep_dt=0.1, rest_time=3.3, acc_x=0.6, yaw_rate=0.15):
+    """A ROS-free `Measurements` sequence for the replay driver: the sensor rests for rest_time seconds (IMU
+    initialisation), then accelerates along its x axis while yawing.  Returns a list of dicts
+    (time_frame, imu_t, imu_acc, imu_gyr, pts_raw, pts_timestamp, time_sweep_begin, time_sweep_offset) and the
+    ground-truth odometry poses (relative to the first sensor pose) at every sweep end."""
+    rng = np.random.default_rng(seed)
+    t0 = 1000.0
+    q0 = quat_from_rotvec([0.0, 0.0, 0.4]); p0 = np.array([2.1, 1.3, 0.05])        # scene pose of the odometry origin
+    R0 = quat_to_rot(q0)
+    g = np.array([0.0, 0.0, 9.81])
+    n_rest = int(round(rest_time / sweep_dt)) + 1
+    per = int(round(imu_rate * sweep_dt))
+    t_move0 = t0 + n_rest * sweep_dt
+
+    def pose(tt):               # odometry-frame pose at absolute time tt
+        s = max(tt - t_move0, 0.0)
+        yaw = yaw_rate * s
+        # body-x acceleration integrated numerically on a fine grid (smooth, deterministic)
+        k = max(int(s / 1e-3), 0)
+        ts = (np.arange(k + 1) + 0.5) * 1e-3 if k else np.zeros(0)
+        vel = np.zeros(3); pos = np.zeros(3)
+        if k:
+            a = acc_x * np.column_stack([np.cos(yaw_rate * ts), np.sin(yaw_rate * ts), np.zeros_like(ts)])
+            v = np.cumsum(a, 0) * 1e-3
+            pos = np.sum(v, 0) * 1e-3
+            vel = v[-1]
+        return quat_from_rotvec([0.0, 0.0, yaw]), pos, vel
+
+    meas, gt = [], []
+    for f in range(n_rest + n_moving):
+        tb = t0 + f * sweep_dt
+        te = tb + sweep_dt
+        it = tb + (np.arange(per) + 1) / imu_rate
+        moving = it > t_move0
+        yaw = yaw_rate * np.maximum(it - t_move0, 0.0)
+        acc_w = np.where(moving[:, None], acc_x * np.column_stack([np.cos(yaw), np.sin(yaw), np.zeros_like(yaw)]), 0.0) + g
+        acc_b = np.stack([quat_to_rot(quat_from_rotvec([0, 0, y])).T @ a for y, a in zip(yaw, acc_w)])
+        gyr_b = np.where(moving[:, None], np.array([0.0, 0.0, yaw_rate]), 0.0)
+        acc_b = acc_b + rng.normal(0, 0.02, acc_b.shape)
+        gyr_b = gyr_b + rng.normal(0, 0.002, gyr_b.shape) + np.array([0.001, -0.0005, 0.0008])
+        q, p, _ = pose(te)
+        qs = quat_mul(q0, q); ps = p0 + R0 @ p
+        raw = sweep_from_pose(rng, n_pts, L, qs, ps)
+        ts = np.sort(rng.uniform(tb, te, n_pts)); ts[-1] = te
+        meas.append(dict(time_frame=te, imu_t=it, imu_acc=acc_b, imu_gyr=gyr_b, pts_raw=raw, pts_timestamp=ts,
+                         time_sweep_begin=tb, time_sweep_offset=sweep_dt))
+        gt.append((q, p))
+    return meas, gt, (q0, p0)

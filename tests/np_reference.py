@@ -259,3 +259,42 @@ def update_iekf(keys, counts, xyz, raw, eskf_state, eskf_cov, state16, t_last, m
             break
     state = np.concatenate([q, t, vel, ba, bg])
     return dict(iters=iters, dx=dxs, state=state, eskf_state=es, eskf_cov=P)
+
+
+# ---------------------------------------------------------------------------------------------
+# eskfEstimator::tryInit statistics (eskfEstimator.cpp:93-118), written independently: running mean and the
+# biased running variance recurrence, then the acceptance test of :47-63.
+def try_init_stats(batches, g_norm=9.81):
+    """batches: list of (t, gyr, acc). Returns dict with the statistics after the last batch and the batch index
+    at which initialisation happened (or None)."""
+    n = 1
+    mean_g = mean_a = None
+    var_g = np.zeros(3); var_a = np.zeros(3)
+    t0 = None
+    done_at = None
+    for bi, (t, gyr, acc) in enumerate(batches):
+        if t0 is None:
+            t0 = t[0]; mean_g = np.array(gyr[0], float); mean_a = np.array(acc[0], float)
+        for w, a in zip(gyr, acc):
+            mean_g = mean_g + (w - mean_g) / n
+            mean_a = mean_a + (a - mean_a) / n
+            var_g = var_g * (n - 1.0) / n + (w - mean_g) ** 2 * (n - 1.0) / (n * n)
+            var_a = var_a * (n - 1.0) / n + (a - mean_a) ** 2 * (n - 1.0) / (n * n)
+            n += 1
+        if n > 10 and t[-1] - t0 > 3.0:
+            var_a = var_a * (g_norm / np.linalg.norm(mean_a)) ** 2
+            if np.linalg.norm(var_g) > 0.5:
+                return dict(code=-1, at=bi, mean_gyr=mean_g, mean_acc=mean_a, gyr_cov=var_g, acc_cov=var_a, n=n)
+            if np.linalg.norm(var_a) > 0.6:
+                return dict(code=-2, at=bi, mean_gyr=mean_g, mean_acc=mean_a, gyr_cov=var_g, acc_cov=var_a, n=n)
+            done_at = bi
+            break
+    return dict(code=1 if done_at is not None else 0, at=done_at, mean_gyr=mean_g, mean_acc=mean_a, gyr_cov=var_g, acc_cov=var_a,
+                n=n, bg=mean_g, gravity=mean_a / np.linalg.norm(mean_a) * g_norm)
+
+
+def state_initialization_const_velocity(q2, t2, q1, t1):
+    """constant-velocity prior (lioOptimization.cpp:906-917) with rotation matrices (unit quaternions)."""
+    R1, R2 = quat_to_rot(q1), quat_to_rot(q2)
+    D = R1 @ R2.T
+    return D @ R1, t1 + D @ (t1 - t2)

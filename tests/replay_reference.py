@@ -1,0 +1,137 @@
+"""The LIO part of lioOptimization::run() / process() / buildFrame() / stateEstimation()
+(src/lioOptimization.cpp:1427-1584, :1036-1133, :821-893, :991-1034) restated in Python on top of the oracle's
+pieces, as the checker for the product's ROS-free replay driver.  Test infrastructure only."""
+import numpy as np
+
+
+def quat_to_rot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+class OracleReplay:
+    def __init__(self, po, backend, oo, icp_oracle, R_il=None, t_il=None):
+        self.po, self.backend, self.oo, self.icp = po, backend, oo, icp_oracle
+        self.R_il = np.eye(3) if R_il is None else R_il
+        self.t_il = np.zeros(3) if t_il is None else t_il
+        self.m = po.Map(backend)
+        self.e = po.Eskf(backend)
+        self.e.set_noise(oo["acc_cov"], oo["gyr_cov"], oo["b_acc_cov"], oo["b_gyr_cov"])
+        self.initial_flag = False
+        self.index_frame = 1
+        self.frames = []                    # all_cloud_frame: dict(state16, time_sweep_end)
+        self.imu_meas = []
+        self.current_time = -1.0
+        self.acc_0 = np.zeros(3); self.gyr_0 = np.zeros(3)
+        self.trajectory = []
+        self.last = {}
+
+    # ---- eskf accessors (state19: p, q, v, ba, bg, g)
+    def _es(self):
+        s = self.e.get_state()
+        return dict(p=s[0:3], q=s[3:7], v=s[7:10], ba=s[10:13], bg=s[13:16], g=s[16:19])
+
+    def _imu_state(self, un_acc, un_gyr):
+        s = self._es()
+        return np.r_[self.current_time, un_acc, un_gyr, s["p"], s["q"], s["v"]]
+
+    def run_measurement(self, ms):
+        time_frame = ms["time_frame"]
+        acc = np.zeros(3); gyr = np.zeros(3)
+        if not self.initial_flag:
+            for t, a, w in zip(ms["imu_t"], ms["imu_acc"], ms["imu_gyr"]):
+                if t <= time_frame:
+                    self.current_time = t; acc = a.copy(); gyr = w.copy()
+                else:
+                    dt_1 = time_frame - self.current_time; dt_2 = t - time_frame
+                    self.current_time = time_frame
+                    w1 = dt_2 / (dt_1 + dt_2); w2 = dt_1 / (dt_1 + dt_2)
+                    acc = w1 * acc + w2 * a; gyr = w1 * gyr + w2 * w
+                self.imu_meas.append((self.current_time, gyr.copy(), acc.copy()))
+            ts = np.array([x[0] for x in self.imu_meas]); g = np.array([x[1] for x in self.imu_meas]); a = np.array([x[2] for x in self.imu_meas])
+            r = self.e.try_init(ts, g, a)
+            self.acc_0 = a[-1].copy(); self.gyr_0 = g[-1].copy()
+            self.initial_flag = (r == 1) or self.e.init_stats()["initial_flag"]
+            self.imu_meas = []
+            return None
+        s = self._es()
+        imu_states = [self._imu_state(quat_to_rot(s["q"]) @ (self.acc_0 - s["ba"]), self.gyr_0 - s["bg"])]
+        for t, a, w in zip(ms["imu_t"], ms["imu_acc"], ms["imu_gyr"]):
+            if t <= time_frame:
+                dt = t - self.current_time
+                if dt < -1e-6:
+                    continue
+                self.current_time = t; acc = a.copy(); gyr = w.copy()
+            else:
+                dt_1 = time_frame - self.current_time; dt_2 = t - time_frame
+                self.current_time = time_frame
+                w1 = dt_2 / (dt_1 + dt_2); w2 = dt_1 / (dt_1 + dt_2)
+                acc = w1 * acc + w2 * a; gyr = w1 * gyr + w2 * w
+                dt = dt_1
+            s = self._es()
+            un_acc = quat_to_rot(s["q"]) @ (0.5 * (self.acc_0 + acc) - s["ba"])
+            un_gyr = 0.5 * (self.gyr_0 + gyr) - s["bg"]
+            self.e.predict(dt, acc, gyr)
+            self.acc_0 = acc.copy(); self.gyr_0 = gyr.copy()
+            imu_states.append(self._imu_state(un_acc, un_gyr))
+        out = self.process(ms, np.array(imu_states))
+        self.index_frame += 1
+        return out
+
+    def process(self, ms, imu_states):
+        po, oo, be = self.po, self.oo, self.backend
+        es = self._es()
+        prev1 = np.r_[self.frames[-1]["state"][0:7]] if len(self.frames) >= 1 else np.r_[1, np.zeros(6)]
+        prev2 = np.r_[self.frames[-2]["state"][0:7]] if len(self.frames) >= 2 else prev1
+        q0, t0 = po.state_initialization(self.index_frame, oo["initialization"], self.initial_flag, prev2, prev1, es["q"], es["p"], backend=be)
+        state = np.r_[q0, t0, np.zeros(9)]
+        # buildFrame
+        tb = ms["time_sweep_begin"]; te = tb + ms["time_sweep_offset"]
+        rel, alpha, keep = po.make_point_timestamp(ms["pts_timestamp"], tb, te, oo["point_time_enable"], backend=be)
+        raw = ms["pts_raw"][keep]; rel = rel[keep]
+        imu_pt, _ = po.distort_frame(raw, rel, imu_states, tb, oo["motion_compensation"], self.R_il, self.t_il, backend=be)
+        sample = oo["init_voxel_size"] if self.index_frame < oo["init_num_frames"] else oo["voxel_size"]
+        order = po.build_frame_order(raw, sample, oo["voxel_size"] > 0, backend=be)
+        corr = po.transform_all_imu_point(imu_pt, imu_states, self.R_il, self.t_il, backend=be)
+        frame_raw = corr[order]
+        if self.index_frame > 2:
+            world = po.transform_points(frame_raw, q0, t0, self.R_il, self.t_il, backend=be)
+        else:
+            world = po.transform_points(frame_raw, [1, 0, 0, 0], [0, 0, 0], self.R_il, self.t_il, backend=be)
+        frame = dict(state=state, time_sweep_end=te, frame_id=self.index_frame, raw=frame_raw, imu_point=imu_pt[order])
+        self.frames.append(frame)
+        # stateEstimation
+        info = dict(success=True, iters=0, num_residuals=0, keypoints=0, frame_points=len(frame_raw))
+        if frame["frame_id"] > 1:
+            svs = oo["init_sample_voxel_size"] if frame["frame_id"] < oo["init_num_frames"] else oo["sample_voxel_size"]
+            kidx = po.grid_sampling(world, svs, backend=be)
+            info["keypoints"] = len(kidx)
+            t_last = self.frames[-2]["state"][4:7]
+            u = po.update_iekf(self.m, self.e, self.icp, frame_raw[kidx], state, t_last, R_il=self.R_il, t_il=self.t_il, frame_id=frame["frame_id"])
+            info["iters"] = u["rc"]; info["num_residuals"] = u["num_residuals"]
+            if u["rc"] < 0:
+                info["success"] = False
+                self.last = info
+                return info
+            frame["state"] = u["state"]
+            world = po.transform_points(frame_raw, u["state"][0:4], u["state"][4:7], self.R_il, self.t_il, backend=be)
+        else:
+            es = self._es()
+            frame["state"] = np.r_[es["q"], es["p"], es["v"], es["ba"], es["bg"]]
+        frame["point"] = world
+        before = self.m.size()
+        self.m.add_points(world, voxel_size=self.icp.size_voxel_map, min_dist=oo["min_distance_points"], cap=oo["max_num_points_in_voxel"])
+        info["points_added"] = self.m.size() - before
+        info["state"] = frame["state"].copy()
+        # sliding window (lioOptimization.cpp:1103-1130)
+        if self.initial_flag:
+            if self.index_frame > 1:
+                while len(self.frames) > 2:
+                    f = self.frames.pop(0); self.trajectory.append((f["time_sweep_end"], f["state"][4:7].copy(), f["state"][0:4].copy()))
+        else:
+            while len(self.frames) > oo["num_for_initialization"]:
+                f = self.frames.pop(0); self.trajectory.append((f["time_sweep_end"], f["state"][4:7].copy(), f["state"][0:4].copy()))
+        self.last = info
+        return info

@@ -729,3 +729,108 @@ def test_resident_replay_matches_oracle(oracle_lib, oracle_backend):
         assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
     finally:
         lio.close()
+
+
+# ----------------------------------------------------------------------------- sweep reconstruction (row f4)
+def _imu_track(rng, S, t0, dt):
+    st = np.zeros((S, 17))
+    q = synth.quat_from_rotvec([0.1, -0.05, 0.3]); p = np.array([1.0, 2.0, 0.3]); v = np.array([1.5, -0.4, 0.1])
+    for k in range(S):
+        st[k, 0] = t0 + k * dt
+        st[k, 1:4] = rng.normal(0, 0.5, 3); st[k, 4:7] = rng.normal(0, 0.3, 3)
+        st[k, 7:10] = p; st[k, 10:14] = q; st[k, 14:17] = v
+        q = synth.quat_mul(q, synth.quat_from_rotvec(st[k, 4:7] * dt)); p = p + v * dt; v = v + st[k, 1:4] * dt
+    return st
+
+
+UNDISTORT_TOL = 1e-12     # device sin / cos / acos vs glibc: a few ulp of FP64 on O(10 m) coordinates
+
+
+@pytest.mark.parametrize("mode", [capi.MC_CONSTANT_VELOCITY, capi.MC_IMU, capi.MC_NONE])
+def test_frame_undistort_matches_oracle(oracle_lib, oracle_backend, mode):
+    """distortFrameByConstant / distortFrameByImu + transformAllImuPoint on the device vs the oracle, including
+    points on interval boundaries, a time reversal that stops the IMU interval walk, and identical quaternions
+    (slerp's linear branch)."""
+    rng = np.random.default_rng(21)
+    st = _imu_track(rng, 11, 200.0, 0.01)
+    n = 50_000
+    raw = rng.uniform(-30, 30, (n, 3)); rt = np.sort(rng.uniform(0, 100.0, n))
+    rt[0] = 0.0; rt[-1] = 100.0; rt[100] = 10.0; rt[101] = 10.0 + 4e-4
+    rt = np.sort(rt)
+    R_il = synth.quat_to_rot(synth.quat_from_rotvec([0.02, 0.01, -0.04])); t_il = np.array([0.05, 0.02, -0.03])
+    sentinel = rng.normal(0, 1, (n, 3))
+    ctx = srl.Context(0)
+    try:
+        cases = [(rt, st)]
+        rt_back = rt.copy(); rt_back[30_000] = rt_back[5]            # goes back in time: the walk stops there
+        cases.append((rt_back, st))
+        st_same = st.copy(); st_same[:, 10:14] = st[0, 10:14]             # q_begin == q_end
+        cases.append((rt, st_same))
+        for rl, s in cases:
+            imu_g, raw_g = ctx.frame_undistort(raw, rl, s, 200.0, mode, R_il, t_il, imu_point_in=sentinel)
+            imu_o, k = oracle_lib.distort_frame(raw, rl, s, 200.0, mode, R_il, t_il, imu_point_in=sentinel, backend=oracle_backend)
+            raw_o = oracle_lib.transform_all_imu_point(imu_o, s, R_il, t_il, backend=oracle_backend)
+            assert rel(imu_g, imu_o) < UNDISTORT_TOL and rel(raw_g, raw_o) < UNDISTORT_TOL
+            if mode == capi.MC_IMU and rl is rt_back:
+                assert k == 30_000 and np.array_equal(imu_g[k:], sentinel[k:])      # untouched behind the stop
+            if mode == capi.MC_NONE:
+                assert np.array_equal(imu_g, sentinel)
+        # the corrected sweep is resident: take a subset as the frame, select keypoints from it
+        imu_g, raw_g = ctx.frame_undistort(raw, rt, st, 200.0, mode, R_il, t_il)
+        order = oracle_lib.build_frame_order(raw, 0.5, backend=oracle_backend)
+        ctx.frame_take(order)
+        q = synth.quat_from_rotvec([0.0, 0.0, 0.2]); t = np.array([0.3, -0.1, 0.0])
+        got = ctx.frame_select_keypoints(q, t, 1.5, R_il, t_il)
+        want = oracle_lib.grid_sampling(oracle_lib.transform_points(raw_g[order], q, t, R_il, t_il, backend=oracle_backend), 1.5, backend=oracle_backend)
+        assert np.array_equal(got, want)
+        with pytest.raises(srl.SrlError):
+            ctx.frame_take(np.array([n], dtype=np.int32))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("mc", [capi.MC_CONSTANT_VELOCITY, capi.MC_IMU])
+def test_replay_driver_matches_reference_loop(oracle_lib, oracle_backend, mc):
+    """The ROS-free replay driver (tryInit -> IMU propagation -> stateInitialization -> buildFrame on the device ->
+    device keypoints + ESIKF -> device map insert -> sliding window) against the same loop restated on the oracle's
+    pieces (tests/replay_reference.py): per-frame poses, counts, frame contents and the final maps."""
+    from replay_reference import OracleReplay
+    pts, L = synth.map_candidates(555, 60_000)
+    meas, gt, _ = synth.make_sequence(31, 7, 24_000, L)
+    oo = dict(init_voxel_size=0.2, init_sample_voxel_size=1.0, init_num_frames=6, num_for_initialization=10, voxel_size=0.2,
+              sample_voxel_size=1.5, max_num_points_in_voxel=20, min_distance_points=0.1, motion_compensation=mc, initialization=0,
+              point_time_enable=1, acc_cov=0.1, gyr_cov=0.1, b_acc_cov=1e-4, b_gyr_cov=1e-4)
+    icp_p = srl.default_opts(max_num_residuals=600)
+    ref = OracleReplay(oracle_lib, oracle_backend, oo, oracle_lib.opts_from_product(icp_p))
+    lio = srl.Lio(0)
+    try:
+        lio.set_initial_flag(False)
+        lio.set_odometry_options(icp=icp_p, **oo)
+        processed = 0
+        for i, ms in enumerate(meas):
+            want = ref.run_measurement(ms)
+            got = lio.run_measurement(ms["time_frame"], ms["imu_t"], ms["imu_acc"], ms["imu_gyr"], ms["pts_raw"], ms["pts_timestamp"],
+                                      ms["time_sweep_begin"], ms["time_sweep_offset"])
+            assert got["rc"] == 0
+            assert got["processed"] == (want is not None) and got["initialized"] == ref.initial_flag
+            assert got["index_frame"] == ref.index_frame
+            if want is None:
+                continue
+            processed += 1
+            assert got["success"] and want["success"]
+            assert got["frame_points"] == want["frame_points"] and got["keypoints"] == want["keypoints"]
+            assert got["iters"] == want["iters"] and got["num_residuals"] == want["num_residuals"]
+            assert got["points_added"] == want["points_added"]
+            assert rel(got["state"], want["state"]) < 1e-9
+            f = lio.last_frame(); fo = ref.frames[-1]
+            assert rel(f["raw_point"], fo["raw"]) < 1e-11 and rel(f["imu_point"], fo["imu_point"]) < 1e-11
+            assert rel(f["point"], fo["point"]) < 1e-9
+            assert rel(lio.eskf_get_cov(), ref.e.get_cov()) < 1e-8
+        assert processed == ref.index_frame - 1 and processed >= 9
+        # the estimate follows the motion (odometry frame = first sensor pose)
+        assert np.linalg.norm(got["state"][4:7] - gt[-1][1]) < 0.05
+        kg, cg, xg = lio.ctx.map_download(); ko, co, xo = ref.m.export()
+        assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
+    finally:
+        lio.set_initial_flag(False)
+        lio.close()

@@ -121,3 +121,82 @@ def test_grid_sampling_keeps_first_point_per_voxel():
     assert sorted(idx.tolist()) == sorted(first.values())          # one point per voxel: the first in frame order
     assert np.array_equal(idx, srl.grid_sampling(pts, 1.5))          # deterministic (tr1 iteration order)
     assert len(srl.grid_sampling(np.zeros((0, 3)), 1.0)) == 0
+
+
+# ----------------------------------------------------------------------------- row f3: tryInit / stateInitialization
+def _imu_batches(rng, n_batches, per_batch, dt, sigma_g, sigma_a, tilt):
+    g_dir = np.array([np.sin(tilt), 0.0, np.cos(tilt)])
+    out = []
+    t = 100.0
+    for _ in range(n_batches):
+        ts = t + dt * np.arange(1, per_batch + 1)
+        t = ts[-1]
+        out.append((ts, np.array([0.002, -0.001, 0.0005]) + rng.normal(0, sigma_g, (per_batch, 3)),
+                    9.79 * g_dir + rng.normal(0, sigma_a, (per_batch, 3))))
+    return out
+
+
+@pytest.mark.parametrize("sigma_g,sigma_a,want", [(0.01, 0.05, 1), (0.6, 0.05, -1), (0.01, 0.7, -2)])
+def test_try_init_matches_oracle_and_numpy(sigma_g, sigma_a, want):
+    import np_reference as npr
+    rng = np.random.default_rng(5)
+    batches = _imu_batches(rng, 8, 100, 0.005, sigma_g, sigma_a, 0.05)      # 0.5 s per batch: initialises in batch 7
+    lio = srl.Lio(-1)
+    lio.set_initial_flag(False)
+    e = po.Eskf()
+    lio.eskf_set_noise(0.1, 0.2, 1e-4, 2e-4); e.set_noise(0.1, 0.2, 1e-4, 2e-4)
+    ref = npr.try_init_stats(batches)
+    codes = []
+    for bi, (t, g, a) in enumerate(batches):
+        r_h = lio.eskf_try_init(t, g, a); r_o = e.try_init(t, g, a)
+        assert r_h == r_o
+        codes.append(r_h)
+        sh, so = lio.eskf_init_stats(), e.init_stats()
+        for k in ("mean_gyr", "mean_acc", "gyr_cov", "acc_cov"):
+            assert rel(sh[k], so[k]) < 1e-15, k
+        assert sh["num_init_meas"] == so["num_init_meas"] and sh["initial_flag"] == so["initial_flag"]
+        if r_h != 0:
+            break
+    assert codes[-1] == want == ref["code"] and len(codes) - 1 == ref["at"] == 6
+    if want == 1:
+        assert all(c == 0 for c in codes[:-1])
+        s = lio.eskf_get_state()
+        assert rel(s[13:16], ref["bg"]) < 1e-12 and rel(s[16:19], ref["gravity"]) < 1e-12
+        assert rel(lio.eskf_get_state(), e.get_state()) < 1e-15 and np.array_equal(lio.eskf_get_cov(), e.get_cov())
+        P = lio.eskf_get_cov()
+        assert np.allclose(np.diag(P)[9:17], [1e-3] * 3 + [1e-4] * 3 + [1e-5] * 2)
+        # the filters predict identically afterwards (noise = *_cov_scale, last IMU sample = last of the batch)
+        acc, gyr = np.array([0.1, 0.0, 9.8]), np.array([0.01, 0.0, -0.01])
+        lio.eskf_predict(0.005, acc, gyr); e.predict(0.005, acc, gyr)
+        assert rel(lio.eskf_get_cov(), e.get_cov()) < 1e-14 and rel(lio.eskf_get_state(), e.get_state()) < 1e-14
+    else:
+        st = lio.eskf_init_stats()
+        assert not st["initial_flag"]
+        assert rel(st["gyr_cov"], ref["gyr_cov"]) < 1e-10 and rel(st["acc_cov"], ref["acc_cov"]) < 1e-10
+    lio.set_initial_flag(False)
+
+
+def test_state_initialization_matches_oracle_and_rotation_algebra():
+    import np_reference as npr
+    lio = srl.Lio(-1)
+    q2 = synth.quat_from_rotvec([0.02, -0.3, 0.5]); t2 = np.array([1.0, 2.0, 0.1])
+    q1 = synth.quat_from_rotvec([0.05, -0.28, 0.61]); t1 = np.array([1.4, 2.3, 0.12])
+    p2, p1 = np.r_[q2, t2], np.r_[q1, t1]
+    es = lio.eskf_get_state(); es[0:3] = [7.0, 8.0, 9.0]; es[3:7] = synth.quat_from_rotvec([0.3, 0.2, 0.1]); lio.eskf_set_state(es)
+    for index_frame in (1, 2, 3, 4, 50):
+        for init in (0, 1, 7):
+            for flag in (False, True):
+                lio.set_initial_flag(flag)
+                q, t = lio.state_initialization(index_frame, init, p2, p1)
+                qo, to = po.state_initialization(index_frame, init, flag, p2, p1, es[3:7], es[0:3])
+                assert np.array_equal(q, qo) and np.array_equal(t, to)
+                if index_frame <= 2:
+                    assert np.array_equal(q, [1, 0, 0, 0]) and np.array_equal(t, [0, 0, 0])
+                elif init == 1 or (init == 0 and not flag):
+                    R, tt = npr.state_initialization_const_velocity(q2, t2, q1, t1)
+                    assert np.allclose(npr.quat_to_rot(q), R, atol=1e-14) and np.allclose(t, tt, atol=1e-14)
+                elif init == 0:
+                    assert np.array_equal(q, es[3:7]) and np.array_equal(t, es[0:3])
+                else:
+                    assert np.array_equal(q, q1) and np.array_equal(t, t1)
+    lio.set_initial_flag(False)

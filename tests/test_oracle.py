@@ -264,3 +264,107 @@ def test_transform_points_and_grid_sampling(oracle_lib):
         assert np.array_equal(idx, oracle_lib.grid_sampling(world, size))
         assert np.array_equal(idx, srl.grid_sampling(world, size))      # host mirror uses the same container type
     assert len(oracle_lib.grid_sampling(np.zeros((0, 3)), 1.0)) == 0
+
+
+# ----------------------------------------------------------------------------- sweep reconstruction (row f4)
+def _imu_track(rng, S, t0, dt):
+    """S imu states along a smooth motion; rows of 17 doubles."""
+    st = np.zeros((S, 17))
+    q = Rotation.from_rotvec([0.1, -0.05, 0.3])
+    p = np.array([1.0, 2.0, 0.3]); v = np.array([1.5, -0.4, 0.1])
+    for k in range(S):
+        st[k, 0] = t0 + k * dt
+        st[k, 1:4] = rng.normal(0, 0.5, 3)                     # un_acc (world, gravity-free here)
+        st[k, 4:7] = rng.normal(0, 0.3, 3)                     # un_gyr
+        st[k, 7:10] = p
+        x, y, z, w = q.as_quat(); st[k, 10:14] = [w, x, y, z]
+        st[k, 14:17] = v
+        q = q * Rotation.from_rotvec(st[k, 4:7] * dt); p = p + v * dt; v = v + st[k, 1:4] * dt
+    return st
+
+
+def test_mt19937_64_known_answer(oracle_lib):
+    # C++11 [rand.predef]: the 10000th consecutive invocation of a default-constructed mt19937_64
+    # (boost::mt19937_64 documents the same check value)
+    assert oracle_lib.mt19937_64_nth(10000) == 9981545732273789042
+
+
+def test_distort_by_constant_velocity_vs_scipy_slerp(oracle_lib):
+    from scipy.spatial.transform import Slerp
+    rng = np.random.default_rng(3)
+    st = _imu_track(rng, 12, 50.0, 0.01)
+    n = 4000
+    raw = rng.uniform(-20, 20, (n, 3)); rel = np.sort(rng.uniform(0, 110.0, n)); rel[0] = 0.0; rel[-1] = 110.0
+    R_il = Rotation.from_rotvec([0.01, 0.02, -0.03]).as_matrix(); t_il = np.array([0.05, -0.02, 0.1])
+    imu, k = oracle_lib.distort_frame(raw, rel, st, 50.0, 1, R_il, t_il)
+    assert k == n
+    tb, te = 50.0, st[-1, 0]
+    tp = tb + rel / 1000.0
+    tp = np.where(np.abs(tp - tb) < 1e-6, tb + 1e-6, tp); tp = np.where(np.abs(tp - te) < 1e-6, te - 1e-6, tp)
+    a = np.clip((tp - tb) / (te - tb), 0, 1)
+    wxyz = st[[0, -1], 10:14]
+    sl = Slerp([0, 1], Rotation.from_quat(wxyz[:, [1, 2, 3, 0]]))
+    Rm = sl(a).as_matrix()
+    want = np.einsum("nij,nj->ni", Rm, raw @ R_il.T + t_il) + (1 - a)[:, None] * st[0, 7:10] + a[:, None] * st[-1, 7:10]
+    assert np.max(np.abs(imu - want)) < 1e-11
+    # transformAllImuPoint: back into the lidar frame at the sweep end
+    back = oracle_lib.transform_all_imu_point(imu, st, R_il, t_il)
+    Re = Rotation.from_quat(st[-1, [11, 12, 13, 10]]).as_matrix()
+    want_raw = ((imu - st[-1, 7:10]) @ Re - t_il) @ R_il
+    assert np.max(np.abs(back - want_raw)) < 1e-11
+    # points at the very end of the sweep are their own correction
+    last = rel >= (te - tb) * 1000.0 - 1e-3
+    assert np.max(np.abs(back[last] - raw[last])) < 1e-4
+
+
+def test_distort_by_imu_interval_walk(oracle_lib):
+    rng = np.random.default_rng(4)
+    st = _imu_track(rng, 9, 10.0, 0.0125)
+    n = 3000
+    raw = rng.uniform(-15, 15, (n, 3)); rel = np.sort(rng.uniform(0, 100.0, n))
+    rel[5] = 12.5; rel[6] = 12.5 + 5e-4                      # on / within 1e-6 of an interval boundary
+    rel = np.sort(rel)
+    imu, k = oracle_lib.distort_frame(raw, rel, st, 10.0, 0)
+    assert k == n
+    # independent: interval of each point, first-order propagation from its start state
+    tp = 10.0 + rel / 1000.0
+    seg = np.clip(np.searchsorted(st[:, 0], tp, side="right") - 1, 0, len(st) - 2)
+    want = np.empty_like(raw)
+    for i in range(n):
+        a, b = st[seg[i]], st[seg[i] + 1]
+        t = tp[i]
+        if abs(t - a[0]) < 1e-6: t = a[0] + 1e-6
+        if abs(t - b[0]) < 1e-6: t = b[0] - 1e-6
+        dt = t - a[0]
+        Rq = Rotation.from_quat(a[[11, 12, 13, 10]]) * Rotation.from_rotvec(b[4:7] * dt)
+        want[i] = Rq.apply(raw[i]) + a[7:10] + a[14:17] * dt + 0.5 * b[1:4] * dt * dt
+    bad = np.abs(imu - want).max(axis=1) > 1e-9
+    # only points within 1e-6 s of a boundary may legitimately sit in the neighbouring interval
+    near = np.min(np.abs(tp[:, None] - st[None, :, 0]), axis=1) < 2e-6
+    assert not np.any(bad & ~near)
+    # a point that goes back in time stops the walk: everything behind it keeps its old imu_point
+    rel2 = rel.copy(); rel2[1000] = rel2[10]
+    sentinel = np.full_like(raw, 7.0)
+    imu2, k2 = oracle_lib.distort_frame(raw, rel2, st, 10.0, 0, imu_point_in=sentinel)
+    assert k2 == 1000 and np.array_equal(imu2[1000:], sentinel[1000:]) and np.array_equal(imu2[:1000], imu[:1000])
+
+
+def test_build_frame_order_and_point_timestamps(oracle_lib):
+    rng = np.random.default_rng(8)
+    pts = rng.uniform(-10, 10, (6000, 3))
+    full = oracle_lib.build_frame_order(pts, 0.5, do_subsample=False)
+    assert sorted(full.tolist()) == list(range(6000)) and not np.array_equal(full, np.arange(6000))
+    sub = oracle_lib.build_frame_order(pts, 0.5)
+    # one point per voxel: the first of the voxel in the shuffled order
+    pos = np.empty(6000, int); pos[full] = np.arange(6000)
+    keys = np.trunc(pts / 0.5).astype(int)
+    first = {}
+    for i in full:
+        first.setdefault(tuple(keys[i]), i)
+    assert sorted(sub.tolist()) == sorted(first.values())
+    assert np.array_equal(sub, oracle_lib.build_frame_order(pts, 0.5))
+    ts = np.array([9.99, 10.0, 10.05, 10.1, 10.11])
+    rel, alpha, keep = oracle_lib.make_point_timestamp(ts, 10.0, 10.1, True)
+    assert keep.all() and np.allclose(rel, (ts - 10.0) * 1000) and alpha[-1] == 1.0 - 1e-5 and alpha[0] < 0
+    rel, alpha, keep = oracle_lib.make_point_timestamp(ts, 10.0, 10.1, False)
+    assert keep.tolist() == [False, True, True, True, False] and np.allclose(alpha[1:4], [0, 0.5, 1.0])
