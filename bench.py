@@ -84,7 +84,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n_kp, map_pts, pattern, seed = synth.CONFIGS[args.workload]
-    sharded = (world > 1 and args.mode == "sharded")
+    sharded = ((world > 1 or (args.force_comm and "RANK" in os.environ)) and args.mode == "sharded")
     sweep_seed = seed + 1000 + (rank if (world > 1 and not sharded) else 0)
     map_seed = seed + (rank if (world > 1 and not sharded) else 0)
 
@@ -143,6 +143,24 @@ def main():
     barrier()
     pcie_elapsed = time.perf_counter() - t2
 
+    # N > 1, sharded: also report the other way to use N GPUs (BASELINE config 5: one sweep per GPU, no collective),
+    # measured after the timed region on the same contexts; informational, never `value`.
+    replicas_rate = None
+    if sharded:
+        r_sharded = r
+        lio.ctx.comm_destroy()
+        lio.resident_sweep(sweep["raw"])
+        solve()
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            solve()
+        barrier()
+        te = torch.tensor([time.perf_counter() - t3], device="cuda", dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        replicas_rate = world * args.steps / float(te.item())
+        r = r_sharded
+
     iters = r["iters"]
     sweeps_per_step = world if (world > 1 and not sharded) else 1
     value = sweeps_per_step * args.steps / elapsed
@@ -191,6 +209,9 @@ def main():
         "pcie_inclusive_sweeps_per_s": (world if (world > 1 and not sharded) else 1) * n_pcie / pcie_elapsed,
         "setup_s": setup_s,
     }
+    if replicas_rate is not None:
+        out["aux_independent_sweeps_per_s"] = {"value": replicas_rate, "what": "the same N GPUs each solving its own 64k sweep "
+                                               "(replicas, no collective; BASELINE config 5), measured after the timed region"}
 
     # ---------------- CPU baseline + parity figure (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -146,6 +146,7 @@ int srl_frame_undistort(srl_ctx *ctx, const double *raw_xyz, const double *relat
                         int motion_compensation, const double R_il[9], const double t_il[3], double *imu_point_out,
                         double *raw_out);
 int srl_frame_take(srl_ctx *ctx, const int32_t *index, int m);
+int srl_frame_size(srl_ctx *ctx, int *n);      /* points of the resident frame (capacity needed for keypoint_index) */
 int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3], const double R_il[9],
                                const double t_il[3], double sample_voxel_size,
                                int32_t *keypoint_index /* capacity n, or NULL */, int *num_keypoints);

@@ -118,6 +118,7 @@ def load_library():
         "srl_frame_upload": ([p, p, C.c_int], C.c_int),
         "srl_frame_undistort": ([p, p, p, p, C.c_int, p, C.c_int, C.c_double, C.c_int, dp, dp, p, p], C.c_int),
         "srl_frame_take": ([p, p, C.c_int], C.c_int),
+        "srl_frame_size": ([p, C.POINTER(C.c_int)], C.c_int),
         "srl_frame_select_keypoints": ([p, dp, dp, dp, dp, C.c_double, p, C.POINTER(C.c_int)], C.c_int),
         "srl_frame_commit": ([p, dp, dp, dp, dp, C.c_double, C.c_int, C.c_double, C.c_int, p, C.POINTER(C.c_int)], C.c_int),
         "srl_comm_unique_id": ([p], C.c_int),
@@ -366,7 +367,6 @@ class Context:
     # --- frame-resident pipeline
     def frame_upload(self, raw_xyz):
         r = _f64(raw_xyz, (-1, 3))
-        self._frame_n = len(r)
         self._chk(self.lib.srl_frame_upload(self.h, _ptr(r), len(r)), "srl_frame_upload")
 
     def frame_undistort(self, raw_xyz, relative_time_ms, imu_states, time_frame_begin, mode, R_il=None, t_il=None, imu_point_in=None):
@@ -384,13 +384,17 @@ class Context:
 
     def frame_take(self, index):
         idx = np.ascontiguousarray(index, dtype=np.int32)
-        self._frame_n = len(idx)
         self._chk(self.lib.srl_frame_take(self.h, _ptr(idx), len(idx)), "srl_frame_take")
+
+    def frame_size(self):
+        n = C.c_int()
+        self._chk(self.lib.srl_frame_size(self.h, C.byref(n)), "srl_frame_size")
+        return n.value
 
     def frame_select_keypoints(self, q, t, sample_voxel_size, R_il=None, t_il=None):
         R_il = _f64(np.eye(3) if R_il is None else R_il).ravel()
         t_il = _f64(np.zeros(3) if t_il is None else t_il)
-        idx = np.empty(max(self._frame_n, 1), dtype=np.int32)
+        idx = np.empty(max(self.frame_size(), 1), dtype=np.int32)
         m = C.c_int()
         self._chk(self.lib.srl_frame_select_keypoints(self.h, _dptr(_f64(q)), _dptr(_f64(t)), _dptr(R_il), _dptr(t_il),
                                                       float(sample_voxel_size), _ptr(idx), C.byref(m)), "srl_frame_select_keypoints")
@@ -399,7 +403,7 @@ class Context:
     def frame_commit(self, q, t, voxel_size=1.0, cap=20, min_dist=0.15, min_num_points=0, R_il=None, t_il=None, want_world=True):
         R_il = _f64(np.eye(3) if R_il is None else R_il).ravel()
         t_il = _f64(np.zeros(3) if t_il is None else t_il)
-        world = np.empty((self._frame_n, 3)) if want_world else None
+        world = np.empty((self.frame_size(), 3)) if want_world else None
         added = C.c_int()
         self._chk(self.lib.srl_frame_commit(self.h, _dptr(_f64(q)), _dptr(_f64(t)), _dptr(R_il), _dptr(t_il), float(voxel_size), cap,
                                             float(min_dist), min_num_points, _ptr(world) if want_world else None, C.byref(added)),
@@ -418,6 +422,9 @@ class Context:
     def comm_init_rank(self, nranks, rank, uid):
         buf = (C.c_ubyte * SRL_COMM_ID_BYTES).from_buffer_copy(uid)
         self._chk(self.lib.srl_comm_init_rank(self.h, nranks, rank, buf), "srl_comm_init_rank")
+
+    def comm_destroy(self):
+        self._chk(self.lib.srl_comm_destroy(self.h), "srl_comm_destroy")
 
     def comm_set_host_callbacks(self, nranks, rank, allreduce, allgather):
         """allreduce(np.ndarray float64) -> in place sum; allgather(int) -> list of ints."""
@@ -620,11 +627,10 @@ class Lio:
         rc = self._chk(self.lib.srl_lio_optimize_resident(self.h, C.byref(opts), float(sample_voxel_size), _ptr(raw), len(raw), _dptr(st),
                                                           _dptr(_f64(t_last)), int(frame_id), _ptr(kidx), C.byref(nk), C.byref(iters),
                                                           C.byref(nres)), "optimize_resident", ok=allow)
-        self._frame_n = len(raw)
         return dict(rc=rc, state=st, keypoint_index=kidx[: nk.value].copy(), iters=iters.value, num_residuals=nres.value)
 
     def commit_frame(self, state, voxel_size=1.0, cap=20, min_dist=0.15, min_num_points=0, want_world=True):
-        world = np.empty((self._frame_n, 3)) if want_world else None
+        world = np.empty((self.ctx.frame_size(), 3)) if want_world else None
         added = C.c_int()
         self._chk(self.lib.srl_lio_commit_frame(self.h, _dptr(_f64(state)), float(voxel_size), cap, float(min_dist), min_num_points,
                                                 _ptr(world) if want_world else None, C.byref(added)), "commit_frame")

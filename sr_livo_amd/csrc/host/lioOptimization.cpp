@@ -637,7 +637,9 @@ optimizeSummary lioOptimization::optimizeBuiltFrame(cloudFrame *p_frame, const i
     releaseSweep();
     const Quat &q = p_frame->p_state->rotation;
     const double qv[4] = {q.w, q.x, q.y, q.z};
-    std::vector<int32_t> idx(std::max<size_t>(p_frame->point_frame.size(), 1));
+    int frame_n = 0;
+    check(ctx, srl_frame_size(ctx, &frame_n), "srl_frame_size");
+    std::vector<int32_t> idx((size_t)std::max(frame_n, 1));        // capacity = points of the resident frame
     int m = 0;
     check(ctx, srl_frame_select_keypoints(ctx, qv, p_frame->p_state->translation.a, R_imu_lidar.a, t_imu_lidar.a, sample_voxel_size,
                                           idx.data(), &m), "srl_frame_select_keypoints");

@@ -345,6 +345,12 @@ int srl_frame_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     return SRL_OK;
 }
 
+int srl_frame_size(srl_ctx *ctx, int *n) {
+    if (!ctx || !n) return SRL_ERR_BAD_ARG;
+    *n = ctx->frame_n < 0 ? 0 : ctx->frame_n;
+    return ctx->frame_n < 0 ? SRL_ERR_NO_SWEEP : SRL_OK;
+}
+
 int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3], const double R_il[9], const double t_il[3],
                                double sample_voxel_size, int32_t *keypoint_index, int *num_keypoints) {
     if (!ctx || !q || !t || !R_il || !t_il || !(sample_voxel_size > 0.0)) return SRL_ERR_BAD_ARG;

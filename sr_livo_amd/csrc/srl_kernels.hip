@@ -235,12 +235,13 @@ __device__ __forceinline__ void select_topk(double qx, double qy, double qz, int
 //             equal ranks among the first K (= an exact distance tie) or > 64 survivors defer to the
 //             general path (returns false).
 struct LaneRole {
-    int pdx, pdy, pdz;     // probe offset (lane < 27)
+    int pdx, pdy, pdz;     // probe offset (half-wave lane < 27)
     int c0, slot;          // candidate role: voxel-in-round (0..2, 3 = idle) and slot (0..19)
 };
 __device__ __forceinline__ LaneRole lane_role(int lane) {
     LaneRole r;
-    const int ix = lane / 9, iy = (lane / 3) % 3, iz = lane % 3;
+    const int pl = lane & 31;            // the two half-waves probe for two consecutive keypoints
+    const int ix = pl / 9, iy = (pl / 3) % 3, iz = pl % 3;
     r.pdx = ix - 1; r.pdy = iy - 1; r.pdz = iz - 1;
     r.c0 = lane / SRL_CAP;
     r.slot = lane - r.c0 * SRL_CAP;
@@ -255,25 +256,30 @@ struct ProbeReq {
     unsigned h;
     SrlMapSlot s0, s1;
 };
-__device__ __forceinline__ ProbeReq probe_issue(int kx, int ky, int kz, const LaneRole &role, const SrlMapSlot *table,
+// kv: the wave's voxel keys (4 ints per keypoint); half-wave h = lane >> 5 probes for keypoint kl + h
+__device__ __forceinline__ ProbeReq probe_issue(const int *kv, int kl, const LaneRole &role, const SrlMapSlot *table,
                                                 unsigned mask, int lane) {
     ProbeReq r;
     r.key = SRL_EMPTY_KEY; r.h = 0;
     r.s0.key = SRL_EMPTY_KEY; r.s0.slab = 0; r.s0.count = 0;
     r.s1 = r.s0;
-    if (lane < 27) {
-        r.key = srl_pack_key((short)(kx + role.pdx), (short)(ky + role.pdy), (short)(kz + role.pdz));
+    if ((lane & 31) < 27) {
+        const int *k = kv + (kl + (lane >> 5)) * 4;
+        r.key = srl_pack_key((short)(k[0] + role.pdx), (short)(k[1] + role.pdy), (short)(k[2] + role.pdz));
         r.h = srl_hash_key(r.key) & mask;
         r.s0 = table[r.h];
         r.s1 = table[(r.h + 1) & mask];
     }
     return r;
 }
+// Compacts the occupied voxels of both keypoints into their lists (list h at vox + 32 h, visit order kept,
+// zero-filled up to 27 entries so the candidate rounds need no bounds branch).  Returns nv_A | nv_B << 8.
 __device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, const SrlMapSlot *table, unsigned mask,
                                             VoxEnt *vox, int lane) {
     bool found = false;
     unsigned slab = 0, cnt = 0;
-    if (lane < 27) {
+    const bool prober = (lane & 31) < 27;
+    if (prober) {
         if (r.s0.key == r.key) { slab = r.s0.slab; cnt = r.s0.count; found = true; }
         else if (r.s0.key != SRL_EMPTY_KEY) {
             if (r.s1.key == r.key) { slab = r.s1.slab; cnt = r.s1.count; found = true; }
@@ -290,16 +296,20 @@ __device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, cons
         found = found && (int)cnt >= thr_cap && cnt > 0;        // NumPoints() < threshold -> skipped (optimize.cpp:389)
     }
     const unsigned long long m = __ballot(found);
-    const int nv = __popcll(m);
-    if (lane < 27) {
-        // found voxels first (visit order kept), the other probe lanes zero-fill the tail: entries [nv, 27)
-        // read as "count 0", so the candidate rounds need no bounds branch
+    const unsigned m_lo = (unsigned)m, m_hi = (unsigned)(m >> 32);
+    const int nv_a = __popc(m_lo), nv_b = __popc(m_hi);
+    if (prober) {
+        const bool upper = lane >= 32;
+        // rank inside the own half: mbcnt_lo counts the low-half bits below a low lane, mbcnt_hi the high-half bits
+        // below a high lane (and nothing for low lanes)
+        const unsigned f_lo = found ? m_lo : (~m_lo & 0x7FFFFFFu), f_hi = found ? m_hi : (~m_hi & 0x7FFFFFFu);
+        const int below = upper ? (int)__builtin_amdgcn_mbcnt_hi(f_hi, 0u) : (int)__builtin_amdgcn_mbcnt_lo(f_lo, 0u);
+        const int nv_own = upper ? nv_b : nv_a;
         VoxEnt ve; ve.slab = found ? slab : 0u; ve.count = found ? cnt : 0u;
-        const int pos = found ? lanes_below(m) : nv + lanes_below(~m & 0x7FFFFFFull);
-        vox[pos] = ve;
+        vox[(upper ? 32 : 0) + (found ? below : nv_own + below)] = ve;
     }
     __builtin_amdgcn_wave_barrier();
-    return nv;
+    return nv_a | (nv_b << 8);
 }
 
 template <class Sink>
@@ -435,10 +445,12 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     const int cbase = role.c0 < 3 ? role.c0 : 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) ve[j] = vox[3 * j + cbase];
+    bool has[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         px[j] = kInfF; py[j] = kInfF; pz[j] = kInfF;
-        if (role.c0 < 3 && (unsigned)role.slot < ve[j].count) {
+        has[j] = role.c0 < 3 && (unsigned)role.slot < ve[j].count;
+        if (has[j]) {
             const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve[j].slab * SRL_SLAB_BYTES + role.slot * 12);
             px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
         }
@@ -450,7 +462,7 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     for (int j = 0; j < R; ++j) {
         d2f[j] = d2_f32(px[j], py[j], pz[j], qxf, qyf, qzf);
         lmin = fminf(lmin, d2f[j]);
-        total += __popcll(__ballot(d2f[j] < kInfF));
+        total += __popcll(__ballot(has[j]));              // the load predicate IS the validity (no float compares)
     }
     total_out = total;
 
@@ -465,14 +477,15 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     const float tau_f = __uint_as_float(lo | 0x3FFFFu);   // >= K candidates have d2f <= tau_f (if that many exist)
     // FP32 error model: a = abs error of fl32(q) per axis; per-axis difference error <= a + u*|d|; sum of
     // squares (3 terms, FMA or not) adds <= 4u relative.  For d2, d2f <= T:  |d2f - d2| <= m(T) with
-    //   m(T) = 4 a sqrt(T) + 8 u T + 4 a^2   (u = 2^-24), evaluated at T = 2 tau_f + 1e-6 and doubled
-    //   (raw v_sqrt_f32, 1 ulp, inflated by 1e-4: this is a bound, not a result).
-    float thr = kInfF;
+    //   m(T) = 4 a sqrt(T) + 8 u T + 4 a^2   (u = 2^-24), evaluated at T = 2 tau_f + 1e-6 with sqrt(T) replaced by
+    //   its upper bound (T + 1) / 2 (AM-GM; no transcendental), and doubled.
+    // Fewer than K candidates: every candidate survives (FLT_MAX; empty lanes hold +inf and never pass).
+    float thr = 3.4028235e38f;
     if (tau_f < kInfF) {
         const float u = 5.9604645e-8f;
         const float amax = fmaxf(fmaxf(fabsf(qxf), fabsf(qyf)), fabsf(qzf)) * u + 1e-30f;
         const float T = 2.0f * tau_f + 1e-6f;
-        const float m = 4.0f * amax * (__builtin_amdgcn_sqrtf(T) * 1.0001f) + 8.0f * u * T + 4.0f * amax * amax;
+        const float m = 4.0f * amax * ((T + 1.0f) * 0.5001f) + 8.0f * u * T + 4.0f * amax * amax;
         thr = (tau_f + 2.0f * m) * 1.000001f;
     }
 
@@ -482,7 +495,7 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     int c = 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const bool sv = d2f[j] <= thr && d2f[j] < kInfF;
+        const bool sv = d2f[j] <= thr;
         const unsigned long long m = __ballot(sv);
         int pos = c + lanes_below(m);
         pos = pos < 63 ? pos : 63;          // > 64 survivors bail out below; the clamp only keeps the stores in bounds
@@ -683,7 +696,7 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels) {
     L.off_kv = o;      o += SRL_KPW * 4 * 4;
     L.off_nfound = o;  o += SRL_KPW * 4;
     L.off_ncand = o;   o += SRL_KPW * 4;
-    L.off_vox = o;     o += (nb_voxels == 1 ? 32 : 128) * 8;
+    L.off_vox = o;     o += (nb_voxels == 1 ? 64 : 128) * 8;     // r = 1: two 32-entry lists (a keypoint pair is probed at once)
     L.off_scratch = o; o += SRL_WAVE_SCRATCH;
     L.wave_bytes = o;
     L.off_wpart = 4 * o;
@@ -771,7 +784,8 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     {
         const LaneRole role0 = lane_role(lane);
         ProbeReq preq;
-        if constexpr (NB == 1 && FAST != 0) { if (!(a.ablate & 32)) preq = probe_issue(s_kv[0], s_kv[1], s_kv[2], role0, a.table, a.table_mask, lane); }
+        int nv_pair = 0;
+        if constexpr (NB == 1 && FAST != 0) { if (!(a.ablate & 32)) preq = probe_issue(s_kv, 0, role0, a.table, a.table_mask, lane); }
         for (int kl = 0; kl < SRL_KPW; ++kl) {
             LaneRole role = role0;
             asm volatile("" : "+v"(role.c0), "+v"(role.slot));   // recompute the few role-derived values per keypoint instead of spilling them
@@ -784,19 +798,24 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
             sink.tap_ids = a.tap_ids ? (a.tap_ids + (size_t)g * a.K) : nullptr;
             int total = 0, fb = 0;
             bool done = false;
+            VoxEnt *voxl = vox;
             if constexpr (NB == 1 && FAST != 0) {
-                int nv = 0;
-                const ProbeReq cur = preq;
-                if (kl + 1 < SRL_KPW && !(a.ablate & 32))      // hash lookup of the NEXT keypoint goes out before this one is consumed
-                    preq = probe_issue(s_kv[kl * 4 + 4], s_kv[kl * 4 + 5], s_kv[kl * 4 + 6], role, a.table, a.table_mask, lane);
-                if (!(a.ablate & 8)) nv = probe_finish(cur, a.thr_cap, a.table, a.table_mask, vox, lane);
+                // hash lookups run for a PAIR of keypoints (one per half-wave) and one pair ahead, so their L2 round
+                // trip overlaps the selection of the current pair
+                if ((kl & 1) == 0) {
+                    const ProbeReq cur = preq;
+                    if (kl + 2 < SRL_KPW && !(a.ablate & 32)) preq = probe_issue(s_kv, kl + 2, role, a.table, a.table_mask, lane);
+                    nv_pair = (a.ablate & 8) ? 0 : probe_finish(cur, a.thr_cap, a.table, a.table_mask, vox, lane);
+                }
+                const int nv = (kl & 1) ? (nv_pair >> 8) : (nv_pair & 0xFF);
+                voxl = vox + 32 * (kl & 1);
                 if (a.ablate & 4) { done = true; total = nv; }
-                else if constexpr (FAST == 1) done = select_topk_f32(qx, qy, qz, nv, vox, a.slabs, a.K, surv, lane, role, sink, total, a.ablate);
-                else done = select_topk_fast(qx, qy, qz, nv, vox, a.slabs, a.K, surv, lane, role, sink, total);
+                else if constexpr (FAST == 1) done = select_topk_f32(qx, qy, qz, nv, voxl, a.slabs, a.K, surv, lane, role, sink, total, a.ablate);
+                else done = select_topk_fast(qx, qy, qz, nv, voxl, a.slabs, a.K, surv, lane, role, sink, total);
             }
             if (!done) {
-                const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, vox, lane);
-                select_topk(qx, qy, qz, nv, vox, a.slabs, a.K, a.select_mode, surv, lane, sink, total, fb);
+                const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, voxl, lane);
+                select_topk(qx, qy, qz, nv, voxl, a.slabs, a.K, a.select_mode, surv, lane, sink, total, fb);
                 fb = (NB == 1) ? 1 : fb;       // r = 1: anything off the fast path counts as a fallback
             }
             n_fallback += fb;
