@@ -160,6 +160,7 @@ int srl_map_upload(srl_ctx *ctx, const int16_t *keys_xyz, const int32_t *counts,
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // capacity with headroom so that srl_map_insert can add voxels without an immediate rebuild
     const unsigned slab_cap = std::max<unsigned>(1024u, (unsigned)V + (unsigned)V / 2u + 4096u);
+    if (slab_cap > SRL_MAX_SLABS) { ctx->err = "map too large: slab byte offsets are 32-bit (16.7 M voxels)"; return SRL_ERR_UNSUPPORTED; }
     const unsigned table_cap = next_pow2(std::max<unsigned>(2048u, SRL_TABLE_FACTOR * slab_cap));
     std::vector<SrlSlab> slabs((size_t)V);
     std::vector<SrlMapSlot> table((size_t)table_cap);
@@ -187,7 +188,8 @@ int srl_map_upload(srl_ctx *ctx, const int16_t *keys_xyz, const int32_t *counts,
     }
     if (ctx->d_slabs) { HIPCHK(ctx, hipFree(ctx->d_slabs)); ctx->d_slabs = nullptr; }
     if (ctx->d_table) { HIPCHK(ctx, hipFree(ctx->d_table)); ctx->d_table = nullptr; }
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_slabs, (size_t)slab_cap * SRL_SLAB_BYTES));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_slabs, ((size_t)slab_cap + 1) * SRL_SLAB_BYTES));       // + the all-inf slab
+    HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_slabs + (size_t)slab_cap * SRL_SLAB_BYTES), 0x7f800000, SRL_SLAB_BYTES / 4, ctx->stream));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_table, (size_t)table_cap * sizeof(SrlMapSlot)));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_slabs, 0, (size_t)slab_cap * SRL_SLAB_BYTES, ctx->stream));
     if (V > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->d_slabs, slabs.data(), (size_t)V * SRL_SLAB_BYTES, hipMemcpyHostToDevice, ctx->stream));
@@ -317,6 +319,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     a.table = ctx->d_table;
     a.table_mask = ctx->table_cap - 1;
     a.slabs = ctx->d_slabs;
+    a.inf_off = ctx->slab_cap * (unsigned)SRL_SLAB_BYTES;
     {
         const srl::Quat q(f->q[0], f->q[1], f->q[2], f->q[3]);
         const srl::Mat3 Rn = q.normalized().toRotationMatrix();    // optimize.cpp:35

@@ -18,6 +18,7 @@
 
 #define SRL_CAP 20
 #define SRL_SLAB_BYTES 256
+#define SRL_MAX_SLABS 16777215u      // slab * 256 + slot offset must fit 32 bits (kernels address slabs with 32-bit byte offsets)
 #define SRL_KPB 64            // keypoints per workgroup
 #define SRL_BLOCK 256         // threads per workgroup (4 waves)
 #define SRL_SURV_CAP 64       // per-wave survivor scratch entries (general path; more survivors -> extraction)
@@ -77,6 +78,7 @@ struct SrlAssocArgs {
     const SrlMapSlot *table;
     unsigned table_mask;
     const unsigned char *slabs;
+    unsigned inf_off;                  // byte offset of the slab whose 20 points are (+inf, +inf, +inf): lanes without a candidate load from it
     // pose (computed on the host exactly like the reference: optimize.cpp:35 and :95)
     double Rn[9];       // end_quat.normalized().toRotationMatrix()
     double R[9];        // end_quat.toRotationMatrix()

@@ -25,7 +25,7 @@
 
 namespace {
 
-struct VoxEnt { unsigned slab; unsigned count; };
+struct alignas(8) VoxEnt { unsigned slab; unsigned count; };   // 8-B aligned: one ds_read_b64 with an immediate offset per entry
 struct Surv { double d2; float x, y, z; unsigned id; };
 static_assert(sizeof(Surv) == 24, "survivor record is 24 bytes");
 static_assert(SRL_SURV_CAP * 24 <= SRL_WAVE_SCRATCH, "general-path scratch must fit");
@@ -432,37 +432,42 @@ __device__ __forceinline__ float d2_f32(float px, float py, float pz, float qx, 
 // R = compile-time number of candidate rounds (3 voxels each): straight-line code, arrays stay in registers
 template <int R, class Sink>
 __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double qz, int nv, const VoxEnt *vox,
-                                                  const unsigned char *slabs, int K, void *scratch, int lane,
+                                                  const unsigned char *slabs, unsigned inf_off, int K, void *scratch, int lane,
                                                   const LaneRole &role, Sink &sink, int &total_out, int ablate) {
     const float kInfF = __builtin_huge_valf();
     const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
     float px[R], py[R], pz[R];
     // all voxel entries (branch-free LDS reads; the list is zero-filled up to 27 entries), then every round's
-    // coalesced 12-B load, all in flight before the first use.  Lanes without a candidate keep +inf
-    // coordinates, so their FP32 distance is +inf with no validity flag to carry around.
+    // coalesced 12-B load, all in flight before the first use.
     (void)nv;
     VoxEnt ve[R];
     const int cbase = role.c0 < 3 ? role.c0 : 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) ve[j] = vox[3 * j + cbase];
-    bool has[R];
+    // Branch-free loads: a lane without a candidate (slot >= count, zero-filled list tail, idle lanes 60..63) reads the
+    // all-inf slab instead, so its FP32 distance is +inf by arithmetic -- no predicate to keep, no exec juggling.
+    // Slab byte offsets stay in 32 bits (map < 16.7 M voxels, checked at map growth): scalar base + lane offset.
+    const unsigned slot_eff = role.c0 < 3 ? (unsigned)role.slot : 31u;
+    const unsigned slot_off = (unsigned)role.slot * 12u;
+    unsigned off[R];
+    int total = 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        px[j] = kInfF; py[j] = kInfF; pz[j] = kInfF;
-        has[j] = role.c0 < 3 && (unsigned)role.slot < ve[j].count;
-        if (has[j]) {
-            const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve[j].slab * SRL_SLAB_BYTES + role.slot * 12);
-            px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
-        }
+        const bool h = slot_eff < ve[j].count;
+        total += __popcll(__ballot(h));
+        off[j] = h ? ve[j].slab * (unsigned)SRL_SLAB_BYTES + slot_off : inf_off;
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const float *p = reinterpret_cast<const float *>(slabs + off[j]);
+        px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
     }
     float d2f[R];
     float lmin = kInfF;
-    int total = 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         d2f[j] = d2_f32(px[j], py[j], pz[j], qxf, qyf, qzf);
         lmin = fminf(lmin, d2f[j]);
-        total += __popcll(__ballot(has[j]));              // the load predicate IS the validity (no float compares)
     }
     total_out = total;
 
@@ -492,20 +497,24 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));            // [64], 16-B aligned
     double *keys = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024);  // [66]
     int *owner = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scratch) + 1024 + 66 * 8 + 8);  // [32]
+    unsigned long long svm[R];
     int c = 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const bool sv = d2f[j] <= thr;
-        const unsigned long long m = __ballot(sv);
-        int pos = c + lanes_below(m);
-        pos = pos < 63 ? pos : 63;          // > 64 survivors bail out below; the clamp only keeps the stores in bounds
-        if (sv) {
-            SurvRec r; r.x = px[j]; r.y = py[j]; r.z = pz[j]; r.code = ((3 * j + role.c0) << 5) | role.slot;
-            recs[pos] = r;
-        }
-        c += __popcll(m);
+        svm[j] = __ballot(d2f[j] <= thr);
+        c += __popcll(svm[j]);
     }
-    if (c > 64) return false;
+    if (c > 64) return false;              // checked before anything is written: the stores below need no clamp
+    const int code0 = (role.c0 << 5) | role.slot;
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if (d2f[j] <= thr) {
+            SurvRec r; r.x = px[j]; r.y = py[j]; r.z = pz[j]; r.code = code0 + ((3 * j) << 5);
+            recs[base + lanes_below(svm[j])] = r;
+        }
+        base += __popcll(svm[j]);
+    }
     if (ablate & 2) return true;
     __builtin_amdgcn_wave_barrier();
 
@@ -545,17 +554,17 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
 
 template <class Sink>
 __device__ __forceinline__ bool select_topk_f32(double qx, double qy, double qz, int nv, const VoxEnt *vox,
-                                                const unsigned char *slabs, int K, void *scratch, int lane,
+                                                const unsigned char *slabs, unsigned inf_off, int K, void *scratch, int lane,
                                                 const LaneRole &role, Sink &sink, int &total_out, int ablate) {
     // straight-line instantiation per number of candidate rounds (3 voxels per round)
     switch ((nv + 2) / 3) {
         case 0: case 1: case 2: case 3:
-            return select_topk_f32_r<3>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
-        case 4: return select_topk_f32_r<4>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
-        case 5: return select_topk_f32_r<5>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
-        case 6: return select_topk_f32_r<6>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
-        case 7: return select_topk_f32_r<7>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
-        default: return select_topk_f32_r<9>(qx, qy, qz, nv, vox, slabs, K, scratch, lane, role, sink, total_out, ablate);
+            return select_topk_f32_r<3>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
+        case 4: return select_topk_f32_r<4>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
+        case 5: return select_topk_f32_r<5>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
+        case 6: return select_topk_f32_r<6>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
+        case 7: return select_topk_f32_r<7>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
+        default: return select_topk_f32_r<9>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
     }
 }
 
@@ -810,7 +819,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
                 const int nv = (kl & 1) ? (nv_pair >> 8) : (nv_pair & 0xFF);
                 voxl = vox + 32 * (kl & 1);
                 if (a.ablate & 4) { done = true; total = nv; }
-                else if constexpr (FAST == 1) done = select_topk_f32(qx, qy, qz, nv, voxl, a.slabs, a.K, surv, lane, role, sink, total, a.ablate);
+                else if constexpr (FAST == 1) done = select_topk_f32(qx, qy, qz, nv, voxl, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
                 else done = select_topk_fast(qx, qy, qz, nv, voxl, a.slabs, a.K, surv, lane, role, sink, total);
             }
             if (!done) {

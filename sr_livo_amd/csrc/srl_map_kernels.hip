@@ -153,11 +153,13 @@ unsigned next_pow2u(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return 
 // grow slab storage / hash table so that `need_slabs` voxels fit with load <= 0.5
 int srl_ctx_grow_map(srl_ctx *ctx, unsigned need_slabs, unsigned need_slots) {
     const unsigned new_slab_cap = ctx->slab_cap >= need_slabs ? ctx->slab_cap : std::max(need_slabs + need_slabs / 2u, 1024u);
+    if (new_slab_cap > SRL_MAX_SLABS) { ctx->err = "map too large: slab byte offsets are 32-bit (16.7 M voxels)"; return SRL_ERR_UNSUPPORTED; }
     unsigned new_table_cap = ctx->table_cap;
     while (new_table_cap < need_slots || new_table_cap < SRL_TABLE_FACTOR * new_slab_cap) new_table_cap = next_pow2u(new_table_cap ? new_table_cap * 2u : 2048u);
     if (new_slab_cap != ctx->slab_cap) {
         unsigned char *ns = nullptr;
-        HIPCHK(ctx, hipMalloc((void **)&ns, (size_t)new_slab_cap * SRL_SLAB_BYTES));
+        HIPCHK(ctx, hipMalloc((void **)&ns, ((size_t)new_slab_cap + 1) * SRL_SLAB_BYTES));          // + the all-inf slab
+        HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ns + (size_t)new_slab_cap * SRL_SLAB_BYTES), 0x7f800000, SRL_SLAB_BYTES / 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ns, 0, (size_t)new_slab_cap * SRL_SLAB_BYTES, ctx->stream));
         if (ctx->d_slabs && ctx->num_voxels > 0)
             HIPCHK(ctx, hipMemcpyAsync(ns, ctx->d_slabs, (size_t)ctx->num_voxels * SRL_SLAB_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
