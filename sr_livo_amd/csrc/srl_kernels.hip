@@ -837,20 +837,30 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     __builtin_amdgcn_wave_barrier();
 
     if (a.ablate & 64) return;                                            // debug: phase 0 + loop skeleton only
+    // Phase 2 re-reads its parameters from the kernarg segment through a laundered pointer: kept live across phase 1
+    // they cost ~70 SGPRs and pushed the selection loop into SGPR spills (v_readlane / v_writelane).
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
+    KernargPtr bp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();     // the struct is the kernel's only argument
+    asm volatile("" : "+s"(bp));
+    const __attribute__((address_space(4))) SrlAssocArgs &b = *bp;
+#else
+    const SrlAssocArgs &b = a;
+#endif
     // ---------------- phase 2: plane fit + residual + Jacobian for this wave's 16 keypoints, 4 lanes each.
     // Sub-lane s accumulates neighbours s, s+4, ...; quad butterflies make the sums identical in the 4 lanes,
     // which then run the (scalar) eigen-solve / weights redundantly and split the 28 H^T H / H^T h / loss
     // products between them (7 each) before the sum over keypoints.
     const int kl = (lane >> 2) < SRL_KPW ? (lane >> 2) : (SRL_KPW - 1), sl = lane & 3;
     const bool owner_lane = (lane >> 2) < SRL_KPW;          // KPW < 16: the upper quads idle through phase 2
-    const int g = owner_lane ? wbase_kp + kl : a.n;
+    const int g = owner_lane ? wbase_kp + kl : b.n;
     int status = 3;
     bool nan_bad = false;
     double J[6] = {0, 0, 0, 0, 0, 0};
     double dist = 0.0, weight = 0.0;
     const int nf = s_nfound[kl];
-    if (g < a.n) status = 0;
-    const bool fit = (g < a.n) && (nf >= a.min_nb) && !(a.ablate & 1);
+    if (g < b.n) status = 0;
+    const bool fit = (g < b.n) && (nf >= b.min_nb) && !(b.ablate & 1);
     // the butterflies need all four sub-lanes of a quad active together: `fit` is uniform inside a quad
     if (fit) {
         const D3 p_imu = d3(s_pimu[kl * 3 + 0], s_pimu[kl * 3 + 1], s_pimu[kl * 3 + 2]);
@@ -879,38 +889,38 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
         C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
         double ev[3];
         D3 nrm;
-        if (a.select_mode == 4) { eig3_jacobi(C, ev, nrm); nrm = normalized3(nrm); }   // .col(0).normalized() (optimize.cpp:340)
+        if (b.select_mode == 4) { eig3_jacobi(C, ev, nrm); nrm = normalized3(nrm); }   // .col(0).normalized() (optimize.cpp:340)
         else eig3_closed(C, ev, nrm);                              // already unit length (re-normalised once more at :93 below)
         const double sigma_1 = sqrt(fabs(ev[2]));
         const double sigma_2 = sqrt(fabs(ev[1]));
         const double sigma_3 = sqrt(fabs(ev[0]));
         const double a2D = (sigma_2 - sigma_3) / sigma_1;          // optimize.cpp:343-346
         if (a2D != a2D) nan_bad = true;                           // optimize.cpp:348-350
-        const double w_plan = (a.power_planarity == 2.0) ? a2D * a2D : pow(a2D, a.power_planarity);
+        const double w_plan = (b.power_planarity == 2.0) ? a2D * a2D : pow(a2D, b.power_planarity);
         // normal flip: world-frame last translation minus body-frame location (optimize.cpp:49-51)
-        const D3 tl = d3(a.t_last[0], a.t_last[1], a.t_last[2]);
+        const D3 tl = d3(b.t_last[0], b.t_last[1], b.t_last[2]);
         if (dot3(nrm, sub(tl, p_imu)) < 0.0) nrm = d3(-1.0 * nrm.x, -1.0 * nrm.y, -1.0 * nrm.z);
         const D3 nn0 = d3((double)s_nb[kl], (double)s_nb[nb_plane + kl], (double)s_nb[2 * nb_plane + kl]);
         const D3 dq = sub(nn0, p_w);
-        weight = a.lambda_w * w_plan + a.lambda_n * exp(-sqrt(dot3(dq, dq)) / a.nbr_scale);   // optimize.cpp:87-88
+        weight = b.lambda_w * w_plan + b.lambda_n * exp(-sqrt(dot3(dq, dq)) / b.nbr_scale);   // optimize.cpp:87-88
         const D3 nv = normalized3(nrm);                            // optimize.cpp:93
         const double off = -dot3(nv, nn0);                         // optimize.cpp:94
-        const D3 pe = add(matvec(a.R, p_imu), d3(a.t[0], a.t[1], a.t[2]));
+        const D3 pe = add(matvec(b.R, p_imu), d3(b.t[0], b.t[1], b.t[2]));
         dist = dot3(nv, pe) + off;                                 // optimize.cpp:95
         status = 1;
-        if (a.tap_normal && sl == 0) {
-            a.tap_normal[(size_t)g * 3 + 0] = nv.x; a.tap_normal[(size_t)g * 3 + 1] = nv.y; a.tap_normal[(size_t)g * 3 + 2] = nv.z;
-            a.tap_a2d[g] = a2D;
-            a.tap_offset[g] = off;
+        if (b.tap_normal && sl == 0) {
+            b.tap_normal[(size_t)g * 3 + 0] = nv.x; b.tap_normal[(size_t)g * 3 + 1] = nv.y; b.tap_normal[(size_t)g * 3 + 2] = nv.z;
+            b.tap_a2d[g] = a2D;
+            b.tap_offset[g] = off;
         }
-        if (dist < a.max_dist) {                                   // signed gate (optimize.cpp:98)
+        if (dist < b.max_dist) {                                   // signed gate (optimize.cpp:98)
             status = 2;
             J[0] = nv.x * weight; J[1] = nv.y * weight; J[2] = nv.z * weight;
             // - n^T * R * skew(p_imu) * weight, left to right (optimize.cpp:101)
             const double m0 = -nv.x, m1 = -nv.y, m2 = -nv.z;
-            const double r0 = (m0 * a.R[0] + m1 * a.R[3]) + m2 * a.R[6];
-            const double r1 = (m0 * a.R[1] + m1 * a.R[4]) + m2 * a.R[7];
-            const double r2 = (m0 * a.R[2] + m1 * a.R[5]) + m2 * a.R[8];
+            const double r0 = (m0 * b.R[0] + m1 * b.R[3]) + m2 * b.R[6];
+            const double r1 = (m0 * b.R[1] + m1 * b.R[4]) + m2 * b.R[7];
+            const double r2 = (m0 * b.R[2] + m1 * b.R[5]) + m2 * b.R[8];
             // skew(p) = [[0,-pz,py],[pz,0,-px],[-py,px,0]]
             const double s0 = (r0 * 0.0 + r1 * p_imu.z) + r2 * (-p_imu.y);
             const double s1 = (r0 * (-p_imu.z) + r1 * 0.0) + r2 * p_imu.x;
@@ -918,17 +928,17 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
             J[3] = s0 * weight; J[4] = s1 * weight; J[5] = s2 * weight;
         }
     }
-    if (g < a.n) {
+    if (g < b.n) {
         // per-keypoint record {J[6], distance, weight} (ordered cut-off path + taps): the four lanes of a quad hold
         // identical values, so sub-lane s stores doubles 2s, 2s+1 -- one fully coalesced 16-B store per lane
         // (1 KB per wave) instead of eight scattered 8-B stores.
         double2 v;
         v.x = (sl == 0) ? J[0] : ((sl == 1) ? J[2] : ((sl == 2) ? J[4] : dist));
         v.y = (sl == 0) ? J[1] : ((sl == 1) ? J[3] : ((sl == 2) ? J[5] : weight));
-        *reinterpret_cast<double2 *>(a.rec + (size_t)g * 8 + 2 * sl) = v;
+        *reinterpret_cast<double2 *>(b.rec + (size_t)g * 8 + 2 * sl) = v;
         if (sl == 0) {
-            a.status[g] = (unsigned char)status;
-            if (a.tap_ncand) a.tap_ncand[g] = s_ncand[kl];
+            b.status[g] = (unsigned char)status;
+            if (b.tap_ncand) b.tap_ncand[g] = s_ncand[kl];
         }
     }
 
@@ -957,7 +967,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     {
         const unsigned long long acc_mask = __ballot(status == 2 && sl == 0);
         const unsigned long long nan_mask = __ballot(nan_bad);
-        int pk = (lane < SRL_KPW && wbase_kp + lane < a.n) ? s_ncand[lane] : 0;
+        int pk = (lane < SRL_KPW && wbase_kp + lane < b.n) ? s_ncand[lane] : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
         if (lane == 0) {
@@ -972,7 +982,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
     // ---- block partial = wave partials added in wave order (deterministic)
     if (tid < 28) {
         const double v = ((s_wpart[tid] + s_wpart[32 + tid]) + s_wpart[64 + tid]) + s_wpart[96 + tid];
-        a.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] = v;
+        b.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] = v;
     }
     if (tid == 0) {
         SrlBlockInfo bi;
@@ -980,7 +990,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
         bi.sum_pk = (unsigned)(s_winfo[1] + s_winfo[5] + s_winfo[9] + s_winfo[13]);
         bi.nan_flag = (s_winfo[2] | s_winfo[6] | s_winfo[10] | s_winfo[14]) ? 1 : 0;
         bi.num_fallback = s_winfo[3] + s_winfo[7] + s_winfo[11] + s_winfo[15];
-        a.binfo[blockIdx.x] = bi;
+        b.binfo[blockIdx.x] = bi;
     }
 }
 
