@@ -19,7 +19,12 @@
 #define SRL_CAP 20
 #define SRL_SLAB_BYTES 256
 #define SRL_MAX_SLABS 16777215u      // slab * 256 + slot offset must fit 32 bits (kernels address slabs with 32-bit byte offsets)
+#ifndef SRL_KPB
 #define SRL_KPB 64            // keypoints per workgroup
+#endif
+#ifndef SRL_ASSOC_WAVES_PER_SIMD
+#define SRL_ASSOC_WAVES_PER_SIMD 4
+#endif
 #define SRL_BLOCK 256         // threads per workgroup (4 waves)
 #define SRL_SURV_CAP 64       // per-wave survivor scratch entries (general path; more survivors -> extraction)
 #define SRL_WAVE_SCRATCH 2048  // bytes of LDS scratch per wave (fast path: 64 x 16 B records + 66 keys + 32 owners = 1688 B)

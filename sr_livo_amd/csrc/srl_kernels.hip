@@ -509,11 +509,13 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     int base = 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        if (d2f[j] <= thr) {
-            SurvRec r; r.x = px[j]; r.y = py[j]; r.z = pz[j]; r.code = code0 + ((3 * j) << 5);
-            recs[base + lanes_below(svm[j])] = r;
+        if (svm[j] != 0ull) {                  // wave-uniform: most rounds (far voxels) have no survivor at all
+            if (d2f[j] <= thr) {
+                SurvRec r; r.x = px[j]; r.y = py[j]; r.z = pz[j]; r.code = code0 + ((3 * j) << 5);
+                recs[base + lanes_below(svm[j])] = r;
+            }
+            base += __popcll(svm[j]);
         }
-        base += __popcll(svm[j]);
     }
     if (ablate & 2) return true;
     __builtin_amdgcn_wave_barrier();
@@ -700,11 +702,12 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels) {
     LdsLayout L;
     int o = 0;
     L.off_nb = o;      o += ((3 * K * NB_ROW * 4 + 15) / 16) * 16;   // planes x | y | z, K rows of NB_ROW floats
-    L.off_pw = o;      o += SRL_KPW * 3 * 8;
-    L.off_pimu = o;    o += SRL_KPW * 3 * 8;
-    L.off_kv = o;      o += SRL_KPW * 4 * 4;
-    L.off_nfound = o;  o += SRL_KPW * 4;
-    L.off_ncand = o;   o += SRL_KPW * 4;
+    auto up16 = [](int x) { return (x + 15) & ~15; };
+    L.off_pw = o;      o += up16(SRL_KPW * 3 * 8);
+    L.off_pimu = o;    o += up16(SRL_KPW * 3 * 8);
+    L.off_kv = o;      o += up16((SRL_KPW + 1) * 4 * 4);           // + one zero entry: the pair probe of an odd KPW reads it
+    L.off_nfound = o;  o += up16(SRL_KPW * 4);
+    L.off_ncand = o;   o += up16(SRL_KPW * 4);
     L.off_vox = o;     o += (nb_voxels == 1 ? 64 : 128) * 8;     // r = 1: two 32-entry lists (a keypoint pair is probed at once)
     L.off_scratch = o; o += SRL_WAVE_SCRATCH;
     L.wave_bytes = o;
@@ -744,7 +747,7 @@ __device__ __forceinline__ double kp_sum(double v) {
 
 // FAST: 0 = general path only, 1 = FP32-prefilter fast path, 2 = FP64-retained fast path (r = 1 only)
 template <int NB, int FAST>
-__global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocArgs a) {
+__global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc_kernel(const SrlAssocArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout L = lds_layout(a.K, NB);
     const int tid = threadIdx.x;
@@ -785,6 +788,8 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
         s_kv[lane * 4 + 2] = (int)(short)(int)(unit ? p_w.z : p_w.z / a.size_voxel);
         s_nfound[lane] = 0;
         s_ncand[lane] = 0;
+    } else if (lane == SRL_KPW) {
+        s_kv[lane * 4 + 0] = 0; s_kv[lane * 4 + 1] = 0; s_kv[lane * 4 + 2] = 0;
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -797,7 +802,6 @@ __global__ void __launch_bounds__(SRL_BLOCK, 4) srl_assoc_kernel(const SrlAssocA
         if constexpr (NB == 1 && FAST != 0) { if (!(a.ablate & 32)) preq = probe_issue(s_kv, 0, role0, a.table, a.table_mask, lane); }
         for (int kl = 0; kl < SRL_KPW; ++kl) {
             LaneRole role = role0;
-            asm volatile("" : "+v"(role.c0), "+v"(role.slot));   // recompute the few role-derived values per keypoint instead of spilling them
             const int g = wbase_kp + kl;
             if (g >= a.n) break;
             const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
