@@ -189,6 +189,9 @@ int srl_transform_points(srl_ctx *ctx, const double *raw_xyz, int n, const doubl
 int srl_comm_unique_id(void *id /* SRL_COMM_ID_BYTES */);
 int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id);
 int srl_comm_destroy(srl_ctx *ctx);
+/* suspend != 0: run unsharded (whole sweep, no collective) while keeping the communicator; 0: back to sharded mode.
+ * Re-upload the sweep after switching. */
+int srl_comm_suspend(srl_ctx *ctx, int suspend);
 /* test hook: a host all-reduce callback (sum over ranks of `count` doubles, in place) used INSTEAD of
  * RCCL when set -- lets the sharded logic run over gloo/MPI or G logical shards on one device. */
 typedef int (*srl_allreduce_fn)(double *buf, int count, void *user);
@@ -222,7 +225,10 @@ typedef struct srl_timing {
     double  sum_host_total_us;  /* host wall: whole srl_build_residuals call */
 } srl_timing;
 int srl_get_timing(srl_ctx *ctx, srl_timing *t);
-int srl_set_profiling(srl_ctx *ctx, int enable);   /* event timing on/off (off by default); switching on resets the sums */
+int srl_set_profiling(srl_ctx *ctx, int mode);     /* 0 off (default); 1 full: four events + a sync per call (kernel, reduce,
+                                                      * device total, host splits); 2 light: one event pair around the association
+                                                      * kernel, read back lazily (calls / sum_assoc_ms / sum_algorithmic_bytes only).
+                                                      * Switching on resets the sums. */
 
 #ifdef __cplusplus
 }

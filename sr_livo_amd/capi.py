@@ -124,6 +124,7 @@ def load_library():
         "srl_comm_unique_id": ([p], C.c_int),
         "srl_comm_init_rank": ([p, C.c_int, C.c_int, p], C.c_int),
         "srl_comm_destroy": ([p], C.c_int),
+        "srl_comm_suspend": ([p, C.c_int], C.c_int),
         "srl_comm_set_host_callbacks": ([p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, p], C.c_int),
         "srl_shard_range": ([C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], None),
         "srl_shard_budget": ([C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)], None),
@@ -422,6 +423,9 @@ class Context:
     def comm_init_rank(self, nranks, rank, uid):
         buf = (C.c_ubyte * SRL_COMM_ID_BYTES).from_buffer_copy(uid)
         self._chk(self.lib.srl_comm_init_rank(self.h, nranks, rank, buf), "srl_comm_init_rank")
+
+    def comm_suspend(self, suspend=True):
+        self._chk(self.lib.srl_comm_suspend(self.h, int(bool(suspend))), "srl_comm_suspend")
 
     def comm_destroy(self):
         self._chk(self.lib.srl_comm_destroy(self.h), "srl_comm_destroy")

@@ -138,6 +138,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
+    if (ctx->parked_comm) ncclCommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
                     ctx->d_out, ctx->d_count, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
                     ctx->d_tap_offset, ctx->d_gather};
@@ -146,6 +147,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->h_count) hipHostFree(ctx->h_count);
     if (ctx->h_mail) hipHostFree(ctx->h_mail);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < srl_ctx::PROF_RING; i++) for (int k = 0; k < 2; k++) if (ctx->ring[i][k]) hipEventDestroy(ctx->ring[i][k]);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return SRL_OK;
@@ -280,15 +282,41 @@ int srl_set_taps(srl_ctx *ctx, int enable) {
     return SRL_OK;
 }
 
+namespace {
+// light profiling: read the (start, end) event pairs of association launches that have completed by now
+int drain_ring(srl_ctx *ctx, bool all) {
+    while (ctx->ring_tail != ctx->ring_head) {
+        hipEvent_t *e = ctx->ring[ctx->ring_tail % srl_ctx::PROF_RING];
+        if (!all && hipEventQuery(e[1]) != hipSuccess) break;
+        if (all) HIPCHK(ctx, hipEventSynchronize(e[1]));
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, e[0], e[1]));
+        ctx->timing.assoc_ms = ms;
+        ctx->timing.sum_assoc_ms += ms;
+        ctx->timing.calls += 1;
+        ctx->ring_tail++;
+    }
+    return SRL_OK;
+}
+}  // namespace
+
 int srl_set_profiling(srl_ctx *ctx, int enable) {
-    if (!ctx) return SRL_ERR_BAD_ARG;
-    ctx->profiling = enable != 0;
+    if (!ctx || enable < 0 || enable > 2) return SRL_ERR_BAD_ARG;
+    if (ctx->profiling == 2) { int rc = drain_ring(ctx, true); if (rc) return rc; }
+    ctx->profiling = enable;
     if (ctx->profiling) std::memset(&ctx->timing, 0, sizeof ctx->timing);
+    if (ctx->profiling == 2) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        for (int i = 0; i < srl_ctx::PROF_RING; i++)
+            for (int k = 0; k < 2; k++) if (!ctx->ring[i][k]) HIPCHK(ctx, hipEventCreate(&ctx->ring[i][k]));
+        ctx->ring_head = ctx->ring_tail = 0;
+    }
     return SRL_OK;
 }
 
 int srl_get_timing(srl_ctx *ctx, srl_timing *t) {
     if (!ctx || !t) return SRL_ERR_BAD_ARG;
+    if (ctx->profiling == 2) { int rc = drain_ring(ctx, true); if (rc) return rc; }
     *t = ctx->timing;
     return SRL_OK;
 }
@@ -369,11 +397,19 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         }
     }
     const int nblocks = (ctx->n + SRL_KPB - 1) / SRL_KPB;
-    const bool prof = ctx->profiling;
+    const bool prof = ctx->profiling == 1;
+    const bool prof_light = ctx->profiling == 2;
+    hipEvent_t *ring_ev = nullptr;
+    if (prof_light) {
+        if (ctx->ring_head - ctx->ring_tail >= (unsigned)srl_ctx::PROF_RING) { int rc = drain_ring(ctx, true); if (rc) return rc; }
+        ring_ev = ctx->ring[ctx->ring_head % srl_ctx::PROF_RING];
+    }
 
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (prof_light) HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
     HIPCHK(ctx, srl_launch_assoc(a, nb, ctx->stream));
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (prof_light) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_head++; }
 
     // residual budget of this rank (sequential early exit, optimize.cpp:107, across ordered shards)
     int64_t budget = o->max_num_residuals;
@@ -495,7 +531,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         const long long per_kp = 24 + 12 * side * side * side;
         const double pk_share = (ctx->nranks > 1 && ctx->total_n > 0) ? r.d_sum_pk * ((double)ctx->n / (double)ctx->total_n) : r.d_sum_pk;
         ctx->timing.algorithmic_bytes = per_kp * (long long)ctx->n + (long long)(12.0 * pk_share);
-        if (prof) ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes;
+        if (prof || prof_light) { ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes; ctx->timing.sum_keypoints += prof_light ? ctx->n : 0; }
     }
     if (out->nan_error) { ctx->err = "NaN planarity"; return SRL_ERR_NAN_PLANARITY; }
     return SRL_OK;
@@ -643,8 +679,24 @@ int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id) {
     return rc;
 }
 
+int srl_comm_suspend(srl_ctx *ctx, int suspend) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (suspend) {
+        if (ctx->parked_nranks == 0) {
+            ctx->parked_comm = ctx->comm; ctx->parked_nranks = ctx->nranks; ctx->parked_rank = ctx->rank;
+            ctx->comm = nullptr; ctx->nranks = 1; ctx->rank = 0;
+        }
+    } else if (ctx->parked_nranks != 0) {
+        ctx->comm = ctx->parked_comm; ctx->nranks = ctx->parked_nranks; ctx->rank = ctx->parked_rank;
+        ctx->parked_comm = nullptr; ctx->parked_nranks = 0; ctx->parked_rank = 0;
+    }
+    return SRL_OK;
+}
+
 int srl_comm_destroy(srl_ctx *ctx) {
     if (!ctx) return SRL_ERR_BAD_ARG;
+    if (ctx->parked_comm) { ncclCommDestroy(ctx->parked_comm); ctx->parked_comm = nullptr; }
+    ctx->parked_nranks = 0; ctx->parked_rank = 0;
     if (ctx->comm) { ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
     ctx->nranks = 1; ctx->rank = 0;
     ctx->cb_ar = nullptr; ctx->cb_ag = nullptr; ctx->cb_user = nullptr;

@@ -66,6 +66,8 @@ struct srl_ctx {
     // comm
     int nranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
+    ncclComm_t parked_comm = nullptr;  // srl_comm_suspend: the communicator set aside while the context runs unsharded
+    int parked_nranks = 0, parked_rank = 0;
     bool force_coll = false;           // env SRL_FORCE_COLLECTIVES=1: run the RCCL calls even with one rank (test hook)
     srl_allreduce_fn cb_ar = nullptr;
     srl_allgather_i64_fn cb_ag = nullptr;
@@ -73,7 +75,11 @@ struct srl_ctx {
     long long *d_gather = nullptr;     // nranks
 
     // timing
-    bool profiling = false;
+    int profiling = 0;                 // 0 off, 1 full (4 events + sync per call), 2 light (assoc kernel only, read lazily)
+    static constexpr int PROF_RING = 512;
+    hipEvent_t ring[PROF_RING][2] = {};
+    unsigned ring_head = 0, ring_tail = 0;   // [tail, head) recorded and not yet read
+
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     srl_timing timing = {};
     int last_nb = 1;
