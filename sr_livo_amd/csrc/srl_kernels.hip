@@ -431,11 +431,11 @@ __device__ __forceinline__ float d2_f32(float px, float py, float pz, float qx, 
 
 // R = compile-time number of candidate rounds (3 voxels each): straight-line code, arrays stay in registers
 template <int R, class Sink>
-__device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double qz, int nv, const VoxEnt *vox,
+__device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
                                                   const unsigned char *slabs, unsigned inf_off, int K, void *scratch, int lane,
                                                   const LaneRole &role, Sink &sink, int &total_out, int ablate) {
     const float kInfF = __builtin_huge_valf();
-    const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
+    const float qxf = qf[0], qyf = qf[1], qzf = qf[2];      // FP32 query and margin coefficients, prepared in phase 0
     float px[R], py[R], pz[R];
     // all voxel entries (branch-free LDS reads; the list is zero-filled up to 27 entries), then every round's
     // coalesced 12-B load, all in flight before the first use.
@@ -483,16 +483,10 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     // FP32 error model: a = abs error of fl32(q) per axis; per-axis difference error <= a + u*|d|; sum of
     // squares (3 terms, FMA or not) adds <= 4u relative.  For d2, d2f <= T:  |d2f - d2| <= m(T) with
     //   m(T) = 4 a sqrt(T) + 8 u T + 4 a^2   (u = 2^-24), evaluated at T = 2 tau_f + 1e-6 with sqrt(T) replaced by
-    //   its upper bound (T + 1) / 2 (AM-GM; no transcendental), and doubled.
+    //   its upper bound (T + 1) / 2 (AM-GM; no transcendental), and doubled: linear in tau_f, coefficients from phase 0.
     // Fewer than K candidates: every candidate survives (FLT_MAX; empty lanes hold +inf and never pass).
     float thr = 3.4028235e38f;
-    if (tau_f < kInfF) {
-        const float u = 5.9604645e-8f;
-        const float amax = fmaxf(fmaxf(fabsf(qxf), fabsf(qyf)), fabsf(qzf)) * u + 1e-30f;
-        const float T = 2.0f * tau_f + 1e-6f;
-        const float m = 4.0f * amax * ((T + 1.0f) * 0.5001f) + 8.0f * u * T + 4.0f * amax * amax;
-        thr = (tau_f + 2.0f * m) * 1.000001f;
-    }
+    if (tau_f < kInfF) thr = qf[3] + qf[4] * tau_f;      // (tau + 2 m(2 tau + 1e-6)) (1 + eps), linear in tau
 
     SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));            // [64], 16-B aligned
     double *keys = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024);  // [66]
@@ -535,11 +529,26 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     if (lane < 2) keys[64 + lane] = __builtin_huge_val();
     __builtin_amdgcn_wave_barrier();
     int rank = 0;
+    if (c <= 32) {
+        // the usual case: both half-waves work on the same <= 32 keys -- half h counts the keys [16 h, 16 h + 16) below
+        // key (lane & 31), one cross-half add finishes the rank.  Fixed trip count: slots >= c hold +inf and never count.
+        const double mine = keys[lane & 31];
+        const double2 *kp = reinterpret_cast<const double2 *>(keys + (lane >> 5) * 16);
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double2 kk = kp[j];
+            r += (kk.x < mine) ? 1 : 0;
+            r += (kk.y < mine) ? 1 : 0;
+        }
+        rank = r + __shfl_xor(r, 32);
+    } else {
 #pragma unroll 4
-    for (int j = 0; j < c; j += 2) {
-        const double2 kk = *reinterpret_cast<const double2 *>(keys + j);
-        rank += (kk.x < my) ? 1 : 0;
-        rank += (kk.y < my) ? 1 : 0;
+        for (int j = 0; j < c; j += 2) {
+            const double2 kk = *reinterpret_cast<const double2 *>(keys + j);
+            rank += (kk.x < my) ? 1 : 0;
+            rank += (kk.y < my) ? 1 : 0;
+        }
     }
     const bool win = act && rank < K;
     if (win) owner[rank] = lane;
@@ -555,18 +564,18 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
 }
 
 template <class Sink>
-__device__ __forceinline__ bool select_topk_f32(double qx, double qy, double qz, int nv, const VoxEnt *vox,
+__device__ __forceinline__ bool select_topk_f32(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
                                                 const unsigned char *slabs, unsigned inf_off, int K, void *scratch, int lane,
                                                 const LaneRole &role, Sink &sink, int &total_out, int ablate) {
     // straight-line instantiation per number of candidate rounds (3 voxels per round)
     switch ((nv + 2) / 3) {
         case 0: case 1: case 2: case 3:
-            return select_topk_f32_r<3>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
-        case 4: return select_topk_f32_r<4>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
-        case 5: return select_topk_f32_r<5>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
-        case 6: return select_topk_f32_r<6>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
-        case 7: return select_topk_f32_r<7>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
-        default: return select_topk_f32_r<9>(qx, qy, qz, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
+            return select_topk_f32_r<3>(qx, qy, qz, qf, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
+        case 4: return select_topk_f32_r<4>(qx, qy, qz, qf, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
+        case 5: return select_topk_f32_r<5>(qx, qy, qz, qf, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
+        case 6: return select_topk_f32_r<6>(qx, qy, qz, qf, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
+        case 7: return select_topk_f32_r<7>(qx, qy, qz, qf, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
+        default: return select_topk_f32_r<9>(qx, qy, qz, qf, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
     }
 }
 
@@ -695,7 +704,7 @@ __device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], 
 #define NB_ROW (SRL_KPW + 1)       // row stride (floats) of the neighbour planes
 struct LdsLayout {
     int wave_bytes;                // per-wave region size
-    int off_nb, off_pw, off_pimu, off_kv, off_nfound, off_ncand, off_vox, off_scratch;   // offsets inside a wave region
+    int off_nb, off_pw, off_pimu, off_kv, off_nfound, off_ncand, off_vox, off_scratch, off_qf;   // offsets inside a wave region
     int off_wpart, off_winfo, total;                                                      // block-level tail
 };
 __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels) {
@@ -705,6 +714,7 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels) {
     auto up16 = [](int x) { return (x + 15) & ~15; };
     L.off_pw = o;      o += up16(SRL_KPW * 3 * 8);
     L.off_pimu = o;    o += up16(SRL_KPW * 3 * 8);
+    L.off_qf = o;      o += up16(SRL_KPW * 8 * 4);                 // per keypoint: FP32 query (3), prefilter margin coefficients (2), pad
     L.off_kv = o;      o += up16((SRL_KPW + 1) * 4 * 4);           // + one zero entry: the pair probe of an odd KPW reads it
     L.off_nfound = o;  o += up16(SRL_KPW * 4);
     L.off_ncand = o;   o += up16(SRL_KPW * 4);
@@ -758,6 +768,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
     const int nb_plane = a.K * NB_ROW;
     double *s_pw = reinterpret_cast<double *>(wbase + L.off_pw);
     double *s_pimu = reinterpret_cast<double *>(wbase + L.off_pimu);
+    float *s_qf = reinterpret_cast<float *>(wbase + L.off_qf);
     int *s_kv = reinterpret_cast<int *>(wbase + L.off_kv);
     int *s_nfound = reinterpret_cast<int *>(wbase + L.off_nfound);
     int *s_ncand = reinterpret_cast<int *>(wbase + L.off_ncand);
@@ -780,6 +791,21 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
         }
         s_pw[lane * 3 + 0] = p_w.x; s_pw[lane * 3 + 1] = p_w.y; s_pw[lane * 3 + 2] = p_w.z;
         s_pimu[lane * 3 + 0] = p_imu.x; s_pimu[lane * 3 + 1] = p_imu.y; s_pimu[lane * 3 + 2] = p_imu.z;
+        {
+            // FP32 prefilter constants of this keypoint (used once per keypoint by every lane of the wave later):
+            // error model of select_topk_f32_r, m(T) = 4 a (T + 1)/2 + 8 u T + 4 a^2 at T = 2 tau + 1e-6, thr = (tau + 2 m)(1 + 1e-6)
+            // = c0 + c1 tau
+            const float qxf = (float)p_w.x, qyf = (float)p_w.y, qzf = (float)p_w.z;
+            const float u = 5.9604645e-8f;
+            const float am = fmaxf(fmaxf(fabsf(qxf), fabsf(qyf)), fabsf(qzf)) * u + 1e-30f;
+            const float h = 4.0f * am * 0.5001f;                                  // 4 a / 2, rounded up
+            const float m0 = h * (1.0f + 1e-6f) + 8.0f * u * 1e-6f + 4.0f * am * am;   // m at tau = 0
+            const float m1 = 2.0f * h + 16.0f * u;                                  // d m / d tau
+            float *qf = s_qf + lane * 8;
+            qf[0] = qxf; qf[1] = qyf; qf[2] = qzf;
+            qf[3] = (2.0f * m0) * 1.00001f;                                         // c0
+            qf[4] = (1.0f + 2.0f * m1) * 1.00001f;                                  // c1
+        }
         // static_cast<short>(point / size_voxel_map): truncation toward zero (optimize.cpp:372-374)
         // (x / 1.0 == x exactly: the shipped size_voxel_map = 1.0 skips three FP64 divisions)
         const bool unit = a.size_voxel == 1.0;
@@ -823,7 +849,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
                 const int nv = (kl & 1) ? (nv_pair >> 8) : (nv_pair & 0xFF);
                 voxl = vox + 32 * (kl & 1);
                 if (a.ablate & 4) { done = true; total = nv; }
-                else if constexpr (FAST == 1) done = select_topk_f32(qx, qy, qz, nv, voxl, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
+                else if constexpr (FAST == 1) done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv, voxl, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
                 else done = select_topk_fast(qx, qy, qz, nv, voxl, a.slabs, a.K, surv, lane, role, sink, total);
             }
             if (!done) {
