@@ -972,26 +972,35 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
         }
     }
 
-    // ---- wave partial of H^T H (21 upper-tri), H^T h (6), loss (1): component c = 4 m + sub-lane, m = 0..6.
-    // The four candidates of every m are compile-time index pairs; the sub-lane picks one (no per-lane index math).
+    // ---- wave partial of H^T H (21 upper-tri), H^T h (6), loss (1).  Every accepted keypoint leaves the row
+    // {J[0..5], h, distance} in LDS (zeros otherwise); lane c < 28 then owns component c and walks the 16 keypoints in
+    // order -- two LDS reads, one multiply, one add each, no cross-lane traffic, fixed summation order.
     {
-        const double h = dist * weight;                           // optimize.cpp:169
+        double *s_row = reinterpret_cast<double *>(surv);            // [16][8], phase-1 scratch is free now
         const bool accd = status == 2;
-        // upper-triangular (row, column) of component c < 21; indices fold to constants after unrolling
-        constexpr int IA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
-        constexpr int IB[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
-        auto comp = [&](int c) -> double {
-            if (c < 21) return J[IA[c]] * J[IB[c]];
-            if (c < 27) return J[c - 21] * h;
-            return dist * dist;                                   // loss (optimize.cpp:104)
-        };
+        if (owner_lane && sl < 2) {
+            // sub-lane 0 stores J[0..3], sub-lane 1 stores J[4], J[5], h, distance (optimize.cpp:169,104)
+            const double h = dist * weight;
+            double4 v;
+            v.x = sl == 0 ? J[0] : J[4]; v.y = sl == 0 ? J[1] : J[5]; v.z = sl == 0 ? J[2] : h; v.w = sl == 0 ? J[3] : dist;
+            if (!accd) { v.x = 0.0; v.y = 0.0; v.z = 0.0; v.w = 0.0; }
+            *reinterpret_cast<double4 *>(s_row + kl * 8 + 4 * sl) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 28) {
+            // (row, column) of component c: upper triangle of H^T H, then J_i h, then distance^2
+            int ia, ib;
+            if (lane < 21) {
+                // triangular index -> (ia, ib), ia <= ib < 6
+                int c = lane, r = 0;
+                while (c >= 6 - r) { c -= 6 - r; ++r; }
+                ia = r; ib = r + c;
+            } else if (lane < 27) { ia = lane - 21; ib = 6; }
+            else { ia = 7; ib = 7; }
+            double acc = 0.0;
 #pragma unroll
-        for (int m = 0; m < 7; ++m) {
-            const double v0 = comp(4 * m), v1 = comp(4 * m + 1), v2 = comp(4 * m + 2), v3 = comp(4 * m + 3);
-            double v = (sl == 0) ? v0 : ((sl == 1) ? v1 : ((sl == 2) ? v2 : v3));
-            v = accd ? v : 0.0;
-            v = kp_sum(v);
-            if (lane < 4) s_wpart[wave * 32 + 4 * m + sl] = v;
+            for (int k = 0; k < SRL_KPW; ++k) acc += s_row[k * 8 + ia] * s_row[k * 8 + ib];
+            s_wpart[wave * 32 + lane] = acc;
         }
     }
     {
