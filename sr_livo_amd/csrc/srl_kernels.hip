@@ -591,6 +591,20 @@ __device__ __forceinline__ D3 matvec(const double *M, D3 v) {
               (M[6] * v.x + M[7] * v.y) + M[8] * v.z);
 }
 __device__ __forceinline__ D3 add(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+// 1 / b for the tolerance-bound arithmetic of phase 2 (plane fit, weights): hardware reciprocal + two Newton steps
+// (error below one ulp of the result) instead of the ~12-instruction IEEE division; never used where bits decide
+// (voxel keys, candidate distances).
+__device__ __forceinline__ double rcp_nr(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ D3 normalized3_fast(D3 a) {
+    const double z = dot3(a, a);
+    if (z > 0.0) { const double inv = rcp_nr(sqrt(z)); return d3(a.x * inv, a.y * inv, a.z * inv); }
+    return a;
+}
 __device__ __forceinline__ D3 normalized3(D3 a) {
     const double z = dot3(a, a);
     if (z > 0.0) { const double n = sqrt(z); return d3(a.x / n, a.y / n, a.z / n); }
@@ -665,7 +679,7 @@ __device__ void eig3_jacobi(const double Ain[3][3], double ev[3], D3 &n0) {
 __device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], D3 &n0) {
     const double a00 = A[0][0], a11 = A[1][1], a22 = A[2][2], a01 = A[0][1], a02 = A[0][2], a12 = A[1][2];
     const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
-    const double q = (a00 + a11 + a22) / 3.0;
+    const double q = (a00 + a11 + a22) * 0.33333333333333333;
     const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
     const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
     if (!(p2 > 0.0)) {               // multiple of the identity (or zero)
@@ -673,12 +687,12 @@ __device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], 
         n0 = d3(1.0, 0.0, 0.0);
         return;
     }
-    const double p = sqrt(p2 / 6.0);
-    const double ip = 1.0 / p;
+    const double p = sqrt(p2 * 0.16666666666666667);
+    const double ip = rcp_nr(p);
     const double c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
     double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
     r = fmin(1.0, fmax(-1.0, r));
-    const double phi = acos(r) / 3.0;
+    const double phi = acos(r) * 0.33333333333333333;
     const double e2 = q + 2.0 * p * cos(phi);                                   // largest
     const double e0 = q + 2.0 * p * cos(phi + 2.0943951023931954923084289221863);  // smallest (+ 2 pi / 3)
     const double e1 = 3.0 * q - e0 - e2;
@@ -694,7 +708,7 @@ __device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], 
     if (n02 > nb) { best = x02; nb = n02; }
     if (n12 > nb) { best = x12; nb = n12; }
     if (!(nb > 0.0)) { n0 = d3(1.0, 0.0, 0.0); return; }
-    const double inv = 1.0 / sqrt(nb);
+    const double inv = rcp_nr(sqrt(nb));
     n0 = d3(best.x * inv, best.y * inv, best.z * inv);
 }
 
@@ -902,8 +916,8 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
             bc = add(bc, d3((double)p[0], (double)p[nb_plane], (double)p[2 * nb_plane]));
         }
         bc = d3(quad_sum(bc.x), quad_sum(bc.y), quad_sum(bc.z));
-        const double cnt = (double)nf;
-        bc = d3(bc.x / cnt, bc.y / cnt, bc.z / cnt);
+        const double icnt = rcp_nr((double)nf);
+        bc = d3(bc.x * icnt, bc.y * icnt, bc.z * icnt);
         // scatter matrix, upper triangle (optimize.cpp:328-337)
         double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
         for (int i = sl; i < nf; i += 4) {
@@ -924,7 +938,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
         const double sigma_1 = sqrt(fabs(ev[2]));
         const double sigma_2 = sqrt(fabs(ev[1]));
         const double sigma_3 = sqrt(fabs(ev[0]));
-        const double a2D = (sigma_2 - sigma_3) / sigma_1;          // optimize.cpp:343-346
+        const double a2D = (sigma_2 - sigma_3) * rcp_nr(sigma_1);  // optimize.cpp:343-346 (0 / 0 still yields NaN)
         if (a2D != a2D) nan_bad = true;                           // optimize.cpp:348-350
         const double w_plan = (b.power_planarity == 2.0) ? a2D * a2D : pow(a2D, b.power_planarity);
         // normal flip: world-frame last translation minus body-frame location (optimize.cpp:49-51)
@@ -932,8 +946,8 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
         if (dot3(nrm, sub(tl, p_imu)) < 0.0) nrm = d3(-1.0 * nrm.x, -1.0 * nrm.y, -1.0 * nrm.z);
         const D3 nn0 = d3((double)s_nb[kl], (double)s_nb[nb_plane + kl], (double)s_nb[2 * nb_plane + kl]);
         const D3 dq = sub(nn0, p_w);
-        weight = b.lambda_w * w_plan + b.lambda_n * exp(-sqrt(dot3(dq, dq)) / b.nbr_scale);   // optimize.cpp:87-88
-        const D3 nv = normalized3(nrm);                            // optimize.cpp:93
+        weight = b.lambda_w * w_plan + b.lambda_n * exp(-sqrt(dot3(dq, dq)) * rcp_nr(b.nbr_scale));   // optimize.cpp:87-88
+        const D3 nv = normalized3_fast(nrm);                       // optimize.cpp:93
         const double off = -dot3(nv, nn0);                         // optimize.cpp:94
         const D3 pe = add(matvec(b.R, p_imu), d3(b.t[0], b.t[1], b.t[2]));
         dist = dot3(nv, pe) + off;                                 // optimize.cpp:95
