@@ -671,7 +671,7 @@ __device__ void eig3_jacobi(const double Ain[3][3], double ev[3], D3 &n0) {
     (void)i2;
 }
 
-// Closed-form symmetric 3x3 eigen-decomposition (trigonometric eigenvalues + cross-product eigenvector
+// Closed-form symmetric 3x3 eigen-decomposition (eigenvalues from the depressed cubic + cross-product eigenvector
 // of the smallest one): ~5x fewer FP64 instructions than the Jacobi sweeps above and no data-dependent
 // loop.  Same outputs (eigenvalues ascending, unit eigenvector of the smallest) to ~1e-13 relative for
 // the well-separated, near-planar neighbourhoods the path weights up; used by the fused kernel, the
@@ -692,9 +692,27 @@ __device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], 
     const double c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
     double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
     r = fmin(1.0, fmax(-1.0, r));
-    const double phi = acos(r) * 0.33333333333333333;
-    const double e2 = q + 2.0 * p * cos(phi);                                   // largest
-    const double e0 = q + 2.0 * p * cos(phi + 2.0943951023931954923084289221863);  // smallest (+ 2 pi / 3)
+    // Roots of 4 x^3 - 3 x = r (x = cos of the three angles of the trigonometric form) without acos / cos:
+    // Newton from -1 on the root y in [-1, -sqrt(3)/2] of 4 y^3 - 3 y = -|r| -- a simple root with f' >= 6 there,
+    // monotone convergence (f concave increasing), error 0.13 -> 4e-2 -> 3e-3 -> 1e-5 -> 4e-10 -> < 1e-16; the
+    // hardware reciprocal is enough for the step.  By symmetry y is the smallest root for r <= 0 and minus the largest
+    // root for r > 0; the quadratic gives the other two.
+    const double tneg = -fabs(r);
+    double y = -1.0;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const double y2 = y * y;
+        const double f = __builtin_fma(y, __builtin_fma(4.0, y2, -3.0), -tneg);
+        const double fp = __builtin_fma(12.0, y2, -3.0);
+        y = __builtin_fma(-f, __builtin_amdgcn_rcp(fp), y);
+    }
+    const double rho = (r <= 0.0) ? y : -y;                                  // a root of the cubic in x
+    const double sq = sqrt(fmax(0.0, 3.0 * __builtin_fma(-rho, rho, 1.0)));  // the other two: (-rho +- sq) / 2
+    const double xa = 0.5 * (-rho - sq), xb = 0.5 * (-rho + sq);
+    const double x_small = (r <= 0.0) ? rho : xa;
+    const double x_large = (r <= 0.0) ? xb : rho;
+    const double e2 = q + 2.0 * p * x_large;                                 // largest
+    const double e0 = q + 2.0 * p * x_small;                                 // smallest
     const double e1 = 3.0 * q - e0 - e2;
     ev[0] = e0; ev[1] = e1; ev[2] = e2;
     // null vector of (A - e0 I): the largest of the three row cross products
