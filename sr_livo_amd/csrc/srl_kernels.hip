@@ -677,6 +677,7 @@ __device__ void eig3_jacobi(const double Ain[3][3], double ev[3], D3 &n0) {
 // the well-separated, near-planar neighbourhoods the path weights up; used by the fused kernel, the
 // Jacobi version stays as the reference form (selected with select_mode 4, and used by the oracle).
 __device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], D3 &n0) {
+#pragma clang fp contract(fast)      // tolerance-bound arithmetic: let the products fuse
     const double a00 = A[0][0], a11 = A[1][1], a22 = A[2][2], a01 = A[0][1], a02 = A[0][2], a12 = A[1][2];
     const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
     const double q = (a00 + a11 + a22) * 0.33333333333333333;
@@ -925,6 +926,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
     const bool fit = (g < b.n) && (nf >= b.min_nb) && !(b.ablate & 1);
     // the butterflies need all four sub-lanes of a quad active together: `fit` is uniform inside a quad
     if (fit) {
+#pragma clang fp contract(fast)      // plane fit / weights / Jacobian are tolerance-bound (1e-9 vs the oracle): products may fuse
         const D3 p_imu = d3(s_pimu[kl * 3 + 0], s_pimu[kl * 3 + 1], s_pimu[kl * 3 + 2]);
         const D3 p_w = d3(s_pw[kl * 3 + 0], s_pw[kl * 3 + 1], s_pw[kl * 3 + 2]);
         // barycenter (optimize.cpp:320-325)
