@@ -855,14 +855,10 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
     // ---------------- phase 1: searchNeighbors, the whole wave on one keypoint at a time
     int n_fallback = 0;
     {
-        const LaneRole role0 = lane_role(lane);
-        ProbeReq preq;
-        int nv_pair = 0;
-        if constexpr (NB == 1 && FAST != 0) { if (!(a.ablate & 32)) preq = probe_issue(s_kv, 0, role0, a.table, a.table_mask, lane); }
-        for (int kl = 0; kl < SRL_KPW; ++kl) {
-            LaneRole role = role0;
+        const LaneRole role = lane_role(lane);
+        // one keypoint: fast path on its probed voxel list, general path otherwise
+        auto keypoint = [&](int kl, int nv_fast, VoxEnt *voxl) {
             const int g = wbase_kp + kl;
-            if (g >= a.n) break;
             const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
             LdsSink sink;
             sink.col = s_nb + kl;
@@ -870,20 +866,10 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
             sink.tap_ids = a.tap_ids ? (a.tap_ids + (size_t)g * a.K) : nullptr;
             int total = 0, fb = 0;
             bool done = false;
-            VoxEnt *voxl = vox;
             if constexpr (NB == 1 && FAST != 0) {
-                // hash lookups run for a PAIR of keypoints (one per half-wave) and one pair ahead, so their L2 round
-                // trip overlaps the selection of the current pair
-                if ((kl & 1) == 0) {
-                    const ProbeReq cur = preq;
-                    if (kl + 2 < SRL_KPW && !(a.ablate & 32)) preq = probe_issue(s_kv, kl + 2, role, a.table, a.table_mask, lane);
-                    nv_pair = (a.ablate & 8) ? 0 : probe_finish(cur, a.thr_cap, a.table, a.table_mask, vox, lane);
-                }
-                const int nv = (kl & 1) ? (nv_pair >> 8) : (nv_pair & 0xFF);
-                voxl = vox + 32 * (kl & 1);
-                if (a.ablate & 4) { done = true; total = nv; }
-                else if constexpr (FAST == 1) done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv, voxl, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
-                else done = select_topk_fast(qx, qy, qz, nv, voxl, a.slabs, a.K, surv, lane, role, sink, total);
+                if (a.ablate & 4) { done = true; total = nv_fast; }
+                else if constexpr (FAST == 1) done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv_fast, voxl, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
+                else done = select_topk_fast(qx, qy, qz, nv_fast, voxl, a.slabs, a.K, surv, lane, role, sink, total);
             }
             if (!done) {
                 const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, voxl, lane);
@@ -895,6 +881,25 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
                 s_nfound[kl] = total < a.K ? total : a.K;
                 s_ncand[kl] = total;
             }
+        };
+        const int n_here = __builtin_amdgcn_readfirstlane(a.n - wbase_kp);    // keypoints of this wave that exist (may be <= 0)
+        if constexpr (NB == 1 && FAST != 0) {
+            // hash lookups run for a PAIR of keypoints (one per half-wave) and one pair ahead, so their L2 round trip
+            // overlaps the selection of the current pair
+            ProbeReq preq;
+            if (!(a.ablate & 32)) preq = probe_issue(s_kv, 0, role, a.table, a.table_mask, lane);
+            for (int kp = 0; kp < SRL_KPW && kp < n_here; kp += 2) {
+                const ProbeReq cur = preq;
+                if (kp + 2 < SRL_KPW && !(a.ablate & 32)) preq = probe_issue(s_kv, kp + 2, role, a.table, a.table_mask, lane);
+                const int nv_pair = __builtin_amdgcn_readfirstlane((a.ablate & 8) ? 0 : probe_finish(cur, a.thr_cap, a.table, a.table_mask, vox, lane));
+#pragma nounroll
+                for (int h = 0; h < 2; ++h) {
+                    if (kp + h >= n_here) break;
+                    keypoint(kp + h, h ? (nv_pair >> 8) : (nv_pair & 0xFF), vox + 32 * h);
+                }
+            }
+        } else {
+            for (int kl = 0; kl < SRL_KPW && kl < n_here; ++kl) keypoint(kl, 0, vox);
         }
     }
     __builtin_amdgcn_wave_barrier();
