@@ -463,10 +463,9 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     if (coll) {
         // one ncclAllReduce of 49 doubles on the context's stream; last_visited sits behind the reduced range
         NCCLCHK(ctx, ncclAllReduce(ctx->d_out, ctx->d_out, n_red, ncclDouble, ncclSum, ctx->comm, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        visited_local = ctx->h_out->last_visited + 1;
-    } else if (mailbox) {
+        HIPCHK(ctx, srl_launch_publish(ctx->d_out, ctx->h_mail, ra.seq, ctx->stream));
+    }
+    if (coll || mailbox) {
         volatile unsigned long long *seqp = &ctx->h_mail->seq;
         unsigned long long spins = 0;
         while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != ra.seq) {

@@ -147,6 +147,7 @@ struct SrlSearchArgs {
 hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, hipStream_t s);
 hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s);
 hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, long long *out_total, hipStream_t s);
+hipError_t srl_launch_publish(const SrlDevOut *src, SrlMailbox *mb, unsigned long long seq, hipStream_t s);
 hipError_t srl_launch_search(const SrlSearchArgs &a, int nb_voxels, hipStream_t s);
 struct SrlXform { double R[9], t[3], R_il[9], t_il[3]; };
 hipError_t srl_launch_transform(const double *raw_aos, int n, const SrlXform &X, double *out_aos, hipStream_t s);

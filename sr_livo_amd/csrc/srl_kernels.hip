@@ -1297,6 +1297,23 @@ hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s) {
     return hipGetLastError();
 }
 
+// After the all-reduce: forward the reduced result (device memory) to the host-mapped mailbox, same protocol as the
+// single-rank reduce kernel -- the host spins on the sequence word instead of a D2H copy + stream synchronisation.
+__global__ void __launch_bounds__(64) srl_publish_kernel(const SrlDevOut *src, SrlMailbox *mb, unsigned long long seq) {
+    const int tid = threadIdx.x;
+    constexpr int NW = (int)(sizeof(SrlDevOut) / 8);
+    const unsigned long long *s = reinterpret_cast<const unsigned long long *>(src);
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(&mb->out);
+    if (tid < NW) __hip_atomic_store(d + tid, s[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t srl_launch_publish(const SrlDevOut *src, SrlMailbox *mb, unsigned long long seq, hipStream_t s) {
+    static_assert(sizeof(SrlDevOut) / 8 <= 64, "one wave publishes the result");
+    hipLaunchKernelGGL(srl_publish_kernel, dim3(1), dim3(64), 0, s, src, mb, seq);
+    return hipGetLastError();
+}
+
 hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, long long *out_total, hipStream_t s) {
     hipLaunchKernelGGL(srl_count_kernel, dim3(1), dim3(256), 0, s, binfo, nblocks, out_total);
     return hipGetLastError();
