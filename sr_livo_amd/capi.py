@@ -564,6 +564,27 @@ class Lio:
                        "update_iekf", ok=allow)
         return dict(rc=rc, state=st, iters=iters.value, num_residuals=nres.value, log=None if log is None else log[: iters.value])
 
+    def bound_solver(self, opts, eskf_state, eskf_cov, state, t_last, frame_id, n_resident):
+        """A zero-allocation closure for repeated solves of the resident sweep from the same prior (bench / replay
+        loops): every argument is converted once; each call = srl_lio_eskf_set_state + _set_cov + srl_lio_update_iekf.
+        Returns (status, iterations, residuals); the solved state is left in `solver.state`."""
+        es = _f64(eskf_state).copy(); ec = _f64(eskf_cov).ravel().copy()
+        st0 = _f64(state).copy(); st = st0.copy(); tl = _f64(t_last).copy()
+        iters, nres = C.c_int(), C.c_int()
+        lib, h = self.lib, self.h
+        p_es, p_ec, p_st, p_tl = _dptr(es), _dptr(ec), _dptr(st), _dptr(tl)
+        o = C.byref(opts); bi, bn = C.byref(iters), C.byref(nres)
+        set_state, set_cov, upd = lib.srl_lio_eskf_set_state, lib.srl_lio_eskf_set_cov, lib.srl_lio_update_iekf
+        fid, n = int(frame_id), int(n_resident)
+
+        def solve():
+            st[:] = st0
+            rc = set_state(h, p_es) or set_cov(h, p_ec) or upd(h, o, None, n, p_st, p_tl, fid, None, 0, bi, bn)
+            return rc, iters.value, nres.value
+        solve.state = st
+        solve._keep = (es, ec, st0, tl, opts)
+        return solve
+
     def update_iekf_provided(self, opts, provider, n, state, t_last, frame_id=100, log_iters=0,
                              allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):
         """provider(frame: Frame, opts: IcpOpts, out: NormalEq) -> int status."""
