@@ -348,6 +348,9 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     a.table_mask = ctx->table_cap - 1;
     a.slabs = ctx->d_slabs;
     a.inf_off = ctx->slab_cap * (unsigned)SRL_SLAB_BYTES;
+    // records {J, d, w} + status feed the ordered cut-off (optimize.cpp:107) and the parity taps only: 4 MB of stores per
+    // 64k sweep that the throughput configuration (max_num_residuals > number of keypoints) never reads
+    a.write_rec = (ctx->taps || o->max_num_residuals <= 0 || (long long)o->max_num_residuals <= (long long)ctx->total_n) ? 1 : 0;
     {
         const srl::Quat q(f->q[0], f->q[1], f->q[2], f->q[3]);
         const srl::Mat3 Rn = q.normalized().toRotationMatrix();    // optimize.cpp:35

@@ -83,6 +83,7 @@ struct SrlAssocArgs {
     const SrlMapSlot *table;
     unsigned table_mask;
     const unsigned char *slabs;
+    int write_rec;                     // per-keypoint records + status are needed (ordered cut-off can trigger, or taps); else skipped
     unsigned inf_off;                  // byte offset of the slab whose 20 points are (+inf, +inf, +inf): lanes without a candidate load from it
     // pose (computed on the host exactly like the reference: optimize.cpp:35 and :95)
     double Rn[9];       // end_quat.normalized().toRotationMatrix()

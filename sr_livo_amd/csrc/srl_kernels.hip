@@ -997,7 +997,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
             J[3] = s0 * weight; J[4] = s1 * weight; J[5] = s2 * weight;
         }
     }
-    if (g < b.n) {
+    if (g < b.n && b.write_rec) {
         // per-keypoint record {J[6], distance, weight} (ordered cut-off path + taps): the four lanes of a quad hold
         // identical values, so sub-lane s stores doubles 2s, 2s+1 -- one fully coalesced 16-B store per lane
         // (1 KB per wave) instead of eight scattered 8-B stores.
