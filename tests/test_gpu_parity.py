@@ -369,6 +369,37 @@ def test_rccl_single_rank_communicator(golden, monkeypatch):
             assert np.array_equal(np.array(g["neq"].Hth), np.array(base["neq"].Hth))
             assert g["neq"].num_residuals == base["neq"].num_residuals and g["neq"].last_visited == base["neq"].last_visited
             assert np.array_equal(g["status"], base["status"])
+            # park the communicator (bench.py's "replicas" leg), run unsharded, bring it back
+            ctx.comm_suspend(True)
+            assert ctx.sweep_shard()[1] == len(golden["raw"])
+            p = gpu_pass(ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=max_res)
+            assert np.array_equal(np.array(p["neq"].HtH), np.array(base["neq"].HtH))
+            ctx.comm_suspend(False)
+    finally:
+        ctx.close()
+
+
+def test_profiling_modes_report_consistent_kernel_times(golden):
+    """srl_set_profiling: mode 1 (four events + sync per call) and mode 2 (one lazily read event pair per association
+    launch) must count the same launches, the same algorithmic bytes, and kernel times of the same size."""
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        ctx.sweep_upload(golden["raw"])
+        f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+        opts = srl.default_opts(max_num_residuals=INT_MAX)
+        out = {}
+        for mode in (1, 2):
+            for _ in range(3):
+                ctx.build_residuals(f, opts)
+            ctx.set_profiling(mode)
+            for _ in range(600 if mode == 2 else 20):          # mode 2: more launches than the event ring holds
+                ctx.build_residuals(f, opts)
+            t = ctx.timing(); ctx.set_profiling(0)
+            out[mode] = (t.calls, t.sum_assoc_ms / t.calls, t.sum_algorithmic_bytes / t.calls)
+        assert out[1][0] == 20 and out[2][0] == 600
+        assert out[1][2] == out[2][2] > 0
+        assert 0.5 < out[1][1] / out[2][1] < 2.0 and out[2][1] > 0
     finally:
         ctx.close()
 
