@@ -146,6 +146,8 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->h_out) hipHostFree(ctx->h_out);
     if (ctx->h_count) hipHostFree(ctx->h_count);
     if (ctx->h_mail) hipHostFree(ctx->h_mail);
+    for (auto &b : ctx->pool_free) hipFree(b.p);
+    ctx->pool_free.clear();
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < srl_ctx::PROF_RING; i++) for (int k = 0; k < 2; k++) if (ctx->ring[i][k]) hipEventDestroy(ctx->ring[i][k]);
     if (ctx->stream) hipStreamDestroy(ctx->stream);

@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <string>
+#include <vector>
 
 struct srl_ctx {
     int device = 0;
@@ -75,6 +76,11 @@ struct srl_ctx {
     long long *d_gather = nullptr;     // nranks
 
     // timing
+    // scratch pool: device blocks handed out to the map-insert / frame pipeline calls and kept for the next call
+    // (hipMalloc / hipFree per call cost more than the kernels they serve; hipFree also synchronises the device)
+    struct PoolBlock { void *p; size_t bytes; };
+    std::vector<PoolBlock> pool_free;
+
     int profiling = 0;                 // 0 off, 1 full (4 events + sync per call), 2 light (assoc kernel only, read lazily)
     static constexpr int PROF_RING = 512;
     hipEvent_t ring[PROF_RING][2] = {};
@@ -111,3 +117,30 @@ int ensure(srl_ctx *ctx, T *&p, size_t count) {
     return SRL_OK;
 }
 
+// RAII scratch block from the context's pool (best fit, grow-only; everything is released by srl_ctx_destroy)
+struct DevBuf {
+    srl_ctx *ctx = nullptr;
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p && ctx) ctx->pool_free.push_back({p, bytes}); else if (p) hipFree(p); }
+    hipError_t alloc(srl_ctx *c, size_t want) {
+        ctx = c;
+        if (want < 256) want = 256;
+        int best = -1;
+        for (int i = 0; i < (int)c->pool_free.size(); i++)
+            if (c->pool_free[i].bytes >= want && (best < 0 || c->pool_free[i].bytes < c->pool_free[best].bytes)) best = i;
+        if (best >= 0 && c->pool_free[best].bytes <= 4 * want + (1u << 20)) {
+            p = c->pool_free[best].p; bytes = c->pool_free[best].bytes;
+            c->pool_free.erase(c->pool_free.begin() + best);
+            return hipSuccess;
+        }
+        const size_t cap = ((want + want / 4 + 255) / 256) * 256;
+        hipError_t e = hipMalloc(&p, cap);
+        bytes = (e == hipSuccess) ? cap : 0;
+        return e;
+    }
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};

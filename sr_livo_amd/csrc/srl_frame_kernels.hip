@@ -27,13 +27,6 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
 
 namespace {
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    template <class T> T *as() { return reinterpret_cast<T *>(p); }
-};
-
 struct Xf { double R[9], t[3], R_il[9], t_il[3]; };
 
 // point = R(q) * (R_il * raw + t_il) + t (utility.cpp:314-318), key = short(point / size) (utility.cpp:171-173)
@@ -259,7 +252,7 @@ int srl_frame_undistort(srl_ctx *ctx, const double *raw_xyz, const double *relat
     if (n == 0) { ctx->corr_n = 0; return SRL_OK; }
     hipStream_t st = ctx->stream;
     DevBuf b_states;
-    HIPCHK(ctx, b_states.alloc((size_t)n_states * sizeof(srl_imu_state)));
+    HIPCHK(ctx, b_states.alloc(ctx, (size_t)n_states * sizeof(srl_imu_state)));
     static_assert(sizeof(srl_imu_state) == 17 * sizeof(double), "srl_imu_state is 17 packed doubles");
     HIPCHK(ctx, hipMemcpyAsync(b_states.p, imu_states, (size_t)n_states * sizeof(srl_imu_state), hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_corr_in, raw_xyz, (size_t)n * 24, hipMemcpyHostToDevice, st));
@@ -323,7 +316,7 @@ int srl_frame_take(srl_ctx *ctx, const int32_t *index, int m) {
     ctx->frame_n = m;
     if (m > 0) {
         DevBuf b_sel;
-        HIPCHK(ctx, b_sel.alloc((size_t)m * 4));
+        HIPCHK(ctx, b_sel.alloc(ctx, (size_t)m * 4));
         HIPCHK(ctx, hipMemcpyAsync(b_sel.p, index, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_gather_aos, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_corr_raw, b_sel.as<int>(), m, ctx->d_frame_raw);
         HIPCHK(ctx, hipGetLastError());
@@ -365,10 +358,10 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         Xf X;
         fill_xf(X, q, t, R_il, t_il);
         DevBuf b_keys, b_keys2, b_idx, b_idx2, b_ukeys, b_len, b_start, b_nruns, b_first, b_tmp;
-        HIPCHK(ctx, b_keys.alloc((size_t)n * 8)); HIPCHK(ctx, b_keys2.alloc((size_t)n * 8));
-        HIPCHK(ctx, b_idx.alloc((size_t)n * 4)); HIPCHK(ctx, b_idx2.alloc((size_t)n * 4));
-        HIPCHK(ctx, b_ukeys.alloc((size_t)n * 8)); HIPCHK(ctx, b_len.alloc((size_t)n * 4)); HIPCHK(ctx, b_start.alloc((size_t)n * 4));
-        HIPCHK(ctx, b_first.alloc((size_t)n * 4)); HIPCHK(ctx, b_nruns.alloc(16));
+        HIPCHK(ctx, b_keys.alloc(ctx, (size_t)n * 8)); HIPCHK(ctx, b_keys2.alloc(ctx, (size_t)n * 8));
+        HIPCHK(ctx, b_idx.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_idx2.alloc(ctx, (size_t)n * 4));
+        HIPCHK(ctx, b_ukeys.alloc(ctx, (size_t)n * 8)); HIPCHK(ctx, b_len.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_start.alloc(ctx, (size_t)n * 4));
+        HIPCHK(ctx, b_first.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_nruns.alloc(ctx, 16));
         hipLaunchKernelGGL(k_frame_keys, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, n, X, sample_voxel_size,
                            (double *)nullptr, b_keys.as<unsigned long long>(), b_idx.as<unsigned>());
         HIPCHK(ctx, hipGetLastError());
@@ -381,7 +374,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         tmp_bytes = std::max(tmp_bytes, need);
         hipcub::DeviceScan::ExclusiveSum(nullptr, need, b_len.as<int>(), b_start.as<int>(), n, st);
         tmp_bytes = std::max(tmp_bytes, need) + 4096;
-        HIPCHK(ctx, b_tmp.alloc(tmp_bytes));
+        HIPCHK(ctx, b_tmp.alloc(ctx, tmp_bytes));
         size_t tb = tmp_bytes;
         HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
                                                        b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st));
@@ -430,7 +423,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
     if (rc) return rc;
     if (m > 0) {
         DevBuf b_sel;
-        HIPCHK(ctx, b_sel.alloc((size_t)m * 4));
+        HIPCHK(ctx, b_sel.alloc(ctx, (size_t)m * 4));
         HIPCHK(ctx, hipMemcpyAsync(b_sel.p, order.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_gather_soa, dim3((m + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, b_sel.as<int>(), m,
                            ctx->d_raw, ctx->d_raw + ctx->sweep_cap, ctx->d_raw + 2 * (size_t)ctx->sweep_cap);

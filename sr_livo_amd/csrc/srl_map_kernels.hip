@@ -139,13 +139,6 @@ __global__ void k_fill_empty(SrlMapSlot *table, unsigned cap) {
     table[i] = s;
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    template <class T> T *as() { return reinterpret_cast<T *>(p); }
-};
-
 unsigned next_pow2u(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return p; }
 
 }  // namespace
@@ -210,18 +203,18 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
     DevBuf b_xyz, b_keys, b_keys2, b_idx, b_idx2, b_ukeys, b_len, b_start, b_nruns, b_tmp;
     const double *d_xyz = world_xyz;
     if (!on_device) {
-        HIPCHK(ctx, b_xyz.alloc((size_t)n * 3 * sizeof(double)));
+        HIPCHK(ctx, b_xyz.alloc(ctx, (size_t)n * 3 * sizeof(double)));
         HIPCHK(ctx, hipMemcpyAsync(b_xyz.p, world_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
         d_xyz = b_xyz.as<double>();
     }
-    HIPCHK(ctx, b_keys.alloc((size_t)n * 8));
-    HIPCHK(ctx, b_keys2.alloc((size_t)n * 8));
-    HIPCHK(ctx, b_idx.alloc((size_t)n * 4));
-    HIPCHK(ctx, b_idx2.alloc((size_t)n * 4));
-    HIPCHK(ctx, b_ukeys.alloc((size_t)n * 8));
-    HIPCHK(ctx, b_len.alloc((size_t)n * 4));
-    HIPCHK(ctx, b_start.alloc((size_t)n * 4));
-    HIPCHK(ctx, b_nruns.alloc(16));
+    HIPCHK(ctx, b_keys.alloc(ctx, (size_t)n * 8));
+    HIPCHK(ctx, b_keys2.alloc(ctx, (size_t)n * 8));
+    HIPCHK(ctx, b_idx.alloc(ctx, (size_t)n * 4));
+    HIPCHK(ctx, b_idx2.alloc(ctx, (size_t)n * 4));
+    HIPCHK(ctx, b_ukeys.alloc(ctx, (size_t)n * 8));
+    HIPCHK(ctx, b_len.alloc(ctx, (size_t)n * 4));
+    HIPCHK(ctx, b_start.alloc(ctx, (size_t)n * 4));
+    HIPCHK(ctx, b_nruns.alloc(ctx, 16));
     hipLaunchKernelGGL(k_point_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, voxel_size,
                        b_keys.as<unsigned long long>(), b_idx.as<unsigned>());
     HIPCHK(ctx, hipGetLastError());
@@ -237,7 +230,7 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
     hipcub::DeviceScan::ExclusiveSum(nullptr, need, b_len.as<int>(), b_start.as<int>(), n, st);
     tmp_bytes = std::max(tmp_bytes, need);
     tmp_bytes += 4096;
-    HIPCHK(ctx, b_tmp.alloc(tmp_bytes));
+    HIPCHK(ctx, b_tmp.alloc(ctx, tmp_bytes));
     size_t tb = tmp_bytes;
     HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
                                                    b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st));
@@ -261,14 +254,14 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
     const unsigned mask = ctx->table_cap - 1;
 
     DevBuf b_slot, b_isnew, b_first, b_first2, b_seg, b_seg2, b_nsel, b_added;
-    HIPCHK(ctx, b_slot.alloc((size_t)S * 4));
-    HIPCHK(ctx, b_isnew.alloc((size_t)S));
-    HIPCHK(ctx, b_first.alloc((size_t)S * 4));
-    HIPCHK(ctx, b_first2.alloc((size_t)S * 4));
-    HIPCHK(ctx, b_seg.alloc((size_t)S * 4));
-    HIPCHK(ctx, b_seg2.alloc((size_t)S * 4));
-    HIPCHK(ctx, b_nsel.alloc(16));
-    HIPCHK(ctx, b_added.alloc(16));
+    HIPCHK(ctx, b_slot.alloc(ctx, (size_t)S * 4));
+    HIPCHK(ctx, b_isnew.alloc(ctx, (size_t)S));
+    HIPCHK(ctx, b_first.alloc(ctx, (size_t)S * 4));
+    HIPCHK(ctx, b_first2.alloc(ctx, (size_t)S * 4));
+    HIPCHK(ctx, b_seg.alloc(ctx, (size_t)S * 4));
+    HIPCHK(ctx, b_seg2.alloc(ctx, (size_t)S * 4));
+    HIPCHK(ctx, b_nsel.alloc(ctx, 16));
+    HIPCHK(ctx, b_added.alloc(ctx, 16));
     HIPCHK(ctx, hipMemsetAsync(b_added.p, 0, 16, st));
     hipLaunchKernelGGL(k_lookup, dim3((S + 255) / 256), dim3(256), 0, st, b_ukeys.as<unsigned long long>(), b_start.as<int>(),
                        b_idx2.as<unsigned>(), S, ctx->d_table, mask, b_slot.as<int>(), b_isnew.as<unsigned char>(), b_first.as<unsigned>());
@@ -278,7 +271,7 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
     if (min_num_points <= 0) {
         // new voxels, ranked by the index of their first point = creation order of the sequential loop
         DevBuf b_tmp2, b_newfirst;
-        HIPCHK(ctx, b_newfirst.alloc((size_t)S * 4));
+        HIPCHK(ctx, b_newfirst.alloc(ctx, (size_t)S * 4));
         hipcub::CountingInputIterator<int> seg_ids(0);
         size_t need2 = 0, t2 = 0;
         hipcub::DeviceSelect::Flagged(nullptr, need2, seg_ids, b_isnew.as<unsigned char>(), b_seg.as<int>(), b_nsel.as<int>(), S, st);
@@ -287,7 +280,7 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
         t2 = std::max(t2, need2);
         hipcub::DeviceRadixSort::SortPairs(nullptr, need2, b_newfirst.as<unsigned>(), b_first2.as<unsigned>(), b_seg.as<int>(), b_seg2.as<int>(), S, 0, 32, st);
         t2 = std::max(t2, need2) + 4096;
-        HIPCHK(ctx, b_tmp2.alloc(t2));
+        HIPCHK(ctx, b_tmp2.alloc(ctx, t2));
         size_t tt = t2;
         HIPCHK(ctx, hipcub::DeviceSelect::Flagged(b_tmp2.p, tt, seg_ids, b_isnew.as<unsigned char>(), b_seg.as<int>(), b_nsel.as<int>(), S, st));
         tt = t2;
