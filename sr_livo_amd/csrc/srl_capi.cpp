@@ -324,10 +324,8 @@ int srl_get_timing(srl_ctx *ctx, srl_timing *t) {
 }
 
 // ------------------------------------------------------------------------------------------ hot path
-int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, srl_normal_eq *out) {
-    if (!ctx || !f || !o || !out) return SRL_ERR_BAD_ARG;
-    if (!ctx->d_table) return SRL_ERR_NO_MAP;
-    if (ctx->total_n <= 0 && ctx->n <= 0) return SRL_ERR_NO_SWEEP;
+// one association + reduction pass over the first n_eff keypoints of this rank's shard (n_eff == ctx->n: all of them)
+static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, srl_normal_eq *out, int n_eff) {
     const auto t_entry = std::chrono::steady_clock::now();
     HIPCHK(ctx, hipSetDevice(ctx->device));
 
@@ -345,7 +343,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     a.raw_x = ctx->d_raw;
     a.raw_y = ctx->d_raw + ctx->sweep_cap;
     a.raw_z = ctx->d_raw + 2 * (size_t)ctx->sweep_cap;
-    a.n = ctx->n;
+    a.n = n_eff;
     a.table = ctx->d_table;
     a.table_mask = ctx->table_cap - 1;
     a.slabs = ctx->d_slabs;
@@ -401,7 +399,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
             HIPCHK(ctx, hipMemsetAsync(ctx->d_tap_offset, 0, (size_t)ctx->n * sizeof(double), ctx->stream));
         }
     }
-    const int nblocks = (ctx->n + SRL_KPB - 1) / SRL_KPB;
+    const int nblocks = (n_eff + SRL_KPB - 1) / SRL_KPB;
     const bool prof = ctx->profiling == 1;
     const bool prof_light = ctx->profiling == 2;
     hipEvent_t *ring_ev = nullptr;
@@ -449,7 +447,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     ra.status = ctx->d_status;
     ra.partials = ctx->d_partials;
     ra.binfo = ctx->d_binfo;
-    ra.n = ctx->n;
+    ra.n = n_eff;
     ra.nblocks = nblocks;
     ra.max_res = budget;
     ra.out = ctx->d_out;
@@ -522,7 +520,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         ctx->timing.sum_assoc_ms += ctx->timing.assoc_ms;
         ctx->timing.sum_reduce_ms += ctx->timing.reduce_ms;
         ctx->timing.sum_total_ms += ctx->timing.total_ms;
-        ctx->timing.sum_keypoints += ctx->n;
+        ctx->timing.sum_keypoints += n_eff;
         const auto t_end = std::chrono::steady_clock::now();
         ctx->timing.sum_host_launch_us += std::chrono::duration<double, std::micro>(t_enq - t_entry).count();
         ctx->timing.sum_host_wait_us += std::chrono::duration<double, std::micro>(t_res - t_enq).count();
@@ -534,8 +532,8 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         const long long side = 2 * nb + 1;
         const long long per_kp = 24 + 12 * side * side * side;
         const double pk_share = (ctx->nranks > 1 && ctx->total_n > 0) ? r.d_sum_pk * ((double)ctx->n / (double)ctx->total_n) : r.d_sum_pk;
-        ctx->timing.algorithmic_bytes = per_kp * (long long)ctx->n + (long long)(12.0 * pk_share);
-        if (prof || prof_light) { ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes; ctx->timing.sum_keypoints += prof_light ? ctx->n : 0; }
+        ctx->timing.algorithmic_bytes = per_kp * (long long)n_eff + (long long)(12.0 * pk_share);
+        if (prof || prof_light) { ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes; ctx->timing.sum_keypoints += prof_light ? n_eff : 0; }
     }
     if (out->nan_error) { ctx->err = "NaN planarity"; return SRL_ERR_NAN_PLANARITY; }
     return SRL_OK;
@@ -655,6 +653,27 @@ void srl_shard_budget(int max_num_residuals, const int64_t *accepted_per_rank, i
     }
     if (budget) *budget = b;
     if (mode) *mode = m;
+}
+
+int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, srl_normal_eq *out) {
+    if (!ctx || !f || !o || !out) return SRL_ERR_BAD_ARG;
+    if (!ctx->d_table) return SRL_ERR_NO_MAP;
+    if (ctx->total_n <= 0 && ctx->n <= 0) return SRL_ERR_NO_SWEEP;
+    // Finite max_num_residuals (600 in the shipped yaml files): the sequential loop of optimize.cpp:68-107 stops at the
+    // max-th accepted keypoint and never looks at the rest, so a single rank first runs only a prefix that almost surely
+    // contains it (4 x max + 2048 keypoints; ~95 % of visited keypoints are accepted).  If the prefix holds fewer accepted
+    // keypoints than max, nothing can be concluded and the pass is repeated over the whole shard.  Results are identical
+    // to the full pass either way (same workgroups, same partials, same cut).  Taps keep the full pass.
+    int n_eff = ctx->n;
+    const bool single = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
+    if (single && !ctx->taps && o->max_num_residuals > 0) {
+        const long long pre = ((4LL * o->max_num_residuals + 2048 + SRL_KPB - 1) / SRL_KPB) * SRL_KPB;
+        if (pre < (long long)ctx->n) n_eff = (int)pre;
+    }
+    int rc = build_residuals_pass(ctx, f, o, out, n_eff);
+    if ((rc == SRL_OK || rc == SRL_ERR_NAN_PLANARITY) && n_eff < ctx->n && out->num_residuals < o->max_num_residuals)
+        rc = build_residuals_pass(ctx, f, o, out, ctx->n);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------ comm

@@ -404,6 +404,37 @@ def test_profiling_modes_report_consistent_kernel_times(golden):
         ctx.close()
 
 
+def test_prefix_pass_for_finite_max_num_residuals(oracle_lib, scene100k):
+    """max_num_residuals = 600 (the shipped yaml value) on a 20k-keypoint sweep: without taps the context runs only a
+    prefix of the sweep (4 x 600 + 2048 keypoints) -- the result must be the one of the full pass, bit for bit, and the
+    oracle's; when the prefix cannot hold 600 accepted keypoints (its keypoints see no map) the full pass is taken."""
+    m = scene100k["map"]
+    sw = synth.make_sweep(77, 20_000, scene100k["L"])
+    far = sw["raw"].copy(); far[:6000] += np.array([0.0, 0.0, 500.0])      # the first 6000 keypoints find no neighbours
+    ctx = srl.Context(0)
+    try:
+        ctx.map_insert(scene100k["candidates"])
+        for raw in (sw["raw"], far):
+            for max_res in (600, 37):
+                full = gpu_pass(ctx, raw, sw["q_pred"], sw["t_pred"], sw["t_last"], max_num_residuals=max_res)     # taps on: full pass
+                opts = srl.default_opts(max_num_residuals=max_res)
+                ctx.sweep_upload(raw)
+                ctx.set_profiling(1)
+                neq, rc = ctx.build_residuals(capi.make_frame(sw["q_pred"], sw["t_pred"], sw["t_last"]), opts)
+                t = ctx.timing(); ctx.set_profiling(0)
+                assert rc == 0 and neq.num_residuals == full["neq"].num_residuals == max_res
+                assert neq.last_visited == full["neq"].last_visited
+                assert np.array_equal(np.array(neq.HtH), np.array(full["neq"].HtH))
+                assert np.array_equal(np.array(neq.Hth), np.array(full["neq"].Hth)) and neq.loss_sum == full["neq"].loss_sum
+                # one prefix pass when it suffices; prefix + full pass when it does not
+                pre = -(-(4 * max_res + 2048) // 64) * 64
+                assert (t.calls, t.sum_keypoints) == ((1, pre) if raw is sw["raw"] else (2, pre + len(raw)))
+                o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=max_res), raw, sw["q_pred"], sw["t_pred"], sw["t_last"], full=False)
+                assert o["neq"].num_residuals == neq.num_residuals and rel(np.array(neq.HtH).reshape(6, 6), o["HtH"]) < TIGHT
+    finally:
+        ctx.close()
+
+
 # ----------------------------------------------------------------------------- class-surface forms
 def test_signature_compatible_build_plane_residuals(golden):
     lio = srl.Lio(0)
