@@ -32,7 +32,8 @@ unsigned next_pow2(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return p
 int ensure_work(srl_ctx *ctx, int n) {
     if (n <= ctx->work_cap) return SRL_OK;
     const int cap = std::max(n, 1024);
-    const int nblocks = (cap + SRL_KPB - 1) / SRL_KPB;
+    // small passes use 16 or 32 keypoints per workgroup (srl_keypoints_per_block): size for whichever gives more workgroups
+    const int nblocks = std::max((cap + SRL_KPB - 1) / SRL_KPB, 1024 + 8);
     int rc;
     if ((rc = ensure(ctx, ctx->d_rec, (size_t)cap * 8))) return rc;
     if ((rc = ensure(ctx, ctx->d_status, (size_t)cap))) return rc;
@@ -399,7 +400,8 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             HIPCHK(ctx, hipMemsetAsync(ctx->d_tap_offset, 0, (size_t)ctx->n * sizeof(double), ctx->stream));
         }
     }
-    const int nblocks = (n_eff + SRL_KPB - 1) / SRL_KPB;
+    const int kpb = srl_keypoints_per_block(n_eff);
+    const int nblocks = (n_eff + kpb - 1) / kpb;
     const bool prof = ctx->profiling == 1;
     const bool prof_light = ctx->profiling == 2;
     hipEvent_t *ring_ev = nullptr;
@@ -410,7 +412,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
 
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (prof_light) HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
-    HIPCHK(ctx, srl_launch_assoc(a, nb, ctx->stream));
+    HIPCHK(ctx, srl_launch_assoc(a, nb, kpb, ctx->stream));
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if (prof_light) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_head++; }
 
@@ -448,6 +450,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     ra.partials = ctx->d_partials;
     ra.binfo = ctx->d_binfo;
     ra.n = n_eff;
+    ra.kpb = kpb;
     ra.nblocks = nblocks;
     ra.max_res = budget;
     ra.out = ctx->d_out;
@@ -662,12 +665,13 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     // Finite max_num_residuals (600 in the shipped yaml files): the sequential loop of optimize.cpp:68-107 stops at the
     // max-th accepted keypoint and never looks at the rest, so a single rank first runs only a prefix that almost surely
     // contains it (4 x max + 2048 keypoints; ~95 % of visited keypoints are accepted).  If the prefix holds fewer accepted
-    // keypoints than max, nothing can be concluded and the pass is repeated over the whole shard.  Results are identical
-    // to the full pass either way (same workgroups, same partials, same cut).  Taps keep the full pass.
+    // keypoints than max, nothing can be concluded and the pass is repeated over the whole shard.  Same accepted set and
+    // same cut as the full pass; the sums agree up to FP64 summation order (a short pass uses fewer keypoints per
+    // workgroup, srl_keypoints_per_block).  Taps keep the full pass.
     int n_eff = ctx->n;
     const bool single = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
     if (single && !ctx->taps && o->max_num_residuals > 0) {
-        const long long pre = ((4LL * o->max_num_residuals + 2048 + SRL_KPB - 1) / SRL_KPB) * SRL_KPB;
+        const long long pre = ((4LL * o->max_num_residuals + 2048 + 63) / 64) * 64;
         if (pre < (long long)ctx->n) n_eff = (int)pre;
     }
     int rc = build_residuals_pass(ctx, f, o, out, n_eff);

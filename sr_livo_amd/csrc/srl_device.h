@@ -127,6 +127,7 @@ struct SrlReduceArgs {
     SrlDevOut *out;             // device result (multi-rank: all-reduced afterwards) ...
     SrlMailbox *mailbox;        // ... or, single rank: host-mapped mailbox written with system-scope stores (no memcpy)
     unsigned long long seq;
+    int kpb;                    // keypoints per workgroup of the association pass that produced the partials
 };
 
 struct SrlSearchArgs {
@@ -145,7 +146,9 @@ struct SrlSearchArgs {
 };
 
 // launchers (srl_kernels.hip)
-hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, hipStream_t s);
+hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpb, hipStream_t s);
+// keypoints per workgroup for a pass over n keypoints: the largest of 16 / 32 / 64 that still yields >= ~1024 workgroups
+static inline int srl_keypoints_per_block(int n) { return n <= 16384 ? 16 : (n <= 32768 ? 32 : SRL_KPB); }
 hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s);
 hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, long long *out_total, hipStream_t s);
 hipError_t srl_launch_publish(const SrlDevOut *src, SrlMailbox *mb, unsigned long long seq, hipStream_t s);

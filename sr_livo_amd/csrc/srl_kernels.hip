@@ -733,24 +733,26 @@ __device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], 
 
 // dynamic LDS carve (all offsets multiples of 16; guide G17).  Every wave owns its 16 keypoints from
 // transform to partial normal equations, so all areas below are PER WAVE (no block barrier until the end).
-#define SRL_KPW (SRL_KPB / 4)      // keypoints per wave
-#define NB_ROW (SRL_KPW + 1)       // row stride (floats) of the neighbour planes
+// keypoints per wave KPW in {4, 8, 16} (template parameter of the kernel): 16 amortises the per-wave phases best and is
+// used for large sweeps; small sweeps take fewer keypoints per wave so that the grid still fills the chip and the serial
+// chain of a wave is short (latency, not throughput, is what a 3k-keypoint sweep pays for).
 struct LdsLayout {
     int wave_bytes;                // per-wave region size
     int off_nb, off_pw, off_pimu, off_kv, off_nfound, off_ncand, off_vox, off_scratch, off_qf;   // offsets inside a wave region
     int off_wpart, off_winfo, total;                                                      // block-level tail
 };
-__host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels) {
+__host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw) {
+    const int nb_row = kpw + 1;          // row stride (floats) of the neighbour planes
     LdsLayout L;
     int o = 0;
-    L.off_nb = o;      o += ((3 * K * NB_ROW * 4 + 15) / 16) * 16;   // planes x | y | z, K rows of NB_ROW floats
+    L.off_nb = o;      o += ((3 * K * nb_row * 4 + 15) / 16) * 16;   // planes x | y | z, K rows of nb_row floats
     auto up16 = [](int x) { return (x + 15) & ~15; };
-    L.off_pw = o;      o += up16(SRL_KPW * 3 * 8);
-    L.off_pimu = o;    o += up16(SRL_KPW * 3 * 8);
-    L.off_qf = o;      o += up16(SRL_KPW * 8 * 4);                 // per keypoint: FP32 query (3), prefilter margin coefficients (2), pad
-    L.off_kv = o;      o += up16((SRL_KPW + 1) * 4 * 4);           // + one zero entry: the pair probe of an odd KPW reads it
-    L.off_nfound = o;  o += up16(SRL_KPW * 4);
-    L.off_ncand = o;   o += up16(SRL_KPW * 4);
+    L.off_pw = o;      o += up16(kpw * 3 * 8);
+    L.off_pimu = o;    o += up16(kpw * 3 * 8);
+    L.off_qf = o;      o += up16(kpw * 8 * 4);                 // per keypoint: FP32 query (3), prefilter margin coefficients (2), pad
+    L.off_kv = o;      o += up16((kpw + 1) * 4 * 4);           // + one zero entry: the pair probe of an odd KPW reads it
+    L.off_nfound = o;  o += up16(kpw * 4);
+    L.off_ncand = o;   o += up16(kpw * 4);
     L.off_vox = o;     o += (nb_voxels == 1 ? 64 : 128) * 8;     // r = 1: two 32-entry lists (a keypoint pair is probed at once)
     L.off_scratch = o; o += SRL_WAVE_SCRATCH;
     L.wave_bytes = o;
@@ -761,11 +763,12 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels) {
 }
 
 struct LdsSink {
-    float *col;         // &nbx[0][kl]; planes x | y | z, each K rows of NB_ROW floats
-    int plane;          // K * NB_ROW
+    float *col;         // &nbx[0][kl]; planes x | y | z, each K rows of `row` floats
+    int row;            // KPW + 1
+    int plane;          // K * row
     int *tap_ids;       // global row or null
     __device__ __forceinline__ void put(int rank, float x, float y, float z, unsigned id) {
-        float *p = col + rank * NB_ROW;
+        float *p = col + rank * row;
         p[0] = x;
         p[plane] = y;
         p[2 * plane] = z;
@@ -789,10 +792,11 @@ __device__ __forceinline__ double kp_sum(double v) {
 }
 
 // FAST: 0 = general path only, 1 = FP32-prefilter fast path, 2 = FP64-retained fast path (r = 1 only)
-template <int NB, int FAST>
+template <int NB, int FAST, int KPW>
 __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc_kernel(const SrlAssocArgs a) {
+    constexpr int NB_ROW = KPW + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayout L = lds_layout(a.K, NB);
+    const LdsLayout L = lds_layout(a.K, NB, KPW);
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wave = tid >> 6;
@@ -810,11 +814,11 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
     double *s_wpart = reinterpret_cast<double *>(smem + L.off_wpart);     // [4][32]
     int *s_winfo = reinterpret_cast<int *>(smem + L.off_winfo);           // [4][4]: accepted, sum_pk, nan, fallback
 
-    const int wbase_kp = blockIdx.x * SRL_KPB + wave * SRL_KPW;           // first keypoint of this wave
+    const int wbase_kp = blockIdx.x * (4 * KPW) + wave * KPW;           // first keypoint of this wave
     if (a.ablate & 16) return;                                            // debug: launch/drain floor
 
     // ---------------- phase 0: transformKeypoints (optimize.cpp:30-40), location (optimize.cpp:83), voxel key
-    if (lane < SRL_KPW) {
+    if (lane < KPW) {
         const int g = wbase_kp + lane;
         D3 p_imu = d3(0, 0, 0), p_w = d3(0, 0, 0);
         if (g < a.n) {
@@ -847,7 +851,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
         s_kv[lane * 4 + 2] = (int)(short)(int)(unit ? p_w.z : p_w.z / a.size_voxel);
         s_nfound[lane] = 0;
         s_ncand[lane] = 0;
-    } else if (lane == SRL_KPW) {
+    } else if (lane == KPW) {
         s_kv[lane * 4 + 0] = 0; s_kv[lane * 4 + 1] = 0; s_kv[lane * 4 + 2] = 0;
     }
     __builtin_amdgcn_wave_barrier();
@@ -862,6 +866,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
             const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
             LdsSink sink;
             sink.col = s_nb + kl;
+            sink.row = NB_ROW;
             sink.plane = nb_plane;
             sink.tap_ids = a.tap_ids ? (a.tap_ids + (size_t)g * a.K) : nullptr;
             int total = 0, fb = 0;
@@ -888,9 +893,9 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
             // overlaps the selection of the current pair
             ProbeReq preq;
             if (!(a.ablate & 32)) preq = probe_issue(s_kv, 0, role, a.table, a.table_mask, lane);
-            for (int kp = 0; kp < SRL_KPW && kp < n_here; kp += 2) {
+            for (int kp = 0; kp < KPW && kp < n_here; kp += 2) {
                 const ProbeReq cur = preq;
-                if (kp + 2 < SRL_KPW && !(a.ablate & 32)) preq = probe_issue(s_kv, kp + 2, role, a.table, a.table_mask, lane);
+                if (kp + 2 < KPW && !(a.ablate & 32)) preq = probe_issue(s_kv, kp + 2, role, a.table, a.table_mask, lane);
                 const int nv_pair = __builtin_amdgcn_readfirstlane((a.ablate & 8) ? 0 : probe_finish(cur, a.thr_cap, a.table, a.table_mask, vox, lane));
 #pragma nounroll
                 for (int h = 0; h < 2; ++h) {
@@ -899,7 +904,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
                 }
             }
         } else {
-            for (int kl = 0; kl < SRL_KPW && kl < n_here; ++kl) keypoint(kl, 0, vox);
+            for (int kl = 0; kl < KPW && kl < n_here; ++kl) keypoint(kl, 0, vox);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -919,8 +924,8 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
     // Sub-lane s accumulates neighbours s, s+4, ...; quad butterflies make the sums identical in the 4 lanes,
     // which then run the (scalar) eigen-solve / weights redundantly and split the 28 H^T H / H^T h / loss
     // products between them (7 each) before the sum over keypoints.
-    const int kl = (lane >> 2) < SRL_KPW ? (lane >> 2) : (SRL_KPW - 1), sl = lane & 3;
-    const bool owner_lane = (lane >> 2) < SRL_KPW;          // KPW < 16: the upper quads idle through phase 2
+    const int kl = (lane >> 2) < KPW ? (lane >> 2) : (KPW - 1), sl = lane & 3;
+    const bool owner_lane = (lane >> 2) < KPW;          // KPW < 16: the upper quads idle through phase 2
     const int g = owner_lane ? wbase_kp + kl : b.n;
     int status = 3;
     bool nan_bad = false;
@@ -1038,14 +1043,14 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
             else { ia = 7; ib = 7; }
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < SRL_KPW; ++k) acc += s_row[k * 8 + ia] * s_row[k * 8 + ib];
+            for (int k = 0; k < KPW; ++k) acc += s_row[k * 8 + ia] * s_row[k * 8 + ib];
             s_wpart[wave * 32 + lane] = acc;
         }
     }
     {
         const unsigned long long acc_mask = __ballot(status == 2 && sl == 0);
         const unsigned long long nan_mask = __ballot(nan_bad);
-        int pk = (lane < SRL_KPW && wbase_kp + lane < b.n) ? s_ncand[lane] : 0;
+        int pk = (lane < KPW && wbase_kp + lane < b.n) ? s_ncand[lane] : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
         if (lane == 0) {
@@ -1131,8 +1136,8 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
             cut_block = b;
             allowed = (int)(a.max_res - before);
             int seen = 0;
-            int k = b * SRL_KPB;
-            const int kend = (k + SRL_KPB < a.n) ? k + SRL_KPB : a.n;
+            int k = b * a.kpb;
+            const int kend = (k + a.kpb < a.n) ? k + a.kpb : a.n;
             for (; k < kend; ++k) { if (a.status[k] == 2) { ++seen; if (seen == allowed) break; } }
             last_visited = k;
             num_res = a.max_res;
@@ -1180,7 +1185,7 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
             if (tid < 21) { int c = tid; int rowlen = 6; while (c >= rowlen) { c -= rowlen; ia++; rowlen--; } ib = ia + c; }
             else if (tid < 27) ia = tid - 21;
             double accd = 0.0;
-            for (int k = cut_block * SRL_KPB; k <= last_visited; ++k) {
+            for (int k = cut_block * a.kpb; k <= last_visited; ++k) {
                 if (a.status[k] != 2) continue;
                 const double *r = a.rec + (size_t)k * 8;
                 if (tid < 21) accd += r[ia] * r[ib];
@@ -1278,18 +1283,25 @@ __global__ void srl_aos_to_soa_kernel(const double *aos, int n, double *x, doubl
 
 }  // namespace
 
-hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, hipStream_t s) {
-    if (a.n <= 0) return hipSuccess;
-    const int nblocks = (a.n + SRL_KPB - 1) / SRL_KPB;
-    const LdsLayout L = lds_layout(a.K, nb_voxels);
+template <int KPW>
+static hipError_t launch_assoc_kpw(const SrlAssocArgs &a, int nb_voxels, hipStream_t s) {
+    const int nblocks = (a.n + 4 * KPW - 1) / (4 * KPW);
+    const LdsLayout L = lds_layout(a.K, nb_voxels, KPW);
     if (nb_voxels == 1) {
-        if (a.select_mode == 0 || a.select_mode == 4) hipLaunchKernelGGL((srl_assoc_kernel<1, 1>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
-        else if (a.select_mode == 3) hipLaunchKernelGGL((srl_assoc_kernel<1, 2>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
-        else hipLaunchKernelGGL((srl_assoc_kernel<1, 0>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+        if (a.select_mode == 0 || a.select_mode == 4) hipLaunchKernelGGL((srl_assoc_kernel<1, 1, KPW>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+        else if (a.select_mode == 3) hipLaunchKernelGGL((srl_assoc_kernel<1, 2, KPW>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+        else hipLaunchKernelGGL((srl_assoc_kernel<1, 0, KPW>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
     } else {
-        hipLaunchKernelGGL((srl_assoc_kernel<2, 0>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+        hipLaunchKernelGGL((srl_assoc_kernel<2, 0, KPW>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
     }
     return hipGetLastError();
+}
+// kpb = keypoints per workgroup (srl_keypoints_per_block): 64, 32 or 16
+hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpb, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    if (kpb == 16) return launch_assoc_kpw<4>(a, nb_voxels, s);
+    if (kpb == 32) return launch_assoc_kpw<8>(a, nb_voxels, s);
+    return launch_assoc_kpw<16>(a, nb_voxels, s);
 }
 
 hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s) {
