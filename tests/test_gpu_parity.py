@@ -436,6 +436,33 @@ def test_prefix_pass_for_finite_max_num_residuals(oracle_lib, scene100k):
         ctx.close()
 
 
+def test_volumetric_map_all_27_voxels_occupied(oracle_lib, oracle_backend):
+    """A map that fills space (not surfaces): every one of the 27 probed voxels is occupied and full, so the fast path
+    runs its 9-round instance, the survivor set is large, and min-distance pruning shapes the slabs.  Ids, status and
+    normal equations against the oracle, for the default K = 20 and for K = 32 (more than 32 survivors: long rank loop)."""
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-6.0, 6.0, (400_000, 3))                     # ~230 candidates per 1 m voxel: all voxels saturate at 20
+    raw = rng.uniform(-4.0, 4.0, (6000, 3))
+    q = synth.quat_from_rotvec([0.01, -0.02, 0.03]); t = np.array([0.1, -0.05, 0.02]); t_last = t - 0.01
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(pts)
+    ctx = srl.Context(0)
+    try:
+        assert ctx.map_insert(pts) == m.size()
+        for K in (20, 32):
+            kw = dict(max_number_neighbors=K, min_number_neighbors=min(K, 20), max_num_residuals=INT_MAX)
+            g = gpu_pass(ctx, raw, q, t, t_last, **kw)
+            o = m.build_plane_residuals(oracle_lib.default_opts(**kw), raw, q, t, t_last)
+            assert o["neq"].num_ties == 0
+            assert int(g["ncand"].min()) == 27 * 20                 # every probed voxel present and full
+            assert np.array_equal(g["status"], o["status"]) and np.array_equal(g["ids"], o["ids"])
+            assert g["neq"].num_residuals == o["neq"].num_residuals
+            assert rel(np.array(g["neq"].HtH).reshape(6, 6), o["HtH"]) < TIGHT and rel(np.array(g["neq"].Hth), o["Hth"]) < TIGHT
+            assert g["neq"].num_fallback == 0 or K == 32
+    finally:
+        ctx.close()
+
+
 # ----------------------------------------------------------------------------- class-surface forms
 def test_signature_compatible_build_plane_residuals(golden):
     lio = srl.Lio(0)
