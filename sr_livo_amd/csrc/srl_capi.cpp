@@ -317,6 +317,17 @@ int srl_set_profiling(srl_ctx *ctx, int enable) {
     return SRL_OK;
 }
 
+// debug (SRL_ABLATE=128): per-workgroup {start, end, xcc} stamps of the last association launch, 100 MHz ticks
+extern "C" int srl_debug_block_times(srl_ctx *ctx, double *out, int max_blocks, int *nblocks) {
+    if (!ctx || !out || !nblocks) return SRL_ERR_BAD_ARG;
+    const int nb = std::min(max_blocks, ctx->last_nblocks);
+    std::vector<double> tmp((size_t)nb * SRL_PART_STRIDE);
+    HIPCHK(ctx, hipMemcpy(tmp.data(), ctx->d_partials, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int b = 0; b < nb; b++) for (int k = 0; k < 3; k++) out[(size_t)b * 3 + k] = tmp[(size_t)b * SRL_PART_STRIDE + 28 + k];
+    *nblocks = nb;
+    return SRL_OK;
+}
+
 int srl_get_timing(srl_ctx *ctx, srl_timing *t) {
     if (!ctx || !t) return SRL_ERR_BAD_ARG;
     if (ctx->profiling == 2) { int rc = drain_ring(ctx, true); if (rc) return rc; }
@@ -400,8 +411,12 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             HIPCHK(ctx, hipMemsetAsync(ctx->d_tap_offset, 0, (size_t)ctx->n * sizeof(double), ctx->stream));
         }
     }
-    const int kpb = srl_keypoints_per_block(n_eff);
+    // launch shape: keypoints per wave by sweep size; 16-wave workgroups (one per CU) whenever their LDS footprint fits
+    const int kpw = srl_keypoints_per_wave(n_eff);
+    const int wpb = srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT ? 16 : 4;
+    const int kpb = kpw * wpb;
     const int nblocks = (n_eff + kpb - 1) / kpb;
+    ctx->last_nblocks = nblocks;
     const bool prof = ctx->profiling == 1;
     const bool prof_light = ctx->profiling == 2;
     hipEvent_t *ring_ev = nullptr;
@@ -412,7 +427,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
 
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (prof_light) HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
-    HIPCHK(ctx, srl_launch_assoc(a, nb, kpb, ctx->stream));
+    HIPCHK(ctx, srl_launch_assoc(a, nb, kpw, wpb, ctx->stream));
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if (prof_light) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_head++; }
 

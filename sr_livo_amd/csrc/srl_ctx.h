@@ -81,6 +81,7 @@ struct srl_ctx {
     struct PoolBlock { void *p; size_t bytes; };
     std::vector<PoolBlock> pool_free;
 
+    int last_nblocks = 0;
     int profiling = 0;                 // 0 off, 1 full (4 events + sync per call), 2 light (assoc kernel only, read lazily)
     static constexpr int PROF_RING = 512;
     hipEvent_t ring[PROF_RING][2] = {};

@@ -146,9 +146,11 @@ struct SrlSearchArgs {
 };
 
 // launchers (srl_kernels.hip)
-hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpb, hipStream_t s);
-// keypoints per workgroup for a pass over n keypoints: the largest of 16 / 32 / 64 that still yields >= ~1024 workgroups
-static inline int srl_keypoints_per_block(int n) { return n <= 16384 ? 16 : (n <= 32768 ? 32 : SRL_KPB); }
+hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpw, int wpb, hipStream_t s);
+int srl_assoc_lds_bytes(int K, int nb_voxels, int kpw, int wpb);
+// keypoints per wave for a pass over n keypoints: the largest of 4 / 8 / 16 that still yields >= ~4096 waves
+static inline int srl_keypoints_per_wave(int n) { return n <= 16384 ? 4 : (n <= 32768 ? 8 : 16); }
+#define SRL_LDS_LIMIT (160 * 1024)
 hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s);
 hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, long long *out_total, hipStream_t s);
 hipError_t srl_launch_publish(const SrlDevOut *src, SrlMailbox *mb, unsigned long long seq, hipStream_t s);

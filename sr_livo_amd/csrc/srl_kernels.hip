@@ -737,28 +737,36 @@ __device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], 
 // used for large sweeps; small sweeps take fewer keypoints per wave so that the grid still fills the chip and the serial
 // chain of a wave is short (latency, not throughput, is what a 3k-keypoint sweep pays for).
 struct LdsLayout {
-    int wave_bytes;                // per-wave region size
-    int off_nb, off_pw, off_pimu, off_kv, off_nfound, off_ncand, off_vox, off_scratch, off_qf;   // offsets inside a wave region
-    int off_wpart, off_winfo, total;                                                      // block-level tail
+    // workgroup-level keypoint arrays (KPB = WPB x KPW keypoints), then one region per wave, then the block tail
+    int nb_row;                    // row stride (floats) of the neighbour planes
+    int off_nb, off_pw, off_pimu, off_qf, off_kv, off_nfound, off_ncand, off_next;
+    int off_wave, wave_bytes, off_vox, off_scratch;     // per-wave: off_wave + w * wave_bytes + {off_vox, off_scratch}
+    int off_wpart, off_winfo, total;
 };
-__host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw) {
-    const int nb_row = kpw + 1;          // row stride (floats) of the neighbour planes
+__host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, int wpb) {
+    const int kpb = wpb * kpw;
     LdsLayout L;
-    int o = 0;
-    L.off_nb = o;      o += ((3 * K * nb_row * 4 + 15) / 16) * 16;   // planes x | y | z, K rows of nb_row floats
+    // stride = 17 (mod 32): the K winner lanes of one keypoint and the (keypoint, sub-lane) readers of phase 2 spread over the banks
+    L.nb_row = ((kpb + 31) & ~31) + 17;
     auto up16 = [](int x) { return (x + 15) & ~15; };
-    L.off_pw = o;      o += up16(kpw * 3 * 8);
-    L.off_pimu = o;    o += up16(kpw * 3 * 8);
-    L.off_qf = o;      o += up16(kpw * 8 * 4);                 // per keypoint: FP32 query (3), prefilter margin coefficients (2), pad
-    L.off_kv = o;      o += up16((kpw + 1) * 4 * 4);           // + one zero entry: the pair probe of an odd KPW reads it
-    L.off_nfound = o;  o += up16(kpw * 4);
-    L.off_ncand = o;   o += up16(kpw * 4);
-    L.off_vox = o;     o += (nb_voxels == 1 ? 64 : 128) * 8;     // r = 1: two 32-entry lists (a keypoint pair is probed at once)
-    L.off_scratch = o; o += SRL_WAVE_SCRATCH;
-    L.wave_bytes = o;
-    L.off_wpart = 4 * o;
-    L.off_winfo = L.off_wpart + 4 * 32 * 8;
-    L.total = L.off_winfo + 4 * 4 * 4;
+    int o = 0;
+    L.off_nb = o;      o += up16(3 * K * L.nb_row * 4);        // planes x | y | z, K rows of nb_row floats
+    L.off_pw = o;      o += up16(kpb * 3 * 8);
+    L.off_pimu = o;    o += up16(kpb * 3 * 8);
+    L.off_qf = o;      o += up16(kpb * 8 * 4);                 // per keypoint: FP32 query (3), prefilter margin coefficients (2), pad
+    L.off_kv = o;      o += up16((kpb + 2) * 4 * 4);           // + zero entries behind the last pair
+    L.off_nfound = o;  o += up16(kpb * 4);
+    L.off_ncand = o;   o += up16(kpb * 4);
+    L.off_next = o;    o += 16;                                // pair counter of the workgroup
+    L.off_wave = o;
+    int w = 0;
+    L.off_vox = w;     w += (nb_voxels == 1 ? 64 : 128) * 8;   // r = 1: two 32-entry lists (a keypoint pair is probed at once)
+    L.off_scratch = w; w += SRL_WAVE_SCRATCH;
+    L.wave_bytes = w;
+    o += wpb * w;
+    L.off_wpart = o;   o += wpb * 32 * 8;
+    L.off_winfo = o;   o += wpb * 4 * 4;
+    L.total = o;
     return L;
 }
 
@@ -792,33 +800,47 @@ __device__ __forceinline__ double kp_sum(double v) {
 }
 
 // FAST: 0 = general path only, 1 = FP32-prefilter fast path, 2 = FP64-retained fast path (r = 1 only)
-template <int NB, int FAST, int KPW>
-__global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc_kernel(const SrlAssocArgs a) {
-    constexpr int NB_ROW = KPW + 1;
+// WPB = waves per workgroup: 16 (one workgroup per CU; every wave of a SIMD belongs to it) or 4 (when the 16-wave LDS
+// footprint does not fit: K > 24).  With four independent 4-wave workgroups per CU the SIMD arbiter's age priority let
+// the oldest wave of every SIMD finish its 16 keypoints in 34 us and the youngest in 47 us; with 16-wave workgroups the
+// pair counter of phase 1 evens that out (workgroups 45..48 us).  The kernel itself is not shorter for it -- a CU is busy
+// (instruction issue + LDS) for the same ~47 us either way, tools/block_times.py -- but the reduce kernel sums 256
+// partials instead of 1 024 and a short sweep needs fewer workgroups to fill the chip.
+template <int NB, int FAST, int KPW, int WPB>
+__global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_SIMD) srl_assoc_kernel(const SrlAssocArgs a) {
+    constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayout L = lds_layout(a.K, NB, KPW);
+    const LdsLayout L = lds_layout(a.K, NB, KPW, WPB);
+    const int NB_ROW = L.nb_row;
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wave = tid >> 6;
-    unsigned char *wbase = smem + wave * L.wave_bytes;
-    float *s_nb = reinterpret_cast<float *>(wbase + L.off_nb);
+    // workgroup-level keypoint arrays: any wave may search any keypoint pair of the workgroup (phase 1 hands pairs out
+    // dynamically), phase 2 then takes the KPW keypoints of its own quarter
+    float *s_nb = reinterpret_cast<float *>(smem + L.off_nb);
     const int nb_plane = a.K * NB_ROW;
-    double *s_pw = reinterpret_cast<double *>(wbase + L.off_pw);
-    double *s_pimu = reinterpret_cast<double *>(wbase + L.off_pimu);
-    float *s_qf = reinterpret_cast<float *>(wbase + L.off_qf);
-    int *s_kv = reinterpret_cast<int *>(wbase + L.off_kv);
-    int *s_nfound = reinterpret_cast<int *>(wbase + L.off_nfound);
-    int *s_ncand = reinterpret_cast<int *>(wbase + L.off_ncand);
+    double *s_pw = reinterpret_cast<double *>(smem + L.off_pw);
+    double *s_pimu = reinterpret_cast<double *>(smem + L.off_pimu);
+    float *s_qf = reinterpret_cast<float *>(smem + L.off_qf);
+    int *s_kv = reinterpret_cast<int *>(smem + L.off_kv);
+    int *s_nfound = reinterpret_cast<int *>(smem + L.off_nfound);
+    int *s_ncand = reinterpret_cast<int *>(smem + L.off_ncand);
+    int *s_next = reinterpret_cast<int *>(smem + L.off_next);
+    unsigned char *wbase = smem + L.off_wave + wave * L.wave_bytes;
     VoxEnt *vox = reinterpret_cast<VoxEnt *>(wbase + L.off_vox);
     Surv *surv = reinterpret_cast<Surv *>(wbase + L.off_scratch);
     double *s_wpart = reinterpret_cast<double *>(smem + L.off_wpart);     // [4][32]
     int *s_winfo = reinterpret_cast<int *>(smem + L.off_winfo);           // [4][4]: accepted, sum_pk, nan, fallback
 
-    const int wbase_kp = blockIdx.x * (4 * KPW) + wave * KPW;           // first keypoint of this wave
+    const int bbase_kp = blockIdx.x * KPB;                                // first keypoint of this workgroup
+    const int wbase_kp = bbase_kp + wave * KPW;                           // first keypoint of this wave's quarter (phases 0 and 2)
     if (a.ablate & 16) return;                                            // debug: launch/drain floor
+    const long long dbg_t0 = (a.ablate & 128) ? (long long)wall_clock64() : 0;   // debug: workgroup start (100 MHz clock)
 
     // ---------------- phase 0: transformKeypoints (optimize.cpp:30-40), location (optimize.cpp:83), voxel key
+    if (tid == 0) *s_next = 0;
     if (lane < KPW) {
+        const int kq = wave * KPW + lane;                                  // index inside the workgroup
         const int g = wbase_kp + lane;
         D3 p_imu = d3(0, 0, 0), p_w = d3(0, 0, 0);
         if (g < a.n) {
@@ -826,8 +848,8 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
             p_imu = add(matvec(a.R_il, raw), d3(a.t_il[0], a.t_il[1], a.t_il[2]));
             p_w = add(matvec(a.Rn, p_imu), d3(a.t[0], a.t[1], a.t[2]));
         }
-        s_pw[lane * 3 + 0] = p_w.x; s_pw[lane * 3 + 1] = p_w.y; s_pw[lane * 3 + 2] = p_w.z;
-        s_pimu[lane * 3 + 0] = p_imu.x; s_pimu[lane * 3 + 1] = p_imu.y; s_pimu[lane * 3 + 2] = p_imu.z;
+        s_pw[kq * 3 + 0] = p_w.x; s_pw[kq * 3 + 1] = p_w.y; s_pw[kq * 3 + 2] = p_w.z;
+        s_pimu[kq * 3 + 0] = p_imu.x; s_pimu[kq * 3 + 1] = p_imu.y; s_pimu[kq * 3 + 2] = p_imu.z;
         {
             // FP32 prefilter constants of this keypoint (used once per keypoint by every lane of the wave later):
             // error model of select_topk_f32_r, m(T) = 4 a (T + 1)/2 + 8 u T + 4 a^2 at T = 2 tau + 1e-6, thr = (tau + 2 m)(1 + 1e-6)
@@ -838,7 +860,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
             const float h = 4.0f * am * 0.5001f;                                  // 4 a / 2, rounded up
             const float m0 = h * (1.0f + 1e-6f) + 8.0f * u * 1e-6f + 4.0f * am * am;   // m at tau = 0
             const float m1 = 2.0f * h + 16.0f * u;                                  // d m / d tau
-            float *qf = s_qf + lane * 8;
+            float *qf = s_qf + kq * 8;
             qf[0] = qxf; qf[1] = qyf; qf[2] = qzf;
             qf[3] = (2.0f * m0) * 1.00001f;                                         // c0
             qf[4] = (1.0f + 2.0f * m1) * 1.00001f;                                  // c1
@@ -846,15 +868,16 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
         // static_cast<short>(point / size_voxel_map): truncation toward zero (optimize.cpp:372-374)
         // (x / 1.0 == x exactly: the shipped size_voxel_map = 1.0 skips three FP64 divisions)
         const bool unit = a.size_voxel == 1.0;
-        s_kv[lane * 4 + 0] = (int)(short)(int)(unit ? p_w.x : p_w.x / a.size_voxel);
-        s_kv[lane * 4 + 1] = (int)(short)(int)(unit ? p_w.y : p_w.y / a.size_voxel);
-        s_kv[lane * 4 + 2] = (int)(short)(int)(unit ? p_w.z : p_w.z / a.size_voxel);
-        s_nfound[lane] = 0;
-        s_ncand[lane] = 0;
-    } else if (lane == KPW) {
-        s_kv[lane * 4 + 0] = 0; s_kv[lane * 4 + 1] = 0; s_kv[lane * 4 + 2] = 0;
+        s_kv[kq * 4 + 0] = (int)(short)(int)(unit ? p_w.x : p_w.x / a.size_voxel);
+        s_kv[kq * 4 + 1] = (int)(short)(int)(unit ? p_w.y : p_w.y / a.size_voxel);
+        s_kv[kq * 4 + 2] = (int)(short)(int)(unit ? p_w.z : p_w.z / a.size_voxel);
+        s_nfound[kq] = 0;
+        s_ncand[kq] = 0;
+    } else if (wave == WPB - 1 && lane < KPW + 2) {
+        const int kq = KPB + (lane - KPW);                                 // the two zero entries behind the last pair
+        s_kv[kq * 4 + 0] = 0; s_kv[kq * 4 + 1] = 0; s_kv[kq * 4 + 2] = 0;
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
     // ---------------- phase 1: searchNeighbors, the whole wave on one keypoint at a time
     int n_fallback = 0;
@@ -862,7 +885,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
         const LaneRole role = lane_role(lane);
         // one keypoint: fast path on its probed voxel list, general path otherwise
         auto keypoint = [&](int kl, int nv_fast, VoxEnt *voxl) {
-            const int g = wbase_kp + kl;
+            const int g = bbase_kp + kl;
             const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
             LdsSink sink;
             sink.col = s_nb + kl;
@@ -887,27 +910,37 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
                 s_ncand[kl] = total;
             }
         };
-        const int n_here = __builtin_amdgcn_readfirstlane(a.n - wbase_kp);    // keypoints of this wave that exist (may be <= 0)
+        const int left = a.n - bbase_kp;
+        const int n_here = __builtin_amdgcn_readfirstlane(left < KPB ? left : KPB);   // keypoints of this workgroup that exist
         if constexpr (NB == 1 && FAST != 0) {
-            // hash lookups run for a PAIR of keypoints (one per half-wave) and one pair ahead, so their L2 round trip
-            // overlaps the selection of the current pair
+            // The waves of the workgroup take keypoint PAIRS from a shared counter: a wave whose keypoints were cheap
+            // simply takes more of them (per-keypoint cost varies ~3x with the number of occupied voxels; with static
+            // shares the slowest wave sets the pace).  Hash lookups run
+            // for the pair (one keypoint per half-wave) and one pair ahead, so their L2 round trip overlaps the selection
+            // of the current pair.  Results do not depend on who searched what: phase 2 is static.
+            const int npairs = (n_here + 1) >> 1;
+            auto take = [&]() { int p = 0; if (lane == 0) p = atomicAdd(s_next, 1); return __builtin_amdgcn_readfirstlane(p); };
+            int cur = take();
             ProbeReq preq;
-            if (!(a.ablate & 32)) preq = probe_issue(s_kv, 0, role, a.table, a.table_mask, lane);
-            for (int kp = 0; kp < KPW && kp < n_here; kp += 2) {
-                const ProbeReq cur = preq;
-                if (kp + 2 < KPW && !(a.ablate & 32)) preq = probe_issue(s_kv, kp + 2, role, a.table, a.table_mask, lane);
-                const int nv_pair = __builtin_amdgcn_readfirstlane((a.ablate & 8) ? 0 : probe_finish(cur, a.thr_cap, a.table, a.table_mask, vox, lane));
+            if (!(a.ablate & 32)) preq = probe_issue(s_kv, 2 * (cur < npairs ? cur : npairs), role, a.table, a.table_mask, lane);
+            while (cur < npairs) {
+                const int nxt = take();
+                const ProbeReq creq = preq;
+                if (!(a.ablate & 32)) preq = probe_issue(s_kv, 2 * (nxt < npairs ? nxt : npairs), role, a.table, a.table_mask, lane);
+                const int nv_pair = __builtin_amdgcn_readfirstlane((a.ablate & 8) ? 0 : probe_finish(creq, a.thr_cap, a.table, a.table_mask, vox, lane));
 #pragma nounroll
                 for (int h = 0; h < 2; ++h) {
-                    if (kp + h >= n_here) break;
-                    keypoint(kp + h, h ? (nv_pair >> 8) : (nv_pair & 0xFF), vox + 32 * h);
+                    if (2 * cur + h >= n_here) break;
+                    keypoint(2 * cur + h, h ? (nv_pair >> 8) : (nv_pair & 0xFF), vox + 32 * h);
                 }
+                cur = nxt;
             }
         } else {
-            for (int kl = 0; kl < KPW && kl < n_here; ++kl) keypoint(kl, 0, vox);
+            // general path (r = 2 / forced modes): static quarters
+            for (int kl = wave * KPW; kl < (wave + 1) * KPW && kl < n_here; ++kl) keypoint(kl, 0, vox);
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
     if (a.ablate & 64) return;                                            // debug: phase 0 + loop skeleton only
     // Phase 2 re-reads its parameters from the kernarg segment through a laundered pointer: kept live across phase 1
@@ -924,9 +957,10 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
     // Sub-lane s accumulates neighbours s, s+4, ...; quad butterflies make the sums identical in the 4 lanes,
     // which then run the (scalar) eigen-solve / weights redundantly and split the 28 H^T H / H^T h / loss
     // products between them (7 each) before the sum over keypoints.
-    const int kl = (lane >> 2) < KPW ? (lane >> 2) : (KPW - 1), sl = lane & 3;
+    const int klw = (lane >> 2) < KPW ? (lane >> 2) : (KPW - 1), sl = lane & 3;   // keypoint inside this wave's quarter
+    const int kl = wave * KPW + klw;                                                // ... and inside the workgroup
     const bool owner_lane = (lane >> 2) < KPW;          // KPW < 16: the upper quads idle through phase 2
-    const int g = owner_lane ? wbase_kp + kl : b.n;
+    const int g = owner_lane ? bbase_kp + kl : b.n;
     int status = 3;
     bool nan_bad = false;
     double J[6] = {0, 0, 0, 0, 0, 0};
@@ -1028,7 +1062,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
             double4 v;
             v.x = sl == 0 ? J[0] : J[4]; v.y = sl == 0 ? J[1] : J[5]; v.z = sl == 0 ? J[2] : h; v.w = sl == 0 ? J[3] : dist;
             if (!accd) { v.x = 0.0; v.y = 0.0; v.z = 0.0; v.w = 0.0; }
-            *reinterpret_cast<double4 *>(s_row + kl * 8 + 4 * sl) = v;
+            *reinterpret_cast<double4 *>(s_row + klw * 8 + 4 * sl) = v;
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < 28) {
@@ -1050,7 +1084,7 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
     {
         const unsigned long long acc_mask = __ballot(status == 2 && sl == 0);
         const unsigned long long nan_mask = __ballot(nan_bad);
-        int pk = (lane < KPW && wbase_kp + lane < b.n) ? s_ncand[lane] : 0;
+        int pk = (lane < KPW && wbase_kp + lane < b.n) ? s_ncand[wave * KPW + lane] : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
         if (lane == 0) {
@@ -1062,17 +1096,23 @@ __global__ void __launch_bounds__(SRL_BLOCK, SRL_ASSOC_WAVES_PER_SIMD) srl_assoc
     }
     __syncthreads();
 
+    if ((b.ablate & 128) && (tid == 28 || tid == 29 || tid == 30))        // debug: start / end stamps of this workgroup in the spare slots
+        b.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] =
+            (tid == 28) ? (double)dbg_t0 : ((tid == 29) ? (double)(long long)wall_clock64() : (double)__builtin_amdgcn_s_getreg(6164) /* XCC_ID */);
     // ---- block partial = wave partials added in wave order (deterministic)
     if (tid < 28) {
-        const double v = ((s_wpart[tid] + s_wpart[32 + tid]) + s_wpart[64 + tid]) + s_wpart[96 + tid];
+        double v = s_wpart[tid];
+#pragma unroll
+        for (int w = 1; w < WPB; ++w) v += s_wpart[w * 32 + tid];
         b.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] = v;
     }
     if (tid == 0) {
         SrlBlockInfo bi;
-        bi.accepted = s_winfo[0] + s_winfo[4] + s_winfo[8] + s_winfo[12];
-        bi.sum_pk = (unsigned)(s_winfo[1] + s_winfo[5] + s_winfo[9] + s_winfo[13]);
-        bi.nan_flag = (s_winfo[2] | s_winfo[6] | s_winfo[10] | s_winfo[14]) ? 1 : 0;
-        bi.num_fallback = s_winfo[3] + s_winfo[7] + s_winfo[11] + s_winfo[15];
+        bi.accepted = 0; bi.sum_pk = 0; bi.nan_flag = 0; bi.num_fallback = 0;
+        for (int w = 0; w < WPB; ++w) {
+            bi.accepted += s_winfo[w * 4 + 0]; bi.sum_pk += (unsigned)s_winfo[w * 4 + 1];
+            bi.nan_flag |= s_winfo[w * 4 + 2] ? 1 : 0; bi.num_fallback += s_winfo[w * 4 + 3];
+        }
         b.binfo[blockIdx.x] = bi;
     }
 }
@@ -1283,26 +1323,40 @@ __global__ void srl_aos_to_soa_kernel(const double *aos, int n, double *x, doubl
 
 }  // namespace
 
-template <int KPW>
-static hipError_t launch_assoc_kpw(const SrlAssocArgs &a, int nb_voxels, hipStream_t s) {
-    const int nblocks = (a.n + 4 * KPW - 1) / (4 * KPW);
-    const LdsLayout L = lds_layout(a.K, nb_voxels, KPW);
+template <int KPW, int WPB>
+static hipError_t launch_assoc_cfg(const SrlAssocArgs &a, int nb_voxels, hipStream_t s) {
+    const int nblocks = (a.n + WPB * KPW - 1) / (WPB * KPW);
+    const LdsLayout L = lds_layout(a.K, nb_voxels, KPW, WPB);
+    const dim3 blk(64 * WPB);
+    auto launch = [&](auto kern) {
+        if (L.total > 64 * 1024) {      // more dynamic LDS than the default limit: opt in once per kernel
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(nblocks), blk, L.total, s, a);
+        return hipGetLastError();
+    };
     if (nb_voxels == 1) {
-        if (a.select_mode == 0 || a.select_mode == 4) hipLaunchKernelGGL((srl_assoc_kernel<1, 1, KPW>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
-        else if (a.select_mode == 3) hipLaunchKernelGGL((srl_assoc_kernel<1, 2, KPW>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
-        else hipLaunchKernelGGL((srl_assoc_kernel<1, 0, KPW>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
-    } else {
-        hipLaunchKernelGGL((srl_assoc_kernel<2, 0, KPW>), dim3(nblocks), dim3(SRL_BLOCK), L.total, s, a);
+        if (a.select_mode == 0 || a.select_mode == 4) return launch(srl_assoc_kernel<1, 1, KPW, WPB>);
+        if (a.select_mode == 3) return launch(srl_assoc_kernel<1, 2, KPW, WPB>);
+        return launch(srl_assoc_kernel<1, 0, KPW, WPB>);
     }
-    return hipGetLastError();
+    return launch(srl_assoc_kernel<2, 0, KPW, WPB>);
 }
-// kpb = keypoints per workgroup (srl_keypoints_per_block): 64, 32 or 16
-hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpb, hipStream_t s) {
+// kpw = keypoints per wave (16 / 8 / 4), wpb = waves per workgroup (16 / 4): srl_assoc_config
+hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpw, int wpb, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
-    if (kpb == 16) return launch_assoc_kpw<4>(a, nb_voxels, s);
-    if (kpb == 32) return launch_assoc_kpw<8>(a, nb_voxels, s);
-    return launch_assoc_kpw<16>(a, nb_voxels, s);
+    if (wpb == 16) {
+        if (kpw == 4) return launch_assoc_cfg<4, 16>(a, nb_voxels, s);
+        if (kpw == 8) return launch_assoc_cfg<8, 16>(a, nb_voxels, s);
+        return launch_assoc_cfg<16, 16>(a, nb_voxels, s);
+    }
+    if (kpw == 4) return launch_assoc_cfg<4, 4>(a, nb_voxels, s);
+    if (kpw == 8) return launch_assoc_cfg<8, 4>(a, nb_voxels, s);
+    return launch_assoc_cfg<16, 4>(a, nb_voxels, s);
 }
+// LDS bytes of a configuration (host: does the 16-wave workgroup fit?)
+int srl_assoc_lds_bytes(int K, int nb_voxels, int kpw, int wpb) { return lds_layout(K, nb_voxels, kpw, wpb).total; }
 
 hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s) {
     hipLaunchKernelGGL(srl_reduce_kernel, dim3(1), dim3(1024), 0, s, a, mode);
