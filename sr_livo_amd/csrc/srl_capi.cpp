@@ -413,7 +413,9 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     }
     // launch shape: keypoints per wave by sweep size; 16-wave workgroups (one per CU) whenever their LDS footprint fits
     const int kpw = srl_keypoints_per_wave(n_eff);
-    const int wpb = srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT ? 16 : 4;
+    // (only for large sweeps: measured neutral on the kernel, it pays through the 4x fewer partials of the reduce kernel;
+    //  mid-size sweeps -- 16k..32k keypoints -- ran 2-6 us slower with it and keep 4-wave workgroups)
+    const int wpb = (kpw == 16 && n_eff >= 256 * 16 * kpw && srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT) ? 16 : 4;
     const int kpb = kpw * wpb;
     const int nblocks = (n_eff + kpb - 1) / kpb;
     ctx->last_nblocks = nblocks;
