@@ -1329,9 +1329,17 @@ static hipError_t launch_assoc_cfg(const SrlAssocArgs &a, int nb_voxels, hipStre
     const LdsLayout L = lds_layout(a.K, nb_voxels, KPW, WPB);
     const dim3 blk(64 * WPB);
     auto launch = [&](auto kern) {
-        if (L.total > 64 * 1024) {      // more dynamic LDS than the default limit: opt in once per kernel
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-            if (e != hipSuccess) return e;
+        if (L.total > 64 * 1024) {      // more dynamic LDS than the default limit: opt in (once per kernel, device and size)
+            static thread_local const void *done_fn = nullptr;
+            static thread_local int done_bytes = 0, done_dev = -1;
+            int dev = -1;
+            hipGetDevice(&dev);
+            const void *fn = reinterpret_cast<const void *>(kern);
+            if (fn != done_fn || L.total > done_bytes || dev != done_dev) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SRL_LDS_LIMIT);
+                if (e != hipSuccess) return e;
+                done_fn = fn; done_bytes = SRL_LDS_LIMIT; done_dev = dev;
+            }
         }
         hipLaunchKernelGGL(kern, dim3(nblocks), blk, L.total, s, a);
         return hipGetLastError();
