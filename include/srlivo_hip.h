@@ -225,6 +225,9 @@ typedef struct srl_timing {
     double  sum_host_total_us;  /* host wall: whole srl_build_residuals call */
 } srl_timing;
 int srl_get_timing(srl_ctx *ctx, srl_timing *t);
+/* debug (env SRL_ABLATE=128): {start, end, xcc id} stamps of every workgroup of the last association launch, in ticks of
+ * the 100 MHz wall clock; out = max_blocks x 3 doubles.  Used by tools/block_times.py. */
+int srl_debug_block_times(srl_ctx *ctx, double *out, int max_blocks, int *nblocks);
 int srl_set_profiling(srl_ctx *ctx, int mode);     /* 0 off (default); 1 full: four events + a sync per call (kernel, reduce,
                                                       * device total, host splits); 2 light: one event pair around the association
                                                       * kernel, read back lazily (calls / sum_assoc_ms / sum_algorithmic_bytes only).

@@ -129,6 +129,7 @@ def load_library():
         "srl_shard_range": ([C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], None),
         "srl_shard_budget": ([C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)], None),
         "srl_get_timing": ([p, C.POINTER(Timing)], C.c_int),
+        "srl_debug_block_times": ([p, p, C.c_int, C.POINTER(C.c_int)], C.c_int),
         "srl_set_profiling": ([p, C.c_int], C.c_int),
         # host mirror handles
         "srl_lio_create": ([C.c_int, C.POINTER(p)], C.c_int),

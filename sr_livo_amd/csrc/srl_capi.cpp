@@ -318,7 +318,7 @@ int srl_set_profiling(srl_ctx *ctx, int enable) {
 }
 
 // debug (SRL_ABLATE=128): per-workgroup {start, end, xcc} stamps of the last association launch, 100 MHz ticks
-extern "C" int srl_debug_block_times(srl_ctx *ctx, double *out, int max_blocks, int *nblocks) {
+int srl_debug_block_times(srl_ctx *ctx, double *out, int max_blocks, int *nblocks) {
     if (!ctx || !out || !nblocks) return SRL_ERR_BAD_ARG;
     const int nb = std::min(max_blocks, ctx->last_nblocks);
     std::vector<double> tmp((size_t)nb * SRL_PART_STRIDE);
