@@ -27,3 +27,12 @@ _, t_it = timed(lambda: ctx.build_residuals(f, opts))
 _, t_commit = timed(lambda: ctx.frame_commit(sw["q_gt"], sw["t_gt"], want_world=False), reps=3)
 print(f"frame {n_frame} pts: undistort {t_und:.2f} ms, upload {t_up:.2f} ms, select_keypoints {t_sel:.2f} ms -> {len(kidx)} keypoints, "
       f"one ESIKF pass {t_it * 1e3:.0f} us, commit (transform + map insert) {t_commit:.2f} ms")
+
+# a frame spread over the scene like a real reconstructed sweep (24k points drawn from the map's surface candidates)
+rng = np.random.default_rng(3)
+frame = cands[rng.choice(len(cands), 24_000, replace=False)] + rng.normal(0, 0.03, (24_000, 3))
+ident_q = np.array([1.0, 0, 0, 0]); zero = np.zeros(3)
+_, t_up2 = timed(lambda: ctx.frame_upload(frame))
+k2, t_sel2 = timed(lambda: ctx.frame_select_keypoints(ident_q, zero, 1.5))
+_, t_commit2 = timed(lambda: ctx.frame_commit(ident_q, zero, want_world=False), reps=3)
+print(f"scene-spread frame 24000 pts: upload {t_up2:.2f} ms, select_keypoints {t_sel2:.2f} ms -> {len(k2)} keypoints, commit {t_commit2:.2f} ms")
