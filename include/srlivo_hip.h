@@ -58,7 +58,7 @@ typedef struct srl_icp_opts {
     int32_t max_num_residuals;          /* parameters.h:40 */
     double  weight_alpha;               /* parameters.h:46 */
     double  weight_neighborhood;        /* parameters.h:48 */
-    int32_t select_mode;                /* ours: 0 = auto, 1 = force the streaming-extraction selection (test hook) */
+    int32_t select_mode;                /* ours, test hook: 0 = auto; 1 streaming extraction, 2 general two-pass, 3 FP64-retained fast path, 4 Jacobi eigen-solver, 5 heap replay (the reference's literal priority_queue sequence) for every keypoint */
 } srl_icp_opts;
 
 /* per-iteration pose + frame constants read by buildPlaneResiduals (optimize.cpp:21-28,83) */
@@ -225,7 +225,20 @@ typedef struct srl_timing {
     double  sum_host_total_us;  /* host wall: whole srl_build_residuals call */
 } srl_timing;
 int srl_get_timing(srl_ctx *ctx, srl_timing *t);
-/* debug (env SRL_ABLATE=128): {start, end, xcc id} stamps of every workgroup of the last association launch, in ticks of
+/* ---- debug / parity hooks: never called by the product path ----
+ * srl_debug_set_ablate: bit mask that switches parts of the association kernel off (profiling tools only; results are
+ *   wrong while it is set).  Replaces the SRL_ABLATE environment variable of round 1 -- the library reads no environment
+ *   variable on the per-iteration path.
+ * srl_debug_set_search_select_mode: selection path used by srl_search_neighbors (0 default, 1 extraction, 5 heap replay).
+ * srl_debug_heap_topk: the device kernels' restatement of libstdc++'s push_heap / pop_heap (csrc/srl_heap.h, the
+ *   std::priority_queue of optimize.cpp:355-363,394-404,411-422) run on the host: offers distances[0..n) in order to a
+ *   bounded max-heap of K, writes the read-out order (candidate indices, ascending distance) and returns its size.  No GPU.
+ * srl_debug_device_sqrt: out[i] = the device's sqrt(in[i]) (the tie replay relies on it being correctly rounded). */
+int srl_debug_set_ablate(srl_ctx *ctx, int bits);
+int srl_debug_set_search_select_mode(srl_ctx *ctx, int select_mode);
+int srl_debug_heap_topk(const double *distances, int n, int K, int32_t *out_index);
+int srl_debug_device_sqrt(srl_ctx *ctx, const double *in, int n, double *out);
+/* debug (srl_debug_set_ablate(ctx, 128)): {start, end, xcc id} stamps of every workgroup of the last association launch, in ticks of
  * the 100 MHz wall clock; out = max_blocks x 3 doubles.  Used by tools/block_times.py. */
 int srl_debug_block_times(srl_ctx *ctx, double *out, int max_blocks, int *nblocks);
 int srl_set_profiling(srl_ctx *ctx, int mode);     /* 0 off (default); 1 full: four events + a sync per call (kernel, reduce,

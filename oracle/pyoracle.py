@@ -54,6 +54,7 @@ def load(backend="plain"):
     lib.orc_map_size.argtypes = [p]; lib.orc_map_size.restype = C.c_size_t
     lib.orc_map_num_voxels.argtypes = [p]; lib.orc_map_num_voxels.restype = C.c_int
     lib.orc_map_export.argtypes = [p, C.c_int, p, p, p]
+    lib.orc_map_import.argtypes = [p, p, p, p, C.c_int, C.c_int]; lib.orc_map_import.restype = C.c_int
     lib.orc_voxel_hash.argtypes = [C.c_int16, C.c_int16, C.c_int16]; lib.orc_voxel_hash.restype = C.c_uint64
     lib.orc_voxel_coord.argtypes = [C.c_double, C.c_double]; lib.orc_voxel_coord.restype = C.c_int16
     lib.orc_map_backend.restype = C.c_char_p
@@ -86,6 +87,10 @@ def load(backend="plain"):
     lib.orc_derivative_s2.argtypes = [dp, dp]
     lib.orc_inverse17.argtypes = [dp, dp]; lib.orc_inverse17.restype = C.c_int
     lib.orc_eig3.argtypes = [dp, dp, dp]
+    lib.orc_eig3_solver.argtypes = [C.c_int, dp, dp, dp]; lib.orc_eig3_solver.restype = C.c_int
+    lib.orc_set_eig_solver.argtypes = [C.c_int]
+    lib.orc_get_eig_solver.restype = C.c_int
+    lib.orc_heap_topk.argtypes = [p, C.c_int, C.c_int, p]; lib.orc_heap_topk.restype = C.c_int
     lib.orc_distort_frame_by_constant.argtypes = [p, p, C.c_int, p, C.c_int, C.c_double, dp, dp, p]
     lib.orc_distort_frame_by_imu.argtypes = [p, p, C.c_int, p, C.c_int, C.c_double, dp, dp, p]
     lib.orc_distort_frame_by_imu.restype = C.c_int
@@ -158,6 +163,12 @@ class Map:
         keys = np.zeros((V, 3), dtype=np.int16); counts = np.zeros(V, dtype=np.int32); xyz = np.zeros((V, cap, 3), dtype=np.float32)
         self.lib.orc_map_export(self.h, cap, _vp(keys), _vp(counts), _vp(xyz))
         return keys, counts, xyz
+
+    def import_(self, keys, counts, xyz, cap=20):
+        keys = np.ascontiguousarray(keys, dtype=np.int16); counts = np.ascontiguousarray(counts, dtype=np.int32)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        if self.lib.orc_map_import(self.h, _vp(keys), _vp(counts), _vp(xyz), len(counts), cap) != 0:
+            raise ValueError("orc_map_import: duplicate key or count out of range")
 
     def search_neighbors(self, p, nb=1, size=1.0, K=20, thr=1, cap=20):
         p = _f64(p)
@@ -319,3 +330,40 @@ def make_point_timestamp(timestamp, time_begin, time_end, point_time_enable=True
 
 def mt19937_64_nth(n, backend="plain"):
     return int(load(backend).orc_mt19937_64_nth(int(n)))
+
+
+EIG_EIGEN_QL, EIG_JACOBI = 0, 1
+
+
+def eig3(A, solver=EIG_EIGEN_QL, backend="plain"):
+    """SelfAdjointEigenSolver<Matrix3d> restated: (eigenvalues ascending, eigenvectors as columns, converged)."""
+    lib = load(backend)
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(9)
+    ev = np.empty(3); V = np.empty(9)
+    rc = lib.orc_eig3_solver(int(solver), _dp(A), _dp(ev), _dp(V))
+    return ev, V.reshape(3, 3), rc == 0
+
+
+class eig_solver:
+    """with eig_solver(EIG_JACOBI): ...  -- switches the solver inside computeNeighborhoodDistribution (both backends)."""
+
+    def __init__(self, solver):
+        self.solver = solver
+
+    def __enter__(self):
+        self.libs = [load("plain")] + ([load("tsl")] if os.path.exists(LIB_TSL) else [])
+        self.old = [lib.orc_get_eig_solver() for lib in self.libs]
+        for lib in self.libs:
+            lib.orc_set_eig_solver(int(self.solver))
+
+    def __exit__(self, *exc):
+        for lib, o in zip(self.libs, self.old):
+            lib.orc_set_eig_solver(o)
+
+
+def heap_topk(distances, K, backend="plain"):
+    """optimize.cpp:394-404,411-422 with the real std::priority_queue on a list of distances: read-out order of indices."""
+    d = np.ascontiguousarray(distances, dtype=np.float64)
+    out = np.empty(K, dtype=np.int32)
+    n = load(backend).orc_heap_topk(_vp(d), len(d), int(K), _vp(out))
+    return out[:n].copy()

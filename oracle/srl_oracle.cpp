@@ -8,7 +8,10 @@
 // is restated from its published algorithms:
 //   * Quaterniond::toRotationMatrix / Quaterniond(Matrix3d) (Shepperd) / normalized()
 //   * Matrix<double,17,17>::inverse()  -> partial-pivot LU
-//   * SelfAdjointEigenSolver<Matrix3d> -> FP64 cyclic Jacobi, eigenvalues ascending
+//   * SelfAdjointEigenSolver<Matrix3d> -> eig3_eigen_ql: Eigen 3.3.7's own algorithm (scale by max |a_ij|, the 3x3
+//     real specialisation of tridiagonalization_inplace, implicit symmetric QR steps with Wilkinson shift and
+//     Givens rotations, selection sort ascending), operation by operation.  eig3_jacobi (FP64 cyclic Jacobi) is kept
+//     as an independent second solver (orc_set_eig_solver) to bound the difference on every configuration.
 //   * 3-vector reductions in the fixed order (x*x + y*y) + z*z, no FMA contraction
 //   * std::priority_queue is used literally (libstdc++ heap), so tie order is the real one.
 //
@@ -293,6 +296,176 @@ void eig3_jacobi(const double Ain[3][3], double evals[3], double V[3][3]) {
     std::memcpy(V, Vs, sizeof Vs);
 }
 
+// SelfAdjointEigenSolver<Matrix3d>::compute(matrix, ComputeEigenvectors) as the reference instantiates it
+// (src/optimize.cpp:339).  Eigen is a system dependency of the reference (CMakeLists.txt:51; README.md:64 tested
+// with 3.3.7) and absent from /root/reference and from this image; what follows restates the published 3.3.7
+// sources, operation by operation, so that rounding follows the same path:
+//   Eigen/src/Eigenvalues/SelfAdjointEigenSolver.h   compute(): lower triangle, scale = max |coeff| (0 -> 1), /= scale,
+//                                                    tridiagonalise, computeFromTridiagonal_impl, eigenvalues *= scale
+//   Eigen/src/Eigenvalues/Tridiagonalization.h       tridiagonalization_inplace_selector<MatrixType, 3, false>::run
+//   SelfAdjointEigenSolver.h                         computeFromTridiagonal_impl (deflation test with precision
+//                                                    2 eps and considerAsZero = DBL_MIN, m_maxIterations = 30 per row),
+//                                                    tridiagonal_qr_step (Wilkinson shift, chase the bulge)
+//   Eigen/src/Jacobi/Jacobi.h                        JacobiRotation::makeGivens (real), applyOnTheRight
+//   Eigen/src/Core/MathFunctions.h                   numext::hypot (3.3 hypot_impl)
+// Eigenvalues ascending, eigenvectors = columns of V.  Returns false on NoConvergence (Eigen then leaves the
+// eigenvalues unsorted; the reference never checks info()).
+namespace eigen337 {
+struct Givens { double c, s; };
+inline Givens make_givens(double p, double q) {       // JacobiRotation<double>::makeGivens(p, q, 0, false_type)
+    Givens g;
+    if (q == 0.0) {
+        g.c = p < 0.0 ? -1.0 : 1.0;
+        g.s = 0.0;
+    } else if (p == 0.0) {
+        g.c = 0.0;
+        g.s = q < 0.0 ? 1.0 : -1.0;
+    } else if (std::fabs(p) > std::fabs(q)) {
+        double t = q / p;
+        double u = std::sqrt(1.0 + t * t);
+        if (p < 0.0) u = -u;
+        g.c = 1.0 / u;
+        g.s = -t * g.c;
+    } else {
+        double t = p / q;
+        double u = std::sqrt(1.0 + t * t);
+        if (q < 0.0) u = -u;
+        g.s = -1.0 / u;
+        g.c = -t * g.s;
+    }
+    return g;
+}
+inline double hypot_impl(double x, double y) {        // numext::hypot, Eigen 3.3 hypot_impl<double>::run
+    double ax = std::fabs(x), ay = std::fabs(y);
+    double p, qp;
+    if (ax > ay) { p = ax; qp = ay / p; } else { p = ay; qp = ax / p; }
+    if (p == 0.0) return 0.0;
+    return p * std::sqrt(1.0 + qp * qp);
+}
+// tridiagonal_qr_step<ColMajor>(diag, subdiag, start, end, matrixQ, n = 3); Q[row][col]
+inline void qr_step(double *diag, double *subdiag, int start, int end, double Q[3][3]) {
+    double td = (diag[end - 1] - diag[end]) * 0.5;
+    double e = subdiag[end - 1];
+    double mu = diag[end];
+    if (td == 0.0) {
+        mu -= std::fabs(e);
+    } else {
+        double e2 = subdiag[end - 1] * subdiag[end - 1];     // numext::abs2
+        double h = hypot_impl(td, e);
+        if (e2 == 0.0) mu -= (e / (td + (td > 0.0 ? 1.0 : -1.0))) * (e / h);
+        else mu -= e2 / (td + (td > 0.0 ? h : -h));
+    }
+    double x = diag[start] - mu;
+    double z = subdiag[start];
+    for (int k = start; k < end; ++k) {
+        Givens rot = make_givens(x, z);
+        // do T = G' T G
+        double sdk = rot.s * diag[k] + rot.c * subdiag[k];
+        double dkp1 = rot.s * subdiag[k] + rot.c * diag[k + 1];
+        diag[k] = rot.c * (rot.c * diag[k] - rot.s * subdiag[k]) - rot.s * (rot.c * subdiag[k] - rot.s * diag[k + 1]);
+        diag[k + 1] = rot.s * sdk + rot.c * dkp1;
+        subdiag[k] = rot.c * sdk - rot.s * dkp1;
+        if (k > start) subdiag[k - 1] = rot.c * subdiag[k - 1] - rot.s * z;
+        x = subdiag[k];
+        if (k < end - 1) {
+            z = -rot.s * subdiag[k + 1];
+            subdiag[k + 1] = rot.c * subdiag[k + 1];
+        }
+        // Q = Q * G: q.applyOnTheRight(k, k + 1, rot) = apply_rotation_in_the_plane(col k, col k + 1, rot.transpose())
+        if (!(rot.c == 1.0 && rot.s == 0.0)) {
+            for (int i = 0; i < 3; ++i) {
+                double xi = Q[i][k], yi = Q[i][k + 1];
+                Q[i][k] = rot.c * xi - rot.s * yi;
+                Q[i][k + 1] = rot.s * xi + rot.c * yi;
+            }
+        }
+    }
+}
+}  // namespace eigen337
+
+bool eig3_eigen_ql(const double Ain[3][3], double evals[3], double V[3][3]) {
+    using namespace eigen337;
+    // mat = matrix.triangularView<Lower>(); scale = mat.cwiseAbs().maxCoeff(); mat.triangularView<Lower>() /= scale
+    double m00 = Ain[0][0], m10 = Ain[1][0], m11 = Ain[1][1], m20 = Ain[2][0], m21 = Ain[2][1], m22 = Ain[2][2];
+    double scale = 0.0;
+    {
+        // maxCoeff over the 3x3 with a zero strict upper triangle, column-major visit; NaNs are not propagated specially
+        const double col_major[9] = {std::fabs(m00), std::fabs(m10), std::fabs(m20), 0.0, std::fabs(m11), std::fabs(m21), 0.0, 0.0, std::fabs(m22)};
+        scale = col_major[0];
+        for (int i = 1; i < 9; i++) if (col_major[i] > scale) scale = col_major[i];
+    }
+    if (scale == 0.0) scale = 1.0;
+    m00 /= scale; m10 /= scale; m11 /= scale; m20 /= scale; m21 /= scale; m22 /= scale;
+
+    // tridiagonalization_inplace_selector<Matrix3d, 3, false>::run(mat, diag, subdiag, extractQ = true)
+    double diag[3], subdiag[2];
+    double Q[3][3];
+    const double tol = std::numeric_limits<double>::min();
+    diag[0] = m00;
+    double v1norm2 = m20 * m20;
+    if (v1norm2 <= tol) {
+        diag[1] = m11;
+        diag[2] = m22;
+        subdiag[0] = m10;
+        subdiag[1] = m21;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Q[i][j] = (i == j) ? 1.0 : 0.0;
+    } else {
+        double beta = std::sqrt(m10 * m10 + v1norm2);
+        double invBeta = 1.0 / beta;
+        double m01 = m10 * invBeta;
+        double m02 = m20 * invBeta;
+        double q = 2.0 * m01 * m21 + m02 * (m22 - m11);
+        diag[1] = m11 + m02 * q;
+        diag[2] = m22 - m02 * q;
+        subdiag[0] = beta;
+        subdiag[1] = m21 - m01 * q;
+        Q[0][0] = 1.0; Q[0][1] = 0.0; Q[0][2] = 0.0;
+        Q[1][0] = 0.0; Q[1][1] = m01; Q[1][2] = m02;
+        Q[2][0] = 0.0; Q[2][1] = m02; Q[2][2] = -m01;
+    }
+
+    // computeFromTridiagonal_impl(diag, subdiag, maxIterations = 30, computeEigenvectors = true, eivec)
+    const int n = 3;
+    int end = n - 1, start = 0, iter = 0;
+    const int maxIterations = 30;
+    const double considerAsZero = std::numeric_limits<double>::min();
+    const double precision = 2.0 * std::numeric_limits<double>::epsilon();
+    while (end > 0) {
+        for (int i = start; i < end; ++i)
+            // internal::isMuchSmallerThan(|subdiag[i]|, |diag[i]| + |diag[i+1]|, precision)  ==  |x| <= |y| * prec
+            if (std::fabs(subdiag[i]) <= (std::fabs(diag[i]) + std::fabs(diag[i + 1])) * precision || std::fabs(subdiag[i]) <= considerAsZero)
+                subdiag[i] = 0.0;
+        // find the largest unreduced block
+        while (end > 0 && subdiag[end - 1] == 0.0) end--;
+        if (end <= 0) break;
+        // if we spent too many iterations, we give up
+        iter++;
+        if (iter > maxIterations * n) break;
+        start = end - 1;
+        while (start > 0 && subdiag[start - 1] != 0.0) start--;
+        qr_step(diag, subdiag, start, end, Q);
+    }
+    const bool ok = iter <= maxIterations * n;
+    // Sort eigenvalues and corresponding vectors (selection sort; minCoeff returns the first minimum)
+    if (ok) {
+        for (int i = 0; i < n - 1; ++i) {
+            int k = 0;
+            for (int j = 1; j < n - i; ++j) if (diag[i + j] < diag[i + k]) k = j;
+            if (k > 0) {
+                std::swap(diag[i], diag[k + i]);
+                for (int r = 0; r < 3; ++r) std::swap(Q[r][i], Q[r][k + i]);
+            }
+        }
+    }
+    // scale back the eigen values
+    for (int i = 0; i < 3; i++) evals[i] = diag[i] * scale;
+    std::memcpy(V, Q, sizeof(double) * 9);
+    return ok;
+}
+
+// which solver compute_neighborhood uses: 0 = eig3_eigen_ql (what the reference executes), 1 = eig3_jacobi
+static int g_eig_solver = 0;
+
 // ---------------------------------------------------------------------------------------------
 // map types (include/cloudMap.h)
 // ---------------------------------------------------------------------------------------------
@@ -515,8 +688,9 @@ bool compute_neighborhood(const std::vector<V3> &points, Neighborhood &nb) {
     nb.covariance = cov;
 
     double V[3][3];
-    eig3_jacobi(cov.m, nb.evals, V);
-    nb.normal = normalized(v3(V[0][0], V[1][0], V[2][0]));
+    if (g_eig_solver == 1) eig3_jacobi(cov.m, nb.evals, V);
+    else eig3_eigen_ql(cov.m, nb.evals, V);          // Eigen::SelfAdjointEigenSolver<Eigen::Matrix3d> es(covariance_Matrix)
+    nb.normal = normalized(v3(V[0][0], V[1][0], V[2][0]));   // es.eigenvectors().col(0).normalized()
 
     double sigma_1 = std::sqrt(std::abs(nb.evals[2]));
     double sigma_2 = std::sqrt(std::abs(nb.evals[1]));
@@ -1107,6 +1281,28 @@ void orc_map_export(const orc_map *m, int cap, int16_t *keys, int32_t *counts, f
         }
     }
 }
+// ORACLE ADDITION (tests only): rebuild a map from exported arrays, voxel by voxel, WITHOUT the insertion rules of
+// addPointToMap -- lets a test hand both sides a map those rules would never produce (e.g. 20 identical points in one
+// voxel, whose planarity is NaN: optimize.cpp:348-350).
+int orc_map_import(orc_map *m, const int16_t *keys, const int32_t *counts, const float *xyz, int V, int cap) {
+    m->map.clear();
+    m->creation_order.clear();
+    for (int v = 0; v < V; v++) {
+        voxel k(keys[3 * v], keys[3 * v + 1], keys[3 * v + 2]);
+        if (m->map.find(k) != m->map.end() || counts[v] < 0 || counts[v] > cap) return -1;
+        voxelBlock b(cap);
+        for (int i = 0; i < counts[v]; i++) {
+            const float *p = xyz + ((size_t)v * cap + i) * 3;
+            rgbPoint pt(v3(0, 0, 0));                   // position is what the hot path reads (cloudMap.h:54)
+            pt.position[0] = p[0]; pt.position[1] = p[1]; pt.position[2] = p[2];
+            b.AddPoint(pt);
+        }
+        b.voxel_index = v;
+        m->creation_order.push_back(k);
+        m->map[k] = std::move(b);
+    }
+    return 0;
+}
 uint64_t orc_voxel_hash(int16_t x, int16_t y, int16_t z) { return (uint64_t)voxel_hash()(voxel(x, y, z)); }
 int16_t orc_voxel_coord(double v, double size) { return static_cast<short>(v / size); }
 const char *orc_map_backend(void) { return kBackend; }
@@ -1459,8 +1655,42 @@ int orc_inverse17(const double A[289], double Ainv[289]) { return lu_inverse<17>
 void orc_eig3(const double A[9], double evals[3], double evecs[9]) {
     double a[3][3], V[3][3];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[i][j] = A[3 * i + j];
-    eig3_jacobi(a, evals, V);
+    if (g_eig_solver == 1) eig3_jacobi(a, evals, V); else eig3_eigen_ql(a, evals, V);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) evecs[3 * i + j] = V[i][j];
+}
+int orc_eig3_solver(int solver, const double A[9], double evals[3], double evecs[9]) {
+    double a[3][3], V[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[i][j] = A[3 * i + j];
+    bool ok = true;
+    if (solver == 1) eig3_jacobi(a, evals, V); else ok = eig3_eigen_ql(a, evals, V);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) evecs[3 * i + j] = V[i][j];
+    return ok ? 0 : -1;
+}
+void orc_set_eig_solver(int solver) { g_eig_solver = solver == 1 ? 1 : 0; }
+int  orc_get_eig_solver(void) { return g_eig_solver; }
+
+// the literal bounded priority queue of searchNeighbors (optimize.cpp:355-363, 394-404, 411-422) over a plain list of
+// distances offered in index order: read-out order of the surviving indices (ascending distance).  Returns their number.
+int orc_heap_topk(const double *distances, int n, int max_num_neighbors, int32_t *out_index) {
+    priority_queue_t priority_queue;
+    const voxel vx(0, 0, 0);
+    for (int i = 0; i < n; i++) {
+        double distance = distances[i];
+        if ((int)priority_queue.size() == max_num_neighbors) {
+            if (distance < std::get<0>(priority_queue.top())) {
+                priority_queue.pop();
+                priority_queue.emplace(distance, v3(0, 0, 0), vx, i);
+            }
+        } else {
+            priority_queue.emplace(distance, v3(0, 0, 0), vx, i);
+        }
+    }
+    auto size = priority_queue.size();
+    for (size_t i = 0; i < size; ++i) {
+        out_index[size - 1 - i] = std::get<3>(priority_queue.top());
+        priority_queue.pop();
+    }
+    return (int)size;
 }
 
 }  // extern "C"

@@ -59,6 +59,8 @@ size_t   orc_map_size(const orc_map *m);          /* mapSize(): total points */
 int      orc_map_num_voxels(const orc_map *m);
 /* export in voxel CREATION order: keys[V*3], counts[V], xyz[V*cap*3] (AoS f32, unused slots 0) */
 void     orc_map_export(const orc_map *m, int cap, int16_t *keys, int32_t *counts, float *xyz);
+/* tests only: rebuild the map from exported arrays without the insertion rules (maps addPointToMap cannot produce) */
+int      orc_map_import(orc_map *m, const int16_t *keys, const int32_t *counts, const float *xyz, int V, int cap);
 /* std::hash<voxel> (cloudMap.h:173-184) */
 uint64_t orc_voxel_hash(int16_t x, int16_t y, int16_t z);
 /* static_cast<short>(v / size) (optimize.cpp:372) */
@@ -192,7 +194,17 @@ void   orc_rot_to_so3(const double R[9], double w[3]);
 double orc_angular_distance_so3(const double w[3]);
 void   orc_derivative_s2(const double g[3], double B[6]);
 int    orc_inverse17(const double A[289], double Ainv[289]);
-void   orc_eig3(const double A[9], double evals[3], double evecs[9]); /* ascending; evecs columns, row-major */
+void   orc_eig3(const double A[9], double evals[3], double evecs[9]); /* ascending; evecs columns, row-major; current solver */
+/* SelfAdjointEigenSolver<Matrix3d> (optimize.cpp:339).  solver 0 = Eigen 3.3.7's own algorithm restated (3x3
+ * tridiagonalisation + implicit symmetric QR with Wilkinson shift; the default everywhere in the oracle), 1 = FP64 cyclic
+ * Jacobi (an independent second solver used to bound the Eigen-boundary uncertainty).  orc_eig3_solver returns -1 when
+ * the QR iteration did not converge (Eigen: info() == NoConvergence). */
+int    orc_eig3_solver(int solver, const double A[9], double evals[3], double evecs[9]);
+void   orc_set_eig_solver(int solver);     /* process-wide: solver used by computeNeighborhoodDistribution */
+int    orc_get_eig_solver(void);
+/* the literal std::priority_queue sequence of searchNeighbors (optimize.cpp:394-404, 411-422) on a list of distances
+ * offered in index order; out_index (capacity max_num_neighbors) = surviving indices in read-out order */
+int    orc_heap_topk(const double *distances, int n, int max_num_neighbors, int32_t *out_index);
 
 #ifdef __cplusplus
 }

@@ -130,6 +130,10 @@ def load_library():
         "srl_shard_budget": ([C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)], None),
         "srl_get_timing": ([p, C.POINTER(Timing)], C.c_int),
         "srl_debug_block_times": ([p, p, C.c_int, C.POINTER(C.c_int)], C.c_int),
+        "srl_debug_set_ablate": ([p, C.c_int], C.c_int),
+        "srl_debug_set_search_select_mode": ([p, C.c_int], C.c_int),
+        "srl_debug_heap_topk": ([p, C.c_int, C.c_int, p], C.c_int),
+        "srl_debug_device_sqrt": ([p, p, C.c_int, p], C.c_int),
         "srl_set_profiling": ([p, C.c_int], C.c_int),
         # host mirror handles
         "srl_lio_create": ([C.c_int, C.POINTER(p)], C.c_int),
@@ -220,6 +224,16 @@ def default_opts(**kw):
     return o
 
 
+def heap_topk(distances, K):
+    """The device kernels' libstdc++-heap restatement (csrc/srl_heap.h) run on the host: read-out order of candidate indices."""
+    d = np.ascontiguousarray(distances, dtype=np.float64)
+    out = np.empty(K, dtype=np.int32)
+    n = load_library().srl_debug_heap_topk(_ptr(d), len(d), int(K), _ptr(out))
+    if n < 0:
+        raise SrlError(n, "srl_debug_heap_topk")
+    return out[:n].copy()
+
+
 def shard_range(n, nranks, rank):
     b, c = C.c_int(), C.c_int()
     load_library().srl_shard_range(n, nranks, rank, C.byref(b), C.byref(c))
@@ -269,6 +283,8 @@ class Context:
             handle = h
         self.h = handle
         self._cb = None
+        if os.environ.get("SRL_ABLATE"):      # profiling tools only (tools/*.py, tools/*.sh): the library itself reads no env
+            self.lib.srl_debug_set_ablate(self.h, int(os.environ["SRL_ABLATE"]))
 
     def close(self):
         if self.h and self._own:
@@ -357,6 +373,15 @@ class Context:
         nf = np.empty(len(q), dtype=np.int32)
         self._chk(self.lib.srl_search_neighbors(self.h, _ptr(q), len(q), nb, size, K, thr, _ptr(ids), _ptr(xyz), _ptr(nf)), "srl_search_neighbors")
         return ids, xyz, nf
+
+    def set_search_select_mode(self, mode):
+        self._chk(self.lib.srl_debug_set_search_select_mode(self.h, int(mode)), "srl_debug_set_search_select_mode")
+
+    def device_sqrt(self, x):
+        x = _f64(x).ravel()
+        out = np.empty_like(x)
+        self._chk(self.lib.srl_debug_device_sqrt(self.h, _ptr(x), len(x), _ptr(out)), "srl_debug_device_sqrt")
+        return out
 
     def transform_points(self, raw_xyz, q, t, R_il=None, t_il=None):
         r = _f64(raw_xyz, (-1, 3))

@@ -172,17 +172,17 @@ optimizeSummary lioOptimization::buildPlaneResiduals(const icpOptions &cur_icp_o
 // ---------------------------------------------------------------- optimize.cpp:133-314
 optimizeSummary lioOptimization::updateIEKF(const icpOptions &cur_icp_options, voxelHashMap &voxel_map_temp,
                                             std::vector<point3D> &keypoints, cloudFrame *p_frame) {
-    (void)voxel_map_temp;
     if (!provider) {
-        srl_ctx *ctx = voxel_map.ctx;
+        // the keypoints given here are the sweep: always uploaded (a pinned sweep is only ever used by solveIEKF, which
+        // takes no keypoint vector -- never guessed from a matching count)
+        srl_ctx *ctx = voxel_map_temp.ctx;
         if (!ctx) throw std::runtime_error("updateIEKF: no HIP context (the product has no CPU path)");
-        if (!sweep_pinned || resident_n != (int)keypoints.size() || keypoints.empty()) {
-            const int n = (int)keypoints.size();
-            std::vector<double> raw((size_t)n * 3);
-            for (int k = 0; k < n; k++) for (int d = 0; d < 3; d++) raw[(size_t)k * 3 + d] = keypoints[k].raw_point[d];
-            check(ctx, srl_sweep_upload(ctx, raw.data(), n), "srl_sweep_upload");
-        }
-        if (!sweep_pinned) resident_n = -1;
+        if (ctx != voxel_map.ctx) throw std::runtime_error("updateIEKF: voxel_map_temp must be the node's voxel_map (one device map per lioOptimization)");
+        const int n = (int)keypoints.size();
+        std::vector<double> raw((size_t)n * 3);
+        for (int k = 0; k < n; k++) for (int d = 0; d < 3; d++) raw[(size_t)k * 3 + d] = keypoints[k].raw_point[d];
+        check(ctx, srl_sweep_upload(ctx, raw.data(), n), "srl_sweep_upload");
+        releaseSweep();
     }
     return solveIEKF(cur_icp_options, p_frame);
 }
@@ -377,42 +377,11 @@ Neighborhood lioOptimization::computeNeighborhoodDistribution(const std::vector<
     cov(2, 0) = cov(0, 2);
     cov(2, 1) = cov(1, 2);
     nb.covariance = cov;
-    // cyclic Jacobi (the restated SelfAdjointEigenSolver<Matrix3d>)
-    double a[3][3], V[3][3], scale = 0.0;
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) scale = std::max(scale, std::fabs(cov(i, j)));
-    if (!(scale > 0.0)) scale = 1.0;
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { a[i][j] = cov(i, j) / scale; V[i][j] = i == j ? 1.0 : 0.0; }
-    for (int sweep = 0; sweep < 32; sweep++) {
-        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-        if (off < 1e-40) break;
-        for (int p = 0; p < 2; p++)
-            for (int q = p + 1; q < 3; q++) {
-                const double apq = a[p][q];
-                if (apq == 0.0) continue;
-                const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
-                double t = 1.0 / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                if (theta < 0.0) t = -t;
-                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-                const int r = 3 - p - q;
-                const double app = a[p][p], aqq = a[q][q];
-                a[p][p] = app - t * apq;
-                a[q][q] = aqq + t * apq;
-                a[p][q] = a[q][p] = 0.0;
-                const double arp = a[r][p], arq = a[r][q];
-                a[r][p] = a[p][r] = c * arp - s * arq;
-                a[r][q] = a[q][r] = s * arp + c * arq;
-                for (int k = 0; k < 3; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
-            }
-    }
-    double d[3] = {a[0][0] * scale, a[1][1] * scale, a[2][2] * scale};
-    int idx[3] = {0, 1, 2};
-    if (d[idx[1]] < d[idx[0]]) std::swap(idx[0], idx[1]);
-    if (d[idx[2]] < d[idx[1]]) std::swap(idx[1], idx[2]);
-    if (d[idx[1]] < d[idx[0]]) std::swap(idx[0], idx[1]);
-    nb.normal = srl::vec3(V[0][idx[0]], V[1][idx[0]], V[2][idx[0]]).normalized();
-    const double sigma_1 = std::sqrt(std::abs(d[idx[2]]));
-    const double sigma_2 = std::sqrt(std::abs(d[idx[1]]));
-    const double sigma_3 = std::sqrt(std::abs(d[idx[0]]));
+    srl::SelfAdjointEigenSolver3 es(cov);                                 // optimize.cpp:339
+    nb.normal = es.eigenvector(0).normalized();                          // es.eigenvectors().col(0).normalized()
+    const double sigma_1 = std::sqrt(std::abs(es.eigenvalues()[2]));
+    const double sigma_2 = std::sqrt(std::abs(es.eigenvalues()[1]));
+    const double sigma_3 = std::sqrt(std::abs(es.eigenvalues()[0]));
     nb.a2D = (sigma_2 - sigma_3) / sigma_1;
     if (nb.a2D != nb.a2D) throw std::runtime_error("error");
     return nb;

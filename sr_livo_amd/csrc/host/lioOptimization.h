@@ -136,8 +136,8 @@ public:
     int last_frame_keypoints = 0, last_frame_points = 0, last_points_added = 0;
 
     // ---- ours ----
-    // pin a sweep in HBM: until releaseSweep(), updateIEKF calls with the same keypoint count skip their
-    // own upload (bench: inputs resident before the timed region).
+    // pin a sweep in HBM (bench: inputs resident before the timed region): solveIEKF() then runs on it.  updateIEKF()
+    // with a keypoint vector always uploads that vector and releases the pin.
     int residentSweep(const double *raw_xyz, int n);
     bool sweepPinned(int n) const { return sweep_pinned && resident_n == n; }
     // updateIEKF on the sweep already resident in HBM (no keypoint vector needed)

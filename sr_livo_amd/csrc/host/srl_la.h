@@ -3,7 +3,8 @@
 // so the product ships the few operations the path needs, following Eigen 3.3 semantics where they
 // decide bits or branches: column-wise 3x3 products summed k = 0,1,2,
 // Quaternion::toRotationMatrix, Quaternion(Matrix3) (Shepperd), normalized() = v / sqrt(v.v),
-// fixed-size inverse() for N > 4 = partial-pivot LU.  Row-major storage (an ABI detail only).
+// fixed-size inverse() for N > 4 = partial-pivot LU, SelfAdjointEigenSolver<Matrix3d> = tridiagonalisation + implicit
+// symmetric QR.  Row-major storage (an ABI detail only).
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -168,5 +169,142 @@ bool inverse(const Mat<N, N> &A, Mat<N, N> &Ainv) {
     }
     return true;
 }
+
+// Eigen::SelfAdjointEigenSolver<Matrix3d> as the reference uses it (src/optimize.cpp:339-346): constructed from a
+// symmetric 3x3, then eigenvalues() ascending and eigenvectors().col(i).  Follows Eigen 3.3.7's iterative path
+// (SelfAdjointEigenSolver.h compute(): scale the lower triangle by its largest |coefficient|; Tridiagonalization.h:
+// the 3x3 real specialisation, one Householder reflector; computeFromTridiagonal_impl: deflate sub-diagonal entries
+// below 2 eps (|d_i| + |d_i+1|), implicit symmetric QR steps with Wilkinson shift (tridiagonal_qr_step) built from
+// Givens rotations (Jacobi.h makeGivens), at most 30 n iterations; selection sort).  Same operation order, so the result
+// rounds the way Eigen's does; the normal of a near-degenerate neighbourhood depends on exactly that.
+class SelfAdjointEigenSolver3 {
+public:
+    enum Info { Success = 0, NoConvergence = 1 };
+    explicit SelfAdjointEigenSolver3(const Mat3 &matrix) { compute(matrix); }
+    const Vec3 &eigenvalues() const { return m_eivalues; }
+    const Mat3 &eigenvectors() const { return m_eivec; }
+    Vec3 eigenvector(int c) const { return vec3(m_eivec(0, c), m_eivec(1, c), m_eivec(2, c)); }   // eigenvectors().col(c)
+    Info info() const { return m_info; }
+
+private:
+    Vec3 m_eivalues;
+    Mat3 m_eivec;
+    double m_subdiag[2];
+    Info m_info = Success;
+
+    struct Rot { double c, s; };
+    static Rot givens(double p, double q) {
+        Rot r;
+        if (q == 0.0) { r.c = p < 0.0 ? -1.0 : 1.0; r.s = 0.0; }
+        else if (p == 0.0) { r.c = 0.0; r.s = q < 0.0 ? 1.0 : -1.0; }
+        else if (std::fabs(p) > std::fabs(q)) {
+            const double t = q / p;
+            double u = std::sqrt(1.0 + t * t);
+            if (p < 0.0) u = -u;
+            r.c = 1.0 / u;
+            r.s = -t * r.c;
+        } else {
+            const double t = p / q;
+            double u = std::sqrt(1.0 + t * t);
+            if (q < 0.0) u = -u;
+            r.s = -1.0 / u;
+            r.c = -t * r.s;
+        }
+        return r;
+    }
+    static double hypot3(double x, double y) {          // numext::hypot of Eigen 3.3
+        const double ax = std::fabs(x), ay = std::fabs(y);
+        const double p = ax > ay ? ax : ay;
+        if (p == 0.0) return 0.0;
+        const double qp = (ax > ay ? ay : ax) / p;
+        return p * std::sqrt(1.0 + qp * qp);
+    }
+    void tridiagonalize(const double l[6]) {            // l = {m00, m10, m11, m20, m21, m22}, already scaled
+        const double m00 = l[0], m10 = l[1], m11 = l[2], m20 = l[3], m21 = l[4], m22 = l[5];
+        m_eivalues[0] = m00;
+        const double v1norm2 = m20 * m20;
+        if (v1norm2 <= 2.2250738585072014e-308) {        // std::numeric_limits<double>::min()
+            m_eivalues[1] = m11; m_eivalues[2] = m22;
+            m_subdiag[0] = m10; m_subdiag[1] = m21;
+            m_eivec = Mat3::Identity();
+        } else {
+            const double beta = std::sqrt(m10 * m10 + v1norm2);
+            const double invBeta = 1.0 / beta;
+            const double m01 = m10 * invBeta, m02 = m20 * invBeta;
+            const double q = 2.0 * m01 * m21 + m02 * (m22 - m11);
+            m_eivalues[1] = m11 + m02 * q;
+            m_eivalues[2] = m22 - m02 * q;
+            m_subdiag[0] = beta;
+            m_subdiag[1] = m21 - m01 * q;
+            m_eivec = Mat3::Zero();
+            m_eivec(0, 0) = 1.0;
+            m_eivec(1, 1) = m01; m_eivec(1, 2) = m02;
+            m_eivec(2, 1) = m02; m_eivec(2, 2) = -m01;
+        }
+    }
+    void qrStep(int start, int end) {
+        double *diag = m_eivalues.a, *sub = m_subdiag;
+        const double td = (diag[end - 1] - diag[end]) * 0.5;
+        const double e = sub[end - 1];
+        double mu = diag[end];
+        if (td == 0.0) mu -= std::fabs(e);
+        else {
+            const double e2 = e * e;
+            const double h = hypot3(td, e);
+            if (e2 == 0.0) mu -= (e / (td + (td > 0.0 ? 1.0 : -1.0))) * (e / h);
+            else mu -= e2 / (td + (td > 0.0 ? h : -h));
+        }
+        double x = diag[start] - mu, z = sub[start];
+        for (int k = start; k < end; ++k) {
+            const Rot g = givens(x, z);
+            const double sdk = g.s * diag[k] + g.c * sub[k];
+            const double dkp1 = g.s * sub[k] + g.c * diag[k + 1];
+            diag[k] = g.c * (g.c * diag[k] - g.s * sub[k]) - g.s * (g.c * sub[k] - g.s * diag[k + 1]);
+            diag[k + 1] = g.s * sdk + g.c * dkp1;
+            sub[k] = g.c * sdk - g.s * dkp1;
+            if (k > start) sub[k - 1] = g.c * sub[k - 1] - g.s * z;
+            x = sub[k];
+            if (k < end - 1) { z = -g.s * sub[k + 1]; sub[k + 1] = g.c * sub[k + 1]; }
+            if (!(g.c == 1.0 && g.s == 0.0))
+                for (int i = 0; i < 3; ++i) {                 // Q.applyOnTheRight(k, k + 1, g)
+                    const double xi = m_eivec(i, k), yi = m_eivec(i, k + 1);
+                    m_eivec(i, k) = g.c * xi - g.s * yi;
+                    m_eivec(i, k + 1) = g.s * xi + g.c * yi;
+                }
+        }
+    }
+    void compute(const Mat3 &m) {
+        double l[6] = {m(0, 0), m(1, 0), m(1, 1), m(2, 0), m(2, 1), m(2, 2)};       // triangularView<Lower>()
+        double scale = 0.0;
+        for (double v : l) { const double av = std::fabs(v); if (av > scale) scale = av; }
+        if (scale == 0.0) scale = 1.0;
+        for (double &v : l) v /= scale;
+        tridiagonalize(l);
+        const double tiny = 2.2250738585072014e-308, precision = 2.0 * 2.220446049250313e-16;
+        double *diag = m_eivalues.a, *sub = m_subdiag;
+        int end = 2, start = 0, iter = 0;
+        while (end > 0) {
+            for (int i = start; i < end; ++i)
+                if (std::fabs(sub[i]) <= (std::fabs(diag[i]) + std::fabs(diag[i + 1])) * precision || std::fabs(sub[i]) <= tiny) sub[i] = 0.0;
+            while (end > 0 && sub[end - 1] == 0.0) end--;
+            if (end <= 0) break;
+            if (++iter > 30 * 3) break;
+            start = end - 1;
+            while (start > 0 && sub[start - 1] != 0.0) start--;
+            qrStep(start, end);
+        }
+        m_info = iter <= 30 * 3 ? Success : NoConvergence;
+        if (m_info == Success)
+            for (int i = 0; i < 2; ++i) {
+                int k = 0;
+                for (int j = 1; j < 3 - i; ++j) if (diag[i + j] < diag[i + k]) k = j;
+                if (k > 0) {
+                    const double t = diag[i]; diag[i] = diag[i + k]; diag[i + k] = t;
+                    for (int r = 0; r < 3; ++r) { const double u = m_eivec(r, i); m_eivec(r, i) = m_eivec(r, i + k); m_eivec(r, i + k) = u; }
+                }
+            }
+        for (int i = 0; i < 3; ++i) diag[i] *= scale;
+    }
+};
 
 }  // namespace srl

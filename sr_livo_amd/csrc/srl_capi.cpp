@@ -5,6 +5,7 @@
 #include "host/srl_la.h"
 #include "srl_device.h"
 #include "srl_hash.h"
+#include "srl_heap.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -252,6 +253,7 @@ int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     ctx->total_n = n;
     ctx->shard_begin = b;
     ctx->n = cnt;
+    ctx->sweep_loaded = true;
     ctx->taps_valid = false;
     if (cnt > ctx->sweep_cap) {
         const int cap = std::max(cnt, 1024);
@@ -390,7 +392,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     a.min_nb = o->min_number_neighbors;
     a.thr_cap = thr;
     a.select_mode = o->select_mode;
-    { const char *ab = std::getenv("SRL_ABLATE"); a.ablate = ab ? std::atoi(ab) : 0; }   // debug/profiling only
+    a.ablate = ctx->ablate;                                     // 0 unless srl_debug_set_ablate was called (profiling tools only)
     a.rec = ctx->d_rec;
     a.status = ctx->d_status;
     a.partials = ctx->d_partials;
@@ -437,28 +439,30 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     int64_t budget = o->max_num_residuals;
     int mode = 0;
     const bool coll = ctx->comm && (ctx->nranks > 1 || ctx->force_coll);
-    // the ordered cut can only trigger when max_num_residuals <= number of keypoints: otherwise no exchange of counts
-    const bool cut_possible = (long long)o->max_num_residuals <= (long long)ctx->total_n;
-    if (o->max_num_residuals <= 0 || (ctx->nranks == 1 && !coll) || !cut_possible) {
+    const bool multi = ctx->nranks > 1 || coll;
+    // the ordered cut can only trigger when max_num_residuals <= number of keypoints: otherwise no exchange of counts.
+    // max_num_residuals <= 0: the loop stops at the first keypoint with a plane, wherever (in whichever shard) that is.
+    const bool cut_possible = o->max_num_residuals <= 0 || (long long)o->max_num_residuals <= (long long)ctx->total_n;
+    const long long *gather_dev = nullptr;
+    if (!multi || !cut_possible) {
         srl_shard_budget(o->max_num_residuals, nullptr, ctx->nranks, ctx->rank, &budget, &mode);
     } else {
-        HIPCHK(ctx, srl_launch_count(ctx->d_binfo, nblocks, ctx->d_count, ctx->stream));
-        std::vector<long long> all((size_t)ctx->nranks, 0);
+        // per-rank counts (accepted residuals; keypoints with a plane when max_num_residuals <= 0)
+        HIPCHK(ctx, srl_launch_count(ctx->d_binfo, nblocks, o->max_num_residuals <= 0 ? 1 : 0, ctx->d_count, ctx->stream));
         if (ctx->comm) {
+            // gathered on the stream; the reduce kernel derives its budget and mode from the counts of earlier ranks
+            // itself -- no D2H copy, no host synchronisation in the loop
             NCCLCHK(ctx, ncclAllGather(ctx->d_count, ctx->d_gather, 1, ncclInt64, ctx->comm, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(all.data(), ctx->d_gather, sizeof(long long) * ctx->nranks, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            gather_dev = ctx->d_gather;
         } else {
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_count, ctx->d_count, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             if (!ctx->cb_ag) { ctx->err = "nranks > 1 without communicator"; return SRL_ERR_COMM; }
             int64_t mine = *ctx->h_count;
-            std::vector<int64_t> tmp((size_t)ctx->nranks, 0);
-            if (ctx->cb_ag(&mine, tmp.data(), ctx->cb_user) != 0) { ctx->err = "allgather callback failed"; return SRL_ERR_COMM; }
-            for (int r = 0; r < ctx->nranks; r++) all[r] = tmp[r];
+            std::vector<int64_t> all64((size_t)ctx->nranks, 0);
+            if (ctx->cb_ag(&mine, all64.data(), ctx->cb_user) != 0) { ctx->err = "allgather callback failed"; return SRL_ERR_COMM; }
+            srl_shard_budget(o->max_num_residuals, all64.data(), ctx->nranks, ctx->rank, &budget, &mode);
         }
-        std::vector<int64_t> all64(all.begin(), all.end());
-        srl_shard_budget(o->max_num_residuals, all64.data(), ctx->nranks, ctx->rank, &budget, &mode);
     }
 
     SrlReduceArgs ra;
@@ -470,6 +474,9 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     ra.kpb = kpb;
     ra.nblocks = nblocks;
     ra.max_res = budget;
+    ra.gather = gather_dev;
+    ra.rank = ctx->rank;
+    ra.max_num_residuals = o->max_num_residuals;
     ra.out = ctx->d_out;
     // single rank: the reduce kernel publishes straight into host-mapped memory and the host spins on the
     // sequence word -- no D2H copy, no stream synchronisation on the per-iteration critical path
@@ -604,27 +611,27 @@ int srl_search_neighbors(srl_ctx *ctx, const double *world_xyz, int n, int nb_vo
     if (n == 0) return SRL_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int K = max_num_neighbors;
-    double *d_q = nullptr;
-    int *d_ids = nullptr, *d_nf = nullptr;
-    float *d_xyz = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d_q, (size_t)n * 3 * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&d_ids, (size_t)n * K * sizeof(int)));
-    HIPCHK(ctx, hipMalloc((void **)&d_nf, (size_t)n * sizeof(int)));
-    if (nb_xyz) HIPCHK(ctx, hipMalloc((void **)&d_xyz, (size_t)n * K * 3 * sizeof(float)));
+    // scratch from the context's pool (RAII: returned on every exit path, no hipMalloc / hipFree per call)
+    DevBuf b_q, b_ids, b_nf, b_xyz;
+    HIPCHK(ctx, b_q.alloc(ctx, (size_t)n * 3 * sizeof(double)));
+    HIPCHK(ctx, b_ids.alloc(ctx, (size_t)n * K * sizeof(int)));
+    HIPCHK(ctx, b_nf.alloc(ctx, (size_t)n * sizeof(int)));
+    if (nb_xyz) HIPCHK(ctx, b_xyz.alloc(ctx, (size_t)n * K * 3 * sizeof(float)));
+    double *d_q = b_q.as<double>();
+    int *d_ids = b_ids.as<int>(), *d_nf = b_nf.as<int>();
+    float *d_xyz = nb_xyz ? b_xyz.as<float>() : nullptr;
     HIPCHK(ctx, hipMemcpyAsync(d_q, world_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(d_ids, 0xFF, (size_t)n * K * sizeof(int), ctx->stream));
     if (d_xyz) HIPCHK(ctx, hipMemsetAsync(d_xyz, 0, (size_t)n * K * 3 * sizeof(float), ctx->stream));
     SrlSearchArgs a;
     a.q = d_q; a.n = n; a.table = ctx->d_table; a.table_mask = ctx->table_cap - 1; a.slabs = ctx->d_slabs;
-    a.size_voxel = size_voxel_map; a.K = K; a.thr_cap = threshold_voxel_capacity; a.select_mode = 0;
+    a.size_voxel = size_voxel_map; a.K = K; a.thr_cap = threshold_voxel_capacity; a.select_mode = ctx->search_select_mode;
     a.ids = d_ids; a.nb_xyz = d_xyz; a.num_found = d_nf;
     HIPCHK(ctx, srl_launch_search(a, nb_voxels_visited, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ids, d_ids, (size_t)n * K * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(num_found, d_nf, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     if (nb_xyz) HIPCHK(ctx, hipMemcpyAsync(nb_xyz, d_xyz, (size_t)n * K * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d_q); hipFree(d_ids); hipFree(d_nf);
-    if (d_xyz) hipFree(d_xyz);
     return SRL_OK;
 }
 
@@ -633,9 +640,10 @@ int srl_transform_points(srl_ctx *ctx, const double *raw_xyz, int n, const doubl
     if (!ctx || n < 0 || (n > 0 && (!raw_xyz || !out_xyz)) || !q || !t || !R_il || !t_il) return SRL_ERR_BAD_ARG;
     if (n == 0) return SRL_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    double *d_in = nullptr, *d_o = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d_in, (size_t)n * 3 * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&d_o, (size_t)n * 3 * sizeof(double)));
+    DevBuf b_in, b_o;
+    HIPCHK(ctx, b_in.alloc(ctx, (size_t)n * 3 * sizeof(double)));
+    HIPCHK(ctx, b_o.alloc(ctx, (size_t)n * 3 * sizeof(double)));
+    double *d_in = b_in.as<double>(), *d_o = b_o.as<double>();
     HIPCHK(ctx, hipMemcpyAsync(d_in, raw_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     SrlXform X;
     const srl::Mat3 R = srl::Quat(q[0], q[1], q[2], q[3]).toRotationMatrix();   // utility.cpp:317: q_end.toRotationMatrix()
@@ -646,7 +654,42 @@ int srl_transform_points(srl_ctx *ctx, const double *raw_xyz, int n, const doubl
     HIPCHK(ctx, srl_launch_transform(d_in, n, X, d_o, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(out_xyz, d_o, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d_in); hipFree(d_o);
+    return SRL_OK;
+}
+
+// debug / parity hooks (never used by the product path)
+int srl_debug_set_ablate(srl_ctx *ctx, int bits) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    ctx->ablate = bits;
+    return SRL_OK;
+}
+int srl_debug_set_search_select_mode(srl_ctx *ctx, int select_mode) {
+    if (!ctx || select_mode < 0 || select_mode > 5) return SRL_ERR_BAD_ARG;
+    ctx->search_select_mode = select_mode;
+    return SRL_OK;
+}
+int srl_debug_heap_topk(const double *distances, int n, int K, int32_t *out_index) {
+    // the device's heap routines (srl_heap.h) on the host: candidates offered in index order, result = read-out order
+    if (n < 0 || K < 1 || K > SRL_MAX_NEIGHBORS || (n > 0 && !distances) || !out_index) return SRL_ERR_BAD_ARG;
+    double hd[SRL_MAX_NEIGHBORS];
+    int he[SRL_MAX_NEIGHBORS];
+    int size = 0;
+    for (int i = 0; i < n; i++) size = srl_heap_offer(hd, he, size, K, distances[i], i);
+    int out[SRL_MAX_NEIGHBORS];
+    srl_heap_drain(hd, he, size, out);
+    for (int i = 0; i < size; i++) out_index[i] = out[i];
+    return size;
+}
+int srl_debug_device_sqrt(srl_ctx *ctx, const double *in, int n, double *out) {
+    if (!ctx || n < 0 || (n > 0 && (!in || !out))) return SRL_ERR_BAD_ARG;
+    if (n == 0) return SRL_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf b;
+    HIPCHK(ctx, b.alloc(ctx, (size_t)n * sizeof(double)));
+    HIPCHK(ctx, hipMemcpyAsync(b.as<double>(), in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, srl_launch_sqrt(b.as<double>(), n, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out, b.as<double>(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SRL_OK;
 }
 
@@ -663,8 +706,12 @@ void srl_shard_budget(int max_num_residuals, const int64_t *accepted_per_rank, i
     int64_t b = max_num_residuals;
     int m = 0;
     if (max_num_residuals <= 0) {
-        // optimize.cpp:107 with the class default -1: the loop is left after the first keypoint
-        m = (rank == 0) ? 1 : 2;
+        // optimize.cpp:107 with the class default -1: the loop is left at the first keypoint that reaches the break test,
+        // i.e. the first one with >= min_number_neighbors neighbours (:78-79 `continue`s past the others).  Counts given:
+        // keypoints with a plane per rank -- this rank searches only if no earlier rank holds one.
+        int64_t prior = 0;
+        for (int r = 0; r < rank; r++) prior += accepted_per_rank ? accepted_per_rank[r] : (int64_t)1;
+        m = (prior > 0) ? 2 : 1;
     } else {
         int64_t prior = 0;
         for (int r = 0; r < rank; r++) prior += accepted_per_rank ? accepted_per_rank[r] : 0;
@@ -678,7 +725,15 @@ void srl_shard_budget(int max_num_residuals, const int64_t *accepted_per_rank, i
 int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, srl_normal_eq *out) {
     if (!ctx || !f || !o || !out) return SRL_ERR_BAD_ARG;
     if (!ctx->d_table) return SRL_ERR_NO_MAP;
-    if (ctx->total_n <= 0 && ctx->n <= 0) return SRL_ERR_NO_SWEEP;
+    if (!ctx->sweep_loaded) return SRL_ERR_NO_SWEEP;
+    if (ctx->total_n == 0) {
+        // an empty keypoint set is a valid pass: the loop of optimize.cpp:68 does not run, num_residuals = 0 fails the
+        // test at :110 and the caller gets summary.success = false (no exception, nothing visited)
+        std::memset(out, 0, sizeof *out);
+        out->last_visited = -1;
+        ctx->taps_valid = false;
+        return SRL_OK;
+    }
     // Finite max_num_residuals (600 in the shipped yaml files): the sequential loop of optimize.cpp:68-107 stops at the
     // max-th accepted keypoint and never looks at the rest, so a single rank first runs only a prefix that almost surely
     // contains it (4 x max + 2048 keypoints; ~95 % of visited keypoints are accepted).  If the prefix holds fewer accepted

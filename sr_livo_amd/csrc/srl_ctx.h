@@ -28,6 +28,9 @@ struct srl_ctx {
     int n = 0;                         // shard size
     int shard_begin = 0;
     int total_n = 0;
+    bool sweep_loaded = false;         // a sweep (possibly empty) has been uploaded / selected
+    int search_select_mode = 0;        // srl_debug_set_search_select_mode: selection path of srl_search_neighbors (tests)
+    int ablate = 0;                    // srl_debug_set_ablate (profiling tools only; never set by the product)
 
     // frame-resident pipeline (srl_frame_*)
     double *d_frame_raw = nullptr;     // AoS n x 3

@@ -51,9 +51,12 @@ static_assert(sizeof(SrlSlab) == SRL_SLAB_BYTES, "slab must be 256 bytes");
 struct SrlBlockInfo {          // per-workgroup integer results
     int accepted;              // residuals accepted in this block
     unsigned sum_pk;           // candidates visited
-    int nan_flag;
+    int nan_first;             // 1 + block-local index of the first keypoint whose planarity is NaN (optimize.cpp:348-350), 0 = none
     int num_fallback;
+    int planes;                // keypoints with >= min_number_neighbors neighbours (the ones that reach the break test, optimize.cpp:107)
+    int pad[3];
 };
+static_assert(sizeof(SrlBlockInfo) == 32, "block info is 32 bytes");
 
 struct SrlDevOut {             // result of the reduce kernel (device, then copied to host)
     double HtH[36];
@@ -123,7 +126,10 @@ struct SrlReduceArgs {
     const SrlBlockInfo *binfo;
     int n;
     int nblocks;
-    long long max_res;          // residual budget for THIS rank (already reduced by earlier ranks' counts)
+    long long max_res;          // residual budget for THIS rank (already reduced by earlier ranks' counts) ...
+    const long long *gather;    // ... or, when non-null: per-rank counts gathered on the stream (accepted residuals, or keypoints with a
+    int rank;                   //     plane when max_num_residuals <= 0); the kernel derives budget and mode itself from
+    int max_num_residuals;      //     max_num_residuals and the counts of ranks < rank -- no host synchronisation
     SrlDevOut *out;             // device result (multi-rank: all-reduced afterwards) ...
     SrlMailbox *mailbox;        // ... or, single rank: host-mapped mailbox written with system-scope stores (no memcpy)
     unsigned long long seq;
@@ -152,9 +158,10 @@ int srl_assoc_lds_bytes(int K, int nb_voxels, int kpw, int wpb);
 static inline int srl_keypoints_per_wave(int n) { return n <= 16384 ? 4 : (n <= 32768 ? 8 : 16); }
 #define SRL_LDS_LIMIT (160 * 1024)
 hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s);
-hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, long long *out_total, hipStream_t s);
+hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, int count_planes, long long *out_total, hipStream_t s);
 hipError_t srl_launch_publish(const SrlDevOut *src, SrlMailbox *mb, unsigned long long seq, hipStream_t s);
 hipError_t srl_launch_search(const SrlSearchArgs &a, int nb_voxels, hipStream_t s);
 struct SrlXform { double R[9], t[3], R_il[9], t_il[3]; };
 hipError_t srl_launch_transform(const double *raw_aos, int n, const SrlXform &X, double *out_aos, hipStream_t s);
 hipError_t srl_launch_aos_to_soa(const double *aos, int n, double *x, double *y, double *z, hipStream_t s);
+hipError_t srl_launch_sqrt(double *io, int n, hipStream_t s);   // debug: the device's sqrt(double), element-wise

@@ -412,7 +412,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
     if (keypoint_index) for (int k = 0; k < m; k++) keypoint_index[k] = order[k];
 
     // the selection becomes the resident sweep: gather raw points on the device (SoA)
-    ctx->total_n = m; ctx->shard_begin = 0; ctx->n = m; ctx->taps_valid = false;
+    ctx->total_n = m; ctx->shard_begin = 0; ctx->n = m; ctx->sweep_loaded = true; ctx->taps_valid = false;
     if (m > ctx->sweep_cap) {
         if (ctx->d_raw) { HIPCHK(ctx, hipFree(ctx->d_raw)); ctx->d_raw = nullptr; }
         const int cap = std::max(m, 1024);

@@ -20,6 +20,7 @@
 //   srl_search_kernel<NB>  searchNeighbors for a batch of world points (parity / API surface).
 #include "srl_device.h"
 #include "srl_hash.h"
+#include "srl_heap.h"
 
 #include <math.h>
 
@@ -28,7 +29,8 @@ namespace {
 struct alignas(8) VoxEnt { unsigned slab; unsigned count; };   // 8-B aligned: one ds_read_b64 with an immediate offset per entry
 struct Surv { double d2; float x, y, z; unsigned id; };
 static_assert(sizeof(Surv) == 24, "survivor record is 24 bytes");
-static_assert(SRL_SURV_CAP * 24 <= SRL_WAVE_SCRATCH, "general-path scratch must fit");
+static_assert(SRL_SURV_CAP * 24 + (SRL_MAXK + 1) * 8 <= SRL_WAVE_SCRATCH, "general-path scratch (survivors + sorted d2) must fit");
+static_assert(64 * 8 + SRL_MAXK * 16 + SRL_MAXK * 4 <= SRL_WAVE_SCRATCH, "heap replay scratch must fit");
 
 __device__ __forceinline__ int lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
@@ -116,8 +118,54 @@ __device__ __forceinline__ int probe_voxels(double qx, double qy, double qz, dou
     return nv;
 }
 
-// ---- exact top-K selection (ascending distance, ties by visit order) ----
-// Sink::put(rank, x, y, z, id) is called by exactly one lane per selected rank.
+// Selection results: the fast paths hand anything they cannot finish to the general path.
+enum { SEL_OVERFLOW = 0, SEL_DONE = 1, SEL_TIE = 2 };
+// Two squared distances a <= b can only round to the same sqrt (the reference compares norm() = sqrt(d2),
+// optimize.cpp:395,398) when b <= a (1 + 2^-50): sqrt(b) - sqrt(a) >= (b - a) / (2 sqrt(b)) and one ulp of sqrt(a) is
+// at most 2^-52 sqrt(a).  Anything closer than that is treated as a tie and replayed literally.
+#define SRL_NEAR_TIE 0x1.0000000000004p+0
+
+// ---- the reference's literal heap sequence (optimize.cpp:394-404, 411-422; srl_heap.h) for ONE keypoint ----
+// All lanes stage 64 candidate distances per round (visit order = candidate index), lane 0 offers them to the
+// heap one by one; lane i < size then emits rank i.  Slow (one lane) but exact for every input, ties included.
+template <class Sink>
+__device__ __forceinline__ void select_topk_replay(double qx, double qy, double qz, int nv, const VoxEnt *vox,
+                                                const unsigned char *slabs, int K, void *scratch, int lane, Sink &sink,
+                                                int &total_out) {
+    double *stage = reinterpret_cast<double *>(scratch);          // [64]
+    double *hd = stage + 64;                                      // [32]
+    int *he = reinterpret_cast<int *>(hd + SRL_MAXK);             // [32]
+    int *out = he + SRL_MAXK;                                     // [32]
+    const int rounds = (nv * SRL_CAP + 63) >> 6;
+    int size = 0, total = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < rounds; ++j) {
+        const Cand c = eval_cand(lane + 64 * j, nv, vox, slabs, qx, qy, qz);
+        stage[lane] = c.valid ? sqrt(c.d2) : -1.0;                // distance = (neighbor_point - point).norm()
+        total += __popcll(__ballot(c.valid));
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            for (int i = 0; i < 64; ++i) {
+                const double d = stage[i];
+                if (d >= 0.0) size = srl_heap_offer(hd, he, size, K, d, 64 * j + i);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) srl_heap_drain(hd, he, size, out);
+    __builtin_amdgcn_wave_barrier();
+    size = __shfl(size, 0);
+    if (lane < size) {
+        const Cand c = eval_cand(out[lane], nv, vox, slabs, qx, qy, qz);
+        sink.put(lane, c.x, c.y, c.z, c.id);
+    }
+    total_out = total;
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- exact top-K selection, general path (any r, any number of survivors) ----
+// Sink::put(rank, x, y, z, id) is called by exactly one lane per selected rank.  A (near-)tie among the K+1 smallest
+// distances hands the keypoint to select_topk_replay.  select_mode: 1 forces the streaming extraction, 5 the replay.
 template <class Sink>
 __device__ __forceinline__ void select_topk(double qx, double qy, double qz, int nv, const VoxEnt *vox,
                                             const unsigned char *slabs, int K, int select_mode, Surv *surv,
@@ -125,6 +173,11 @@ __device__ __forceinline__ void select_topk(double qx, double qy, double qz, int
     const int rounds = (nv * SRL_CAP + 63) >> 6;
     const float kInfF = __builtin_huge_valf();
     asm volatile("" : "+v"(lane));   // see probe_voxels: no hoisting of the sort network's lane constants
+    if (select_mode == 5) {
+        select_topk_replay(qx, qy, qz, nv, vox, slabs, K, surv, lane, sink, total_out);
+        fallback_out = 1;
+        return;
+    }
 
     // pass 1: stream all candidates, per-lane minimum of (float)d2, count P_k
     float lmin = kInfF;
@@ -138,7 +191,9 @@ __device__ __forceinline__ void select_topk(double qx, double qy, double qz, int
     total_out = total;
     const int nsel = total < K ? total : K;
     bool use_fallback = (select_mode == 1);
+    bool tie = false;
     int c_surv = 0;
+    double *sorted = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(surv) + SRL_SURV_CAP * sizeof(Surv));   // [K + 1]
 
     if (!use_fallback) {
         // K-th smallest of the 64 per-lane minima = an upper bound of the K-th smallest distance
@@ -156,7 +211,10 @@ __device__ __forceinline__ void select_topk(double qx, double qy, double qz, int
                 v = (lo == up) ? mn : mx;
             }
         }
-        const float tau = __uint_as_float(__shfl(v, K - 1));
+        // (float)d2 rounds to nearest: a candidate just above the K-th distance may round onto tau, one just below the
+        // (K+1)-th may round up past it -- the next float up keeps every candidate that can tie with the K-th.
+        const unsigned tbits = __shfl(v, K - 1);
+        const float tau = __uint_as_float(tbits < 0x7f800000u ? tbits + 1u : tbits);
 
         // pass 2: survivors {(float)d2 <= tau} are a prefix of the true order that contains the top-K;
         // compact them (visit order kept) into this wave's LDS scratch.
@@ -176,26 +234,32 @@ __device__ __forceinline__ void select_topk(double qx, double qy, double qz, int
     }
 
     if (!use_fallback) {
-        // exact FP64 rank by counting; equal distances keep visit order (j < i)
-        for (int i0 = 0; i0 < c_surv; i0 += 64) {
-            const int i = i0 + lane;
-            const bool act = i < c_surv;
-            Surv me;
-            if (act) me = surv[i];
-            else { me.d2 = __builtin_huge_val(); me.x = me.y = me.z = 0.0f; me.id = 0; }
-            int rank = 0;
-            for (int j = 0; j < c_surv; ++j) {
-                const double dj = surv[j].d2;
-                rank += ((dj < me.d2) || (dj == me.d2 && j < i)) ? 1 : 0;
-            }
-            if (act && rank < K) sink.put(rank, me.x, me.y, me.z, me.id);
+        // exact FP64 rank by counting (a permutation: equal d2 are separated by survivor index), then the tie check on
+        // neighbours in sorted order; c_surv <= SRL_SURV_CAP = 64: one survivor per lane
+        const int i = lane;
+        const bool act = i < c_surv;
+        Surv me;
+        if (act) me = surv[i];
+        else { me.d2 = __builtin_huge_val(); me.x = me.y = me.z = 0.0f; me.id = 0; }
+        int rank = 0;
+        for (int j = 0; j < c_surv; ++j) {
+            const double dj = surv[j].d2;
+            rank += ((dj < me.d2) || (dj == me.d2 && j < i)) ? 1 : 0;
         }
+        if (act && rank <= K) sorted[rank] = me.d2;
+        __builtin_amdgcn_wave_barrier();
+        bool bad = false;
+        if (act && rank < K && rank + 1 < c_surv) bad = !(sorted[rank + 1] > me.d2 * SRL_NEAR_TIE);
+        tie = __ballot(bad) != 0ull;
+        if (!tie && act && rank < K) sink.put(rank, me.x, me.y, me.z, me.id);
         fallback_out = 0;
     } else {
-        // streaming extraction: nsel passes, each taking the lexicographic successor of (d2, e)
+        // streaming extraction: nsel (+1 for the tie check at the cut-off) passes, each taking the lexicographic
+        // successor of (d2, e)
         double last_d2 = -1.0;
         int last_e = -1;
-        for (int r = 0; r < nsel; ++r) {
+        const int next = total < K + 1 ? total : K + 1;
+        for (int r = 0; r < next; ++r) {
             double bd2 = __builtin_huge_val();
             int be = 0x7fffffff;
             for (int j = 0; j < rounds; ++j) {
@@ -210,7 +274,8 @@ __device__ __forceinline__ void select_topk(double qx, double qy, double qz, int
                 const int oe = __shfl_xor(be, off);
                 if (od < bd2 || (od == bd2 && oe < be)) { bd2 = od; be = oe; }
             }
-            if ((be & 63) == lane) {
+            if (r > 0 && !(bd2 > last_d2 * SRL_NEAR_TIE)) { tie = true; break; }
+            if (r < nsel && (be & 63) == lane) {
                 const Cand c = eval_cand(be, nv, vox, slabs, qx, qy, qz);
                 sink.put(r, c.x, c.y, c.z, c.id);
             }
@@ -220,20 +285,16 @@ __device__ __forceinline__ void select_topk(double qx, double qy, double qz, int
         fallback_out = 1;
     }
     __builtin_amdgcn_wave_barrier();
+    if (tie) {
+        select_topk_replay(qx, qy, qz, nv, vox, slabs, K, surv, lane, sink, total_out);
+        fallback_out = 1;
+    }
 }
 
-// ---- fast exact top-K for r = 1 (<= 27 voxels): candidates' d2 stay in registers --------------------
-// Lane roles are fixed per wave (no integer division in the loop): lane l < 27 probes voxel offset
+// ---- fast path for r = 1 (<= 27 voxels) -------------------------------------------------------------
+// Lane roles are fixed per wave (no integer division in the loop): lane l < 27 of each half-wave probes voxel offset
 // (l/9-1, l/3%3-1, l%3-1) [visit order x,y,z]; in candidate round j lane l evaluates slot l%20 of
 // compacted voxel 3j + l/20 (60 of 64 lanes busy, <= 9 rounds), so visit order = (round, lane).
-//   pass 1  : one coalesced 12-B load per candidate, d2 kept in registers, per-lane min of (float)d2
-//   tau     : bisection on the f32 bit pattern with ballot/popcount (1 VALU + SALU per step): an upper
-//             bound of the K-th smallest per-lane minimum, hence of the K-th smallest distance
-//   pass 2  : survivors {(float)d2 <= tau} (a prefix of the true order holding >= K candidates)
-//             compacted with ballot + mbcnt into LDS as (d2, voxel/slot code) in visit order
-//   rank    : strict FP64 rank by counting over the <= 64 survivors, 2 keys per LDS broadcast read;
-//             equal ranks among the first K (= an exact distance tie) or > 64 survivors defer to the
-//             general path (returns false).
 struct LaneRole {
     int pdx, pdy, pdz;     // probe offset (half-wave lane < 27)
     int c0, slot;          // candidate role: voxel-in-round (0..2, 3 = idle) and slot (0..19)
@@ -312,105 +373,6 @@ __device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, cons
     return nv_a | (nv_b << 8);
 }
 
-template <class Sink>
-__device__ __forceinline__ bool select_topk_fast(double qx, double qy, double qz, int nv, const VoxEnt *vox,
-                                                 const unsigned char *slabs, int K, void *scratch, int lane,
-                                                 const LaneRole &role, Sink &sink, int &total_out) {
-    constexpr int MAXR = 9;
-    const int rounds = (nv + 2) / 3;
-    const double kInf = __builtin_huge_val();
-    double d2r[MAXR];
-    float px[MAXR], py[MAXR], pz[MAXR];
-    unsigned vmask = 0;
-    // issue every round's (LDS voxel entry ->) coalesced 12-B load first, consume afterwards: one L2
-    // round trip per keypoint instead of one per round
-#pragma unroll
-    for (int j = 0; j < MAXR; ++j) {
-        px[j] = py[j] = pz[j] = 0.0f;
-        if (j < rounds) {
-            const int cv = 3 * j + role.c0;
-            if (role.c0 < 3 && cv < nv) {
-                const VoxEnt ve = vox[cv];
-                if ((unsigned)role.slot < ve.count) {
-                    const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve.slab * SRL_SLAB_BYTES + role.slot * 12);
-                    px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
-                    vmask |= 1u << j;
-                }
-            }
-        }
-    }
-    float lmin = __builtin_huge_valf();
-    int total = 0;
-#pragma unroll
-    for (int j = 0; j < MAXR; ++j) {
-        d2r[j] = kInf;
-        if (j < rounds) {
-            const bool valid = (vmask >> j) & 1u;
-            const double dx = (double)px[j] - qx;
-            const double dy = (double)py[j] - qy;
-            const double dz = (double)pz[j] - qz;
-            const double d2 = valid ? (dx * dx + dy * dy) + dz * dz : kInf;
-            d2r[j] = d2;
-            lmin = fminf(lmin, (float)d2);
-            total += __popcll(__ballot(valid));
-        }
-    }
-    total_out = total;
-
-    const unsigned v = __float_as_uint(lmin);
-    unsigned lo = 0;
-#pragma unroll
-    for (int bit = 30; bit >= 18; --bit) {
-        const unsigned trial = lo | (1u << bit);
-        const int cnt = __popcll(__ballot(v < trial));
-        lo = (cnt < K) ? trial : lo;
-    }
-    const unsigned tau = lo | 0x3FFFFu;
-
-    double *keys = reinterpret_cast<double *>(scratch);                                        // [66], 16-B aligned
-    int *codes = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scratch) + 66 * 8); // [64] (voxel << 5) | slot
-    int *owner = codes + 64;                                                                   // [32] rank -> lane
-    int c = 0;
-#pragma unroll
-    for (int j = 0; j < MAXR; ++j) {
-        if (j < rounds) {
-            const bool sv = (d2r[j] < kInf) && (__float_as_uint((float)d2r[j]) <= tau);
-            const unsigned long long m = __ballot(sv);
-            const int pos = c + lanes_below(m);
-            if (sv && pos < 64) { keys[pos] = d2r[j]; codes[pos] = ((3 * j + role.c0) << 5) | role.slot; }
-            c += __popcll(m);
-        }
-    }
-    if (c > 64) return false;
-    if (lane < 2) keys[c + lane] = kInf;          // pad to an even count
-    __builtin_amdgcn_wave_barrier();
-
-    const bool act = lane < c;
-    const double my = act ? keys[lane] : kInf;
-    int rank = 0;
-#pragma unroll 4
-    for (int j = 0; j < c; j += 2) {
-        const double2 kk = *reinterpret_cast<const double2 *>(keys + j);
-        rank += (kk.x < my) ? 1 : 0;
-        rank += (kk.y < my) ? 1 : 0;
-    }
-    // strict ranks are a permutation unless two survivors are exactly equal: detect a clash among the first K
-    const bool win = act && rank < K;
-    if (win) owner[rank] = lane;
-    __builtin_amdgcn_wave_barrier();
-    const bool clash = win && (owner[rank] != lane);
-    if (__ballot(clash)) return false;             // exact distance tie: the general path decides by visit order
-    if (win) {
-        const int code = codes[lane];
-        const VoxEnt ve = vox[code >> 5];
-        const unsigned slot = (unsigned)code & 31u;
-        const float *p = reinterpret_cast<const float *>(slabs + (size_t)ve.slab * SRL_SLAB_BYTES + slot * 12u);
-        sink.put(rank, p[0], p[1], p[2], ve.slab * SRL_CAP + slot);
-    }
-    __builtin_amdgcn_wave_barrier();
-    return true;
-}
-
 // ---- fast exact top-K, FP32 prefilter variant (default for r = 1) -----------------------------------
 // Only the ~25 survivors of a conservative FP32 threshold are ever evaluated in FP64:
 //   pass 1  : coalesced 12-B loads (all rounds in flight), d2f = |p - fl32(q)|^2 in FP32 (FMA allowed: it
@@ -431,7 +393,7 @@ __device__ __forceinline__ float d2_f32(float px, float py, float pz, float qx, 
 
 // R = compile-time number of candidate rounds (3 voxels each): straight-line code, arrays stay in registers
 template <int R, class Sink>
-__device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
+__device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
                                                   const unsigned char *slabs, unsigned inf_off, int K, void *scratch, int lane,
                                                   const LaneRole &role, Sink &sink, int &total_out, int ablate) {
     const float kInfF = __builtin_huge_valf();
@@ -490,7 +452,7 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
 
     SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));            // [64], 16-B aligned
     double *keys = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024);  // [66]
-    int *owner = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scratch) + 1024 + 66 * 8 + 8);  // [32]
+    double *sorted = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024 + 66 * 8 + 8);  // [K + 1] d2 by rank
     unsigned long long svm[R];
     int c = 0;
 #pragma unroll
@@ -498,7 +460,7 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
         svm[j] = __ballot(d2f[j] <= thr);
         c += __popcll(svm[j]);
     }
-    if (c > 64) return false;              // checked before anything is written: the stores below need no clamp
+    if (c > 64) return SEL_OVERFLOW;       // checked before anything is written: the stores below need no clamp
     const int code0 = (role.c0 << 5) | role.slot;
     int base = 0;
 #pragma unroll
@@ -511,7 +473,7 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
             base += __popcll(svm[j]);
         }
     }
-    if (ablate & 2) return true;
+    if (ablate & 2) return SEL_DONE;
     __builtin_amdgcn_wave_barrier();
 
     const bool act = lane < c;
@@ -527,6 +489,7 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
     }
     keys[lane] = my;                                  // lanes >= c write +inf: keys[c], keys[c+1] pad an odd count
     if (lane < 2) keys[64 + lane] = __builtin_huge_val();
+    if (lane <= K) sorted[lane] = -1.0;               // rank -> d2; a rank nobody holds (= an exact tie below it) stays negative
     __builtin_amdgcn_wave_barrier();
     int rank = 0;
     if (c <= 32) {
@@ -550,21 +513,25 @@ __device__ __forceinline__ bool select_topk_f32_r(double qx, double qy, double q
             rank += (kk.y < my) ? 1 : 0;
         }
     }
+    // strict ranks are a permutation unless two survivors are exactly equal (then the next rank stays empty); the
+    // reference compares sqrt(d2) (optimize.cpp:395,398), so a successor in sorted order closer than SRL_NEAR_TIE counts
+    // as a tie too.  Checked over the K+1 smallest: ties further out cannot change the selected set or its order.
     const bool win = act && rank < K;
-    if (win) owner[rank] = lane;
+    if (act && rank <= K) sorted[rank] = my;
     __builtin_amdgcn_wave_barrier();
-    const bool clash = win && (owner[rank] != lane);
-    if (__ballot(clash)) return false;             // exact distance tie: the general path decides by visit order
+    bool bad = false;
+    if (win && rank + 1 < c) bad = !(sorted[rank + 1] > my * SRL_NEAR_TIE);
+    if (__ballot(bad)) return SEL_TIE;             // the reference's literal heap sequence decides (select_topk_replay)
     if (win) {
         const VoxEnt ve = vox[me.code >> 5];
         sink.put(rank, me.x, me.y, me.z, ve.slab * SRL_CAP + ((unsigned)me.code & 31u));
     }
     __builtin_amdgcn_wave_barrier();
-    return true;
+    return SEL_DONE;
 }
 
 template <class Sink>
-__device__ __forceinline__ bool select_topk_f32(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
+__device__ __forceinline__ int select_topk_f32(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
                                                 const unsigned char *slabs, unsigned inf_off, int K, void *scratch, int lane,
                                                 const LaneRole &role, Sink &sink, int &total_out, int ablate) {
     // straight-line instantiation per number of candidate rounds (3 voxels per round)
@@ -765,7 +732,7 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, i
     L.wave_bytes = w;
     o += wpb * w;
     L.off_wpart = o;   o += wpb * 32 * 8;
-    L.off_winfo = o;   o += wpb * 4 * 4;
+    L.off_winfo = o;   o += wpb * 8 * 4;
     L.total = o;
     return L;
 }
@@ -799,7 +766,7 @@ __device__ __forceinline__ double kp_sum(double v) {
     return v;
 }
 
-// FAST: 0 = general path only, 1 = FP32-prefilter fast path, 2 = FP64-retained fast path (r = 1 only)
+// FAST: 0 = general path only, 1 = FP32-prefilter fast path (r = 1 only)
 // WPB = waves per workgroup: 16 (one workgroup per CU; every wave of a SIMD belongs to it) or 4 (when the 16-wave LDS
 // footprint does not fit: K > 24).  With four independent 4-wave workgroups per CU the SIMD arbiter's age priority let
 // the oldest wave of every SIMD finish its 16 keypoints in 34 us and the youngest in 47 us; with 16-wave workgroups the
@@ -830,7 +797,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     VoxEnt *vox = reinterpret_cast<VoxEnt *>(wbase + L.off_vox);
     Surv *surv = reinterpret_cast<Surv *>(wbase + L.off_scratch);
     double *s_wpart = reinterpret_cast<double *>(smem + L.off_wpart);     // [4][32]
-    int *s_winfo = reinterpret_cast<int *>(smem + L.off_winfo);           // [4][4]: accepted, sum_pk, nan, fallback
+    int *s_winfo = reinterpret_cast<int *>(smem + L.off_winfo);           // [WPB][8]: accepted, sum_pk, 1 + first NaN keypoint, fallback, planes
 
     const int bbase_kp = blockIdx.x * KPB;                                // first keypoint of this workgroup
     const int wbase_kp = bbase_kp + wave * KPW;                           // first keypoint of this wave's quarter (phases 0 and 2)
@@ -893,13 +860,18 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             sink.plane = nb_plane;
             sink.tap_ids = a.tap_ids ? (a.tap_ids + (size_t)g * a.K) : nullptr;
             int total = 0, fb = 0;
-            bool done = false;
+            int done = SEL_OVERFLOW;
             if constexpr (NB == 1 && FAST != 0) {
-                if (a.ablate & 4) { done = true; total = nv_fast; }
-                else if constexpr (FAST == 1) done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv_fast, voxl, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
-                else done = select_topk_fast(qx, qy, qz, nv_fast, voxl, a.slabs, a.K, surv, lane, role, sink, total);
+                if (a.ablate & 4) { done = SEL_DONE; total = nv_fast; }
+                else done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv_fast, voxl, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
+                if (done == SEL_TIE) {
+                    // the probed list is complete and in visit order: replay the reference's heap on it directly
+                    select_topk_replay(qx, qy, qz, nv_fast, voxl, a.slabs, a.K, surv, lane, sink, total);
+                    fb = 1;
+                    done = SEL_DONE;
+                }
             }
-            if (!done) {
+            if (done != SEL_DONE) {
                 const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, voxl, lane);
                 select_topk(qx, qy, qz, nv, voxl, a.slabs, a.K, a.select_mode, surv, lane, sink, total, fb);
                 fb = (NB == 1) ? 1 : fb;       // r = 1: anything off the fast path counts as a fallback
@@ -1003,7 +975,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         const double sigma_2 = sqrt(fabs(ev[1]));
         const double sigma_3 = sqrt(fabs(ev[0]));
         const double a2D = (sigma_2 - sigma_3) * rcp_nr(sigma_1);  // optimize.cpp:343-346 (0 / 0 still yields NaN)
-        if (a2D != a2D) nan_bad = true;                           // optimize.cpp:348-350
+        if (a2D != a2D) nan_bad = true;                           // optimize.cpp:348-350 throws here: no residual from this keypoint
         const double w_plan = (b.power_planarity == 2.0) ? a2D * a2D : pow(a2D, b.power_planarity);
         // normal flip: world-frame last translation minus body-frame location (optimize.cpp:49-51)
         const D3 tl = d3(b.t_last[0], b.t_last[1], b.t_last[2]);
@@ -1021,7 +993,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             b.tap_a2d[g] = a2D;
             b.tap_offset[g] = off;
         }
-        if (dist < b.max_dist) {                                   // signed gate (optimize.cpp:98)
+        if (dist < b.max_dist && !nan_bad) {                       // signed gate (optimize.cpp:98)
             status = 2;
             J[0] = nv.x * weight; J[1] = nv.y * weight; J[2] = nv.z * weight;
             // - n^T * R * skew(p_imu) * weight, left to right (optimize.cpp:101)
@@ -1084,14 +1056,17 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     {
         const unsigned long long acc_mask = __ballot(status == 2 && sl == 0);
         const unsigned long long nan_mask = __ballot(nan_bad);
+        const unsigned long long pln_mask = __ballot((status == 1 || status == 2) && sl == 0);
         int pk = (lane < KPW && wbase_kp + lane < b.n) ? s_ncand[wave * KPW + lane] : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
         if (lane == 0) {
-            s_winfo[wave * 4 + 0] = __popcll(acc_mask);
-            s_winfo[wave * 4 + 1] = pk;
-            s_winfo[wave * 4 + 2] = nan_mask ? 1 : 0;
-            s_winfo[wave * 4 + 3] = n_fallback;
+            s_winfo[wave * 8 + 0] = __popcll(acc_mask);
+            s_winfo[wave * 8 + 1] = pk;
+            // first NaN keypoint of this wave as 1 + index inside the workgroup (quad q = keypoint wave * KPW + q)
+            s_winfo[wave * 8 + 2] = nan_mask ? 1 + wave * KPW + ((int)__builtin_ctzll(nan_mask) >> 2) : 0;
+            s_winfo[wave * 8 + 3] = n_fallback;
+            s_winfo[wave * 8 + 4] = __popcll(pln_mask);
         }
     }
     __syncthreads();
@@ -1108,10 +1083,12 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     }
     if (tid == 0) {
         SrlBlockInfo bi;
-        bi.accepted = 0; bi.sum_pk = 0; bi.nan_flag = 0; bi.num_fallback = 0;
+        bi.accepted = 0; bi.sum_pk = 0; bi.nan_first = 0; bi.num_fallback = 0; bi.planes = 0;
+        bi.pad[0] = bi.pad[1] = bi.pad[2] = 0;
         for (int w = 0; w < WPB; ++w) {
-            bi.accepted += s_winfo[w * 4 + 0]; bi.sum_pk += (unsigned)s_winfo[w * 4 + 1];
-            bi.nan_flag |= s_winfo[w * 4 + 2] ? 1 : 0; bi.num_fallback += s_winfo[w * 4 + 3];
+            bi.accepted += s_winfo[w * 8 + 0]; bi.sum_pk += (unsigned)s_winfo[w * 8 + 1];
+            if (bi.nan_first == 0) bi.nan_first = s_winfo[w * 8 + 2];       // waves in order: the first one wins
+            bi.num_fallback += s_winfo[w * 8 + 3]; bi.planes += s_winfo[w * 8 + 4];
         }
         b.binfo[blockIdx.x] = bi;
     }
@@ -1119,39 +1096,61 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
 
 // ---------------------------------------------------------------------------------------------
 // ordered cut-off + final reduction (single workgroup)
-// mode: 0 = budget max_res >= 1; 1 = visit only the first keypoint (max_num_residuals <= 0,
-// optimize.cpp:107 breaks after the first keypoint); 2 = visit nothing (budget spent by earlier shards)
+// mode: 0 = budget max_res >= 1; 1 = max_num_residuals <= 0: the loop stops at the first keypoint that reaches the
+// break test (optimize.cpp:107 sits behind the `continue` of :78-79, so keypoints with too few neighbours are passed
+// over); 2 = visit nothing (budget spent, or the stop keypoint found, in earlier shards).
+// With a.gather the kernel derives mode and budget itself from the per-rank counts gathered on the stream.
+// NaN planarity (optimize.cpp:348-350) is an error only for keypoints the sequential loop reaches (<= last_visited).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a, int mode) {
+__global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a, int mode_in) {
     __shared__ long long s_chunk[1024];
     __shared__ double s_part[32][SRL_PART_STRIDE];
-    __shared__ long long s_tot[4];          // total accepted, sum_pk, nan, fallback
+    __shared__ long long s_tot[4];          // total accepted, sum_pk, (unused), fallback
     __shared__ int s_cut[4];                // cut block, allowed in cut block, last visited local idx, num_res
+    __shared__ int s_nan_min;               // smallest keypoint index with NaN planarity
     const int tid = threadIdx.x;
     const int nb = a.nblocks;
 
+    int mode = mode_in;
+    long long max_res = a.max_res;
+    if (a.gather) {
+        long long prior = 0;
+        for (int r = 0; r < a.rank; ++r) prior += a.gather[r];
+        if (a.max_num_residuals > 0) {
+            max_res = (long long)a.max_num_residuals - prior;      // what the shards before this one left of the budget
+            mode = max_res <= 0 ? 2 : 0;
+        } else {
+            mode = prior > 0 ? 2 : 1;                              // gathered: keypoints with a plane per rank
+        }
+    }
+
     // integer totals
-    long long acc = 0, pk = 0, nanf = 0, fb = 0;
+    long long acc = 0, pk = 0, fb = 0;
+    int nan_min = 0x7fffffff;
     const int per = (nb + 1023) / 1024;
     const int b0 = tid * per;
     const int b1 = (b0 + per < nb) ? b0 + per : nb;
     for (int b = b0; b < b1; ++b) {
         const SrlBlockInfo bi = a.binfo[b];
-        acc += bi.accepted; pk += bi.sum_pk; nanf += bi.nan_flag; fb += bi.num_fallback;
+        acc += bi.accepted; pk += bi.sum_pk; fb += bi.num_fallback;
+        if (bi.nan_first > 0) { const int g = b * a.kpb + bi.nan_first - 1; nan_min = g < nan_min ? g : nan_min; }
     }
     s_chunk[tid] = acc;
     if (tid < 4) s_tot[tid] = 0;
+    if (tid == 0) s_nan_min = 0x7fffffff;
     __syncthreads();
     {   // wave-level sums first (integers: order irrelevant), then one LDS atomic per wave and counter
-        long long w0 = acc, w1 = pk, w2 = nanf, w3 = fb;
+        long long w0 = acc, w1 = pk, w3 = fb;
+        int w2 = nan_min;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            w0 += __shfl_xor(w0, off); w1 += __shfl_xor(w1, off); w2 += __shfl_xor(w2, off); w3 += __shfl_xor(w3, off);
+            w0 += __shfl_xor(w0, off); w1 += __shfl_xor(w1, off); w3 += __shfl_xor(w3, off);
+            const int o2 = __shfl_xor(w2, off); w2 = o2 < w2 ? o2 : w2;
         }
         if ((tid & 63) == 0) {
             if (w0) atomicAdd((unsigned long long *)&s_tot[0], (unsigned long long)w0);
             if (w1) atomicAdd((unsigned long long *)&s_tot[1], (unsigned long long)w1);
-            if (w2) atomicAdd((unsigned long long *)&s_tot[2], (unsigned long long)w2);
+            if (w2 != 0x7fffffff) atomicMin(&s_nan_min, w2);
             if (w3) atomicAdd((unsigned long long *)&s_tot[3], (unsigned long long)w3);
         }
     }
@@ -1164,23 +1163,27 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
         if (mode == 2) {
             cut_block = 0; allowed = 0; last_visited = -1; num_res = 0;
         } else if (mode == 1) {
-            cut_block = 0; allowed = 0; last_visited = (a.n > 0) ? 0 : -1;
-            num_res = (a.n > 0 && a.status[0] == 2) ? 1 : 0;
-        } else if (total >= a.max_res) {
+            // first keypoint with a plane (status 1 or 2): it is the last one visited, and the only possible residual
+            int k = 0;
+            while (k < a.n && !(a.status[k] == 1 || a.status[k] == 2)) ++k;
+            cut_block = 0; allowed = 0;
+            last_visited = (k < a.n) ? k : a.n - 1;
+            num_res = (k < a.n && a.status[k] == 2) ? 1 : 0;
+        } else if (total >= max_res) {
             // find the keypoint holding the max_res-th accepted residual (optimize.cpp:107)
             long long before = 0;
             int c = 0;
-            while (c < 1024 && before + s_chunk[c] < a.max_res) { before += s_chunk[c]; ++c; }
+            while (c < 1024 && before + s_chunk[c] < max_res) { before += s_chunk[c]; ++c; }
             int b = c * per;
-            while (b < nb && before + a.binfo[b].accepted < a.max_res) { before += a.binfo[b].accepted; ++b; }
+            while (b < nb && before + a.binfo[b].accepted < max_res) { before += a.binfo[b].accepted; ++b; }
             cut_block = b;
-            allowed = (int)(a.max_res - before);
+            allowed = (int)(max_res - before);
             int seen = 0;
             int k = b * a.kpb;
             const int kend = (k + a.kpb < a.n) ? k + a.kpb : a.n;
             for (; k < kend; ++k) { if (a.status[k] == 2) { ++seen; if (seen == allowed) break; } }
             last_visited = k;
-            num_res = a.max_res;
+            num_res = max_res;
         }
         s_cut[0] = cut_block; s_cut[1] = allowed; s_cut[2] = last_visited; s_cut[3] = (int)num_res;
     }
@@ -1219,7 +1222,7 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
     if (tid < 28) {
         double s = s_part[0][tid];
         for (int p = 1; p < 32; ++p) s += s_part[p][tid];
-        // cut block (or the single first keypoint in mode 1): re-accumulate from the records, in order
+        // cut block (or the keypoints up to the stop keypoint in mode 1): re-accumulate from the records, in order
         if (mode != 2 && cut_block < nb) {
             int ia = 0, ib = 0;
             if (tid < 21) { int c = tid; int rowlen = 6; while (c >= rowlen) { c -= rowlen; ia++; rowlen--; } ib = ia + c; }
@@ -1250,7 +1253,7 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
         put_f(&out->d_num_res, (double)s_cut[3]);
         put_f(&out->d_total_accepted, (double)s_tot[0]);
         put_f(&out->d_sum_pk, (double)s_tot[1]);
-        put_f(&out->d_nan, (double)s_tot[2]);
+        put_f(&out->d_nan, (s_nan_min <= last_visited) ? 1.0 : 0.0);
         put_f(&out->d_fallback, (double)s_tot[3]);
         put_f(&out->d_visited, (double)(last_visited + 1));
         put_i(&out->last_visited, (long long)last_visited);
@@ -1263,10 +1266,11 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
     }
 }
 
-__global__ void __launch_bounds__(256) srl_count_kernel(const SrlBlockInfo *binfo, int nblocks, long long *out_total) {
+// per-rank count for the ordered cut across shards: accepted residuals, or (max_num_residuals <= 0) keypoints with a plane
+__global__ void __launch_bounds__(256) srl_count_kernel(const SrlBlockInfo *binfo, int nblocks, int count_planes, long long *out_total) {
     __shared__ long long s[256];
     long long acc = 0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) acc += binfo[b].accepted;
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += count_planes ? binfo[b].planes : binfo[b].accepted;
     s[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x == 0) { long long t = 0; for (int i = 0; i < 256; ++i) t += s[i]; *out_total = t; }
@@ -1287,7 +1291,7 @@ struct GlobalSink {
 template <int NB>
 __global__ void __launch_bounds__(SRL_BLOCK) srl_search_kernel(const SrlSearchArgs a) {
     __shared__ __attribute__((aligned(16))) VoxEnt s_vox[4][128];
-    __shared__ __attribute__((aligned(16))) Surv s_surv[4][SRL_SURV_CAP];
+    __shared__ __attribute__((aligned(16))) unsigned char s_scr[4][SRL_WAVE_SCRATCH];     // survivors [64] + sorted [K + 1]
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int nwaves = gridDim.x * 4;
@@ -1298,7 +1302,7 @@ __global__ void __launch_bounds__(SRL_BLOCK) srl_search_kernel(const SrlSearchAr
         sink.ids = a.ids + (size_t)q * a.K;
         sink.xyz = a.nb_xyz ? a.nb_xyz + (size_t)q * a.K * 3 : nullptr;
         int total = 0, fb = 0;
-        select_topk(qx, qy, qz, nv, s_vox[wave], a.slabs, a.K, a.select_mode, s_surv[wave], lane, sink, total, fb);
+        select_topk(qx, qy, qz, nv, s_vox[wave], a.slabs, a.K, a.select_mode, reinterpret_cast<Surv *>(s_scr[wave]), lane, sink, total, fb);
         if (lane == 0) a.num_found[q] = total < a.K ? total : a.K;
     }
 }
@@ -1321,7 +1325,19 @@ __global__ void srl_aos_to_soa_kernel(const double *aos, int n, double *x, doubl
     z[i] = aos[(size_t)i * 3 + 2];
 }
 
+// debug: the device's sqrt(double) (the heap replay relies on it being correctly rounded; tests compare with the host's)
+__global__ void srl_sqrt_kernel(double *io, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) io[i] = sqrt(io[i]);
+}
+
 }  // namespace
+
+hipError_t srl_launch_sqrt(double *io, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(srl_sqrt_kernel, dim3((n + 255) / 256), dim3(256), 0, s, io, n);
+    return hipGetLastError();
+}
 
 template <int KPW, int WPB>
 static hipError_t launch_assoc_cfg(const SrlAssocArgs &a, int nb_voxels, hipStream_t s) {
@@ -1346,7 +1362,7 @@ static hipError_t launch_assoc_cfg(const SrlAssocArgs &a, int nb_voxels, hipStre
     };
     if (nb_voxels == 1) {
         if (a.select_mode == 0 || a.select_mode == 4) return launch(srl_assoc_kernel<1, 1, KPW, WPB>);
-        if (a.select_mode == 3) return launch(srl_assoc_kernel<1, 2, KPW, WPB>);
+        // select_mode 1, 2, 5: general path only
         return launch(srl_assoc_kernel<1, 0, KPW, WPB>);
     }
     return launch(srl_assoc_kernel<2, 0, KPW, WPB>);
@@ -1388,8 +1404,8 @@ hipError_t srl_launch_publish(const SrlDevOut *src, SrlMailbox *mb, unsigned lon
     return hipGetLastError();
 }
 
-hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, long long *out_total, hipStream_t s) {
-    hipLaunchKernelGGL(srl_count_kernel, dim3(1), dim3(256), 0, s, binfo, nblocks, out_total);
+hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, int count_planes, long long *out_total, hipStream_t s) {
+    hipLaunchKernelGGL(srl_count_kernel, dim3(1), dim3(256), 0, s, binfo, nblocks, count_planes, out_total);
     return hipGetLastError();
 }
 

@@ -197,6 +197,52 @@ def eskf_prior(eskf_like, q_pred, t_pred, vel):
     return s
 
 
+def lattice_scene(seed, n_keypoints, K_hint=20):
+    """A scene built to TIE: every map point sits on a 0.25 m lattice (exact in FP32 and FP64) and most keypoints on
+    lattice-symmetric positions (cell centres, edge midpoints, lattice points), so that many candidate distances are
+    exactly equal -- inside the K nearest and across the K-th / (K+1)-th cut.  Which of the tied points the reference
+    keeps, and in which order, is decided by libstdc++'s heap (optimize.cpp:394-404); this scene is what the
+    tie-faithful selection is tested on.  The pose is the identity rotation with a lattice translation, so the world
+    points are exact too.  Returns (map_points in insertion order, sweep dict like make_sweep's)."""
+    rng = np.random.default_rng(seed)
+    h = 0.25
+    ax = np.arange(-32, 33) * h                                    # -8 .. 8
+    gx, gy = np.meshgrid(ax, ax, indexing="ij")
+    ground = np.column_stack([gx.ravel(), gy.ravel(), np.full(gx.size, -1.0)])
+    sel = gx.ravel() >= 0.0
+    upper = np.column_stack([gx.ravel()[sel], gy.ravel()[sel], np.full(sel.sum(), -0.75)])
+    wz = np.arange(-3, 5) * h                                      # -0.75 .. 1.0
+    wy, wzz = np.meshgrid(ax, wz, indexing="ij")
+    wall = np.column_stack([np.full(wy.size, 3.0), wy.ravel(), wzz.ravel()])
+    wall2 = np.column_stack([wy.ravel(), np.full(wy.size, -2.5), wzz.ravel()])
+    pts = np.concatenate([ground, upper, wall, wall2], 0)
+    pts = np.unique(pts, axis=0)
+    rng.shuffle(pts, axis=0)                                       # irregular per-voxel insertion order
+
+    t = np.array([0.5, 0.25, 0.125])
+    q = np.array([1.0, 0.0, 0.0, 0.0])
+    n = int(n_keypoints)
+    base = np.column_stack([rng.integers(-26, 27, n), rng.integers(-26, 27, n)]) * h
+    kind = rng.integers(0, 6, n)
+    off = np.zeros((n, 3))
+    off[kind == 0] = [0.125, 0.125, 0.0]                           # cell centre above / on a layer
+    off[kind == 1] = [0.125, 0.0, 0.0]                             # edge midpoint
+    off[kind == 2] = [0.0, 0.0, 0.0]                               # on a lattice point
+    off[kind == 3] = [0.125, 0.125, 0.125]                         # cell centre between the two layers
+    off[kind == 4] = [0.0, 0.125, 0.0625]
+    jitter = kind == 5                                             # generic positions: tie-free keypoints in between
+    z0 = np.where(rng.random(n) < 0.5, -1.0, -0.875)
+    pw = np.column_stack([base, z0]) + off
+    pw[jitter] += rng.uniform(-0.11, 0.11, (int(jitter.sum()), 3))
+    near_wall = rng.random(n) < 0.2                                # some keypoints next to the x = 3 wall, at wall heights
+    pw[near_wall, 0] = 3.0 - 0.125 * rng.integers(0, 3, int(near_wall.sum()))
+    pw[near_wall, 2] = -0.75 + 0.125 * rng.integers(0, 9, int(near_wall.sum()))
+    raw = pw - t                                                   # identity extrinsics and rotation: p_w = raw + t exactly
+    assert np.array_equal((raw + t)[~jitter], pw[~jitter])
+    vel = np.zeros(3)
+    return pts, dict(raw=raw, q_gt=q, t_gt=t, q_pred=q, t_pred=t, t_last=t + np.array([0.0, 0.0, 0.5]), vel=vel)
+
+
 CONFIGS = {
     # name: (n_keypoints, map_points, pattern, seed)   -- SURVEY.md 8(d)
     "C1": (4096, 100_000, "livox", 20250304 + 1),

@@ -6,6 +6,7 @@ PARITY UNPINNED: the reference ships no golden vectors for this path and cannot 
 (SURVEY.md 8(c)), so these vectors are outputs of oracle/ (the line-by-line restatement), built
 against the real vendored tsl::robin_map when /root/reference is present.  They pin the oracle
 against regressions and travel to the GPU box, where the HIP path is compared with them.
+The symmetric eigen-solver is the oracle's restatement of Eigen 3.3.7's algorithm (eig3_eigen_ql).
 """
 import os
 import sys
@@ -52,6 +53,25 @@ def main():
     for name, frame_id, max_res in (("full", 100, 2**31 - 1), ("cut600", 100, 600), ("init", 5, 2**31 - 1), ("neg1", 100, -1)):
         for k, v in solve_case(m, sweep, frame_id, max_res, backend).items():
             data[f"{name}_{k}"] = v
+    # the tie scene (synth.lattice_scene): most keypoints have exactly tied candidate distances, so ids / order are the
+    # real libstdc++ heap's; one pass with the shipped K = 20 and one with K = 5 (ties across the cut in almost every keypoint)
+    tpts, tsw = synth.lattice_scene(4711, 1536)
+    tm = po.Map(backend)
+    tm.add_points(tpts)
+    tk, tc, tx = tm.export()
+    data.update(tie_map_keys=tk, tie_map_counts=tc, tie_map_xyz=tx, tie_raw=tsw["raw"], tie_q=tsw["q_pred"], tie_t=tsw["t_pred"],
+                tie_t_last=tsw["t_last"])
+    for name, kw in (("tie", {}), ("tie5", dict(max_number_neighbors=5, min_number_neighbors=5))):
+        one = tm.build_plane_residuals(po.default_opts(max_num_residuals=2**31 - 1, **kw), tsw["raw"], tsw["q_pred"], tsw["t_pred"],
+                                       tsw["t_last"], frame_id=100)
+        for k, v in one.items():
+            if isinstance(v, np.ndarray):
+                data[f"{name}_one_{k}"] = v
+        data.update({f"{name}_one_num_residuals": one["neq"].num_residuals, f"{name}_one_loss": one["neq"].loss_sum,
+                     f"{name}_one_num_ties": one["neq"].num_ties, f"{name}_one_success": one["neq"].success,
+                     f"{name}_one_sum_candidates": one["neq"].sum_candidates, f"{name}_one_num_visited": one["neq"].num_visited})
+        print(name, "keypoints", len(tsw["raw"]), "with ties", one["neq"].num_ties, "residuals", one["neq"].num_residuals)
+    data["eig_solver"] = "eigen-3.3.7-ql"
     path = os.path.join(HERE, "golden_small.npz")
     np.savez_compressed(path, **data)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; map", m.size(), "pts", m.num_voxels(), "voxels; backend", backend)

@@ -1,8 +1,9 @@
 """GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle on the same
 seeded inputs and against the committed golden fixtures (tests/golden/).
 
-Bars (BASELINE.json north_star): neighbour indices bit-exact (on tie-free inputs; ties are counted by
-the oracle and must be zero here), residuals / normal equations / ESIKF state within 1e-5 RELATIVE.
+Bars (BASELINE.json north_star): neighbour indices bit-exact -- tied candidate distances included: the oracle runs the
+literal std::priority_queue and the kernels replay libstdc++'s heap whenever they detect a tie --, residuals / normal
+equations / ESIKF state within 1e-5 RELATIVE.
 """
 import threading
 
@@ -54,8 +55,7 @@ def check_pass_against(g, ref, prefix, tol=TIGHT):
     st_ref = ref[f"{prefix}_one_status"]
     assert np.array_equal(g["status"], st_ref), "status (accepted set / cut-off) differs"
     visited = st_ref != 3
-    # neighbour indices: bit-exact
-    assert int(ref[f"{prefix}_one_num_ties"]) == 0
+    # neighbour indices: bit-exact, tied distances included (the kernels replay libstdc++'s heap on ties)
     assert np.array_equal(g["ids"][visited], ref[f"{prefix}_one_ids"][visited]), "neighbour ids differ"
     has_plane = (st_ref == 1) | (st_ref == 2)
     acc = st_ref == 2
@@ -224,9 +224,229 @@ def test_search_neighbors_api_vs_oracle(oracle_lib, scene100k):
             for i in range(len(q)):
                 r = m.search_neighbors(q[i], nb=nb, K=K)
                 assert nf[i] == r["n"]
-                if not r["tie"]:
-                    assert np.array_equal(ids[i, : r["n"]], r["ids"])
-                    assert np.array_equal(xyz[i, : r["n"]].astype(np.float64), r["xyz"])
+                assert np.array_equal(ids[i, : r["n"]], r["ids"])
+                assert np.array_equal(xyz[i, : r["n"]].astype(np.float64), r["xyz"])
+    finally:
+        ctx.close()
+
+
+# ----------------------------------------------------------------------------- ties: the reference's heap order
+@pytest.fixture(scope="module")
+def ctx_tie(golden):
+    ctx = srl.Context(0)
+    ctx.map_upload(golden["tie_map_keys"], golden["tie_map_counts"], golden["tie_map_xyz"])
+    yield ctx
+    ctx.close()
+
+
+PLANE_TOL = 1e-6     # exact-lattice neighbourhoods are exact planes: sigma_3 = sqrt(|lambda_0|) amplifies eps ||A|| to ~1e-8
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 5])
+@pytest.mark.parametrize("prefix,K", [("tie", 20), ("tie5", 5)])
+def test_tied_distances_follow_the_reference_heap(ctx_tie, golden, prefix, K, mode):
+    """synth.lattice_scene: ~86 % of the keypoints have exactly tied candidate distances, inside the K nearest and across
+    the cut.  Which tied points survive, and in which order, is libstdc++'s heap order (optimize.cpp:394-404,411-422); ids
+    must equal the oracle's (literal std::priority_queue) for EVERY keypoint, through every selection path:
+    0 fast path + replay on detection, 1 extraction + replay, 2 general two-pass + replay, 5 replay for all."""
+    assert int(golden[f"{prefix}_one_num_ties"]) > 1000
+    g = gpu_pass(ctx_tie, golden["tie_raw"], golden["tie_q"], golden["tie_t"], golden["tie_t_last"], max_num_residuals=INT_MAX,
+                 max_number_neighbors=K, min_number_neighbors=K, select_mode=mode)
+    check_pass_against(g, golden, prefix, tol=PLANE_TOL)
+    assert g["neq"].sum_candidates == int(golden[f"{prefix}_one_sum_candidates"])
+    if mode == 0:
+        # the fast path must have handed (at least) the tied keypoints to the replay, and only a minority of the rest
+        assert g["neq"].num_fallback >= int(golden[f"{prefix}_one_num_ties"])
+
+
+def test_forced_heap_replay_equals_fast_path_on_tie_free_data(ctx_small, golden):
+    g5 = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX, select_mode=5)
+    check_pass_against(g5, golden, "full")
+    assert g5["neq"].num_fallback == len(golden["raw"])
+    g5i = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], frame_id=5, max_num_residuals=INT_MAX, select_mode=5)
+    check_pass_against(g5i, golden, "init")
+
+
+def test_search_neighbors_api_on_tied_points(oracle_lib, oracle_backend, golden, ctx_tie):
+    m = oracle_lib.Map(oracle_backend)
+    m.import_(golden["tie_map_keys"], golden["tie_map_counts"], golden["tie_map_xyz"])
+    q = golden["tie_raw"][:200] + golden["tie_t"]
+    for mode in (0, 1, 5):
+        ctx_tie.set_search_select_mode(mode)
+        for nb, K in ((1, 20), (2, 20), (1, 4), (2, 32)):
+            ids, xyz, nf = ctx_tie.search_neighbors(q, nb=nb, K=K)
+            ties = 0
+            for i in range(len(q)):
+                r = m.search_neighbors(q[i], nb=nb, K=K)
+                ties += int(r["tie"])
+                assert nf[i] == r["n"]
+                assert np.array_equal(ids[i, : r["n"]], r["ids"]), (mode, nb, K, i)
+            assert ties > 100
+    ctx_tie.set_search_select_mode(0)
+
+
+def test_device_sqrt_is_correctly_rounded(ctx_small):
+    """The tie replay compares sqrt(d2) like the reference (norm(), optimize.cpp:395): the device's sqrt must round like
+    the host's (IEEE correctly rounded)."""
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.uniform(0, 4, 200_000), rng.uniform(0, 1e-6, 50_000), 10.0 ** rng.uniform(-300, 300, 50_000),
+                        np.nextafter(np.arange(1, 2000, dtype=np.float64) ** 2, 0), np.arange(0, 2000, dtype=np.float64) ** 2,
+                        np.nextafter(np.arange(1, 2000, dtype=np.float64) ** 2, np.inf), [0.0, 5e-324, 2.2250738585072014e-308]])
+    assert np.array_equal(ctx_small.device_sqrt(x), np.sqrt(x))
+
+
+# ----------------------------------------------------------------------------- NaN planarity: visited keypoints only
+def _nan_scene(golden):
+    """the small golden map + one voxel far away holding 20 IDENTICAL points (addPointToMap could never build it; a
+    legal srl_map_upload): a keypoint next to it gets a zero scatter matrix, a2D = 0/0 = NaN (optimize.cpp:343-350)."""
+    keys = np.concatenate([golden["map_keys"], np.array([[300, 300, 30]], np.int16)])
+    counts = np.concatenate([golden["map_counts"], np.array([20], np.int32)])
+    xyz = np.concatenate([golden["map_xyz"], np.full((1, 20, 3), [300.5, 300.5, 30.5], np.float32)])
+    return keys, counts, xyz
+
+
+@pytest.mark.parametrize("pos,max_res,expect_nan", [(100, INT_MAX, True), (100, 600, True), (1500, 600, False), (1500, INT_MAX, True),
+                                                    (2047, 2040, False), (0, -1, True), (5, -1, False)])
+def test_nan_planarity_only_counts_for_visited_keypoints(oracle_lib, oracle_backend, golden, pos, max_res, expect_nan):
+    """The reference throws at optimize.cpp:348-350 only for keypoints its sequential loop reaches before the break at
+    :107; a degenerate neighbourhood behind the cut is never looked at."""
+    keys, counts, xyz = _nan_scene(golden)
+    m = oracle_lib.Map(oracle_backend)
+    m.import_(keys, counts, xyz)
+    raw = golden["raw"].copy()
+    R = synth.quat_to_rot(golden["q_pred"] / np.linalg.norm(golden["q_pred"]))
+    raw[pos] = R.T @ (np.array([300.5, 300.5, 30.45]) - golden["t_pred"])       # lands next to the degenerate voxel
+    o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=max_res), raw, golden["q_pred"], golden["t_pred"], golden["t_last"])
+    assert bool(o["neq"].nan_error) == expect_nan
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(keys, counts, xyz)
+        for taps in (1, 0):            # taps off: the single-rank prefix pass for finite max_num_residuals
+            ctx.sweep_upload(raw)
+            ctx.set_taps(taps)
+            neq, rc = ctx.build_residuals(capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"]), srl.default_opts(max_num_residuals=max_res))
+            assert (rc == capi.SRL_ERR_NAN_PLANARITY) == expect_nan and bool(neq.nan_error) == expect_nan
+            if not expect_nan:
+                assert neq.num_residuals == o["neq"].num_residuals and neq.last_visited == o["neq"].num_visited - 1
+                assert rel(np.array(neq.HtH).reshape(6, 6), o["HtH"]) < TIGHT
+        ctx.set_taps(0)
+    finally:
+        ctx.close()
+
+
+def test_nan_planarity_raises_through_the_class_surface(golden):
+    keys, counts, xyz = _nan_scene(golden)
+    raw = golden["raw"].copy()
+    R = synth.quat_to_rot(golden["q_pred"] / np.linalg.norm(golden["q_pred"]))
+    raw[7] = R.T @ (np.array([300.5, 300.5, 30.45]) - golden["t_pred"])
+    lio = srl.Lio(0)
+    try:
+        lio.ctx.map_upload(keys, counts, xyz)
+        lio.eskf_set_state(golden["full_eskf_state0"]); lio.eskf_set_cov(golden["full_eskf_cov0"])
+        r = lio.update_iekf(srl.default_opts(max_num_residuals=INT_MAX), raw, golden["full_state0"], golden["t_last"])
+        assert r["rc"] == capi.SRL_ERR_NAN_PLANARITY            # the mirror rethrows std::runtime_error("error"); the C handle reports it
+    finally:
+        lio.close()
+
+
+# ----------------------------------------------------------------------------- max_num_residuals <= 0, empty sweeps
+def test_class_default_max_num_residuals_stops_at_the_first_keypoint_with_a_plane(oracle_lib, oracle_backend, golden):
+    """optimize.cpp:107 sits behind the `continue` of :78-79: with max_num_residuals = -1 the loop passes over keypoints
+    that have too few neighbours and stops at the first one that has a plane."""
+    m = oracle_lib.Map(oracle_backend)
+    m.import_(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+    raw = golden["raw"].copy()
+    raw[:37] = raw[:37] + np.array([0.0, 0.0, 900.0])             # the first 37 keypoints see no map at all
+    o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=-1), raw, golden["q_pred"], golden["t_pred"], golden["t_last"])
+    assert o["neq"].num_visited == 38 and np.all(o["status"][:37] == 0)
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        g = gpu_pass(ctx, raw, golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=-1)
+        assert np.array_equal(g["status"], o["status"])
+        assert g["neq"].last_visited == 37 and g["neq"].num_residuals == o["neq"].num_residuals == 1
+        assert rel(np.array(g["neq"].HtH).reshape(6, 6), o["HtH"]) < TIGHT
+        # the same across 4 logical shards: the stop keypoint lives in shard 0 here, then in shard 1
+        for shift in (0, 600):
+            raw2 = golden["raw"].copy()
+            raw2[: 37 + shift] = raw2[: 37 + shift] + np.array([0.0, 0.0, 900.0])
+            o2 = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=-1), raw2, golden["q_pred"], golden["t_pred"], golden["t_last"])
+            neq = _logical_shards_pass(golden, raw2, 4, -1)
+            assert neq.last_visited == o2["neq"].num_visited - 1 == 37 + shift
+            assert neq.num_residuals == o2["neq"].num_residuals
+            assert rel(np.array(neq.HtH).reshape(6, 6), o2["HtH"]) < TIGHT
+    finally:
+        ctx.close()
+
+
+def test_empty_keypoint_set_is_a_failed_solve_not_an_error(golden):
+    """0 keypoints: the loop of optimize.cpp:68 does not run, :110 reports failure, process() carries on."""
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        ctx.sweep_upload(np.zeros((0, 3)))
+        neq, rc = ctx.build_residuals(capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"]), srl.default_opts())
+        assert rc == 0 and neq.num_residuals == 0 and neq.success == 0 and neq.last_visited == -1
+        assert not np.any(np.array(neq.HtH)) and not np.any(np.array(neq.Hth))
+    finally:
+        ctx.close()
+    lio = srl.Lio(0)
+    try:
+        lio.ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        lio.eskf_set_state(golden["full_eskf_state0"]); lio.eskf_set_cov(golden["full_eskf_cov0"])
+        r = lio.update_iekf(srl.default_opts(), np.zeros((0, 3)), golden["full_state0"], golden["t_last"])
+        assert r["rc"] == capi.SRL_ERR_NOT_ENOUGH_RESIDUALS and r["num_residuals"] == 0
+        assert np.array_equal(r["state"], golden["full_state0"])
+        # and the next sweep solves normally on the same handle
+        r2 = lio.update_iekf(srl.default_opts(max_num_residuals=INT_MAX), golden["raw"], golden["full_state0"], golden["t_last"])
+        assert r2["rc"] == 0 and r2["iters"] == int(golden["full_solve_rc"])
+    finally:
+        lio.close()
+
+
+# ----------------------------------------------------------------------------- large coordinates, the truncation seam
+@pytest.mark.parametrize("shift", [(20000.0, -20000.0, 150.0), (-19990.25, 19000.5, -40.0), (0.0, 0.0, 0.0)])
+def test_far_from_the_origin_and_across_the_truncation_seam(oracle_lib, oracle_backend, shift):
+    """+-20 km: an FP32 ulp is 2 mm there, which stresses the FP32 prefilter's margin (thr = c0 + c1 tau) -- the result is
+    still the exact FP64 top-K.  shift = 0: the scene straddles the coordinate planes, where truncation toward zero makes
+    voxel 0 two metres wide and insert keys (FP32 position) can differ from query keys (FP64 position)."""
+    shift = np.array(shift)
+    pts, L = synth.map_candidates(4242, 60_000)
+    sw = synth.make_sweep(4243, 6000, L)
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(pts + shift)
+    t_pred = sw["t_pred"] + shift
+    t_last = sw["t_last"] + shift
+    raw = sw["raw"].copy()
+    if not shift.any():
+        # keypoints ON the seam: world coordinates within +-1e-7 of the planes x = 0 / y = 0 / z = -1, and exactly on them
+        R = synth.quat_to_rot(sw["q_pred"] / np.linalg.norm(sw["q_pred"]))
+        rng = np.random.default_rng(1)
+        for i in range(0, 600):
+            pw = R @ raw[i] + t_pred
+            ax = i % 3
+            pw[ax] = [0.0, 0.0, -1.0][ax] + (0.0 if i % 2 else rng.uniform(-1e-7, 1e-7))
+            raw[i] = R.T @ (pw - t_pred)
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(*m.export())
+        g = gpu_pass(ctx, raw, sw["q_pred"], t_pred, t_last, max_num_residuals=INT_MAX)
+        o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=INT_MAX), raw, sw["q_pred"], t_pred, t_last)
+        ref = {f"x_one_{k}": v for k, v in o.items() if isinstance(v, np.ndarray)}
+        ref.update(x_one_num_residuals=o["neq"].num_residuals, x_one_success=o["neq"].success, x_one_loss=o["neq"].loss_sum)
+        # norm_offset = -n . nn0 is ~2e4 at +-20 km: compare absolutely scaled fields with the scene's scale
+        check_pass_against(g, ref, "x", tol=1e-8)
+        assert o["neq"].num_residuals > 4000
+        assert g["neq"].sum_candidates == o["neq"].sum_candidates
+        # device-side insertion builds the same map there (FP32 keys / positions at 2 mm resolution)
+        ctx2 = srl.Context(0)
+        try:
+            ctx2.map_insert(pts + shift)
+            k2, c2, x2 = ctx2.map_download()
+            k1, c1, x1 = m.export()
+            assert np.array_equal(k1, k2) and np.array_equal(c1, c2) and np.array_equal(x1, x2)
+        finally:
+            ctx2.close()
     finally:
         ctx.close()
 
@@ -283,17 +503,9 @@ def test_map_insert_reproduces_the_sequential_map(oracle_lib, oracle_backend):
 
 
 # ----------------------------------------------------------------------------- sharded path on one device
-@pytest.mark.parametrize("max_res", [INT_MAX, 600, 37, -1])
-def test_logical_shards_reproduce_single_rank(golden, max_res):
-    """G = 4 logical shards (threads, one context each, host callbacks standing in for RCCL): same
-    partition / ordered cut-off / reduction code as the multi-GPU path.  Result must equal the single
-    context result (bit-exact counts, 1e-12 on the sums: only the summation order differs)."""
-    G = 4
-    ref_ctx = srl.Context(0)
-    ref_ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
-    ref = gpu_pass(ref_ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=max_res)
-    ref_ctx.close()
-
+def _run_logical_shards(golden, raw, G, max_res):
+    """G logical shards on one device (threads, one context each, host callbacks standing in for RCCL): same partition /
+    ordered cut-off / reduction code as the multi-GPU path.  Returns the per-rank gpu_pass results."""
     barrier = threading.Barrier(G)
     lock = threading.Lock()
     box = {"sum": None, "gather": [0] * G, "n": 0}
@@ -324,7 +536,7 @@ def test_logical_shards_reproduce_single_rank(golden, max_res):
                 return out
 
             ctx.comm_set_host_callbacks(G, rank, allreduce, allgather)
-            results[rank] = gpu_pass(ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=max_res)
+            results[rank] = gpu_pass(ctx, raw, golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=max_res)
             results[rank]["shard"] = ctx.sweep_shard()
             ctx.close()
         except Exception as e:  # noqa: BLE001
@@ -338,6 +550,23 @@ def test_logical_shards_reproduce_single_rank(golden, max_res):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errors, errors
+    return results
+
+
+def _logical_shards_pass(golden, raw, G, max_res):
+    return _run_logical_shards(golden, raw, G, max_res)[0]["neq"]
+
+
+@pytest.mark.parametrize("max_res", [INT_MAX, 600, 37, -1])
+def test_logical_shards_reproduce_single_rank(golden, max_res):
+    """G = 4 logical shards: the result must equal the single context result (bit-exact counts, 1e-12 on the sums:
+    only the summation order differs)."""
+    G = 4
+    ref_ctx = srl.Context(0)
+    ref_ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+    ref = gpu_pass(ref_ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=max_res)
+    ref_ctx.close()
+    results = _run_logical_shards(golden, golden["raw"], G, max_res)
     status = np.concatenate([results[r]["status"] for r in range(G)])
     ids = np.concatenate([results[r]["ids"] for r in range(G)])
     assert np.array_equal(status, ref["status"])
@@ -358,7 +587,7 @@ def test_rccl_single_rank_communicator(golden, monkeypatch):
     ctx = srl.Context(0)
     try:
         ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
-        for max_res in (600, INT_MAX):
+        for max_res in (600, INT_MAX, -1):   # -1: the count of keypoints with a plane is what gets gathered
             ctx.comm_set_host_callbacks(1, 0, lambda b: None, lambda v: [v])      # detach any communicator
             base = gpu_pass(ctx, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=max_res)
             monkeypatch.setenv("SRL_FORCE_COLLECTIVES", "1")
