@@ -27,7 +27,7 @@
 #endif
 #define SRL_BLOCK 256         // threads per workgroup (4 waves)
 #define SRL_SURV_CAP 64       // per-wave survivor scratch entries (general path; more survivors -> extraction)
-#define SRL_WAVE_SCRATCH 2048  // bytes of LDS scratch per wave (fast path: 64 x 16 B records + 66 keys + 32 owners = 1688 B)
+#define SRL_WAVE_SCRATCH 2048  // bytes of LDS scratch per wave (fast path: 64 x 16 B records + 66 keys + 33 ranked d2 = 1816 B; heap replay 1024 B)
 #define SRL_MAXK 32
 #define SRL_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define SRL_TABLE_FACTOR 4u   // hash slots per voxel capacity (load <= 0.25: a 2-slot probe almost always resolves)

@@ -385,12 +385,6 @@ __device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, cons
 //             ((dx*dx + dy*dy) + dz*dz, no FMA), strict rank by counting, clash check, emit from registers.
 struct alignas(16) SurvRec { float x, y, z; int code; };
 
-__device__ __forceinline__ float d2_f32(float px, float py, float pz, float qx, float qy, float qz) {
-#pragma clang fp contract(fast)
-    const float dx = px - qx, dy = py - qy, dz = pz - qz;
-    return dx * dx + dy * dy + dz * dz;
-}
-
 // R = compile-time number of candidate rounds (3 voxels each): straight-line code, arrays stay in registers
 template <int R, class Sink>
 __device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
@@ -452,7 +446,7 @@ __device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz
 
     SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));            // [64], 16-B aligned
     double *keys = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024);  // [66]
-    double *sorted = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024 + 66 * 8 + 8);  // [K + 1] d2 by rank
+    double *sorted = keys + 66;                                                                    // [K + 1] d2 by rank, behind the key pads
     unsigned long long svm[R];
     int c = 0;
 #pragma unroll
@@ -488,8 +482,8 @@ __device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz
         my = (dx * dx + dy * dy) + dz * dz;          // the reference's evaluation order (optimize.cpp:394-395)
     }
     keys[lane] = my;                                  // lanes >= c write +inf: keys[c], keys[c+1] pad an odd count
-    if (lane < 2) keys[64 + lane] = __builtin_huge_val();
-    if (lane <= K) sorted[lane] = -1.0;               // rank -> d2; a rank nobody holds (= an exact tie below it) stays negative
+    // the two +inf key pads and, right behind them, sorted[0..K] = NaN ("nobody holds this rank") in one store
+    if (lane < K + 3) keys[64 + lane] = lane < 2 ? __builtin_huge_val() : __builtin_nan("");
     __builtin_amdgcn_wave_barrier();
     int rank = 0;
     if (c <= 32) {
@@ -513,14 +507,15 @@ __device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz
             rank += (kk.y < my) ? 1 : 0;
         }
     }
-    // strict ranks are a permutation unless two survivors are exactly equal (then the next rank stays empty); the
-    // reference compares sqrt(d2) (optimize.cpp:395,398), so a successor in sorted order closer than SRL_NEAR_TIE counts
-    // as a tie too.  Checked over the K+1 smallest: ties further out cannot change the selected set or its order.
+    // Tie check over the K+1 smallest (ties further out cannot change the selected set or its order).  The reference
+    // compares sqrt(d2) (optimize.cpp:395,398), so neighbours in sorted order closer than SRL_NEAR_TIE count as tied.
+    // Winners file their d2 under their rank; strict ranks are a permutation unless survivors are exactly equal -- then the
+    // rank behind them stays NaN.  Lane i compares ranks i - 1 and i: a NaN on either side fails the comparison too.
     const bool win = act && rank < K;
     if (act && rank <= K) sorted[rank] = my;
     __builtin_amdgcn_wave_barrier();
     bool bad = false;
-    if (win && rank + 1 < c) bad = !(sorted[rank + 1] > my * SRL_NEAR_TIE);
+    if (lane >= 1 && lane <= K && lane < c) bad = !(sorted[lane] > sorted[lane - 1] * SRL_NEAR_TIE);
     if (__ballot(bad)) return SEL_TIE;             // the reference's literal heap sequence decides (select_topk_replay)
     if (win) {
         const VoxEnt ve = vox[me.code >> 5];
@@ -706,7 +701,7 @@ __device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], 
 struct LdsLayout {
     // workgroup-level keypoint arrays (KPB = WPB x KPW keypoints), then one region per wave, then the block tail
     int nb_row;                    // row stride (floats) of the neighbour planes
-    int off_nb, off_pw, off_pimu, off_qf, off_kv, off_nfound, off_ncand, off_next;
+    int off_nb, off_pw, off_pimu, off_qf, off_kv, off_nfound, off_ncand, off_next, off_defer;
     int off_wave, wave_bytes, off_vox, off_scratch;     // per-wave: off_wave + w * wave_bytes + {off_vox, off_scratch}
     int off_wpart, off_winfo, total;
 };
@@ -724,7 +719,8 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, i
     L.off_kv = o;      o += up16((kpb + 2) * 4 * 4);           // + zero entries behind the last pair
     L.off_nfound = o;  o += up16(kpb * 4);
     L.off_ncand = o;   o += up16(kpb * 4);
-    L.off_next = o;    o += 16;                                // pair counter of the workgroup
+    L.off_next = o;    o += 16;                                // workgroup counters: next pair, deferred keypoints, next deferred
+    L.off_defer = o;   o += up16(kpb * 2);                     // keypoints the fast path handed on (index | tie flag << 15)
     L.off_wave = o;
     int w = 0;
     L.off_vox = w;     w += (nb_voxels == 1 ? 64 : 128) * 8;   // r = 1: two 32-entry lists (a keypoint pair is probed at once)
@@ -793,6 +789,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     int *s_nfound = reinterpret_cast<int *>(smem + L.off_nfound);
     int *s_ncand = reinterpret_cast<int *>(smem + L.off_ncand);
     int *s_next = reinterpret_cast<int *>(smem + L.off_next);
+    unsigned short *s_defer = reinterpret_cast<unsigned short *>(smem + L.off_defer);
     unsigned char *wbase = smem + L.off_wave + wave * L.wave_bytes;
     VoxEnt *vox = reinterpret_cast<VoxEnt *>(wbase + L.off_vox);
     Surv *surv = reinterpret_cast<Surv *>(wbase + L.off_scratch);
@@ -805,7 +802,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     const long long dbg_t0 = (a.ablate & 128) ? (long long)wall_clock64() : 0;   // debug: workgroup start (100 MHz clock)
 
     // ---------------- phase 0: transformKeypoints (optimize.cpp:30-40), location (optimize.cpp:83), voxel key
-    if (tid == 0) *s_next = 0;
+    if (tid < 4) s_next[tid] = 0;
     if (lane < KPW) {
         const int kq = wave * KPW + lane;                                  // index inside the workgroup
         const int g = wbase_kp + lane;
@@ -849,47 +846,38 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     // ---------------- phase 1: searchNeighbors, the whole wave on one keypoint at a time
     int n_fallback = 0;
     {
-        const LaneRole role = lane_role(lane);
-        // one keypoint: fast path on its probed voxel list, general path otherwise
-        auto keypoint = [&](int kl, int nv_fast, VoxEnt *voxl) {
-            const int g = bbase_kp + kl;
-            const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
+        const int left = a.n - bbase_kp;
+        const int n_here = __builtin_amdgcn_readfirstlane(left < KPB ? left : KPB);   // keypoints of this workgroup that exist
+        auto make_sink = [&](int kl) {
             LdsSink sink;
             sink.col = s_nb + kl;
             sink.row = NB_ROW;
             sink.plane = nb_plane;
-            sink.tap_ids = a.tap_ids ? (a.tap_ids + (size_t)g * a.K) : nullptr;
+            sink.tap_ids = a.tap_ids ? (a.tap_ids + (size_t)(bbase_kp + kl) * a.K) : nullptr;
+            return sink;
+        };
+        // general path for one keypoint (own hash probes; tie = replay the reference's heap directly)
+        auto keypoint_general = [&](int kl, bool tie) {
+            const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
+            LdsSink sink = make_sink(kl);
             int total = 0, fb = 0;
-            int done = SEL_OVERFLOW;
-            if constexpr (NB == 1 && FAST != 0) {
-                if (a.ablate & 4) { done = SEL_DONE; total = nv_fast; }
-                else done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv_fast, voxl, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
-                if (done == SEL_TIE) {
-                    // the probed list is complete and in visit order: replay the reference's heap on it directly
-                    select_topk_replay(qx, qy, qz, nv_fast, voxl, a.slabs, a.K, surv, lane, sink, total);
-                    fb = 1;
-                    done = SEL_DONE;
-                }
-            }
-            if (done != SEL_DONE) {
-                const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, voxl, lane);
-                select_topk(qx, qy, qz, nv, voxl, a.slabs, a.K, a.select_mode, surv, lane, sink, total, fb);
-                fb = (NB == 1) ? 1 : fb;       // r = 1: anything off the fast path counts as a fallback
-            }
-            n_fallback += fb;
+            const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, vox, lane);
+            select_topk(qx, qy, qz, nv, vox, a.slabs, a.K, tie ? 5 : a.select_mode, surv, lane, sink, total, fb);
+            n_fallback += (NB == 1) ? 1 : fb;      // r = 1: anything off the fast path counts as a fallback
             if (lane == 0) {
                 s_nfound[kl] = total < a.K ? total : a.K;
                 s_ncand[kl] = total;
             }
         };
-        const int left = a.n - bbase_kp;
-        const int n_here = __builtin_amdgcn_readfirstlane(left < KPB ? left : KPB);   // keypoints of this workgroup that exist
         if constexpr (NB == 1 && FAST != 0) {
             // The waves of the workgroup take keypoint PAIRS from a shared counter: a wave whose keypoints were cheap
             // simply takes more of them (per-keypoint cost varies ~3x with the number of occupied voxels; with static
             // shares the slowest wave sets the pace).  Hash lookups run
             // for the pair (one keypoint per half-wave) and one pair ahead, so their L2 round trip overlaps the selection
             // of the current pair.  Results do not depend on who searched what: phase 2 is static.
+            // Keypoints the fast path cannot finish (> 64 survivors, or a tie among the K+1 smallest distances) are only
+            // NOTED here (workgroup list) and handled after the loop: the hot loop carries no general-path code.
+            const LaneRole role = lane_role(lane);
             const int npairs = (n_here + 1) >> 1;
             auto take = [&]() { int p = 0; if (lane == 0) p = atomicAdd(s_next, 1); return __builtin_amdgcn_readfirstlane(p); };
             int cur = take();
@@ -902,14 +890,38 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
                 const int nv_pair = __builtin_amdgcn_readfirstlane((a.ablate & 8) ? 0 : probe_finish(creq, a.thr_cap, a.table, a.table_mask, vox, lane));
 #pragma nounroll
                 for (int h = 0; h < 2; ++h) {
-                    if (2 * cur + h >= n_here) break;
-                    keypoint(2 * cur + h, h ? (nv_pair >> 8) : (nv_pair & 0xFF), vox + 32 * h);
+                    const int kl = 2 * cur + h;
+                    if (kl >= n_here) break;
+                    const int nv_fast = h ? (nv_pair >> 8) : (nv_pair & 0xFF);
+                    const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
+                    LdsSink sink = make_sink(kl);
+                    int total = nv_fast;
+                    int done = SEL_DONE;
+                    if (!(a.ablate & 4)) done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv_fast, vox + 32 * h, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
+                    if (lane == 0) {
+                        if (done == SEL_DONE) {
+                            s_nfound[kl] = total < a.K ? total : a.K;
+                            s_ncand[kl] = total;
+                        } else {
+                            s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)(kl | (done == SEL_TIE ? 0x8000 : 0));
+                        }
+                    }
                 }
                 cur = nxt;
             }
+            __syncthreads();
+            // deferred keypoints (rare; none on tie-free sweeps): handed out one by one to whichever wave comes first
+            const int n_defer = __builtin_amdgcn_readfirstlane(s_next[1]);
+            if (n_defer > 0) {
+                auto take2 = [&]() { int p = 0; if (lane == 0) p = atomicAdd(s_next + 2, 1); return __builtin_amdgcn_readfirstlane(p); };
+                for (int i = take2(); i < n_defer; i = take2()) {
+                    const int e = __builtin_amdgcn_readfirstlane((int)s_defer[i]);
+                    keypoint_general(e & 0x7FFF, (e & 0x8000) != 0);
+                }
+            }
         } else {
             // general path (r = 2 / forced modes): static quarters
-            for (int kl = wave * KPW; kl < (wave + 1) * KPW && kl < n_here; ++kl) keypoint(kl, 0, vox);
+            for (int kl = wave * KPW; kl < (wave + 1) * KPW && kl < n_here; ++kl) keypoint_general(kl, false);
         }
     }
     __syncthreads();

@@ -50,8 +50,25 @@ def gpu_pass(ctx, raw, q, t, t_last, frame_id=100, **optkw):
     return dict(neq=neq, rc=rc, ids=ids, status=status, ncand=ncand, **res)
 
 
-def check_pass_against(g, ref, prefix, tol=TIGHT):
-    """ref: golden dict with keys prefix_one_*"""
+def eigen_gap(ids, map_xyz):
+    """(lambda_1 - lambda_0) / lambda_2 of every keypoint's neighbourhood (NaN without a full id row): where it
+    vanishes the normal is decided by rounding inside the eigen-solver and no two solvers agree on it."""
+    gap = np.full(len(ids), np.nan)
+    flat = np.asarray(map_xyz, np.float64).reshape(-1, 3)
+    for k, row in enumerate(ids):
+        if row.min() < 0:
+            continue
+        P = flat[row]
+        E = P - P.sum(0) / len(P)
+        w = np.linalg.eigvalsh(E.T @ E)
+        gap[k] = (w[1] - w[0]) / max(w[2], 1e-300)
+    return gap
+
+
+def check_pass_against(g, ref, prefix, tol=TIGHT, well_posed=None):
+    """ref: golden dict with keys prefix_one_*.  well_posed (bool per keypoint, optional): keypoints whose normal is
+    determined by the data; the others are compared on ids / status / a2D only (and the normal equations are skipped if
+    any of them was accepted)."""
     st_ref = ref[f"{prefix}_one_status"]
     assert np.array_equal(g["status"], st_ref), "status (accepted set / cut-off) differs"
     visited = st_ref != 3
@@ -59,14 +76,17 @@ def check_pass_against(g, ref, prefix, tol=TIGHT):
     assert np.array_equal(g["ids"][visited], ref[f"{prefix}_one_ids"][visited]), "neighbour ids differ"
     has_plane = (st_ref == 1) | (st_ref == 2)
     acc = st_ref == 2
-    for key in ("normal", "a2D", "weight", "norm_offset", "distance"):
-        assert rel(g[key][has_plane], ref[f"{prefix}_one_{key}"][has_plane]) < tol, key
-    assert rel(g["jacobian"][acc], ref[f"{prefix}_one_jacobian"][acc]) < tol
+    assert rel(g["a2D"][has_plane], ref[f"{prefix}_one_a2D"][has_plane]) < tol, "a2D"
+    ok = np.ones(len(st_ref), bool) if well_posed is None else well_posed
+    for key in ("normal", "weight", "norm_offset", "distance"):
+        assert rel(g[key][has_plane & ok], ref[f"{prefix}_one_{key}"][has_plane & ok]) < tol, key
+    assert rel(g["jacobian"][acc & ok], ref[f"{prefix}_one_jacobian"][acc & ok]) < tol
     assert g["neq"].num_residuals == int(ref[f"{prefix}_one_num_residuals"])
     assert g["neq"].success == int(ref[f"{prefix}_one_success"])
-    assert rel(np.array(g["neq"].HtH).reshape(6, 6), ref[f"{prefix}_one_HtH"]) < tol
-    assert rel(np.array(g["neq"].Hth), ref[f"{prefix}_one_Hth"]) < tol
-    assert rel(g["neq"].loss_sum, ref[f"{prefix}_one_loss"]) < tol
+    if not np.any(acc & ~ok):
+        assert rel(np.array(g["neq"].HtH).reshape(6, 6), ref[f"{prefix}_one_HtH"]) < tol
+        assert rel(np.array(g["neq"].Hth), ref[f"{prefix}_one_Hth"]) < tol
+        assert rel(g["neq"].loss_sum, ref[f"{prefix}_one_loss"]) < tol
 
 
 # ----------------------------------------------------------------------------- one pass vs golden
@@ -252,7 +272,11 @@ def test_tied_distances_follow_the_reference_heap(ctx_tie, golden, prefix, K, mo
     assert int(golden[f"{prefix}_one_num_ties"]) > 1000
     g = gpu_pass(ctx_tie, golden["tie_raw"], golden["tie_q"], golden["tie_t"], golden["tie_t_last"], max_num_residuals=INT_MAX,
                  max_number_neighbors=K, min_number_neighbors=K, select_mode=mode)
-    check_pass_against(g, golden, prefix, tol=PLANE_TOL)
+    # 5 lattice points are often rotationally symmetric (lambda_0 = lambda_1): their normal is not defined by the data
+    gap = eigen_gap(golden[f"{prefix}_one_ids"], golden["tie_map_xyz"])
+    well = ~(gap < 1e-6)
+    assert well.mean() > (0.9 if K == 20 else 0.3)
+    check_pass_against(g, golden, prefix, tol=PLANE_TOL, well_posed=well)
     assert g["neq"].sum_candidates == int(golden[f"{prefix}_one_sum_candidates"])
     if mode == 0:
         # the fast path must have handed (at least) the tied keypoints to the replay, and only a minority of the rest
@@ -343,8 +367,16 @@ def test_nan_planarity_raises_through_the_class_surface(golden):
     try:
         lio.ctx.map_upload(keys, counts, xyz)
         lio.eskf_set_state(golden["full_eskf_state0"]); lio.eskf_set_cov(golden["full_eskf_cov0"])
-        r = lio.update_iekf(srl.default_opts(max_num_residuals=INT_MAX), raw, golden["full_state0"], golden["t_last"])
-        assert r["rc"] == capi.SRL_ERR_NAN_PLANARITY            # the mirror rethrows std::runtime_error("error"); the C handle reports it
+        # the mirror rethrows std::runtime_error("error") (optimize.cpp:348-350); the C handle reports it as a status
+        with pytest.raises(srl.SrlError) as ei:
+            lio.update_iekf(srl.default_opts(max_num_residuals=INT_MAX), raw, golden["full_state0"], golden["t_last"])
+        assert ei.value.status == capi.SRL_ERR_NAN_PLANARITY
+        # behind the cut-off of the shipped max_num_residuals the same keypoint is never reached: the solve goes through
+        raw2 = golden["raw"].copy()
+        raw2[1900] = raw[7]
+        lio.eskf_set_state(golden["cut600_eskf_state0"]); lio.eskf_set_cov(golden["cut600_eskf_cov0"])
+        r = lio.update_iekf(srl.default_opts(max_num_residuals=600), raw2, golden["cut600_state0"], golden["t_last"])
+        assert r["rc"] == 0 and r["num_residuals"] == 600
     finally:
         lio.close()
 
