@@ -385,6 +385,12 @@ __device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, cons
 //             ((dx*dx + dy*dy) + dz*dz, no FMA), strict rank by counting, clash check, emit from registers.
 struct alignas(16) SurvRec { float x, y, z; int code; };
 
+__device__ __forceinline__ float d2_f32(float px, float py, float pz, float qx, float qy, float qz) {
+#pragma clang fp contract(fast)
+    const float dx = px - qx, dy = py - qy, dz = pz - qz;
+    return dx * dx + dy * dy + dz * dz;
+}
+
 // R = compile-time number of candidate rounds (3 voxels each): straight-line code, arrays stay in registers
 template <int R, class Sink>
 __device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
