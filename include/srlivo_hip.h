@@ -111,6 +111,14 @@ int srl_map_download(srl_ctx *ctx, int16_t *keys_xyz, int32_t *counts, float *xy
  * cloudMap.h:40).  AoS n x 3 FP64 in the lidar frame, in keypoint order.  Uploaded once per sweep.
  * With a communicator attached this rank keeps the contiguous range [rank*n/R, (rank+1)*n/R). */
 int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n);
+/* Page-locked host memory for the sweep: srl_sweep_upload DMAs straight out of a buffer obtained here (or registered with
+ * srl_host_register) -- one asynchronous copy on the context's stream, no staging, no synchronisation; such a buffer must stay
+ * untouched until the next call that returns results.  From pageable memory the upload goes through a pinned ring inside
+ * the context (CPU copy of a chunk overlapped with the DMA of the previous one) and the buffer is free on return. */
+int srl_pinned_alloc(size_t bytes, void **out);
+int srl_pinned_free(void *p);
+int srl_host_register(void *p, size_t bytes);
+int srl_host_unregister(void *p);
 int srl_sweep_shard(srl_ctx *ctx, int *begin, int *count, int *total);
 
 /* ------------------------------------------------------------------ frame-resident pipeline (optional)
@@ -189,6 +197,11 @@ int srl_transform_points(srl_ctx *ctx, const double *raw_xyz, int n, const doubl
 int srl_comm_unique_id(void *id /* SRL_COMM_ID_BYTES */);
 int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id);
 int srl_comm_destroy(srl_ctx *ctx);
+/* Which RCCL the communicator calls run on.  The library does not link librccl: it uses the RCCL instance the process has
+ * already loaded (a PyTorch process: torch/lib/librccl.so) or, when there is none, dlopens librccl.so.1 -- one instance per
+ * process, never two.  origin = path of that shared object, version = ncclGetVersion, preloaded = 1 when it was found in the
+ * process.  SRL_ERR_COMM (origin = reason) when no RCCL is available; single-GPU use never needs one. */
+int srl_comm_backend_info(char *origin, int origin_len, int *version, int *preloaded);
 /* suspend != 0: run unsharded (whole sweep, no collective) while keeping the communicator; 0: back to sharded mode.
  * Re-upload the sweep after switching. */
 int srl_comm_suspend(srl_ctx *ctx, int suspend);

@@ -90,6 +90,8 @@ def load(backend="plain"):
     lib.orc_eig3_solver.argtypes = [C.c_int, dp, dp, dp]; lib.orc_eig3_solver.restype = C.c_int
     lib.orc_set_eig_solver.argtypes = [C.c_int]
     lib.orc_get_eig_solver.restype = C.c_int
+    lib.orc_set_threads.argtypes = [C.c_int]
+    lib.orc_get_threads.restype = C.c_int
     lib.orc_heap_topk.argtypes = [p, C.c_int, C.c_int, p]; lib.orc_heap_topk.restype = C.c_int
     lib.orc_distort_frame_by_constant.argtypes = [p, p, C.c_int, p, C.c_int, C.c_double, dp, dp, p]
     lib.orc_distort_frame_by_imu.argtypes = [p, p, C.c_int, p, C.c_int, C.c_double, dp, dp, p]
@@ -367,3 +369,20 @@ def heap_topk(distances, K, backend="plain"):
     out = np.empty(K, dtype=np.int32)
     n = load(backend).orc_heap_topk(_vp(d), len(d), int(K), _vp(out))
     return out[:n].copy()
+
+
+class threads:
+    """with threads(n): ...  -- the all-cores CPU baseline: keypoint blocks visited in parallel, committed in order."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.libs = [load("plain")] + ([load("tsl")] if os.path.exists(LIB_TSL) else [])
+        self.old = [lib.orc_get_threads() for lib in self.libs]
+        for lib in self.libs:
+            lib.orc_set_threads(self.n)
+
+    def __exit__(self, *exc):
+        for lib, o in zip(self.libs, self.old):
+            lib.orc_set_threads(o)

@@ -465,6 +465,8 @@ bool eig3_eigen_ql(const double Ain[3][3], double evals[3], double V[3][3]) {
 
 // which solver compute_neighborhood uses: 0 = eig3_eigen_ql (what the reference executes), 1 = eig3_jacobi
 static int g_eig_solver = 0;
+// threads of the keypoint loop: 1 = the reference's single-threaded loop; > 1 = the all-cores CPU baseline (OpenMP)
+static int g_threads = 1;
 
 // ---------------------------------------------------------------------------------------------
 // map types (include/cloudMap.h)
@@ -759,58 +761,49 @@ int build_plane_residuals(orc_map *om, const orc_icp_opts &o, const double *raw_
     int num_visited = 0, num_ties = 0;
     const bool want_tie = (out && out->tie) || neq;
 
-    NeighborResult nres;
-    for (int k = 0; k < num_keypoints; k++) {
+    // The loop body of optimize.cpp:68-108 in two halves: `visit` = everything one keypoint computes on its own
+    // (searchNeighbors, estimatePointNeighborhood, weight, plane, distance, Jacobian); `commit` = what the sequential
+    // loop does with it (counters, push_back, the break at :107).  Single-threaded (the reference; g_threads == 1) they
+    // alternate keypoint by keypoint.  The all-cores CPU baseline (g_threads > 1, ORACLE ADDITION) visits a block of
+    // keypoints in parallel and then commits the block in keypoint order -- same results bit for bit, because `visit`
+    // has no shared state and `commit` still runs sequentially and stops where the reference stops.
+    struct Visit {
+        NeighborResult nres;
+        bool enough = false, nan = false, accepted = false;
+        Neighborhood neighborhood;
+        planeParam plane;
+    };
+    const M3 R_end = quat_to_rot(end_quat);      // NOT normalised: end_quat.toRotationMatrix()
+    auto visit = [&](int k, Visit &r) {
         V3 raw_point = v3(raw_xyz[3 * k], raw_xyz[3 * k + 1], raw_xyz[3 * k + 2]);
         search_neighbors(om->map, kp_point[k], nb_voxels_visited, o.size_voxel_map, o.max_number_neighbors,
-                         kThresholdCapacity, cap, nres, want_tie);
-        num_visited++;
-        sum_candidates += nres.num_candidates;
-        if (nres.tie) num_ties++;
-        if (out) {
-            if (out->tie) out->tie[k] = nres.tie ? 1 : 0;
-            if (out->ids) for (size_t i = 0; i < nres.ids.size(); i++) out->ids[(size_t)k * K + i] = nres.ids[i];
-            if (out->status) out->status[k] = 0;
-        }
-
-        if ((int)nres.pts.size() < kMinNumNeighbors) continue;
+                         kThresholdCapacity, cap, r.nres, want_tie);
+        r.enough = !((int)r.nres.pts.size() < kMinNumNeighbors);
+        r.nan = false; r.accepted = false;
+        if (!r.enough) return;
 
         double weight;
         V3 location = f.R_imu_lidar * raw_point + f.t_imu_lidar;
 
         // estimatePointNeighborhood (optimize.cpp:42-53)
-        Neighborhood neighborhood;
-        if (!compute_neighborhood(nres.pts, neighborhood)) {
-            if (neq) neq->nan_error = 1;
-            return -2;   // optimize.cpp:348-350 throws std::runtime_error("error")
-        }
-        weight = std::pow(neighborhood.a2D, o.power_planarity);
-        if (dot(neighborhood.normal, f.last_translation - location) < 0) {
-            neighborhood.normal = -1.0 * neighborhood.normal;
+        if (!compute_neighborhood(r.nres.pts, r.neighborhood)) { r.nan = true; return; }   // optimize.cpp:348-350 throws
+        weight = std::pow(r.neighborhood.a2D, o.power_planarity);
+        if (dot(r.neighborhood.normal, f.last_translation - location) < 0) {
+            r.neighborhood.normal = -1.0 * r.neighborhood.normal;
         }
 
         weight = lambda_weight * weight + lambda_neighborhood *
-                 std::exp(-norm(nres.pts[0] - kp_point[k]) / (kMaxPointToPlane * kMinNumNeighbors));
+                 std::exp(-norm(r.nres.pts[0] - kp_point[k]) / (kMaxPointToPlane * kMinNumNeighbors));
 
-        planeParam plane_temp;
+        planeParam &plane_temp = r.plane;
         plane_temp.raw_point = location;
-        plane_temp.norm_vector = normalized(neighborhood.normal);
-        plane_temp.norm_offset = -dot(plane_temp.norm_vector, nres.pts[0]);
-        const M3 R_end = quat_to_rot(end_quat);      // NOT normalised
+        plane_temp.norm_vector = normalized(r.neighborhood.normal);
+        plane_temp.norm_offset = -dot(plane_temp.norm_vector, r.nres.pts[0]);
         plane_temp.distance = dot(plane_temp.norm_vector, R_end * plane_temp.raw_point + end_t) + plane_temp.norm_offset;
         plane_temp.weight = weight;
 
-        if (out) {
-            if (out->status) out->status[k] = 1;
-            if (out->normal) { out->normal[3 * k] = plane_temp.norm_vector.x; out->normal[3 * k + 1] = plane_temp.norm_vector.y; out->normal[3 * k + 2] = plane_temp.norm_vector.z; }
-            if (out->a2D) out->a2D[k] = neighborhood.a2D;
-            if (out->weight) out->weight[k] = weight;
-            if (out->norm_offset) out->norm_offset[k] = plane_temp.norm_offset;
-            if (out->distance) out->distance[k] = plane_temp.distance;
-        }
-
         if (plane_temp.distance < o.max_dist_to_plane_icp) {
-            num_residuals++;
+            r.accepted = true;
             const V3 &nv = plane_temp.norm_vector;
             plane_temp.jacobians[0] = nv.x * weight;
             plane_temp.jacobians[1] = nv.y * weight;
@@ -824,6 +817,31 @@ int build_plane_residuals(orc_map *om, const orc_icp_opts &o, const double *raw_
                 double r2 = (r1[0] * S.m[0][j] + r1[1] * S.m[1][j]) + r1[2] * S.m[2][j];
                 plane_temp.jacobians[3 + j] = r2 * weight;
             }
+        }
+    };
+    // returns 0 = go on, 1 = break (optimize.cpp:107), -2 = NaN planarity
+    auto commit = [&](int k, const Visit &r) -> int {
+        num_visited++;
+        sum_candidates += r.nres.num_candidates;
+        if (r.nres.tie) num_ties++;
+        if (out) {
+            if (out->tie) out->tie[k] = r.nres.tie ? 1 : 0;
+            if (out->ids) for (size_t i = 0; i < r.nres.ids.size(); i++) out->ids[(size_t)k * K + i] = r.nres.ids[i];
+            if (out->status) out->status[k] = 0;
+        }
+        if (!r.enough) return 0;                                  // `continue` (optimize.cpp:78-79)
+        if (r.nan) { if (neq) neq->nan_error = 1; return -2; }
+        const planeParam &plane_temp = r.plane;
+        if (out) {
+            if (out->status) out->status[k] = 1;
+            if (out->normal) { out->normal[3 * k] = plane_temp.norm_vector.x; out->normal[3 * k + 1] = plane_temp.norm_vector.y; out->normal[3 * k + 2] = plane_temp.norm_vector.z; }
+            if (out->a2D) out->a2D[k] = r.neighborhood.a2D;
+            if (out->weight) out->weight[k] = plane_temp.weight;
+            if (out->norm_offset) out->norm_offset[k] = plane_temp.norm_offset;
+            if (out->distance) out->distance[k] = plane_temp.distance;
+        }
+        if (r.accepted) {
+            num_residuals++;
             plane_residuals.push_back(plane_temp);
             loss_sum += plane_temp.distance * plane_temp.distance;
             if (out) {
@@ -831,8 +849,39 @@ int build_plane_residuals(orc_map *om, const orc_icp_opts &o, const double *raw_
                 if (out->jacobian) for (int j = 0; j < 6; j++) out->jacobian[6 * k + j] = plane_temp.jacobians[j];
             }
         }
+        if (num_residuals >= o.max_num_residuals) return 1;
+        return 0;
+    };
 
-        if (num_residuals >= o.max_num_residuals) break;
+    if (g_threads <= 1) {
+        Visit r;
+        for (int k = 0; k < num_keypoints; k++) {
+            visit(k, r);
+            const int c = commit(k, r);
+            if (c == -2) return -2;
+            if (c == 1) break;
+        }
+    } else {
+        // blocks sized like the device path's prefix pass, so that an early break wastes little parallel work
+        const int max_res = o.max_num_residuals > 0 ? o.max_num_residuals : 1;
+        const long long first = std::min<long long>(num_keypoints, 4LL * max_res + 2048);
+        int k0 = 0;
+        long long blk = first;
+        std::vector<Visit> vis;
+        bool stop = false;
+        while (k0 < num_keypoints && !stop) {
+            const int k1 = (int)std::min<long long>(num_keypoints, k0 + blk);
+            vis.resize((size_t)(k1 - k0));
+#pragma omp parallel for schedule(dynamic, 64) num_threads(g_threads)
+            for (int k = k0; k < k1; k++) visit(k, vis[(size_t)(k - k0)]);
+            for (int k = k0; k < k1; k++) {
+                const int c = commit(k, vis[(size_t)(k - k0)]);
+                if (c == -2) return -2;
+                if (c == 1) { stop = true; break; }
+            }
+            k0 = k1;
+            blk = std::max<long long>(blk, 16384);
+        }
     }
 
     if (neq) {
@@ -1667,6 +1716,8 @@ int orc_eig3_solver(int solver, const double A[9], double evals[3], double evecs
     return ok ? 0 : -1;
 }
 void orc_set_eig_solver(int solver) { g_eig_solver = solver == 1 ? 1 : 0; }
+void orc_set_threads(int threads) { g_threads = threads < 1 ? 1 : threads; }
+int  orc_get_threads(void) { return g_threads; }
 int  orc_get_eig_solver(void) { return g_eig_solver; }
 
 // the literal bounded priority queue of searchNeighbors (optimize.cpp:355-363, 394-404, 411-422) over a plain list of

@@ -202,6 +202,11 @@ void   orc_eig3(const double A[9], double evals[3], double evecs[9]); /* ascendi
 int    orc_eig3_solver(int solver, const double A[9], double evals[3], double evecs[9]);
 void   orc_set_eig_solver(int solver);     /* process-wide: solver used by computeNeighborhoodDistribution */
 int    orc_get_eig_solver(void);
+/* ORACLE ADDITION: threads of the keypoint loop of buildPlaneResiduals.  1 (default) = the reference's own single-threaded
+ * loop.  > 1 = the all-cores CPU baseline: blocks of keypoints are visited in parallel (OpenMP) and committed in keypoint
+ * order, so the ordered cut-off at max_num_residuals and every sum are bit-identical to the single-threaded run. */
+void   orc_set_threads(int threads);
+int    orc_get_threads(void);
 /* the literal std::priority_queue sequence of searchNeighbors (optimize.cpp:394-404, 411-422) on a list of distances
  * offered in index order; out_index (capacity max_num_neighbors) = surviving indices in read-out order */
 int    orc_heap_topk(const double *distances, int n, int max_num_neighbors, int32_t *out_index);

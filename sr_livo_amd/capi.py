@@ -109,6 +109,11 @@ def load_library():
         "srl_map_download": ([p, p, p, p, C.c_int], C.c_int),
         "srl_sweep_upload": ([p, p, C.c_int], C.c_int),
         "srl_sweep_shard": ([p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "srl_pinned_alloc": ([C.c_size_t, C.POINTER(p)], C.c_int),
+        "srl_pinned_free": ([p], C.c_int),
+        "srl_host_register": ([p, C.c_size_t], C.c_int),
+        "srl_host_unregister": ([p], C.c_int),
+        "srl_comm_backend_info": ([C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_build_residuals": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq)], C.c_int),
         "srl_set_taps": ([p, C.c_int], C.c_int),
         "srl_fetch_neighbors": ([p, p, p, p], C.c_int),
@@ -232,6 +237,42 @@ def heap_topk(distances, K):
     if n < 0:
         raise SrlError(n, "srl_debug_heap_topk")
     return out[:n].copy()
+
+
+class PinnedArray:
+    """A float64 numpy array in page-locked host memory (srl_pinned_alloc): srl_sweep_upload DMAs straight out of it."""
+
+    def __init__(self, shape):
+        self.lib = load_library()
+        n = int(np.prod(shape))
+        self.ptr = C.c_void_p()
+        rc = self.lib.srl_pinned_alloc(max(n, 1) * 8, C.byref(self.ptr))
+        if rc:
+            raise SrlError(rc, "srl_pinned_alloc")
+        buf = (C.c_double * max(n, 1)).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=np.float64, count=n).reshape(shape)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            self.lib.srl_pinned_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_backend_info():
+    """(path of the RCCL shared object in use, ncclGetVersion, found-already-loaded-in-the-process) or raises."""
+    buf = C.create_string_buffer(512)
+    ver, pre = C.c_int(), C.c_int()
+    rc = load_library().srl_comm_backend_info(buf, 512, C.byref(ver), C.byref(pre))
+    if rc:
+        raise SrlError(rc, "srl_comm_backend_info", buf.value.decode())
+    return buf.value.decode(), ver.value, bool(pre.value)
 
 
 def shard_range(n, nranks, rank):

@@ -8,7 +8,6 @@
 #include "srl_heap.h"
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -42,6 +41,20 @@ int ensure_work(srl_ctx *ctx, int n) {
     if ((rc = ensure(ctx, ctx->d_binfo, (size_t)nblocks))) return rc;
     ctx->work_cap = cap;
     ctx->block_cap = nblocks;
+    return SRL_OK;
+}
+
+// is the host pointer page-locked (hipHostMalloc / hipHostRegister)?  Pageable memory makes the query fail.
+bool srl_is_pinned(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeHost;
+}
+
+int srl_ring_init(srl_ctx *ctx) {
+    if (ctx->h_ring) return SRL_OK;
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_ring, (size_t)srl_ctx::RING_SLOTS * srl_ctx::RING_SLOT_BYTES, hipHostMallocDefault));
+    for (int i = 0; i < srl_ctx::RING_SLOTS; i++) { HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ring_ev[i], hipEventDisableTiming)); ctx->ring_busy[i] = false; }
     return SRL_OK;
 }
 
@@ -139,8 +152,8 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (!ctx) return SRL_OK;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    if (ctx->comm) ncclCommDestroy(ctx->comm);
-    if (ctx->parked_comm) ncclCommDestroy(ctx->parked_comm);
+    if (ctx->comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->comm);
+    if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
                     ctx->d_out, ctx->d_count, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
                     ctx->d_tap_offset, ctx->d_gather};
@@ -148,6 +161,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->h_out) hipHostFree(ctx->h_out);
     if (ctx->h_count) hipHostFree(ctx->h_count);
     if (ctx->h_mail) hipHostFree(ctx->h_mail);
+    if (ctx->h_ring) { hipHostFree(ctx->h_ring); for (int i = 0; i < srl_ctx::RING_SLOTS; i++) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]); }
     for (auto &b : ctx->pool_free) hipFree(b.p);
     ctx->pool_free.clear();
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
@@ -264,11 +278,55 @@ int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     int rc = ensure_work(ctx, cnt);
     if (rc) return rc;
     if (cnt > 0) {
-        // stage AoS in the rec buffer (>= 8 doubles per keypoint), transpose to SoA on the device
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_rec, raw_xyz + (size_t)b * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        // stage AoS in the rec buffer (>= 8 doubles per keypoint), transpose to SoA on the device.  Everything is
+        // stream-ordered with the solve that follows: no synchronisation here.
+        const char *src = reinterpret_cast<const char *>(raw_xyz + (size_t)b * 3);
+        const size_t bytes = (size_t)cnt * 3 * sizeof(double);
+        if (srl_is_pinned(src)) {
+            // caller's buffer is page-locked (srl_pinned_alloc / srl_host_register): one DMA straight from it.  The caller
+            // must leave it untouched until the next call that returns results (srl_build_residuals) or synchronises.
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_rec, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            // pageable memory: through the context's pinned ring, chunk by chunk -- the CPU copy of chunk i + 1 overlaps the
+            // DMA of chunk i, and the caller's buffer is fully consumed when the call returns
+            int rc2 = srl_ring_init(ctx);
+            if (rc2) return rc2;
+            size_t off = 0;
+            while (off < bytes) {
+                const size_t len = std::min(bytes - off, (size_t)srl_ctx::RING_SLOT_BYTES);
+                const int slot = ctx->ring_next++ % srl_ctx::RING_SLOTS;
+                if (ctx->ring_busy[slot]) { HIPCHK(ctx, hipEventSynchronize(ctx->ring_ev[slot])); ctx->ring_busy[slot] = false; }
+                std::memcpy(ctx->h_ring + (size_t)slot * srl_ctx::RING_SLOT_BYTES, src + off, len);
+                HIPCHK(ctx, hipMemcpyAsync(reinterpret_cast<char *>(ctx->d_rec) + off, ctx->h_ring + (size_t)slot * srl_ctx::RING_SLOT_BYTES, len,
+                                           hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipEventRecord(ctx->ring_ev[slot], ctx->stream));
+                ctx->ring_busy[slot] = true;
+                off += len;
+            }
+        }
         HIPCHK(ctx, srl_launch_aos_to_soa(ctx->d_rec, cnt, ctx->d_raw, ctx->d_raw + ctx->sweep_cap, ctx->d_raw + 2 * (size_t)ctx->sweep_cap, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return SRL_OK;
+}
+
+int srl_pinned_alloc(size_t bytes, void **out) {
+    if (!out) return SRL_ERR_BAD_ARG;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return SRL_ERR_HIP; }
+    return SRL_OK;
+}
+int srl_pinned_free(void *p) {
+    if (!p) return SRL_OK;
+    return hipHostFree(p) == hipSuccess ? SRL_OK : SRL_ERR_HIP;
+}
+int srl_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return SRL_ERR_BAD_ARG;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return SRL_ERR_HIP; }
+    return SRL_OK;
+}
+int srl_host_unregister(void *p) {
+    if (!p) return SRL_ERR_BAD_ARG;
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return SRL_ERR_HIP; }
     return SRL_OK;
 }
 
@@ -452,7 +510,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         if (ctx->comm) {
             // gathered on the stream; the reduce kernel derives its budget and mode from the counts of earlier ranks
             // itself -- no D2H copy, no host synchronisation in the loop
-            NCCLCHK(ctx, ncclAllGather(ctx->d_count, ctx->d_gather, 1, ncclInt64, ctx->comm, ctx->stream));
+            NCCLCHK(ctx, AllGather(ctx->d_count, ctx->d_gather, 1, ncclInt64, ctx->comm, ctx->stream));
             gather_dev = ctx->d_gather;
         } else {
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_count, ctx->d_count, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -492,7 +550,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     long long visited_local = 0;
     if (coll) {
         // one ncclAllReduce of 49 doubles on the context's stream; last_visited sits behind the reduced range
-        NCCLCHK(ctx, ncclAllReduce(ctx->d_out, ctx->d_out, n_red, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+        NCCLCHK(ctx, AllReduce(ctx->d_out, ctx->d_out, n_red, ncclDouble, ncclSum, ctx->comm, ctx->stream));
         HIPCHK(ctx, srl_launch_publish(ctx->d_out, ctx->h_mail, ra.seq, ctx->stream));
     }
     if (coll || mailbox) {
@@ -757,7 +815,8 @@ int srl_comm_unique_id(void *id) {
     if (!id) return SRL_ERR_BAD_ARG;
     static_assert(sizeof(ncclUniqueId) <= SRL_COMM_ID_BYTES, "unique id does not fit");
     ncclUniqueId u;
-    if (ncclGetUniqueId(&u) != ncclSuccess) return SRL_ERR_COMM;
+    const SrlRccl *rc = srl_rccl();
+    if (!rc || rc->GetUniqueId(&u) != ncclSuccess) return SRL_ERR_COMM;
     std::memset(id, 0, SRL_COMM_ID_BYTES);
     std::memcpy(id, &u, sizeof u);
     return SRL_OK;
@@ -766,16 +825,25 @@ int srl_comm_unique_id(void *id) {
 int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id) {
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return SRL_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (ctx->comm) { ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
+    if (ctx->comm && srl_rccl()) { srl_rccl()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof u);
-    NCCLCHK(ctx, ncclCommInitRank(&ctx->comm, nranks, u, rank));
+    NCCLCHK(ctx, CommInitRank(&ctx->comm, nranks, u, rank));
     ctx->nranks = nranks;
     ctx->rank = rank;
     ctx->cb_ar = nullptr; ctx->cb_ag = nullptr; ctx->cb_user = nullptr;
     { const char *fc = std::getenv("SRL_FORCE_COLLECTIVES"); ctx->force_coll = fc && std::atoi(fc) != 0; }
     int rc = ensure(ctx, ctx->d_gather, (size_t)nranks);
     return rc;
+}
+
+int srl_comm_backend_info(char *origin, int origin_len, int *version, int *preloaded) {
+    const SrlRccl *rc = srl_rccl();
+    if (!rc) { if (origin && origin_len > 0) std::snprintf(origin, (size_t)origin_len, "%s", srl_rccl_error()); return SRL_ERR_COMM; }
+    if (origin && origin_len > 0) std::snprintf(origin, (size_t)origin_len, "%s", rc->origin);
+    if (version) *version = rc->version;
+    if (preloaded) *preloaded = rc->preloaded ? 1 : 0;
+    return SRL_OK;
 }
 
 int srl_comm_suspend(srl_ctx *ctx, int suspend) {
@@ -794,9 +862,9 @@ int srl_comm_suspend(srl_ctx *ctx, int suspend) {
 
 int srl_comm_destroy(srl_ctx *ctx) {
     if (!ctx) return SRL_ERR_BAD_ARG;
-    if (ctx->parked_comm) { ncclCommDestroy(ctx->parked_comm); ctx->parked_comm = nullptr; }
+    if (ctx->parked_comm && srl_rccl()) { srl_rccl()->CommDestroy(ctx->parked_comm); ctx->parked_comm = nullptr; }
     ctx->parked_nranks = 0; ctx->parked_rank = 0;
-    if (ctx->comm) { ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
+    if (ctx->comm && srl_rccl()) { srl_rccl()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
     ctx->nranks = 1; ctx->rank = 0;
     ctx->cb_ar = nullptr; ctx->cb_ag = nullptr; ctx->cb_user = nullptr;
     return SRL_OK;
@@ -804,7 +872,7 @@ int srl_comm_destroy(srl_ctx *ctx) {
 
 int srl_comm_set_host_callbacks(srl_ctx *ctx, int nranks, int rank, srl_allreduce_fn ar, srl_allgather_i64_fn ag, void *user) {
     if (!ctx || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && (!ar || !ag))) return SRL_ERR_BAD_ARG;
-    if (ctx->comm) { ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
+    if (ctx->comm && srl_rccl()) { srl_rccl()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
     ctx->nranks = nranks; ctx->rank = rank;
     ctx->cb_ar = ar; ctx->cb_ag = ag; ctx->cb_user = user;
     return SRL_OK;

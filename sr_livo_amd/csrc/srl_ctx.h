@@ -4,7 +4,7 @@
 #include "srl_device.h"
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include "srl_rccl.h"
 
 #include <string>
 #include <vector>
@@ -42,6 +42,14 @@ struct srl_ctx {
     int *d_corr_seg = nullptr;
     int corr_cap = 0;
     int corr_n = -1;
+
+    // pinned staging ring of srl_sweep_upload (pageable sources): CPU copy of one chunk overlaps the DMA of the previous
+    static constexpr int RING_SLOTS = 4;
+    static constexpr int RING_SLOT_BYTES = 256 * 1024;
+    char *h_ring = nullptr;
+    hipEvent_t ring_ev[RING_SLOTS] = {};
+    bool ring_busy[RING_SLOTS] = {};
+    unsigned ring_next = 0;
 
     // work buffers
     double *d_rec = nullptr;
@@ -104,11 +112,14 @@ struct srl_ctx {
         }                                                                                      \
     } while (0)
 
+// RCCL calls go through the run-time table: NCCLCHK(ctx, AllReduce(...)) = srl_rccl()->AllReduce(...)
 #define NCCLCHK(ctx, call)                                                                     \
     do {                                                                                       \
-        ncclResult_t r__ = (call);                                                             \
+        const SrlRccl *rc__ = srl_rccl();                                                      \
+        if (!rc__) { (ctx)->err = srl_rccl_error(); return SRL_ERR_COMM; }                     \
+        ncclResult_t r__ = rc__->call;                                                         \
         if (r__ != ncclSuccess) {                                                              \
-            (ctx)->err = std::string(#call) + ": " + ncclGetErrorString(r__);                  \
+            (ctx)->err = std::string(#call) + ": " + rc__->GetErrorString(r__);                \
             return SRL_ERR_COMM;                                                               \
         }                                                                                      \
     } while (0)

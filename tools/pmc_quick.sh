@@ -4,7 +4,7 @@ CNT=${1:-"SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_C
 shift
 OUT=/tmp/pmcq; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --pmc $CNT --output-format csv -d $OUT -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/err.log
+timeout 300 rocprofv3 --pmc $CNT --output-format csv -d $OUT -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-configs "$@" > $OUT/bench.json 2> $OUT/err.log
 python - <<'PY'
 import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -3,16 +3,19 @@
 #   1. rocprofv3 --kernel-trace --stats            -> per-kernel durations
 #   2. separate --pmc passes (no trace domains)     -> SQ / TCC counters of the association kernel
 # Summaries land in gpurun_out/prof_$TAG/; copy the ones to be judged into profiles/.
+#   tools/profile_gpu.sh TAG [STEPS] ["extra bench.py args"]   e.g.  tools/profile_gpu.sh r02_c2 10 "--workload C2"
 TAG=${1:-r01}
 STEPS=${2:-10}
 SUM=$PWD/gpurun_out/prof_$TAG
 OUT=/tmp/prof_raw_$TAG
 rm -rf $OUT; mkdir -p $OUT $SUM
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline"
+EXTRA_ARGS=${3:-}
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-configs $EXTRA_ARGS"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
            "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \
+           "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -o pmc -- $BENCH > /dev/null 2> $OUT/pmc_$name.err

@@ -2,7 +2,7 @@
 # kernel timeline of a few solves: start/end of every kernel relative to the first, in microseconds
 OUT=/tmp/tl; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o tl -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/err.log
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o tl -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs "$@" > $OUT/bench.json 2> $OUT/err.log
 python - <<'PY'
 import csv, glob, re
 rows = []
