@@ -391,6 +391,70 @@ __device__ __forceinline__ float d2_f32(float px, float py, float pz, float qx, 
     return dx * dx + dy * dy + dz * dz;
 }
 
+// The FP64 finish shared by the fast paths: the c <= 64 survivors of the FP32 prefilter sit in LDS as {x, y, z, code};
+// lane i evaluates survivor i exactly, strict rank by counting, tie check, winners emit.
+template <class Sink>
+__device__ __forceinline__ int finish_survivors(double qx, double qy, double qz, int c, const VoxEnt *vox, int K, void *scratch,
+                                                int lane, Sink &sink) {
+    SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));            // [64], 16-B aligned
+    double *keys = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024);  // [66]
+    double *sorted = keys + 66;                                                                    // [K + 1] d2 by rank, behind the key pads
+    __builtin_amdgcn_wave_barrier();
+    const bool act = lane < c;
+    SurvRec me;
+    me.x = me.y = me.z = 0.0f; me.code = 0;
+    double my = __builtin_huge_val();
+    if (act) {
+        me = recs[lane];
+        const double dx = (double)me.x - qx;
+        const double dy = (double)me.y - qy;
+        const double dz = (double)me.z - qz;
+        my = (dx * dx + dy * dy) + dz * dz;          // the reference's evaluation order (optimize.cpp:394-395)
+    }
+    keys[lane] = my;                                  // lanes >= c write +inf: keys[c], keys[c+1] pad an odd count
+    // the two +inf key pads and, right behind them, sorted[0..K] = NaN ("nobody holds this rank") in one store
+    if (lane < K + 3) keys[64 + lane] = lane < 2 ? __builtin_huge_val() : __builtin_nan("");
+    __builtin_amdgcn_wave_barrier();
+    int rank = 0;
+    if (c <= 32) {
+        // the usual case: both half-waves work on the same <= 32 keys -- half h counts the keys [16 h, 16 h + 16) below
+        // key (lane & 31), one cross-half add finishes the rank.  Fixed trip count: slots >= c hold +inf and never count.
+        const double mine = keys[lane & 31];
+        const double2 *kp = reinterpret_cast<const double2 *>(keys + (lane >> 5) * 16);
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double2 kk = kp[j];
+            r += (kk.x < mine) ? 1 : 0;
+            r += (kk.y < mine) ? 1 : 0;
+        }
+        rank = r + __shfl_xor(r, 32);
+    } else {
+#pragma unroll 4
+        for (int j = 0; j < c; j += 2) {
+            const double2 kk = *reinterpret_cast<const double2 *>(keys + j);
+            rank += (kk.x < my) ? 1 : 0;
+            rank += (kk.y < my) ? 1 : 0;
+        }
+    }
+    // Tie check over the K+1 smallest (ties further out cannot change the selected set or its order).  The reference
+    // compares sqrt(d2) (optimize.cpp:395,398), so neighbours in sorted order closer than SRL_NEAR_TIE count as tied.
+    // Winners file their d2 under their rank; strict ranks are a permutation unless survivors are exactly equal -- then the
+    // rank behind them stays NaN.  Lane i compares ranks i - 1 and i: a NaN on either side fails the comparison too.
+    const bool win = act && rank < K;
+    if (act && rank <= K) sorted[rank] = my;
+    __builtin_amdgcn_wave_barrier();
+    bool bad = false;
+    if (lane >= 1 && lane <= K && lane < c) bad = !(sorted[lane] > sorted[lane - 1] * SRL_NEAR_TIE);
+    if (__ballot(bad)) return SEL_TIE;             // the reference's literal heap sequence decides (select_topk_replay)
+    if (win) {
+        const VoxEnt ve = vox[me.code >> 5];
+        sink.put(rank, me.x, me.y, me.z, ve.slab * SRL_CAP + ((unsigned)me.code & 31u));
+    }
+    __builtin_amdgcn_wave_barrier();
+    return SEL_DONE;
+}
+
 // R = compile-time number of candidate rounds (3 voxels each): straight-line code, arrays stay in registers
 template <int R, class Sink>
 __device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
@@ -451,8 +515,6 @@ __device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz
     if (tau_f < kInfF) thr = qf[3] + qf[4] * tau_f;      // (tau + 2 m(2 tau + 1e-6)) (1 + eps), linear in tau
 
     SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));            // [64], 16-B aligned
-    double *keys = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024);  // [66]
-    double *sorted = keys + 66;                                                                    // [K + 1] d2 by rank, behind the key pads
     unsigned long long svm[R];
     int c = 0;
 #pragma unroll
@@ -474,61 +536,7 @@ __device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz
         }
     }
     if (ablate & 2) return SEL_DONE;
-    __builtin_amdgcn_wave_barrier();
-
-    const bool act = lane < c;
-    SurvRec me;
-    me.x = me.y = me.z = 0.0f; me.code = 0;
-    double my = __builtin_huge_val();
-    if (act) {
-        me = recs[lane];
-        const double dx = (double)me.x - qx;
-        const double dy = (double)me.y - qy;
-        const double dz = (double)me.z - qz;
-        my = (dx * dx + dy * dy) + dz * dz;          // the reference's evaluation order (optimize.cpp:394-395)
-    }
-    keys[lane] = my;                                  // lanes >= c write +inf: keys[c], keys[c+1] pad an odd count
-    // the two +inf key pads and, right behind them, sorted[0..K] = NaN ("nobody holds this rank") in one store
-    if (lane < K + 3) keys[64 + lane] = lane < 2 ? __builtin_huge_val() : __builtin_nan("");
-    __builtin_amdgcn_wave_barrier();
-    int rank = 0;
-    if (c <= 32) {
-        // the usual case: both half-waves work on the same <= 32 keys -- half h counts the keys [16 h, 16 h + 16) below
-        // key (lane & 31), one cross-half add finishes the rank.  Fixed trip count: slots >= c hold +inf and never count.
-        const double mine = keys[lane & 31];
-        const double2 *kp = reinterpret_cast<const double2 *>(keys + (lane >> 5) * 16);
-        int r = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double2 kk = kp[j];
-            r += (kk.x < mine) ? 1 : 0;
-            r += (kk.y < mine) ? 1 : 0;
-        }
-        rank = r + __shfl_xor(r, 32);
-    } else {
-#pragma unroll 4
-        for (int j = 0; j < c; j += 2) {
-            const double2 kk = *reinterpret_cast<const double2 *>(keys + j);
-            rank += (kk.x < my) ? 1 : 0;
-            rank += (kk.y < my) ? 1 : 0;
-        }
-    }
-    // Tie check over the K+1 smallest (ties further out cannot change the selected set or its order).  The reference
-    // compares sqrt(d2) (optimize.cpp:395,398), so neighbours in sorted order closer than SRL_NEAR_TIE count as tied.
-    // Winners file their d2 under their rank; strict ranks are a permutation unless survivors are exactly equal -- then the
-    // rank behind them stays NaN.  Lane i compares ranks i - 1 and i: a NaN on either side fails the comparison too.
-    const bool win = act && rank < K;
-    if (act && rank <= K) sorted[rank] = my;
-    __builtin_amdgcn_wave_barrier();
-    bool bad = false;
-    if (lane >= 1 && lane <= K && lane < c) bad = !(sorted[lane] > sorted[lane - 1] * SRL_NEAR_TIE);
-    if (__ballot(bad)) return SEL_TIE;             // the reference's literal heap sequence decides (select_topk_replay)
-    if (win) {
-        const VoxEnt ve = vox[me.code >> 5];
-        sink.put(rank, me.x, me.y, me.z, ve.slab * SRL_CAP + ((unsigned)me.code & 31u));
-    }
-    __builtin_amdgcn_wave_barrier();
-    return SEL_DONE;
+    return finish_survivors(qx, qy, qz, c, vox, K, scratch, lane, sink);
 }
 
 template <class Sink>
@@ -545,6 +553,77 @@ __device__ __forceinline__ int select_topk_f32(double qx, double qy, double qz, 
         case 7: return select_topk_f32_r<7>(qx, qy, qz, qf, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
         default: return select_topk_f32_r<9>(qx, qy, qz, qf, nv, vox, slabs, inf_off, K, scratch, lane, role, sink, total_out, ablate);
     }
+}
+
+// r = 2 (init mode, 125 voxels): the same FP32 prefilter + FP64 finish with the candidate rounds in a loop.  Up to 42
+// rounds do not fit in registers, so the FP32 distances are evaluated twice (threshold pass, survivor pass); the second
+// pass hits L1/L2.  The voxel list is the visit-order list of probe_voxels<2>, zero-filled to a multiple of 3 entries.
+template <class Sink>
+__device__ __forceinline__ int select_topk_f32_loop(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
+                                                    const unsigned char *slabs, unsigned inf_off, int K, void *scratch, int lane,
+                                                    const LaneRole &role, Sink &sink, int &total_out) {
+    const float kInfF = __builtin_huge_valf();
+    const float qxf = qf[0], qyf = qf[1], qzf = qf[2];
+    const int rounds = (nv + 2) / 3;
+    const int cbase = role.c0 < 3 ? role.c0 : 0;
+    const unsigned slot_eff = role.c0 < 3 ? (unsigned)role.slot : 31u;
+    const unsigned slot_off = (unsigned)role.slot * 12u;
+    float lmin = kInfF;
+    int total = 0;
+    constexpr int CH = 4;                 // rounds per chunk: their loads are all in flight before the first use
+    // byte offset of this lane's candidate in round j (the all-inf slab when it has none, or when j is past the list)
+    auto cand_off = [&](int j, bool &has) {
+        const int jj = j < rounds ? j : rounds - 1;                       // wave-uniform clamp: never read past the zero fill
+        const VoxEnt ve = vox[3 * jj + cbase];
+        has = (j < rounds) && (slot_eff < ve.count);
+        return has ? ve.slab * (unsigned)SRL_SLAB_BYTES + slot_off : inf_off;
+    };
+    for (int j0 = 0; j0 < rounds; j0 += CH) {
+        unsigned off[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { bool h; off[u] = cand_off(j0 + u, h); total += __popcll(__ballot(h)); }
+        float x[CH], y[CH], z[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { const float *p = reinterpret_cast<const float *>(slabs + off[u]); x[u] = p[0]; y[u] = p[1]; z[u] = p[2]; }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) lmin = fminf(lmin, d2_f32(x[u], y[u], z[u], qxf, qyf, qzf));
+    }
+    total_out = total;
+    const unsigned v = __float_as_uint(lmin);
+    unsigned lo = 0;
+#pragma unroll
+    for (int bit = 30; bit >= 18; --bit) {
+        const unsigned trial = lo | (1u << bit);
+        const int cnt = __popcll(__ballot(v < trial));
+        lo = (cnt < K) ? trial : lo;
+    }
+    const float tau_f = __uint_as_float(lo | 0x3FFFFu);
+    float thr = 3.4028235e38f;
+    if (tau_f < kInfF) thr = qf[3] + qf[4] * tau_f;      // same margin as select_topk_f32_r
+
+    SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));
+    const int code0 = (role.c0 << 5) | role.slot;
+    int c = 0;
+    for (int j0 = 0; j0 < rounds; j0 += CH) {
+        unsigned off[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { bool h; off[u] = cand_off(j0 + u, h); }
+        float x[CH], y[CH], z[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { const float *p = reinterpret_cast<const float *>(slabs + off[u]); x[u] = p[0]; y[u] = p[1]; z[u] = p[2]; }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const bool sv = d2_f32(x[u], y[u], z[u], qxf, qyf, qzf) <= thr;
+            const unsigned long long m = __ballot(sv);
+            if (m != 0ull) {
+                const int pos = c + lanes_below(m);
+                if (sv && pos < 64) { SurvRec r; r.x = x[u]; r.y = y[u]; r.z = z[u]; r.code = code0 + ((3 * (j0 + u)) << 5); recs[pos] = r; }
+                c += __popcll(m);
+            }
+        }
+    }
+    if (c > 64) return SEL_OVERFLOW;
+    return finish_survivors(qx, qy, qz, c, vox, K, scratch, lane, sink);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -768,7 +847,7 @@ __device__ __forceinline__ double kp_sum(double v) {
     return v;
 }
 
-// FAST: 0 = general path only, 1 = FP32-prefilter fast path (r = 1 only)
+// FAST: 0 = general path only, 1 = FP32-prefilter fast path (r = 1: keypoint pairs, rounds in registers; r = 2: looped)
 // WPB = waves per workgroup: 16 (one workgroup per CU; every wave of a SIMD belongs to it) or 4 (when the 16-wave LDS
 // footprint does not fit: K > 24).  With four independent 4-wave workgroups per CU the SIMD arbiter's age priority let
 // the oldest wave of every SIMD finish its 16 keypoints in 34 us and the youngest in 47 us; with 16-wave workgroups the
@@ -915,6 +994,32 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
                 }
                 cur = nxt;
             }
+        } else if constexpr (NB == 2 && FAST != 0) {
+            // init mode (r = 2): single keypoints from the shared counter, own 125 probes, looped fast path
+            const LaneRole role = lane_role(lane);
+            auto take = [&]() { int p = 0; if (lane == 0) p = atomicAdd(s_next, 1); return __builtin_amdgcn_readfirstlane(p); };
+            for (int kl = take(); kl < n_here; kl = take()) {
+                const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
+                const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, vox, lane);
+                if (lane < 3) { VoxEnt z; z.slab = 0u; z.count = 0u; vox[nv + lane] = z; }      // branch-free reads up to 3 * rounds
+                __builtin_amdgcn_wave_barrier();
+                LdsSink sink = make_sink(kl);
+                int total = 0;
+                const int done = select_topk_f32_loop(qx, qy, qz, s_qf + kl * 8, nv, vox, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total);
+                if (lane == 0) {
+                    if (done == SEL_DONE) {
+                        s_nfound[kl] = total < a.K ? total : a.K;
+                        s_ncand[kl] = total;
+                    } else {
+                        s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)(kl | (done == SEL_TIE ? 0x8000 : 0));
+                    }
+                }
+            }
+        } else {
+            // general path only (forced modes): static quarters
+            for (int kl = wave * KPW; kl < (wave + 1) * KPW && kl < n_here; ++kl) keypoint_general(kl, false);
+        }
+        if constexpr (FAST != 0) {
             __syncthreads();
             // deferred keypoints (rare; none on tie-free sweeps): handed out one by one to whichever wave comes first
             const int n_defer = __builtin_amdgcn_readfirstlane(s_next[1]);
@@ -925,9 +1030,6 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
                     keypoint_general(e & 0x7FFF, (e & 0x8000) != 0);
                 }
             }
-        } else {
-            // general path (r = 2 / forced modes): static quarters
-            for (int kl = wave * KPW; kl < (wave + 1) * KPW && kl < n_here; ++kl) keypoint_general(kl, false);
         }
     }
     __syncthreads();
@@ -1378,12 +1480,10 @@ static hipError_t launch_assoc_cfg(const SrlAssocArgs &a, int nb_voxels, hipStre
         hipLaunchKernelGGL(kern, dim3(nblocks), blk, L.total, s, a);
         return hipGetLastError();
     };
-    if (nb_voxels == 1) {
-        if (a.select_mode == 0 || a.select_mode == 4) return launch(srl_assoc_kernel<1, 1, KPW, WPB>);
-        // select_mode 1, 2, 5: general path only
-        return launch(srl_assoc_kernel<1, 0, KPW, WPB>);
-    }
-    return launch(srl_assoc_kernel<2, 0, KPW, WPB>);
+    // select_mode 0 / 4: fast paths; 1, 2, 5: general path only
+    const bool fast = a.select_mode == 0 || a.select_mode == 4;
+    if (nb_voxels == 1) return fast ? launch(srl_assoc_kernel<1, 1, KPW, WPB>) : launch(srl_assoc_kernel<1, 0, KPW, WPB>);
+    return fast ? launch(srl_assoc_kernel<2, 1, KPW, WPB>) : launch(srl_assoc_kernel<2, 0, KPW, WPB>);
 }
 // kpw = keypoints per wave (16 / 8 / 4), wpb = waves per workgroup (16 / 4): srl_assoc_config
 hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpw, int wpb, hipStream_t s) {

@@ -61,9 +61,9 @@ def main():
     tk, tc, tx = tm.export()
     data.update(tie_map_keys=tk, tie_map_counts=tc, tie_map_xyz=tx, tie_raw=tsw["raw"], tie_q=tsw["q_pred"], tie_t=tsw["t_pred"],
                 tie_t_last=tsw["t_last"])
-    for name, kw in (("tie", {}), ("tie5", dict(max_number_neighbors=5, min_number_neighbors=5))):
+    for name, kw, fid in (("tie", {}, 100), ("tie5", dict(max_number_neighbors=5, min_number_neighbors=5), 100), ("tieinit", {}, 5)):
         one = tm.build_plane_residuals(po.default_opts(max_num_residuals=2**31 - 1, **kw), tsw["raw"], tsw["q_pred"], tsw["t_pred"],
-                                       tsw["t_last"], frame_id=100)
+                                       tsw["t_last"], frame_id=fid)
         for k, v in one.items():
             if isinstance(v, np.ndarray):
                 data[f"{name}_one_{k}"] = v

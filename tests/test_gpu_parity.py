@@ -263,15 +263,16 @@ PLANE_TOL = 1e-6     # exact-lattice neighbourhoods are exact planes: sigma_3 = 
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 5])
-@pytest.mark.parametrize("prefix,K", [("tie", 20), ("tie5", 5)])
+@pytest.mark.parametrize("prefix,K", [("tie", 20), ("tie5", 5), ("tieinit", 20)])
 def test_tied_distances_follow_the_reference_heap(ctx_tie, golden, prefix, K, mode):
     """synth.lattice_scene: ~86 % of the keypoints have exactly tied candidate distances, inside the K nearest and across
     the cut.  Which tied points survive, and in which order, is libstdc++'s heap order (optimize.cpp:394-404,411-422); ids
     must equal the oracle's (literal std::priority_queue) for EVERY keypoint, through every selection path:
-    0 fast path + replay on detection, 1 extraction + replay, 2 general two-pass + replay, 5 replay for all."""
+    0 fast path + replay on detection, 1 extraction + replay, 2 general two-pass + replay, 5 replay for all.
+    "tieinit" = the same scene in init mode (frame_id < 20: r = 2, 125 voxels -- the looped fast path)."""
     assert int(golden[f"{prefix}_one_num_ties"]) > 1000
     g = gpu_pass(ctx_tie, golden["tie_raw"], golden["tie_q"], golden["tie_t"], golden["tie_t_last"], max_num_residuals=INT_MAX,
-                 max_number_neighbors=K, min_number_neighbors=K, select_mode=mode)
+                 max_number_neighbors=K, min_number_neighbors=K, select_mode=mode, frame_id=5 if prefix == "tieinit" else 100)
     # 5 lattice points are often rotationally symmetric (lambda_0 = lambda_1): their normal is not defined by the data
     gap = eigen_gap(golden[f"{prefix}_one_ids"], golden["tie_map_xyz"])
     well = ~(gap < 1e-6)
