@@ -422,11 +422,17 @@ def main():
                                          f"oracle restatement of optimize.cpp, single thread like the reference, "
                                          f"voxel map = {backend}; host has {ncores} cores",
                                "ms_per_solve": cpu_s * 1e3, "ms_per_esikf_iter": cpu_s * 1e3 / max(ou["rc"], 1)}
-        cpu_all, na, oa = cpu_leg(ncores, 10.0, 7)
-        out["cpu_baseline_all_cores"] = {"value": 1.0 / cpu_all, "unit": "sweeps/s", "cores": ncores, "kind": "port",
+        # all cores: the thread count that runs fastest on this host (oversubscribing a 256-core box is slower than 64 threads)
+        tried = {}
+        for nt in sorted({ncores, min(ncores, 128), min(ncores, 64), min(ncores, 32)}, reverse=True):
+            tried[nt] = cpu_leg(nt, 4.0, 5)
+        best = min(tried, key=lambda k: tried[k][0])
+        cpu_all, na, oa = tried[best]
+        out["cpu_baseline_all_cores"] = {"value": 1.0 / cpu_all, "unit": "sweeps/s", "cores": best, "kind": "port",
+                                         "threads_tried_ms_per_solve": {str(k): round(v[0] * 1e3, 2) for k, v in tried.items()},
                                          "sample": f"{na} full solves of the same sweep and map; the oracle's keypoint loop visited in parallel "
-                                                   f"(OpenMP, {ncores} threads), committed in keypoint order: results bit-identical to the single-thread run "
-                                                   f"({bool(np.array_equal(oa['state'], ou['state']))})",
+                                                   f"(OpenMP, {best} threads = the fastest of those tried on this {ncores}-core host), committed in keypoint "
+                                                   f"order: results bit-identical to the single-thread run ({bool(np.array_equal(oa['state'], ou['state']))})",
                                          "ms_per_solve": cpu_all * 1e3, "ms_per_esikf_iter": cpu_all * 1e3 / max(oa["rc"], 1),
                                          "speedup_over_1_core": cpu_s / cpu_all}
         out["parity"] = {"state_rel_err_vs_oracle": state_err, "iterations_gpu": iters, "iterations_oracle": ou["rc"],

@@ -145,6 +145,10 @@ int srl_lio_build_plane_residuals(srl_lio *lio, const srl_icp_opts *opts, const 
 
 /* gridSampling (utility.cpp:188-201) alone: indices of the selected points, in output order */
 int srl_grid_sampling(const double *world_xyz, int n, double size_voxel, int32_t *index_out, int *num_out);
+/* debug / parity hook: iteration order of the std::tr1::unordered_map<voxel, ...> of subSampleFrame (utility.cpp:169-185) after
+ * inserting n DISTINCT voxel keys in the given order, by the flat replay of the container's bucket moves that
+ * srl_frame_select_keypoints uses (csrc/host/tr1_order.h; no container is built).  order_out[r] = index of the r-th element. */
+int srl_debug_tr1_order(const int16_t *keys_xyz, int n, int32_t *order_out);
 
 #ifdef __cplusplus
 }

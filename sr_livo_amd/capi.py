@@ -181,6 +181,7 @@ def load_library():
         "srl_lio_build_plane_residuals": ([p, C.POINTER(IcpOpts), p, C.c_int, dp, dp, C.c_int, p, C.c_int,
                                            C.POINTER(C.c_int), dp, C.POINTER(C.c_int), p], C.c_int),
         "srl_grid_sampling": ([p, C.c_int, C.c_double, p, C.POINTER(C.c_int)], C.c_int),
+        "srl_debug_tr1_order": ([p, C.c_int, p], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)
@@ -297,6 +298,16 @@ def grid_sampling(world_xyz, size_voxel):
     if rc:
         raise SrlError(rc, "srl_grid_sampling")
     return idx[: n.value].copy()
+
+
+def tr1_order(keys_xyz):
+    """Iteration order of std::tr1::unordered_map<voxel, ...> after inserting the distinct int16 keys in order (flat replay)."""
+    k = np.ascontiguousarray(keys_xyz, dtype=np.int16).reshape(-1, 3)
+    out = np.empty(len(k), dtype=np.int32)
+    rc = load_library().srl_debug_tr1_order(_ptr(k), len(k), _ptr(out))
+    if rc:
+        raise SrlError(rc, "srl_debug_tr1_order")
+    return out
 
 
 def make_frame(q, t, t_last, R_il=None, t_il=None, frame_id=100):

@@ -2,6 +2,7 @@
 // harnesses drive the same lioOptimization / eskfEstimator code a C++ consumer links.
 #include "../../../include/srlivo_host.h"
 #include "lioOptimization.h"
+#include "tr1_order.h"
 
 #include <cstring>
 #include <new>
@@ -520,6 +521,19 @@ int srl_grid_sampling(const double *world_xyz, int n, double size_voxel, int32_t
     gridSampling(pts, kp, size_voxel);
     *num_out = (int)kp.size();
     if (index_out) for (size_t i = 0; i < kp.size(); i++) index_out[i] = kp[i].index_frame;
+    return SRL_OK;
+}
+
+// debug / parity hook: iteration order of std::tr1::unordered_map<voxel, ...> after inserting the given DISTINCT voxel keys
+// in order, computed by the flat replay of host/tr1_order.h (what srl_frame_select_keypoints uses); order_out[r] = index
+// into keys of the r-th element.  tests compare it with the real container (srl_grid_sampling).
+int srl_debug_tr1_order(const int16_t *keys_xyz, int n, int32_t *order_out) {
+    if (n < 0 || (n > 0 && (!keys_xyz || !order_out))) return SRL_ERR_BAD_ARG;
+    std::vector<std::size_t> h((size_t)n);
+    for (int i = 0; i < n; i++) h[(size_t)i] = std::hash<voxel>()(voxel(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]));
+    std::vector<int> out((size_t)n);
+    srl::Tr1Order::order(h.data(), n, out.data());
+    for (int i = 0; i < n; i++) order_out[i] = out[(size_t)i];
     return SRL_OK;
 }
 

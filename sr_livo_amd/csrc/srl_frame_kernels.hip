@@ -14,6 +14,7 @@
 #include "srl_ctx.h"
 #include "srl_hash.h"
 #include "host/srl_la.h"
+#include "host/tr1_order.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -388,24 +389,34 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, b_len.as<int>(), b_start.as<int>(), S, st));
         hipLaunchKernelGGL(k_first_index, dim3((S + 255) / 256), dim3(256), 0, st, b_start.as<int>(), b_idx2.as<unsigned>(), S, b_first.as<unsigned>());
         HIPCHK(ctx, hipGetLastError());
+        // unique voxels in FIRST-OCCURRENCE order (= the order subSampleFrame's loop creates them): sort (first, key) by first
+        DevBuf b_first2, b_ukeys2;
+        HIPCHK(ctx, b_first2.alloc(ctx, (size_t)S * 4)); HIPCHK(ctx, b_ukeys2.alloc(ctx, (size_t)S * 8));
+        size_t need2 = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, need2, b_first.as<unsigned>(), b_first2.as<unsigned>(), b_ukeys.as<unsigned long long>(),
+                                           b_ukeys2.as<unsigned long long>(), S, 0, 32, st);
+        if (need2 > tmp_bytes) { ctx->err = "frame select: scratch too small"; return SRL_ERR_HIP; }
+        tb = tmp_bytes;
+        HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_first.as<unsigned>(), b_first2.as<unsigned>(), b_ukeys.as<unsigned long long>(),
+                                                       b_ukeys2.as<unsigned long long>(), S, 0, 32, st));
         std::vector<unsigned long long> ukeys((size_t)S);
         std::vector<unsigned> first((size_t)S);
-        HIPCHK(ctx, hipMemcpyAsync(ukeys.data(), b_ukeys.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(first.data(), b_first.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ukeys.data(), b_ukeys2.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(first.data(), b_first2.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
 
-        // order replay (host, V distinct voxels instead of N points): first-occurrence order into the same container
-        std::vector<int> byfirst((size_t)S);
-        for (int i = 0; i < S; i++) byfirst[i] = i;
-        std::sort(byfirst.begin(), byfirst.end(), [&](int a, int b) { return first[a] < first[b]; });
-        std::tr1::unordered_map<vkey, int, vkey_hash> grid;
-        for (int i : byfirst) {
+        // order replay on the host for the S distinct voxels (not the N points): the iteration order of the
+        // std::tr1::unordered_map of subSampleFrame, by replaying its bucket moves on flat arrays (host/tr1_order.h)
+        std::vector<std::size_t> hashes((size_t)S);
+        for (int i = 0; i < S; i++) {
             vkey k;
-            srl_unpack_key(ukeys[i], &k.x, &k.y, &k.z);
-            grid[k] = (int)first[i];
+            srl_unpack_key(ukeys[(size_t)i], &k.x, &k.y, &k.z);
+            hashes[(size_t)i] = vkey_hash()(k);
         }
-        order.reserve(S);
-        for (const auto &kv : grid) order.push_back(kv.second);
+        std::vector<int> perm((size_t)S);
+        srl::Tr1Order::order(hashes.data(), S, perm.data());
+        order.resize((size_t)S);
+        for (int r = 0; r < S; r++) order[(size_t)r] = (int)first[(size_t)perm[(size_t)r]];
     }
     const int m = (int)order.size();
     if (num_keypoints) *num_keypoints = m;
