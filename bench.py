@@ -87,8 +87,11 @@ def compulsory_bytes(keys, counts, world_pts, nb):
 
 def issue_roofline(assoc_ms):
     """Instruction-issue roofline of the association kernel from the committed PMC pass of this command (bench.py cannot
-    count its own instructions).  Per SIMD a wave64 VALU instruction occupies 2 cycles (FP32 / integer, SIMD-32) or 4
-    (FP64: half rate); SALU and LDS instructions issue once per cycle per CU-quarter at best.  frac = floor / measured."""
+    count its own instructions).  The working set is cache resident and the kernel is bound by VALU issue, so this -- not
+    the HBM figure -- says how close the kernel runs to the machine.  SQ_ACTIVE_INST_VALU counts the quad-cycles (4 shader
+    cycles) the SIMDs spent issuing VALU work: 1.01 per VALU instruction in this kernel, i.e. one wave64 VALU instruction
+    occupies its SIMD for 4 cycles.  floor = busy cycles / (SIMDs x clock): the time the same instruction stream would take
+    with every SIMD issuing VALU back to back; frac = floor / measured launch time."""
     try:
         prof = json.load(open(PROFILE))
         k = [v for n, v in prof["pmc_per_dispatch"].items() if "assoc" in n][0]
@@ -98,17 +101,20 @@ def issue_roofline(assoc_ms):
     if not valu:
         return None
     f64 = sum(k.get(c, 0.0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
-    valu_cycles = (valu - f64) * 2.0 + f64 * 4.0
-    t_valu = valu_cycles / (N_SIMD * CLOCK_HZ) * 1e6
-    t_salu = (salu or 0.0) / (N_SIMD * CLOCK_HZ) * 1e6
-    t_lds = (lds or 0.0) * 2.0 / (N_CU * CLOCK_HZ) * 1e6          # >= 2 cycles per wave64 LDS instruction and CU (128 B/clk/CU x 256 B)
+    busy_quads = k.get("SQ_ACTIVE_INST_VALU") or valu
+    t_valu = busy_quads * 4.0 / (N_SIMD * CLOCK_HZ) * 1e6
+    t_salu = (salu or 0.0) * 4.0 / (N_SIMD * CLOCK_HZ) * 1e6      # one scalar issue per SIMD per quad-cycle
+    t_lds = (k.get("SQ_ACTIVE_INST_LDS") or 0.0) * 4.0 / (N_SIMD * CLOCK_HZ) * 1e6
     floor_us = max(t_valu, t_salu, t_lds)
-    out = {"bound": "valu-issue", "valu_insts": valu, "valu_f64_insts": f64 or None, "salu_insts": salu, "lds_insts": lds,
-           "valu_floor_us": t_valu, "salu_floor_us": t_salu, "lds_floor_us": t_lds, "floor_us": floor_us,
-           "achieved_us": assoc_ms * 1e3, "frac": floor_us / (assoc_ms * 1e3) if assoc_ms > 0 else None,
-           "lds_bank_conflict_cycles": k.get("SQ_LDS_BANK_CONFLICT"), "source": os.path.relpath(PROFILE, ROOT),
-           "model": "wave64 VALU = 2 cycles/SIMD (4 for FP64), SIMDs x 2.4 GHz; measured time is the live HIP-event average"}
-    return out
+    waves = k.get("SQ_WAVES") or 1.0
+    return {"bound": "valu-issue", "valu_insts": valu, "valu_f64_insts": f64 or None, "salu_insts": salu, "lds_insts": lds,
+            "vmem_rd_insts": k.get("SQ_INSTS_VMEM_RD"), "valu_busy_quad_cycles": busy_quads,
+            "valu_floor_us": t_valu, "salu_floor_us": t_salu, "lds_floor_us": t_lds, "floor_us": floor_us,
+            "achieved_us": assoc_ms * 1e3, "frac": floor_us / (assoc_ms * 1e3) if assoc_ms > 0 else None,
+            "valu_busy_share_of_wave_lifetime_x_waves_per_simd": busy_quads / max(k.get("SQ_WAVE_CYCLES") or 1.0, 1.0) * (waves / N_SIMD),
+            "wait_inst_any_share": (k.get("SQ_WAIT_INST_ANY") or 0.0) / max(k.get("SQ_WAVE_CYCLES") or 1.0, 1.0),
+            "lds_bank_conflict_cycles": k.get("SQ_LDS_BANK_CONFLICT"), "source": os.path.relpath(PROFILE, ROOT),
+            "model": "floor = SQ_ACTIVE_INST_VALU quad-cycles x 4 / (1024 SIMDs x 2.4 GHz); measured time = the live HIP-event average"}
 
 
 def traffic_from_profile():

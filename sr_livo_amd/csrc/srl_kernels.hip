@@ -1049,9 +1049,16 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     // Sub-lane s accumulates neighbours s, s+4, ...; quad butterflies make the sums identical in the 4 lanes,
     // which then run the (scalar) eigen-solve / weights redundantly and split the 28 H^T H / H^T h / loss
     // products between them (7 each) before the sum over keypoints.
-    const int klw = (lane >> 2) < KPW ? (lane >> 2) : (KPW - 1), sl = lane & 3;   // keypoint inside this wave's quarter
-    const int kl = wave * KPW + klw;                                                // ... and inside the workgroup
-    const bool owner_lane = (lane >> 2) < KPW;          // KPW < 16: the upper quads idle through phase 2
+    // Phase 2 always runs with full waves: the workgroup's KPB keypoints fill P2W = KPB / 16 waves (16 keypoints x 4 lanes);
+    // with KPW < 16 the remaining waves have nothing to do here (before, every wave ran the ~800 instructions of this phase
+    // with 4 * KPW of its 64 lanes).  Which waves work rotates with the workgroup index, so that the phase-2 waves of the
+    // workgroups sharing a CU sit on different SIMDs.
+    constexpr int P2W = KPB / 16;
+    const int w2 = (wave + WPB - (int)(blockIdx.x % WPB)) % WPB;                    // phase-2 slot of this wave
+    const bool p2_wave = w2 < P2W;
+    const int klw = lane >> 2, sl = lane & 3;                                      // keypoint inside this wave's 16
+    const int kl = (p2_wave ? w2 : 0) * 16 + klw;                                   // ... and inside the workgroup
+    const bool owner_lane = p2_wave;
     const int g = owner_lane ? bbase_kp + kl : b.n;
     int status = 3;
     bool nan_bad = false;
@@ -1145,7 +1152,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     // ---- wave partial of H^T H (21 upper-tri), H^T h (6), loss (1).  Every accepted keypoint leaves the row
     // {J[0..5], h, distance} in LDS (zeros otherwise); lane c < 28 then owns component c and walks the 16 keypoints in
     // order -- two LDS reads, one multiply, one add each, no cross-lane traffic, fixed summation order.
-    {
+    if (p2_wave) {
         double *s_row = reinterpret_cast<double *>(surv);            // [16][8], phase-1 scratch is free now
         const bool accd = status == 2;
         if (owner_lane && sl < 2) {
@@ -1169,24 +1176,26 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             else { ia = 7; ib = 7; }
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < KPW; ++k) acc += s_row[k * 8 + ia] * s_row[k * 8 + ib];
-            s_wpart[wave * 32 + lane] = acc;
+            for (int k = 0; k < 16; ++k) acc += s_row[k * 8 + ia] * s_row[k * 8 + ib];
+            s_wpart[w2 * 32 + lane] = acc;
         }
     }
     {
         const unsigned long long acc_mask = __ballot(status == 2 && sl == 0);
         const unsigned long long nan_mask = __ballot(nan_bad);
         const unsigned long long pln_mask = __ballot((status == 1 || status == 2) && sl == 0);
-        int pk = (lane < KPW && wbase_kp + lane < b.n) ? s_ncand[wave * KPW + lane] : 0;
+        int pk = (p2_wave && lane < 16 && bbase_kp + w2 * 16 + lane < b.n) ? s_ncand[w2 * 16 + lane] : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
         if (lane == 0) {
-            s_winfo[wave * 8 + 0] = __popcll(acc_mask);
-            s_winfo[wave * 8 + 1] = pk;
-            // first NaN keypoint of this wave as 1 + index inside the workgroup (quad q = keypoint wave * KPW + q)
-            s_winfo[wave * 8 + 2] = nan_mask ? 1 + wave * KPW + ((int)__builtin_ctzll(nan_mask) >> 2) : 0;
-            s_winfo[wave * 8 + 3] = n_fallback;
-            s_winfo[wave * 8 + 4] = __popcll(pln_mask);
+            s_winfo[wave * 8 + 3] = n_fallback;                 // phase-1 work of THIS wave
+            if (p2_wave) {                                       // phase-2 results, filed under the phase-2 slot
+                s_winfo[w2 * 8 + 0] = __popcll(acc_mask);
+                s_winfo[w2 * 8 + 1] = pk;
+                // first NaN keypoint of these 16 as 1 + index inside the workgroup (quad q = keypoint w2 * 16 + q)
+                s_winfo[w2 * 8 + 2] = nan_mask ? 1 + w2 * 16 + ((int)__builtin_ctzll(nan_mask) >> 2) : 0;
+                s_winfo[w2 * 8 + 4] = __popcll(pln_mask);
+            }
         }
     }
     __syncthreads();
@@ -1198,17 +1207,18 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     if (tid < 28) {
         double v = s_wpart[tid];
 #pragma unroll
-        for (int w = 1; w < WPB; ++w) v += s_wpart[w * 32 + tid];
+        for (int w = 1; w < P2W; ++w) v += s_wpart[w * 32 + tid];
         b.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] = v;
     }
     if (tid == 0) {
         SrlBlockInfo bi;
         bi.accepted = 0; bi.sum_pk = 0; bi.nan_first = 0; bi.num_fallback = 0; bi.planes = 0;
         bi.pad[0] = bi.pad[1] = bi.pad[2] = 0;
-        for (int w = 0; w < WPB; ++w) {
+        for (int w = 0; w < WPB; ++w) bi.num_fallback += s_winfo[w * 8 + 3];
+        for (int w = 0; w < P2W; ++w) {
             bi.accepted += s_winfo[w * 8 + 0]; bi.sum_pk += (unsigned)s_winfo[w * 8 + 1];
-            if (bi.nan_first == 0) bi.nan_first = s_winfo[w * 8 + 2];       // waves in order: the first one wins
-            bi.num_fallback += s_winfo[w * 8 + 3]; bi.planes += s_winfo[w * 8 + 4];
+            if (bi.nan_first == 0) bi.nan_first = s_winfo[w * 8 + 2];       // slots in keypoint order: the first one wins
+            bi.planes += s_winfo[w * 8 + 4];
         }
         b.binfo[blockIdx.x] = bi;
     }
