@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration array (C1..C4, headline@600, init mode)")
     ap.add_argument("--select-mode", type=int, default=0)
+    ap.add_argument("--no-fused-reduce", action="store_true", help="A/B: always run the separate reduce kernel")
     ap.add_argument("--force-comm", action="store_true",
                     help="attach an RCCL communicator even at world size 1 (exercises the sharded code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -232,6 +233,8 @@ def main():
     cands, L = synth.map_candidates(map_seed, map_pts)
     sweep = synth.make_sweep(sweep_seed, n_kp, L, pattern=pattern)
     lio = srl.Lio(local_rank)
+    if args.no_fused_reduce:
+        lio.ctx.set_fused_reduce(0)
     lio.add_points_to_map(cands)
     n_map = lio.map_size()
     comm_info = None

@@ -248,6 +248,10 @@ int srl_get_timing(srl_ctx *ctx, srl_timing *t);
  *   bounded max-heap of K, writes the read-out order (candidate indices, ascending distance) and returns its size.  No GPU.
  * srl_debug_device_sqrt: out[i] = the device's sqrt(in[i]) (the tie replay relies on it being correctly rounded). */
 int srl_debug_set_ablate(srl_ctx *ctx, int bits);
+/* 0: always run the separate ordered-cut / reduce kernel.  Default 1: when no ordered cut can trigger (max_num_residuals >
+ * number of keypoints), nobody reads per-keypoint records and the context is unsharded, the last workgroup of the association
+ * kernel sums the block partials and publishes the normal equations itself (one kernel per ESIKF iteration). */
+int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable);
 int srl_debug_set_search_select_mode(srl_ctx *ctx, int select_mode);
 int srl_debug_heap_topk(const double *distances, int n, int K, int32_t *out_index);
 int srl_debug_device_sqrt(srl_ctx *ctx, const double *in, int n, double *out);

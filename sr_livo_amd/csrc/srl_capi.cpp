@@ -138,6 +138,7 @@ int srl_ctx_create(int device, srl_ctx **out) {
         delete ctx;
         return SRL_ERR_HIP;
     }
+    if (hipMalloc((void **)&ctx->d_ticket, 64) != hipSuccess || hipMemset(ctx->d_ticket, 0, 64) != hipSuccess) { delete ctx; return SRL_ERR_HIP; }
     if (hipHostMalloc((void **)&ctx->h_mail, sizeof(SrlMailbox), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         delete ctx;
         return SRL_ERR_HIP;
@@ -155,7 +156,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->comm);
     if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
-                    ctx->d_out, ctx->d_count, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
+                    ctx->d_out, ctx->d_count, ctx->d_ticket, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
                     ctx->d_tap_offset, ctx->d_gather};
     for (void *b : bufs) if (b) hipFree(b);
     if (ctx->h_out) hipHostFree(ctx->h_out);
@@ -487,9 +488,22 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         ring_ev = ctx->ring[ctx->ring_head % srl_ctx::PROF_RING];
     }
 
+    // Fused final reduction: single rank, every accepted residual counts (no ordered cut can trigger) and nobody reads
+    // per-keypoint records -- the last workgroup of the association kernel publishes the result itself.
+    const bool single_rank = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
+    const bool fused = single_rank && !a.write_rec && a.ablate == 0 && o->max_num_residuals > 0 && ctx->fuse_reduce;
+    const unsigned long long seq_now = ++ctx->seq;
+    if (fused) {
+        a.ticket = ctx->d_ticket;
+        a.ticket_last = ctx->ticket_total + (unsigned)nblocks - 1u;
+        a.mailbox = ctx->h_mail;
+        a.seq = seq_now;
+    }
+
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (prof_light) HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
     HIPCHK(ctx, srl_launch_assoc(a, nb, kpw, wpb, ctx->stream));
+    if (fused) ctx->ticket_total += (unsigned)nblocks;
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if (prof_light) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_head++; }
 
@@ -540,8 +554,8 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     // sequence word -- no D2H copy, no stream synchronisation on the per-iteration critical path
     const bool mailbox = (ctx->nranks == 1) && !coll;
     ra.mailbox = mailbox ? ctx->h_mail : nullptr;
-    ra.seq = ++ctx->seq;
-    HIPCHK(ctx, srl_launch_reduce(ra, mode, ctx->stream));
+    ra.seq = seq_now;
+    if (!fused) HIPCHK(ctx, srl_launch_reduce(ra, mode, ctx->stream));
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     const auto t_enq = std::chrono::steady_clock::now();
 
@@ -719,6 +733,11 @@ int srl_transform_points(srl_ctx *ctx, const double *raw_xyz, int n, const doubl
 int srl_debug_set_ablate(srl_ctx *ctx, int bits) {
     if (!ctx) return SRL_ERR_BAD_ARG;
     ctx->ablate = bits;
+    return SRL_OK;
+}
+int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    ctx->fuse_reduce = enable != 0;
     return SRL_OK;
 }
 int srl_debug_set_search_select_mode(srl_ctx *ctx, int select_mode) {

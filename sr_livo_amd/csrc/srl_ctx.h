@@ -62,6 +62,9 @@ struct srl_ctx {
     SrlDevOut *h_out = nullptr;        // pinned
     long long *d_count = nullptr;
     long long *h_count = nullptr;      // pinned
+    unsigned *d_ticket = nullptr;      // arrival counter of the fused final reduction (monotonic over launches)
+    bool fuse_reduce = true;           // srl_debug_set_fused_reduce(0): always run the separate reduce kernel (A/B, tests)
+    unsigned ticket_total = 0;         // tickets handed out so far = value the first workgroup of the next launch gets
     SrlMailbox *h_mail = nullptr;      // host-mapped fine-grained mailbox the reduce kernel publishes into
     unsigned long long seq = 0;
 

@@ -106,6 +106,12 @@ struct SrlAssocArgs {
     int thr_cap;        // threshold_voxel_capacity
     int select_mode;
     int ablate;             // debug only (env SRL_ABLATE): bit0 skip phase 2, bit1 stop after compaction, bit2 stop after probe, bit3 skip probe
+    // fused final reduction (single rank, no ordered cut possible, no taps): the last workgroup to finish sums the block
+    // partials and publishes the result itself -- no second kernel, no kernel boundary on the per-iteration critical path
+    unsigned *ticket;           // arrival counter (monotonic over launches; null = not fused)
+    unsigned ticket_last;       // value the counter returns to the LAST workgroup of this launch
+    SrlMailbox *mailbox;        // host-mapped result mailbox
+    unsigned long long seq;     // launch sequence number published with the result
     // outputs
     double *rec;            // n x 8
     unsigned char *status;  // n

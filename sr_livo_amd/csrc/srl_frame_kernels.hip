@@ -53,6 +53,27 @@ __global__ void k_first_index(const int *seg_start, const unsigned *sorted_idx, 
     if (s < S) first_idx[s] = sorted_idx[seg_start[s]];
 }
 
+// run heads of the (key, index)-sorted frame: one {voxel key, index of its first point} pair per occupied voxel, in no
+// particular order (the host re-orders by first index anyway); out[0] of `count` = number of pairs
+__global__ void k_run_heads(const unsigned long long *keys_sorted, const unsigned *idx_sorted, int n, unsigned long long *out_key,
+                            unsigned *out_first, int *count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool head = i < n && (i == 0 || keys_sorted[i] != keys_sorted[i - 1]);
+    // wave-aggregated append: one atomic per wave
+    const unsigned long long m = __ballot(head);
+    if (m == 0ull) return;
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+    const int leader = (int)__builtin_ctzll(m);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, (int)__popcll(m));
+    base = __shfl(base, leader);
+    if (head) {
+        const int p = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        out_key[p] = keys_sorted[i];
+        out_first[p] = idx_sorted[i];
+    }
+}
+
 __global__ void k_gather_soa(const double *raw, const int *sel, int m, double *x, double *y, double *z) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
@@ -358,65 +379,66 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
     if (n > 0) {
         Xf X;
         fill_xf(X, q, t, R_il, t_il);
-        DevBuf b_keys, b_keys2, b_idx, b_idx2, b_ukeys, b_len, b_start, b_nruns, b_first, b_tmp;
+        DevBuf b_keys, b_keys2, b_idx, b_idx2, b_ukeys, b_first, b_cnt, b_tmp;
         HIPCHK(ctx, b_keys.alloc(ctx, (size_t)n * 8)); HIPCHK(ctx, b_keys2.alloc(ctx, (size_t)n * 8));
         HIPCHK(ctx, b_idx.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_idx2.alloc(ctx, (size_t)n * 4));
-        HIPCHK(ctx, b_ukeys.alloc(ctx, (size_t)n * 8)); HIPCHK(ctx, b_len.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_start.alloc(ctx, (size_t)n * 4));
-        HIPCHK(ctx, b_first.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_nruns.alloc(ctx, 16));
+        HIPCHK(ctx, b_ukeys.alloc(ctx, (size_t)n * 8)); HIPCHK(ctx, b_first.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_cnt.alloc(ctx, 16));
         hipLaunchKernelGGL(k_frame_keys, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, n, X, sample_voxel_size,
                            (double *)nullptr, b_keys.as<unsigned long long>(), b_idx.as<unsigned>());
         HIPCHK(ctx, hipGetLastError());
-        size_t need = 0, tmp_bytes = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, need, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
+        // stable sort by voxel key: inside a voxel the point indices stay ascending, so a run's head is its FIRST point
+        size_t tmp_bytes = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
                                            b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st);
-        tmp_bytes = need;
-        hipcub::DeviceRunLengthEncode::Encode(nullptr, need, b_keys2.as<unsigned long long>(), b_ukeys.as<unsigned long long>(),
-                                              b_len.as<int>(), b_nruns.as<int>(), n, st);
-        tmp_bytes = std::max(tmp_bytes, need);
-        hipcub::DeviceScan::ExclusiveSum(nullptr, need, b_len.as<int>(), b_start.as<int>(), n, st);
-        tmp_bytes = std::max(tmp_bytes, need) + 4096;
-        HIPCHK(ctx, b_tmp.alloc(ctx, tmp_bytes));
+        HIPCHK(ctx, b_tmp.alloc(ctx, tmp_bytes + 256));
         size_t tb = tmp_bytes;
         HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
                                                        b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st));
-        tb = tmp_bytes;
-        HIPCHK(ctx, hipcub::DeviceRunLengthEncode::Encode(b_tmp.p, tb, b_keys2.as<unsigned long long>(), b_ukeys.as<unsigned long long>(),
-                                                          b_len.as<int>(), b_nruns.as<int>(), n, st));
-        int S = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&S, b_nruns.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        tb = tmp_bytes;
-        HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, b_len.as<int>(), b_start.as<int>(), S, st));
-        hipLaunchKernelGGL(k_first_index, dim3((S + 255) / 256), dim3(256), 0, st, b_start.as<int>(), b_idx2.as<unsigned>(), S, b_first.as<unsigned>());
+        HIPCHK(ctx, hipMemsetAsync(b_cnt.p, 0, 4, st));
+        hipLaunchKernelGGL(k_run_heads, dim3((n + 255) / 256), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_idx2.as<unsigned>(), n,
+                           b_ukeys.as<unsigned long long>(), b_first.as<unsigned>(), b_cnt.as<int>());
         HIPCHK(ctx, hipGetLastError());
-        // unique voxels in FIRST-OCCURRENCE order (= the order subSampleFrame's loop creates them): sort (first, key) by first
-        DevBuf b_first2, b_ukeys2;
-        HIPCHK(ctx, b_first2.alloc(ctx, (size_t)S * 4)); HIPCHK(ctx, b_ukeys2.alloc(ctx, (size_t)S * 8));
-        size_t need2 = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, need2, b_first.as<unsigned>(), b_first2.as<unsigned>(), b_ukeys.as<unsigned long long>(),
-                                           b_ukeys2.as<unsigned long long>(), S, 0, 32, st);
-        if (need2 > tmp_bytes) { ctx->err = "frame select: scratch too small"; return SRL_ERR_HIP; }
-        tb = tmp_bytes;
-        HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_first.as<unsigned>(), b_first2.as<unsigned>(), b_ukeys.as<unsigned long long>(),
-                                                       b_ukeys2.as<unsigned long long>(), S, 0, 32, st));
-        std::vector<unsigned long long> ukeys((size_t)S);
-        std::vector<unsigned> first((size_t)S);
-        HIPCHK(ctx, hipMemcpyAsync(ukeys.data(), b_ukeys2.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(first.data(), b_first2.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+        // one round trip for small frames (count + all n slots), two for large ones (count first)
+        int S = 0;
+        std::vector<unsigned long long> ukeys;
+        std::vector<unsigned> first;
+        const bool one_trip = n <= 65536;
+        if (one_trip) {
+            ukeys.resize((size_t)n); first.resize((size_t)n);
+            HIPCHK(ctx, hipMemcpyAsync(ukeys.data(), b_ukeys.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(first.data(), b_first.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(ctx, hipMemcpyAsync(&S, b_cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
+        if (!one_trip) {
+            ukeys.resize((size_t)S); first.resize((size_t)S);
+            HIPCHK(ctx, hipMemcpyAsync(ukeys.data(), b_ukeys.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(first.data(), b_first.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+        }
 
-        // order replay on the host for the S distinct voxels (not the N points): the iteration order of the
-        // std::tr1::unordered_map of subSampleFrame, by replaying its bucket moves on flat arrays (host/tr1_order.h)
+        // voxels in FIRST-OCCURRENCE order (= the order subSampleFrame's loop creates them): first indices are distinct
+        // integers below n, so a scatter / compact pass orders them in O(n)
+        std::vector<int> slot_of((size_t)n, -1);
+        for (int i = 0; i < S; i++) slot_of[first[(size_t)i]] = i;
         std::vector<std::size_t> hashes((size_t)S);
-        for (int i = 0; i < S; i++) {
+        std::vector<unsigned> first_sorted((size_t)S);
+        int w = 0;
+        for (int p = 0; p < n; p++) {
+            const int i = slot_of[(size_t)p];
+            if (i < 0) continue;
             vkey k;
             srl_unpack_key(ukeys[(size_t)i], &k.x, &k.y, &k.z);
-            hashes[(size_t)i] = vkey_hash()(k);
+            hashes[(size_t)w] = vkey_hash()(k);
+            first_sorted[(size_t)w] = (unsigned)p;
+            w++;
         }
+        // iteration order of the std::tr1::unordered_map of subSampleFrame, by replaying its bucket moves on flat arrays
+        // (host/tr1_order.h) for the S distinct voxels (not the N points)
         std::vector<int> perm((size_t)S);
         srl::Tr1Order::order(hashes.data(), S, perm.data());
         order.resize((size_t)S);
-        for (int r = 0; r < S; r++) order[(size_t)r] = (int)first[(size_t)perm[(size_t)r]];
+        for (int r = 0; r < S; r++) order[(size_t)r] = (int)first_sorted[(size_t)perm[(size_t)r]];
     }
     const int m = (int)order.size();
     if (num_keypoints) *num_keypoints = m;

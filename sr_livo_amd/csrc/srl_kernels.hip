@@ -1204,7 +1204,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         b.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] =
             (tid == 28) ? (double)dbg_t0 : ((tid == 29) ? (double)(long long)wall_clock64() : (double)__builtin_amdgcn_s_getreg(6164) /* XCC_ID */);
     // ---- block partial = wave partials added in wave order (deterministic)
-    if (tid < 28) {
+    if (tid < 28 && b.ticket == nullptr) {
         double v = s_wpart[tid];
 #pragma unroll
         for (int w = 1; w < P2W; ++w) v += s_wpart[w * 32 + tid];
@@ -1221,6 +1221,94 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             bi.planes += s_winfo[w * 8 + 4];
         }
         b.binfo[blockIdx.x] = bi;
+    }
+    if (b.ticket == nullptr) return;
+
+    // ---------------- fused final reduction: every workgroup publishes its row, the last one to arrive finishes.
+    // Row = 28 partial sums + {accepted, candidates visited, NaN flag, off-fast-path keypoints} carried as doubles.
+    // Visibility across the 8 XCDs (private L2s): the row is stored write-through at agent scope by ONE wave, which
+    // drains its stores before ONE lane takes a ticket (guide G16, write-through payload + counter); the last workgroup
+    // acquires once and reads the rows with agent-scope loads.  The ticket counter is monotonic over launches
+    // (ticket_last = the value the last arrival gets), so no per-launch reset sits on the critical path.
+    typedef __attribute__((address_space(1))) double gdouble;
+    typedef __attribute__((address_space(1))) unsigned gunsigned;
+    int *s_flag = s_next + 3;
+    if (tid < 32) {
+        double v;
+        if (tid < 28) {
+            v = s_wpart[tid];
+#pragma unroll
+            for (int w = 1; w < P2W; ++w) v += s_wpart[w * 32 + tid];
+        } else {
+            int acc = 0, pk = 0, nanf = 0, fb = 0;
+            for (int w = 0; w < WPB; ++w) fb += s_winfo[w * 8 + 3];
+            for (int w = 0; w < P2W; ++w) { acc += s_winfo[w * 8 + 0]; pk += s_winfo[w * 8 + 1]; nanf |= s_winfo[w * 8 + 2]; }
+            v = tid == 28 ? (double)acc : (tid == 29 ? (double)(unsigned)pk : (tid == 30 ? (nanf ? 1.0 : 0.0) : (double)fb));
+        }
+        __hip_atomic_store((gdouble *)(b.partials + (size_t)blockIdx.x * SRL_PART_STRIDE + tid), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the one storing wave drains its row
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add((gunsigned *)b.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_flag = (t == b.ticket_last) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (*s_flag == 0) return;
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    {
+        // deterministic: part p sums rows p, p + NPART, ... ascending; parts are then added in order
+        constexpr int NT = 64 * WPB, NPART = NT / 32;
+        double *s_part = reinterpret_cast<double *>(smem);                 // [NPART][32]: the keypoint arrays are dead now
+        const int comp = tid & 31, part = tid >> 5;
+        const int nbk = (int)gridDim.x;
+        double s0 = 0.0;
+        for (int r0 = part; r0 < nbk; r0 += NPART * 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = r0 + NPART * k;
+                v[k] = (r < nbk) ? __hip_atomic_load((gdouble *)(b.partials + (size_t)r * SRL_PART_STRIDE + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s0 += v[k];
+        }
+        s_part[part * 32 + comp] = s0;
+        __syncthreads();
+        if (tid < 32) {
+            double sum = s_part[tid];
+            for (int p = 1; p < NPART; ++p) sum += s_part[p * 32 + tid];
+            s_part[tid] = sum;                                             // row 0 = the totals
+        }
+        __syncthreads();
+        SrlDevOut *out = &b.mailbox->out;
+        auto put_f = [](double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+        if (tid < 21) {
+            int ia = 0, c = tid, rowlen = 6;
+            while (c >= rowlen) { c -= rowlen; ia++; rowlen--; }
+            const int ib = ia + c;
+            put_f(&out->HtH[ia * 6 + ib], s_part[tid]);
+            if (ib != ia) put_f(&out->HtH[ib * 6 + ia], s_part[tid]);
+        } else if (tid < 27) {
+            put_f(&out->Hth[tid - 21], s_part[tid]);
+        } else if (tid == 27) {
+            put_f(&out->loss, s_part[27]);
+        } else if (tid == 32) {
+            put_f(&out->d_num_res, s_part[28]);                            // no ordered cut possible here: every accepted residual counts
+            put_f(&out->d_total_accepted, s_part[28]);
+            put_f(&out->d_sum_pk, s_part[29]);
+            put_f(&out->d_nan, s_part[30] > 0.0 ? 1.0 : 0.0);              // every keypoint is visited
+            put_f(&out->d_fallback, s_part[31]);
+            put_f(&out->d_visited, (double)b.n);
+            __hip_atomic_store(&out->last_visited, (long long)b.n - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&out->pad, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (tid < 64) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every mailbox writer sits in wave 0
+            if (tid == 0) __hip_atomic_store(&b.mailbox->seq, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

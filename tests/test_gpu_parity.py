@@ -114,6 +114,46 @@ def test_general_selection_paths_match(ctx_small, golden, mode):
     assert np.array_equal(np.array(g0["neq"].HtH), np.array(g["neq"].HtH))
 
 
+def test_fused_final_reduction_equals_the_reduce_kernel(ctx_small, golden, oracle_lib, oracle_backend):
+    """No ordered cut possible + no taps + one rank: the last workgroup of the association kernel finishes the sum itself.
+    Same result as the separate reduce kernel up to FP64 summation order, bitwise reproducible, at 2k and 64k keypoints."""
+    f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    ctx_small.sweep_upload(golden["raw"])
+    outs = {}
+    for fused in (1, 0, 1):
+        ctx_small.set_fused_reduce(fused)
+        runs = [ctx_small.build_residuals(f, opts)[0] for _ in range(3)]
+        for r in runs[1:]:
+            assert np.array_equal(np.array(r.HtH), np.array(runs[0].HtH)) and np.array_equal(np.array(r.Hth), np.array(runs[0].Hth))
+        outs.setdefault(fused, runs[0])
+    ctx_small.set_fused_reduce(1)
+    a, b = outs[1], outs[0]
+    assert rel(np.array(a.HtH), np.array(b.HtH)) < 1e-13 and rel(np.array(a.Hth), np.array(b.Hth)) < 1e-12
+    assert rel(a.loss_sum, b.loss_sum) < 1e-13
+    for k in ("num_residuals", "success", "sum_candidates", "last_visited", "nan_error", "num_fallback"):
+        assert getattr(a, k) == getattr(b, k), k
+    assert rel(np.array(a.HtH).reshape(6, 6), golden["full_one_HtH"]) < TIGHT
+    # 64k keypoints: 256 sixteen-wave workgroups, every XCD involved in the hand-off; many launches back to back
+    pts, L = synth.map_candidates(31, 200_000)
+    sw = synth.make_sweep(32, 65536, L)
+    ctx = srl.Context(0)
+    try:
+        ctx.map_insert(pts)
+        ctx.sweep_upload(sw["raw"])
+        f2 = capi.make_frame(sw["q_pred"], sw["t_pred"], sw["t_last"])
+        ctx.set_fused_reduce(0)
+        ref = ctx.build_residuals(f2, opts)[0]
+        ctx.set_fused_reduce(1)
+        first = ctx.build_residuals(f2, opts)[0]
+        for _ in range(200):
+            r = ctx.build_residuals(f2, opts)[0]
+            assert np.array_equal(np.array(r.HtH), np.array(first.HtH)) and r.num_residuals == ref.num_residuals
+        assert rel(np.array(first.HtH), np.array(ref.HtH)) < 1e-13 and first.sum_candidates == ref.sum_candidates
+    finally:
+        ctx.close()
+
+
 def test_idempotent_bitwise(ctx_small, golden):
     a = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX)
     b = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX)
