@@ -162,6 +162,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->h_out) hipHostFree(ctx->h_out);
     if (ctx->h_count) hipHostFree(ctx->h_count);
     if (ctx->h_mail) hipHostFree(ctx->h_mail);
+    if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
     if (ctx->h_ring) { hipHostFree(ctx->h_ring); for (int i = 0; i < srl_ctx::RING_SLOTS; i++) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]); }
     for (auto &b : ctx->pool_free) hipFree(b.p);
     ctx->pool_free.clear();

@@ -51,6 +51,11 @@ struct srl_ctx {
     bool ring_busy[RING_SLOTS] = {};
     unsigned ring_next = 0;
 
+    // pinned host scratch (grow-only) for the small D2H / H2D hops of the frame pipeline: pageable copies are staged
+    // synchronously by the runtime and cost more than the kernels around them
+    char *h_scratch = nullptr;
+    size_t h_scratch_bytes = 0;
+
     // work buffers
     double *d_rec = nullptr;
     unsigned char *d_status = nullptr;
@@ -126,6 +131,15 @@ struct srl_ctx {
             return SRL_ERR_COMM;                                                               \
         }                                                                                      \
     } while (0)
+
+inline int ensure_host_scratch(srl_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->h_scratch_bytes) return SRL_OK;
+    if (ctx->h_scratch) { HIPCHK(ctx, hipHostFree(ctx->h_scratch)); ctx->h_scratch = nullptr; ctx->h_scratch_bytes = 0; }
+    const size_t cap = ((bytes + bytes / 2 + 4095) / 4096) * 4096;
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_scratch, cap, hipHostMallocDefault));
+    ctx->h_scratch_bytes = cap;
+    return SRL_OK;
+}
 
 template <class T>
 int ensure(srl_ctx *ctx, T *&p, size_t count) {

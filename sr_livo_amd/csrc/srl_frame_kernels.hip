@@ -398,29 +398,31 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         hipLaunchKernelGGL(k_run_heads, dim3((n + 255) / 256), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_idx2.as<unsigned>(), n,
                            b_ukeys.as<unsigned long long>(), b_first.as<unsigned>(), b_cnt.as<int>());
         HIPCHK(ctx, hipGetLastError());
-        // one round trip for small frames (count + all n slots), two for large ones (count first)
+        // one round trip for small frames (count + all n slots), two for large ones (count first); into pinned scratch
+        int rcs = ensure_host_scratch(ctx, (size_t)n * 16 + 64);
+        if (rcs) return rcs;
+        int *h_cnt = reinterpret_cast<int *>(ctx->h_scratch);
+        unsigned long long *ukeys = reinterpret_cast<unsigned long long *>(ctx->h_scratch + 64);
+        unsigned *first = reinterpret_cast<unsigned *>(ctx->h_scratch + 64 + (size_t)n * 8);
         int S = 0;
-        std::vector<unsigned long long> ukeys;
-        std::vector<unsigned> first;
         const bool one_trip = n <= 65536;
         if (one_trip) {
-            ukeys.resize((size_t)n); first.resize((size_t)n);
-            HIPCHK(ctx, hipMemcpyAsync(ukeys.data(), b_ukeys.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipMemcpyAsync(first.data(), b_first.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(ukeys, b_ukeys.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(first, b_first.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
         }
-        HIPCHK(ctx, hipMemcpyAsync(&S, b_cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(h_cnt, b_cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
+        S = *h_cnt;
         if (!one_trip) {
-            ukeys.resize((size_t)S); first.resize((size_t)S);
-            HIPCHK(ctx, hipMemcpyAsync(ukeys.data(), b_ukeys.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipMemcpyAsync(first.data(), b_first.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(ukeys, b_ukeys.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(first, b_first.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
         }
 
         // voxels in FIRST-OCCURRENCE order (= the order subSampleFrame's loop creates them): first indices are distinct
         // integers below n, so a scatter / compact pass orders them in O(n)
         std::vector<int> slot_of((size_t)n, -1);
-        for (int i = 0; i < S; i++) slot_of[first[(size_t)i]] = i;
+        for (int i = 0; i < S; i++) slot_of[(size_t)first[i]] = i;
         std::vector<std::size_t> hashes((size_t)S);
         std::vector<unsigned> first_sorted((size_t)S);
         int w = 0;
@@ -428,7 +430,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
             const int i = slot_of[(size_t)p];
             if (i < 0) continue;
             vkey k;
-            srl_unpack_key(ukeys[(size_t)i], &k.x, &k.y, &k.z);
+            srl_unpack_key(ukeys[i], &k.x, &k.y, &k.z);
             hashes[(size_t)w] = vkey_hash()(k);
             first_sorted[(size_t)w] = (unsigned)p;
             w++;
@@ -457,7 +459,10 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
     if (m > 0) {
         DevBuf b_sel;
         HIPCHK(ctx, b_sel.alloc(ctx, (size_t)m * 4));
-        HIPCHK(ctx, hipMemcpyAsync(b_sel.p, order.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+        int rch = ensure_host_scratch(ctx, (size_t)m * 4);          // (the downloads above have been consumed)
+        if (rch) return rch;
+        std::memcpy(ctx->h_scratch, order.data(), (size_t)m * 4);
+        HIPCHK(ctx, hipMemcpyAsync(b_sel.p, ctx->h_scratch, (size_t)m * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_gather_soa, dim3((m + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, b_sel.as<int>(), m,
                            ctx->d_raw, ctx->d_raw + ctx->sweep_cap, ctx->d_raw + 2 * (size_t)ctx->sweep_cap);
         HIPCHK(ctx, hipGetLastError());

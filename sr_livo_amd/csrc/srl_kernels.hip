@@ -1256,8 +1256,8 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     }
     __syncthreads();
     if (*s_flag == 0) return;
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
+    // every row is read below with agent-scope atomic loads (they bypass this CU's L1 and this XCD's L2, like the granule
+    // sweep of guide G16 R2): no acquire fence, whose cache invalidation alone costs ~1.7 us
     {
         // deterministic: part p sums rows p, p + NPART, ... ascending; parts are then added in order
         constexpr int NT = 64 * WPB, NPART = NT / 32;
@@ -1265,15 +1265,16 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         const int comp = tid & 31, part = tid >> 5;
         const int nbk = (int)gridDim.x;
         double s0 = 0.0;
-        for (int r0 = part; r0 < nbk; r0 += NPART * 8) {
-            double v[8];
+        constexpr int INF = WPB == 16 ? 8 : 32;          // loads in flight per thread: few threads (4-wave workgroups) face many rows
+        for (int r0 = part; r0 < nbk; r0 += NPART * INF) {
+            double v[INF];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < INF; ++k) {
                 const int r = r0 + NPART * k;
                 v[k] = (r < nbk) ? __hip_atomic_load((gdouble *)(b.partials + (size_t)r * SRL_PART_STRIDE + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s0 += v[k];
+            for (int k = 0; k < INF; ++k) s0 += v[k];
         }
         s_part[part * 32 + comp] = s0;
         __syncthreads();
