@@ -138,7 +138,7 @@ int srl_ctx_create(int device, srl_ctx **out) {
         delete ctx;
         return SRL_ERR_HIP;
     }
-    if (hipMalloc((void **)&ctx->d_ticket, 64) != hipSuccess || hipMemset(ctx->d_ticket, 0, 64) != hipSuccess) { delete ctx; return SRL_ERR_HIP; }
+    if (hipMalloc((void **)&ctx->d_ticket, srl_ctx::TICKET_BYTES) != hipSuccess || hipMemset(ctx->d_ticket, 0, srl_ctx::TICKET_BYTES) != hipSuccess) { delete ctx; return SRL_ERR_HIP; }
     if (hipHostMalloc((void **)&ctx->h_mail, sizeof(SrlMailbox), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         delete ctx;
         return SRL_ERR_HIP;
@@ -492,11 +492,11 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     // Fused final reduction: single rank, every accepted residual counts (no ordered cut can trigger) and nobody reads
     // per-keypoint records -- the last workgroup of the association kernel publishes the result itself.
     const bool single_rank = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
-    const bool fused = single_rank && !a.write_rec && a.ablate == 0 && o->max_num_residuals > 0 && ctx->fuse_reduce;
+    const bool fused = single_rank && !a.write_rec && a.ablate == 0 && o->max_num_residuals > 0 && ctx->fuse_reduce &&
+                       (size_t)(nblocks / SRL_TICKET_GROUP + 2) * 256 <= (size_t)srl_ctx::TICKET_BYTES;
     const unsigned long long seq_now = ++ctx->seq;
     if (fused) {
         a.ticket = ctx->d_ticket;
-        a.ticket_last = ctx->ticket_total + (unsigned)nblocks - 1u;
         a.mailbox = ctx->h_mail;
         a.seq = seq_now;
     }
@@ -504,7 +504,6 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (prof_light) HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
     HIPCHK(ctx, srl_launch_assoc(a, nb, kpw, wpb, ctx->stream));
-    if (fused) ctx->ticket_total += (unsigned)nblocks;
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if (prof_light) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_head++; }
 

@@ -67,9 +67,9 @@ struct srl_ctx {
     SrlDevOut *h_out = nullptr;        // pinned
     long long *d_count = nullptr;
     long long *h_count = nullptr;      // pinned
-    unsigned *d_ticket = nullptr;      // arrival counter of the fused final reduction (monotonic over launches)
+    static constexpr int TICKET_BYTES = 1 << 20;   // 4 095 groups of 32 workgroups
+    unsigned *d_ticket = nullptr;      // arrival counters of the fused final reduction (zero between launches)
     bool fuse_reduce = true;           // srl_debug_set_fused_reduce(0): always run the separate reduce kernel (A/B, tests)
-    unsigned ticket_total = 0;         // tickets handed out so far = value the first workgroup of the next launch gets
     SrlMailbox *h_mail = nullptr;      // host-mapped fine-grained mailbox the reduce kernel publishes into
     unsigned long long seq = 0;
 

@@ -19,6 +19,9 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <tr1/unordered_map>
 #include <vector>
@@ -376,6 +379,9 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
     if (num_keypoints) *num_keypoints = 0;
     hipStream_t st = ctx->stream;
     std::vector<int> order;
+    static const bool trace = std::getenv("SRL_FRAME_TIMING") != nullptr;      // stage times on stderr (tools/pipeline_probe.py)
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto tp1 = tp0, tp2 = tp0, tp3 = tp0;
     if (n > 0) {
         Xf X;
         fill_xf(X, q, t, R_il, t_il);
@@ -398,6 +404,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         hipLaunchKernelGGL(k_run_heads, dim3((n + 255) / 256), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_idx2.as<unsigned>(), n,
                            b_ukeys.as<unsigned long long>(), b_first.as<unsigned>(), b_cnt.as<int>());
         HIPCHK(ctx, hipGetLastError());
+        tp1 = std::chrono::steady_clock::now();
         // one round trip for small frames (count + all n slots), two for large ones (count first); into pinned scratch
         int rcs = ensure_host_scratch(ctx, (size_t)n * 16 + 64);
         if (rcs) return rcs;
@@ -419,6 +426,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
             HIPCHK(ctx, hipStreamSynchronize(st));
         }
 
+        tp2 = std::chrono::steady_clock::now();
         // voxels in FIRST-OCCURRENCE order (= the order subSampleFrame's loop creates them): first indices are distinct
         // integers below n, so a scatter / compact pass orders them in O(n)
         std::vector<int> slot_of((size_t)n, -1);
@@ -442,6 +450,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         order.resize((size_t)S);
         for (int r = 0; r < S; r++) order[(size_t)r] = (int)first_sorted[(size_t)perm[(size_t)r]];
     }
+    tp3 = std::chrono::steady_clock::now();
     const int m = (int)order.size();
     if (num_keypoints) *num_keypoints = m;
     if (keypoint_index) for (int k = 0; k < m; k++) keypoint_index[k] = order[k];
@@ -467,6 +476,12 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
                            ctx->d_raw, ctx->d_raw + ctx->sweep_cap, ctx->d_raw + 2 * (size_t)ctx->sweep_cap);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    if (trace) {
+        const auto tp4 = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "[srl_frame_select_keypoints] n %d -> %d: enqueue keys+sort+heads %.0f us, wait + D2H %.0f us, host order replay %.0f us, gather + sync %.0f us\n",
+                     n, m, us(tp0, tp1), us(tp1, tp2), us(tp2, tp3), us(tp3, tp4));
     }
     return SRL_OK;
 }
