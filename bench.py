@@ -292,6 +292,19 @@ def main():
     tim_full = lio.ctx.timing()
     lio.ctx.set_profiling(0)
     elapsed = max_over_ranks(elapsed)
+    # the association work alone: the same launches with the final reduction in its own kernel (the fused tail -- row
+    # publish, arrival counters, final sum by the last workgroup -- is part of the kernel the timed region runs)
+    tim_unfused = None
+    if world == 1 and not args.no_fused_reduce:
+        lio.ctx.set_fused_reduce(0)
+        solve()
+        lio.ctx.set_profiling(2)
+        for _ in range(max(5, min(20, args.steps))):
+            solve()
+        tim_unfused = lio.ctx.timing()
+        lio.ctx.set_profiling(0)
+        lio.ctx.set_fused_reduce(1)
+        solve()
 
     # PCIe-inclusive rates (SURVEY 8(d) quotes the metric "incl. H2D of the sweep"; `value` is the HBM-resident rate the
     # bench contract asks for): the sweep crosses the host boundary on every solve (24 B/keypoint H2D + SoA transpose on
@@ -351,6 +364,13 @@ def main():
             "note": "achieved = ALGORITHMIC bytes (24 + 12 (2r+1)^3 + 12 P_k per keypoint, SURVEY 8(d)) / launch time: the rate at which the "
                     "reference's byte stream is consumed.  The working set is L2/MALL resident, so real HBM traffic (`traffic`, "
                     "`hbm_measured_GBs`) is far below it and the kernel is bound by instruction issue: see `issue`."}
+    if tim_unfused is not None and tim_unfused.calls > 0:
+        ms_u = tim_unfused.sum_assoc_ms / tim_unfused.calls
+        roof["association_only"] = {"avg_launch_ms": ms_u, "launches": tim_unfused.calls,
+                                    "frac": (tim_unfused.sum_algorithmic_bytes / tim_unfused.calls) / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_u > 0 else None,
+                                    "what": "the same launches with the final reduction left to the separate reduce kernel (srl_debug_set_fused_reduce(0)), "
+                                            "measured after the timed region: the association kernel proper.  In the timed region the last workgroup also "
+                                            "sums the block partials and publishes the result (one kernel per ESIKF iteration)"}
     if rank == 0 and world == 1:
         try:
             keys, counts, _ = lio.ctx.map_download()

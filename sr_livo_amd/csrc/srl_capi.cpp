@@ -492,8 +492,11 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     // Fused final reduction: single rank, every accepted residual counts (no ordered cut can trigger) and nobody reads
     // per-keypoint records -- the last workgroup of the association kernel publishes the result itself.
     const bool single_rank = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
+    // Measured (profiles/README.md): with 256 sixteen-wave workgroups the fused tail costs the kernel +4.5 us and saves the
+    // 5.8 us kernel boundary + the 7 us reduce kernel: -5 us per ESIKF iteration.  With ~1 000 small workgroups (mid-size
+    // sweeps) publishing and re-reading 1 000 rows costs as much as the second kernel it replaces: not fused there.
     const bool fused = single_rank && !a.write_rec && a.ablate == 0 && o->max_num_residuals > 0 && ctx->fuse_reduce &&
-                       (size_t)(nblocks / SRL_TICKET_GROUP + 2) * 256 <= (size_t)srl_ctx::TICKET_BYTES;
+                       wpb == 16 && nblocks <= 512;
     const unsigned long long seq_now = ++ctx->seq;
     if (fused) {
         a.ticket = ctx->d_ticket;
