@@ -14,6 +14,19 @@
 #include <string>
 #include <vector>
 
+// When Eigen is on the include path (the reference's own build: CMakeLists.txt:51) the two members whose signatures carry
+// Eigen types -- computeNeighborhoodDistribution and searchNeighbors, include/lioOptimization.h:340-343 -- are ALSO
+// declared with exactly those types, so call sites written against the reference header compile unchanged.  They convert
+// at the boundary and forward to the srl:: versions (the image this was built in has no Eigen: tests/stub_eigen holds the
+// minimal stand-in the signature test compiles against).  -DSRL_NO_EIGEN switches the block off.
+#if defined(__has_include) && !defined(SRL_NO_EIGEN)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#include <Eigen/StdVector>
+#define SRL_HAVE_EIGEN 1
+#endif
+#endif
+
 namespace srlivo {
 
 extern srl::Vec3 G;        // include/utility.h:43 (written by updateIEKF, optimize.cpp:260)
@@ -39,6 +52,15 @@ struct Neighborhood {      // include/lioOptimization.h:127-137
     srl::Mat3 covariance = srl::Mat3::Identity();
     double a2D = 1.0;
 };
+
+#ifdef SRL_HAVE_EIGEN
+struct NeighborhoodEigen {  // include/lioOptimization.h:127-137 with the reference's member types
+    Eigen::Vector3d center = Eigen::Vector3d::Zero();
+    Eigen::Vector3d normal = Eigen::Vector3d::Zero();
+    Eigen::Matrix3d covariance = Eigen::Matrix3d::Identity();
+    double a2D = 1.0;
+};
+#endif
 
 struct optimizeSummary {   // include/lioOptimization.h:181-188
     bool success = false;
@@ -78,6 +100,26 @@ public:
     std::vector<srl::Vec3> searchNeighbors(voxelHashMap &map, const srl::Vec3 &point, int nb_voxels_visited,
                                            double size_voxel_map, int max_num_neighbors, int threshold_voxel_capacity = 1,
                                            std::vector<voxel> *voxels = nullptr);
+#ifdef SRL_HAVE_EIGEN
+    // the reference's own signatures (include/lioOptimization.h:340-343), forwarding to the two members above
+    NeighborhoodEigen computeNeighborhoodDistribution(const std::vector<Eigen::Vector3d, Eigen::aligned_allocator<Eigen::Vector3d>> &points) {
+        std::vector<srl::Vec3> p(points.size());
+        for (size_t i = 0; i < points.size(); i++) p[i] = srl::vec3(points[i][0], points[i][1], points[i][2]);
+        const Neighborhood nb = computeNeighborhoodDistribution(p);
+        NeighborhoodEigen out;
+        for (int i = 0; i < 3; i++) { out.center[i] = nb.center[i]; out.normal[i] = nb.normal[i]; for (int j = 0; j < 3; j++) out.covariance(i, j) = nb.covariance(i, j); }
+        out.a2D = nb.a2D;
+        return out;
+    }
+    std::vector<Eigen::Vector3d, Eigen::aligned_allocator<Eigen::Vector3d>> searchNeighbors(voxelHashMap &map, const Eigen::Vector3d &point,
+            int nb_voxels_visited, double size_voxel_map, int max_num_neighbors, int threshold_voxel_capacity = 1, std::vector<voxel> *voxels = nullptr) {
+        const std::vector<srl::Vec3> r = searchNeighbors(map, srl::vec3(point[0], point[1], point[2]), nb_voxels_visited, size_voxel_map,
+                                                         max_num_neighbors, threshold_voxel_capacity, voxels);
+        std::vector<Eigen::Vector3d, Eigen::aligned_allocator<Eigen::Vector3d>> out(r.size());
+        for (size_t i = 0; i < r.size(); i++) out[i] = Eigen::Vector3d(r[i][0], r[i][1], r[i][2]);
+        return out;
+    }
+#endif
     void addPointToMap(voxelHashMap &map, const srl::Vec3 &point, double voxel_size, int max_num_points_in_voxel,
                        double min_distance_points, int min_num_points, cloudFrame *p_frame);
     void addPointsToMap(voxelHashMap &map, cloudFrame *p_frame, double voxel_size, int max_num_points_in_voxel,

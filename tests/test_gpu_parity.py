@@ -5,6 +5,7 @@ Bars (BASELINE.json north_star): neighbour indices bit-exact -- tied candidate d
 literal std::priority_queue and the kernels replay libstdc++'s heap whenever they detect a tie --, residuals / normal
 equations / ESIKF state within 1e-5 RELATIVE.
 """
+import os
 import threading
 
 import numpy as np
@@ -651,6 +652,56 @@ def test_logical_shards_reproduce_single_rank(golden, max_res):
         assert rel(np.array(n.HtH), np.array(ref["neq"].HtH)) < 1e-12
         assert rel(np.array(n.Hth), np.array(ref["neq"].Hth)) < 1e-12
         assert np.array_equal(np.array(n.HtH), np.array(results[0]["neq"].HtH))   # identical on every rank
+
+
+_TWO_RANK_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import sr_livo_amd as srl
+rank, path = int(sys.argv[2]), sys.argv[3]
+ctx = srl.Context(0)
+if rank == 0:
+    uid = srl.Context.comm_unique_id()
+    open(path + ".tmp", "wb").write(bytes(uid)); os.replace(path + ".tmp", path)
+else:
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > 60: raise SystemExit(3)
+        time.sleep(0.05)
+    uid = open(path, "rb").read()
+print("backend", srl.comm_backend_info(), flush=True)
+try:
+    ctx.comm_init_rank(2, rank, uid)
+except srl.SrlError as e:
+    print("REFUSED", e.status, str(e)[:200], flush=True)
+    raise SystemExit(7)
+print("CONNECTED", flush=True)
+"""
+
+
+def test_two_processes_on_one_gpu_fail_loudly_not_hang(tmp_path):
+    """Two ranks of one communicator on the SAME device (all a 1-GPU box can offer): RCCL must refuse the duplicate GPU and
+    srl_comm_init_rank must hand that back as SRL_ERR_COMM in both processes within the time limit -- a mis-launched job
+    (two ranks mapped to one GPU) has to die with a message, not sit in a bootstrap loop."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "uid.bin")
+    env = dict(os.environ, NCCL_DEBUG="WARN")
+    procs = [subprocess.Popen([_sys.executable, "-c", _TWO_RANK_SCRIPT, root, str(r), path], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=150)
+            outs.append((p.returncode, out.decode(errors="replace")))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        pytest.fail("two ranks on one GPU hung instead of failing: " + repr(outs))
+    for rc, out in outs:
+        assert rc == 7 and "REFUSED" in out and str(capi.SRL_ERR_COMM) in out, (rc, out[-600:])
+        assert "backend" in out
 
 
 def test_rccl_single_rank_communicator(golden, monkeypatch):
