@@ -15,6 +15,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 SRL_OK = 0
 SRL_ERR_NO_DEVICE = -1
+SRL_ERR_COMM = -7
 SRL_ERR_NAN_PLANARITY = -8
 SRL_ERR_NOT_ENOUGH_RESIDUALS = -9
 SRL_COMM_ID_BYTES = 128

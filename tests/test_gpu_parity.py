@@ -700,7 +700,7 @@ def test_two_processes_on_one_gpu_fail_loudly_not_hang(tmp_path):
             p.kill()
         pytest.fail("two ranks on one GPU hung instead of failing: " + repr(outs))
     for rc, out in outs:
-        assert rc == 7 and "REFUSED" in out and str(capi.SRL_ERR_COMM) in out, (rc, out[-600:])
+        assert rc == 7 and f"REFUSED {capi.SRL_ERR_COMM}" in out, (rc, out[-600:])
         assert "backend" in out
 
 
