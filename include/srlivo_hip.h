@@ -252,6 +252,9 @@ int srl_debug_set_ablate(srl_ctx *ctx, int bits);
  * number of keypoints), nobody reads per-keypoint records and the context is unsharded, the last workgroup of the association
  * kernel sums the block partials and publishes the normal equations itself (one kernel per ESIKF iteration). */
 int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable);
+/* tuning experiments: force the association kernel's launch shape -- keypoints per wave (4 / 8 / 16) and waves per workgroup
+ * (4 / 16); 0, 0 = automatic (by sweep size).  Results do not depend on the shape beyond FP64 summation order. */
+int srl_debug_set_launch_shape(srl_ctx *ctx, int keypoints_per_wave, int waves_per_workgroup);
 int srl_debug_set_search_select_mode(srl_ctx *ctx, int select_mode);
 int srl_debug_heap_topk(const double *distances, int n, int K, int32_t *out_index);
 int srl_debug_device_sqrt(srl_ctx *ctx, const double *in, int n, double *out);

@@ -138,6 +138,7 @@ def load_library():
         "srl_debug_block_times": ([p, p, C.c_int, C.POINTER(C.c_int)], C.c_int),
         "srl_debug_set_ablate": ([p, C.c_int], C.c_int),
         "srl_debug_set_fused_reduce": ([p, C.c_int], C.c_int),
+        "srl_debug_set_launch_shape": ([p, C.c_int, C.c_int], C.c_int),
         "srl_debug_set_search_select_mode": ([p, C.c_int], C.c_int),
         "srl_debug_heap_topk": ([p, C.c_int, C.c_int, p], C.c_int),
         "srl_debug_device_sqrt": ([p, p, C.c_int, p], C.c_int),
@@ -427,6 +428,9 @@ class Context:
         nf = np.empty(len(q), dtype=np.int32)
         self._chk(self.lib.srl_search_neighbors(self.h, _ptr(q), len(q), nb, size, K, thr, _ptr(ids), _ptr(xyz), _ptr(nf)), "srl_search_neighbors")
         return ids, xyz, nf
+
+    def set_launch_shape(self, kpw, wpb):
+        self._chk(self.lib.srl_debug_set_launch_shape(self.h, int(kpw), int(wpb)), "srl_debug_set_launch_shape")
 
     def set_fused_reduce(self, on):
         self._chk(self.lib.srl_debug_set_fused_reduce(self.h, 1 if on else 0), "srl_debug_set_fused_reduce")

@@ -474,10 +474,14 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         }
     }
     // launch shape: keypoints per wave by sweep size; 16-wave workgroups (one per CU) whenever their LDS footprint fits
-    const int kpw = srl_keypoints_per_wave(n_eff);
+    int kpw = srl_keypoints_per_wave(n_eff);
     // (only for large sweeps: measured neutral on the kernel, it pays through the 4x fewer partials of the reduce kernel;
     //  mid-size sweeps -- 16k..32k keypoints -- ran 2-6 us slower with it and keep 4-wave workgroups)
-    const int wpb = (kpw == 16 && n_eff >= 256 * 16 * kpw && srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT) ? 16 : 4;
+    int wpb = (kpw == 16 && n_eff >= 256 * 16 * kpw && srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT) ? 16 : 4;
+    if (ctx->force_kpw) {            // srl_debug_set_launch_shape: tuning experiments only
+        kpw = ctx->force_kpw;
+        wpb = (ctx->force_wpb == 16 && srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT) ? 16 : 4;
+    }
     const int kpb = kpw * wpb;
     const int nblocks = (n_eff + kpb - 1) / kpb;
     ctx->last_nblocks = nblocks;
@@ -736,6 +740,14 @@ int srl_transform_points(srl_ctx *ctx, const double *raw_xyz, int n, const doubl
 int srl_debug_set_ablate(srl_ctx *ctx, int bits) {
     if (!ctx) return SRL_ERR_BAD_ARG;
     ctx->ablate = bits;
+    return SRL_OK;
+}
+int srl_debug_set_launch_shape(srl_ctx *ctx, int keypoints_per_wave, int waves_per_workgroup) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (keypoints_per_wave != 0 && keypoints_per_wave != 4 && keypoints_per_wave != 8 && keypoints_per_wave != 16) return SRL_ERR_BAD_ARG;
+    if (waves_per_workgroup != 0 && waves_per_workgroup != 4 && waves_per_workgroup != 16) return SRL_ERR_BAD_ARG;
+    ctx->force_kpw = keypoints_per_wave;
+    ctx->force_wpb = waves_per_workgroup;
     return SRL_OK;
 }
 int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable) {
