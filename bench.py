@@ -172,12 +172,26 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         assoc_ms = tim.sum_assoc_ms / calls
         bytes_per_launch = tim.sum_algorithmic_bytes / calls
         state = solve.state.copy()
+        # the association work alone (final reduction in its own kernel, launch shape chosen for the kernel's own time)
+        lio.ctx.set_fused_reduce(0)
+        solve()
+        lio.ctx.set_profiling(2)
+        for _ in range(max(3, steps // 2)):
+            solve()
+        tu = lio.ctx.timing()
+        lio.ctx.set_profiling(0)
+        lio.ctx.set_fused_reduce(1)
+        ms_u = tu.sum_assoc_ms / max(tu.calls, 1)
         ent = {"name": name, "workload": f"{workload}: {n_kp} keypoints ({pattern}), {lio.map_size()}-pt map, max_num_residuals={max_res}, frame_id={frame_id}"
                                          f" (r={2 if frame_id < 20 else 1})",
                "sweeps_per_s": steps / el, "ms_per_solve": el / steps * 1e3, "esikf_iterations": it, "ms_per_esikf_iter": el / steps * 1e3 / max(it, 1),
                "residuals_used": nr, "assoc_kernel_us": assoc_ms * 1e3, "assoc_launches": tim.calls,
                "keypoints_per_launch": tim.sum_keypoints / calls, "algorithmic_MB_per_launch": bytes_per_launch / 1e6,
-               "hbm_roofline_frac": bytes_per_launch / (assoc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if assoc_ms > 0 else None}
+               "hbm_roofline_frac": bytes_per_launch / (assoc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if assoc_ms > 0 else None,
+               "association_only_us": ms_u * 1e3,
+               "association_only_hbm_roofline_frac": (tu.sum_algorithmic_bytes / max(tu.calls, 1)) / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_u > 0 else None,
+               "note": "assoc_kernel_us = the kernel the timed solves ran (with the fused final reduction where the library fuses); "
+                       "association_only_* = the same pass with the reduction in its own kernel"}
         if po is not None:
             u, _ = oracle_solve(po, backend, lio, opts, sweep, prior_state, prior_cov, state0, frame_id, threads)
             ent["parity"] = {"state_rel_err_vs_oracle": rel(state, u["state"]), "iterations_oracle": int(u["rc"]),

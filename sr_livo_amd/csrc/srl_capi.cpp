@@ -475,9 +475,19 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     }
     // launch shape: keypoints per wave by sweep size; 16-wave workgroups (one per CU) whenever their LDS footprint fits
     int kpw = srl_keypoints_per_wave(n_eff);
-    // (only for large sweeps: measured neutral on the kernel, it pays through the 4x fewer partials of the reduce kernel;
-    //  mid-size sweeps -- 16k..32k keypoints -- ran 2-6 us slower with it and keep 4-wave workgroups)
-    int wpb = (kpw == 16 && n_eff >= 256 * 16 * kpw && srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT) ? 16 : 4;
+    // Fused final reduction (the last workgroup sums the block partials and publishes the result itself: one kernel per ESIKF
+    // iteration) needs: single rank, every accepted residual counts (no ordered cut can trigger), nobody reads per-keypoint
+    // records, and few, large workgroups -- every workgroup publishes a row through memory and the last one re-reads them
+    // all.  Measured per srl_build_residuals call (tools/shape_sweep.py; kernel us / wall us):
+    //   16k keypoints  4-wave workgroups, 2 kernels 23.4 / 41.1    16-wave fused 27.0 / 32.4
+    //   24k keypoints                               30.4 / 47.2                  35.7 / 41.3
+    //   64k keypoints  16-wave, 2 kernels           52   / 78                    58   / 72     (1 000 small workgroups fused: +14 us)
+    const bool single_rank = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
+    const bool can_fuse = single_rank && !a.write_rec && a.ablate == 0 && o->max_num_residuals > 0 && ctx->fuse_reduce;
+    const bool fits16 = srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT;
+    // without fusion: 16-wave workgroups only for large sweeps (measured neutral on the kernel there, 4x fewer partials for
+    // the reduce kernel; mid-size sweeps ran 2-6 us slower with them)
+    int wpb = (fits16 && ((kpw == 16 && n_eff >= 256 * 16 * kpw) || (can_fuse && n_eff >= 2048))) ? 16 : 4;
     if (ctx->force_kpw) {            // srl_debug_set_launch_shape: tuning experiments only
         kpw = ctx->force_kpw;
         wpb = (ctx->force_wpb == 16 && srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT) ? 16 : 4;
@@ -485,6 +495,14 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     const int kpb = kpw * wpb;
     const int nblocks = (n_eff + kpb - 1) / kpb;
     ctx->last_nblocks = nblocks;
+    if (nblocks > ctx->block_cap) {  // a forced launch shape can need more workgroups than ensure_work provided for
+        int rcb;
+        if ((rcb = ensure(ctx, ctx->d_partials, (size_t)nblocks * SRL_PART_STRIDE))) return rcb;
+        if ((rcb = ensure(ctx, ctx->d_binfo, (size_t)nblocks))) return rcb;
+        ctx->block_cap = nblocks;
+        a.partials = ctx->d_partials;
+        a.binfo = ctx->d_binfo;
+    }
     const bool prof = ctx->profiling == 1;
     const bool prof_light = ctx->profiling == 2;
     hipEvent_t *ring_ev = nullptr;
@@ -493,14 +511,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         ring_ev = ctx->ring[ctx->ring_head % srl_ctx::PROF_RING];
     }
 
-    // Fused final reduction: single rank, every accepted residual counts (no ordered cut can trigger) and nobody reads
-    // per-keypoint records -- the last workgroup of the association kernel publishes the result itself.
-    const bool single_rank = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
-    // Measured (profiles/README.md): with 256 sixteen-wave workgroups the fused tail costs the kernel +4.5 us and saves the
-    // 5.8 us kernel boundary + the 7 us reduce kernel: -5 us per ESIKF iteration.  With ~1 000 small workgroups (mid-size
-    // sweeps) publishing and re-reading 1 000 rows costs as much as the second kernel it replaces: not fused there.
-    const bool fused = single_rank && !a.write_rec && a.ablate == 0 && o->max_num_residuals > 0 && ctx->fuse_reduce &&
-                       wpb == 16 && nblocks <= 512;
+    const bool fused = can_fuse && wpb == 16 && nblocks <= 512;
     const unsigned long long seq_now = ++ctx->seq;
     if (fused) {
         a.ticket = ctx->d_ticket;

@@ -21,6 +21,7 @@ for wl in (sys.argv[1:] or ["C1", "C2", "C3", "HEADLINE"]):
         for kpw in (0, 4, 8, 16):
             for wpb in ((0,) if kpw == 0 else (4, 16)):
                 ctx.set_launch_shape(kpw, wpb)
+                print(wl, 'fused', fused, 'kpw', kpw, 'wpb', wpb, file=sys.stderr, flush=True)
                 for _ in range(5):
                     ctx.build_residuals(f, opts)
                 ctx.set_profiling(2)
