@@ -215,6 +215,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration array (C1..C4, headline@600, init mode)")
     ap.add_argument("--select-mode", type=int, default=0)
     ap.add_argument("--no-fused-reduce", action="store_true", help="A/B: always run the separate reduce kernel")
+    ap.add_argument("--no-aux-legs", action="store_true",
+                    help="only the timed configuration runs on the GPU (profiling: no association-only / PCIe legs in the trace)")
     ap.add_argument("--force-comm", action="store_true",
                     help="attach an RCCL communicator even at world size 1 (exercises the sharded code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -309,7 +311,7 @@ def main():
     # the association work alone: the same launches with the final reduction in its own kernel (the fused tail -- row
     # publish, arrival counters, final sum by the last workgroup -- is part of the kernel the timed region runs)
     tim_unfused = None
-    if world == 1 and not args.no_fused_reduce:
+    if world == 1 and not args.no_fused_reduce and not args.no_aux_legs:
         lio.ctx.set_fused_reduce(0)
         solve()
         lio.ctx.set_profiling(2)
@@ -327,8 +329,8 @@ def main():
     n_pcie = max(5, min(20, args.steps))
     pin = srl.PinnedArray(sweep["raw"].shape)
     pin.array[:] = sweep["raw"]
-    rates = {}
-    for label, src in (("pinned", pin.array), ("pageable", sweep["raw"])):
+    rates = {"pinned": None, "pageable": None}
+    for label, src in (() if args.no_aux_legs else (("pinned", pin.array), ("pageable", sweep["raw"]))):
         lio.resident_sweep(src); solve()
         barrier()
         t2 = time.perf_counter()
@@ -423,7 +425,7 @@ def main():
                                      "whole_iteration: the timed region"},
         "pcie_inclusive_sweeps_per_s": rates["pinned"],
         "pcie": {"from_pinned_host_memory_sweeps_per_s": rates["pinned"], "from_pageable_host_memory_sweeps_per_s": rates["pageable"],
-                 "value_over_pinned": value / rates["pinned"], "bytes_h2d_per_sweep": int(sweep["raw"].nbytes),
+                 "value_over_pinned": (value / rates["pinned"]) if rates["pinned"] else None, "bytes_h2d_per_sweep": int(sweep["raw"].nbytes),
                  "note": "`value` (the bench contract's metric) has the sweep resident in HBM; SURVEY 8(d)'s sweeps/s includes the H2D of the "
                          "sweep = these rates (upload + solve per step, no host synchronisation in the upload)"},
         "setup_s": setup_s,
