@@ -138,7 +138,7 @@ int srl_ctx_create(int device, srl_ctx **out) {
         delete ctx;
         return SRL_ERR_HIP;
     }
-    if (hipMalloc((void **)&ctx->d_ticket, srl_ctx::TICKET_BYTES) != hipSuccess || hipMemset(ctx->d_ticket, 0, srl_ctx::TICKET_BYTES) != hipSuccess) { delete ctx; return SRL_ERR_HIP; }
+    if (hipMalloc((void **)&ctx->d_granules, 512 * 64 * 8) != hipSuccess || hipMemset(ctx->d_granules, 0, 512 * 64 * 8) != hipSuccess) { delete ctx; return SRL_ERR_HIP; }
     if (hipHostMalloc((void **)&ctx->h_mail, sizeof(SrlMailbox), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         delete ctx;
         return SRL_ERR_HIP;
@@ -156,7 +156,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->comm);
     if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
-                    ctx->d_out, ctx->d_count, ctx->d_ticket, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
+                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
                     ctx->d_tap_offset, ctx->d_gather};
     for (void *b : bufs) if (b) hipFree(b);
     if (ctx->h_out) hipHostFree(ctx->h_out);
@@ -514,7 +514,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     const bool fused = can_fuse && wpb == 16 && nblocks <= 512;
     const unsigned long long seq_now = ++ctx->seq;
     if (fused) {
-        a.ticket = ctx->d_ticket;
+        a.granules = ctx->d_granules;
         a.mailbox = ctx->h_mail;
         a.seq = seq_now;
     }
@@ -596,6 +596,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             }
         }
         std::memcpy(ctx->h_out, &ctx->h_mail->out, sizeof(SrlDevOut));
+        if (ctx->h_out->pad != 0) { ctx->err = "fused final reduction timed out waiting for a workgroup's row"; return SRL_ERR_HIP; }
         visited_local = ctx->h_out->last_visited + 1;
     } else {
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));

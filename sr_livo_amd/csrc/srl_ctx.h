@@ -67,8 +67,7 @@ struct srl_ctx {
     SrlDevOut *h_out = nullptr;        // pinned
     long long *d_count = nullptr;
     long long *h_count = nullptr;      // pinned
-    static constexpr int TICKET_BYTES = 1 << 20;   // 4 095 groups of 32 workgroups
-    unsigned *d_ticket = nullptr;      // arrival counters of the fused final reduction (zero between launches)
+    unsigned long long *d_granules = nullptr;   // published rows of the fused final reduction: 512 workgroups x 64 granules
     int force_kpw = 0, force_wpb = 0;  // srl_debug_set_launch_shape (0 = automatic)
     bool fuse_reduce = true;           // srl_debug_set_fused_reduce(0): always run the separate reduce kernel (A/B, tests)
     SrlMailbox *h_mail = nullptr;      // host-mapped fine-grained mailbox the reduce kernel publishes into

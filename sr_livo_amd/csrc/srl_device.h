@@ -32,7 +32,6 @@
 #define SRL_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define SRL_TABLE_FACTOR 4u   // hash slots per voxel capacity (load <= 0.25: a 2-slot probe almost always resolves)
 #define SRL_PART_STRIDE 32
-#define SRL_TICKET_GROUP 32u   // workgroups per first-level arrival counter of the fused final reduction
 
 struct SrlMapSlot {
     unsigned long long key;
@@ -109,7 +108,7 @@ struct SrlAssocArgs {
     int ablate;             // debug only (env SRL_ABLATE): bit0 skip phase 2, bit1 stop after compaction, bit2 stop after probe, bit3 skip probe
     // fused final reduction (single rank, no ordered cut possible, no taps): the last workgroup to finish sums the block
     // partials and publishes the result itself -- no second kernel, no kernel boundary on the per-iteration critical path
-    unsigned *ticket;           // arrival counters: [0] groups done, [64 (1 + g)] workgroups of group g done; zero between launches; null = not fused
+    unsigned long long *granules;   // nblocks x 64 tagged 8-byte granules {epoch, 32-bit half}: the published rows (null = not fused)
     SrlMailbox *mailbox;        // host-mapped result mailbox
     unsigned long long seq;     // launch sequence number published with the result
     // outputs

@@ -1204,7 +1204,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         b.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] =
             (tid == 28) ? (double)dbg_t0 : ((tid == 29) ? (double)(long long)wall_clock64() : (double)__builtin_amdgcn_s_getreg(6164) /* XCC_ID */);
     // ---- block partial = wave partials added in wave order (deterministic)
-    if (tid < 28 && b.ticket == nullptr) {
+    if (tid < 28 && b.granules == nullptr) {
         double v = s_wpart[tid];
 #pragma unroll
         for (int w = 1; w < P2W; ++w) v += s_wpart[w * 32 + tid];
@@ -1222,74 +1222,74 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         }
         b.binfo[blockIdx.x] = bi;
     }
-    if (b.ticket == nullptr) return;
+    if (b.granules == nullptr) return;
 
-    // ---------------- fused final reduction: every workgroup publishes its row, the last one to arrive finishes.
+    // ---------------- fused final reduction: every workgroup publishes its row, the LAST workgroup of the grid finishes.
     // Row = 28 partial sums + {accepted, candidates visited, NaN flag, off-fast-path keypoints} carried as doubles.
-    // Visibility across the 8 XCDs (private L2s): the row is stored write-through at agent scope by ONE wave, which
-    // drains its stores before ONE lane takes a ticket (guide G16, write-through payload + counter); the last workgroup
-    // reads the rows with agent-scope loads.  The counters are back at zero when the launch ends (each last arrival
-    // resets the one it closed), so no per-launch reset sits on the critical path.
-    typedef __attribute__((address_space(1))) double gdouble;
-    typedef __attribute__((address_space(1))) unsigned gunsigned;
-    int *s_flag = s_next + 3;
-    if (tid < 32) {
-        double v;
+    // Hand-off across the 8 XCDs (private L2s) in the "data is the flag" form of guide G16 (R2): every double travels as
+    // two 8-byte granules {epoch, 32-bit half}, stored write-through at agent scope -- ONE store instruction per workgroup,
+    // no drain, no counter, no fence; the finisher re-reads the granules it needs (agent-scope loads) until every tag
+    // carries this launch's epoch, then sums the rows in a fixed order.  (Round-2 first version: drained row + two-level
+    // arrival counters = three dependent memory round trips behind the last workgroup, +5.6 us on the 64k launch.)
+    // A stale granule has an older epoch (the epoch is the context's launch sequence number), so nothing is reset
+    // between launches.  The finisher only waits for results every other workgroup produces without it: no co-residency
+    // assumption; its spin is bounded (time-out marker in the mailbox, the host turns it into an error).
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    const unsigned epoch = (unsigned)b.seq;
+    if (tid < 64) {
+        double v = 0.0;
         if (tid < 28) {
             v = s_wpart[tid];
 #pragma unroll
             for (int w = 1; w < P2W; ++w) v += s_wpart[w * 32 + tid];
-        } else {
+        } else if (tid < 32) {
             int acc = 0, pk = 0, nanf = 0, fb = 0;
             for (int w = 0; w < WPB; ++w) fb += s_winfo[w * 8 + 3];
             for (int w = 0; w < P2W; ++w) { acc += s_winfo[w * 8 + 0]; pk += s_winfo[w * 8 + 1]; nanf |= s_winfo[w * 8 + 2]; }
             v = tid == 28 ? (double)acc : (tid == 29 ? (double)(unsigned)pk : (tid == 30 ? (nanf ? 1.0 : 0.0) : (double)fb));
         }
-        __hip_atomic_store((gdouble *)(b.partials + (size_t)blockIdx.x * SRL_PART_STRIDE + tid), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // lane l publishes granule l of the row: half l >> 5 of component l & 31
+        const double vs = __shfl(v, tid & 31);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(vs);
+        const unsigned half = (tid < 32) ? (unsigned)bits : (unsigned)(bits >> 32);
+        __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * 64 + tid), ((unsigned long long)epoch << 32) | half,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid < 64) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the one storing wave drains its row
-        if (tid == 0) {
-            // two-level arrival count: SRL_TICKET_GROUP workgroups share a counter (256 B apart: different channels), the last
-            // arrival of a group counts in the global one.  One flat counter serialises every workgroup of the launch on a
-            // single memory-side atomic: +5 us at 256 workgroups, +14 us at 1 024 (measured).  Each "last" resets its counter.
-            const unsigned g = blockIdx.x / SRL_TICKET_GROUP, ng = (gridDim.x + SRL_TICKET_GROUP - 1) / SRL_TICKET_GROUP;
-            const unsigned gsz = (g + 1 == ng) ? gridDim.x - g * SRL_TICKET_GROUP : SRL_TICKET_GROUP;
-            gunsigned *gc = (gunsigned *)(b.ticket + 64 * (1 + g));
-            int last = 0;
-            if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsz - 1) {
-                __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                gunsigned *tc = (gunsigned *)b.ticket;
-                if (__hip_atomic_fetch_add(tc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1) {
-                    __hip_atomic_store(tc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    last = 1;
-                }
-            }
-            *s_flag = last;
-        }
-    }
-    __syncthreads();
-    if (*s_flag == 0) return;
-    // every row is read below with agent-scope atomic loads (they bypass this CU's L1 and this XCD's L2, like the granule
-    // sweep of guide G16 R2): no acquire fence, whose cache invalidation alone costs ~1.7 us
+    if (blockIdx.x != gridDim.x - 1) return;
     {
         // deterministic: part p sums rows p, p + NPART, ... ascending; parts are then added in order
-        constexpr int NT = 64 * WPB, NPART = NT / 32;
-        double *s_part = reinterpret_cast<double *>(smem);                 // [NPART][32]: the keypoint arrays are dead now
+        constexpr int NT = 64 * WPB, NPART = NT / 32, INF = 8;
+        __syncthreads();                                                   // phase-2 LDS reads are done: smem is free
+        double *s_part = reinterpret_cast<double *>(smem);                 // [NPART][32]
+        int *s_bad = reinterpret_cast<int *>(smem + NPART * 32 * 8);
+        if (tid == 0) *s_bad = 0;
         const int comp = tid & 31, part = tid >> 5;
         const int nbk = (int)gridDim.x;
         double s0 = 0.0;
-        constexpr int INF = WPB == 16 ? 8 : 32;          // loads in flight per thread: few threads (4-wave workgroups) face many rows
+        bool timed_out = false;
         for (int r0 = part; r0 < nbk; r0 += NPART * INF) {
-            double v[INF];
+            unsigned lo[INF], hi[INF];
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
 #pragma unroll
-            for (int k = 0; k < INF; ++k) {
-                const int r = r0 + NPART * k;
-                v[k] = (r < nbk) ? __hip_atomic_load((gdouble *)(b.partials + (size_t)r * SRL_PART_STRIDE + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                for (int k = 0; k < INF; ++k) {
+                    const int r = r0 + NPART * k;
+                    if (r < nbk) {
+                        const unsigned long long x0 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * 64 + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long x1 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * 64 + 32 + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch;
+                        lo[k] = (unsigned)x0; hi[k] = (unsigned)x1;
+                    } else { lo[k] = 0u; hi[k] = 0u; }
+                }
+                if (ok) break;
+                if (++spins > (1u << 18)) { timed_out = true; break; }     // ~0.3 s: something died; do not hang the GPU
+                __builtin_amdgcn_s_sleep(8);
             }
 #pragma unroll
-            for (int k = 0; k < INF; ++k) s0 += v[k];
+            for (int k = 0; k < INF; ++k) s0 += __longlong_as_double((long long)(((unsigned long long)hi[k] << 32) | lo[k]));
         }
+        if (timed_out) atomicOr(s_bad, 1);
         s_part[part * 32 + comp] = s0;
         __syncthreads();
         if (tid < 32) {
@@ -1318,7 +1318,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             put_f(&out->d_fallback, s_part[31]);
             put_f(&out->d_visited, (double)b.n);
             __hip_atomic_store(&out->last_visited, (long long)b.n - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&out->pad, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&out->pad, *s_bad ? 0x7117ll : 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // time-out marker
         }
         if (tid < 64) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every mailbox writer sits in wave 0
