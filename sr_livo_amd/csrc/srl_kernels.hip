@@ -773,7 +773,25 @@ __device__ __forceinline__ void eig3_closed(const double A[3][3], double ev[3], 
     double nb = n01;
     if (n02 > nb) { best = x02; nb = n02; }
     if (n12 > nb) { best = x12; nb = n12; }
-    if (!(nb > 0.0)) { n0 = d3(1.0, 0.0, 0.0); return; }
+    if (!(nb > 0.0)) {
+        // A - e0 I has rank <= 1 (collinear neighbours, or a multiple of the identity): the null space is a plane and the
+        // reference's normal is whatever Eigen's rotations leave in column 0.  Return a unit vector of that plane: orthogonal
+        // to the largest row, built with the axis that row is least aligned with ((1,0,0) when every row vanishes).
+        const double q0 = dot3(r0, r0), q1 = dot3(r1, r1), q2 = dot3(r2, r2);
+        D3 r = r0;
+        double qr = q0;
+        if (q1 > qr) { r = r1; qr = q1; }
+        if (q2 > qr) { r = r2; qr = q2; }
+        if (!(qr > 0.0)) { n0 = d3(1.0, 0.0, 0.0); return; }
+        const double ax = fabs(r.x), ay = fabs(r.y), az = fabs(r.z);
+        D3 c;
+        if (ax <= ay && ax <= az) c = d3(0.0, r.z, -r.y);            // r x e_x
+        else if (ay <= az) c = d3(-r.z, 0.0, r.x);                   // r x e_y
+        else c = d3(r.y, -r.x, 0.0);                                 // r x e_z
+        const double ic = rcp_nr(sqrt(dot3(c, c)));
+        n0 = d3(c.x * ic, c.y * ic, c.z * ic);
+        return;
+    }
     const double inv = rcp_nr(sqrt(nb));
     n0 = d3(best.x * inv, best.y * inv, best.z * inv);
 }

@@ -400,6 +400,42 @@ def test_nan_planarity_only_counts_for_visited_keypoints(oracle_lib, oracle_back
         ctx.close()
 
 
+def test_collinear_neighbourhood_is_handled_like_the_reference(oracle_lib, oracle_backend, golden):
+    """20 collinear neighbours (lambda_0 = lambda_1 = 0): the planarity weight vanishes, the keypoint still contributes with
+    weight 0.1 exp(..) (optimize.cpp:87-88) along a normal that only rounding decides.  What IS defined must agree with the
+    oracle: neighbour ids, status, a2D ~ 0, the weight, and a unit normal orthogonal to the line; nothing blows up."""
+    line = np.column_stack([400.05 + 0.045 * np.arange(20), np.full(20, 400.5), np.full(20, 40.5)]).astype(np.float32)
+    keys = np.concatenate([golden["map_keys"], np.array([[400, 400, 40]], np.int16)])
+    counts = np.concatenate([golden["map_counts"], np.array([20], np.int32)])
+    xyz = np.concatenate([golden["map_xyz"], line[None, :, :]])
+    m = oracle_lib.Map(oracle_backend)
+    m.import_(keys, counts, xyz)
+    raw = golden["raw"].copy()
+    R = synth.quat_to_rot(golden["q_pred"] / np.linalg.norm(golden["q_pred"]))
+    pos = [3, 700, 1999]
+    for i, p in enumerate(pos):
+        raw[p] = R.T @ (np.array([400.3 + 0.2 * i, 400.5, 40.45]) - golden["t_pred"])
+    o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=INT_MAX), raw, golden["q_pred"], golden["t_pred"], golden["t_last"])
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(keys, counts, xyz)
+        g = gpu_pass(ctx, raw, golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX)
+        assert g["rc"] == 0 and not o["neq"].nan_error
+        assert np.array_equal(g["ids"], o["ids"]) and np.array_equal(g["status"], o["status"])
+        for p in pos:
+            assert o["status"][p] in (1, 2)
+            assert abs(g["a2D"][p]) < 1e-6 and abs(o["a2D"][p]) < 1e-6
+            assert abs(g["weight"][p] - o["weight"][p]) < 1e-9 * abs(o["weight"][p]) + 1e-12
+            for n in (g["normal"][p], o["normal"][p]):
+                assert abs(np.linalg.norm(n) - 1.0) < 1e-9 and abs(n[0]) < 1e-5          # the line runs along x
+        # every other keypoint is untouched by the extra voxel
+        others = np.ones(len(raw), bool); others[pos] = False
+        has = ((o["status"] == 1) | (o["status"] == 2)) & others
+        assert rel(g["normal"][has], o["normal"][has]) < TIGHT and rel(g["distance"][has], o["distance"][has]) < TIGHT
+    finally:
+        ctx.close()
+
+
 def test_nan_planarity_raises_through_the_class_surface(golden):
     keys, counts, xyz = _nan_scene(golden)
     raw = golden["raw"].copy()
