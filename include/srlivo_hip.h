@@ -119,6 +119,13 @@ int srl_pinned_alloc(size_t bytes, void **out);
 int srl_pinned_free(void *p);
 int srl_host_register(void *p, size_t bytes);
 int srl_host_unregister(void *p);
+/* The NEXT sweep while the current one is being solved (a node receives sweep k + 1 during the solve of sweep k):
+ * srl_sweep_prefetch uploads it on the context's copy stream into a second sweep buffer and returns at once; the current
+ * sweep stays valid.  srl_sweep_swap makes the prefetched sweep current -- the compute stream waits for the upload's event,
+ * the host does not.  Same buffer rules as srl_sweep_upload (a page-locked source must stay untouched until the first
+ * result computed on the swapped-in sweep has been returned). */
+int srl_sweep_prefetch(srl_ctx *ctx, const double *raw_xyz, int n);
+int srl_sweep_swap(srl_ctx *ctx);
 int srl_sweep_shard(srl_ctx *ctx, int *begin, int *count, int *total);
 
 /* ------------------------------------------------------------------ frame-resident pipeline (optional)

@@ -45,6 +45,10 @@ int srl_lio_map_size(srl_lio *lio, int64_t *num_points);
 
 /* keep a sweep resident in HBM for the next srl_lio_update_iekf (pass raw_xyz = NULL there) */
 int srl_lio_resident_sweep(srl_lio *lio, const double *raw_xyz, int n);
+/* srl_sweep_prefetch / srl_sweep_swap behind the handle: upload the next sweep while srl_lio_update_iekf (raw_xyz = NULL)
+ * solves the current one; the swapped-in sweep becomes the resident one. */
+int srl_lio_prefetch_sweep(srl_lio *lio, const double *raw_xyz, int n);
+int srl_lio_swap_sweep(srl_lio *lio);
 
 /* lioOptimization::updateIEKF (optimize.cpp:133-314).
  * state_io: p_frame->p_state = q(wxyz) t v ba bg (16 doubles) in/out; t_last = previous frame's

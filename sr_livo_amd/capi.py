@@ -110,6 +110,8 @@ def load_library():
         "srl_map_download": ([p, p, p, p, C.c_int], C.c_int),
         "srl_sweep_upload": ([p, p, C.c_int], C.c_int),
         "srl_sweep_shard": ([p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "srl_sweep_prefetch": ([p, p, C.c_int], C.c_int),
+        "srl_sweep_swap": ([p], C.c_int),
         "srl_pinned_alloc": ([C.c_size_t, C.POINTER(p)], C.c_int),
         "srl_pinned_free": ([p], C.c_int),
         "srl_host_register": ([p, C.c_size_t], C.c_int),
@@ -162,6 +164,8 @@ def load_library():
         "srl_lio_add_points_to_map": ([p, p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int], C.c_int),
         "srl_lio_map_size": ([p, C.POINTER(C.c_int64)], C.c_int),
         "srl_lio_resident_sweep": ([p, p, C.c_int], C.c_int),
+        "srl_lio_prefetch_sweep": ([p, p, C.c_int], C.c_int),
+        "srl_lio_swap_sweep": ([p], C.c_int),
         "srl_lio_update_iekf": ([p, C.POINTER(IcpOpts), p, C.c_int, dp, dp, C.c_int, p, C.c_int,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_lio_update_iekf_provided": ([p, C.POINTER(IcpOpts), PROVIDER_FN, p, C.c_int, dp, dp, C.c_int, p, C.c_int,
@@ -385,6 +389,14 @@ class Context:
     def sweep_upload(self, raw_xyz):
         r = _f64(raw_xyz, (-1, 3))
         self._chk(self.lib.srl_sweep_upload(self.h, _ptr(r), len(r)), "srl_sweep_upload")
+
+    def sweep_prefetch(self, raw_xyz):
+        r = _f64(raw_xyz, (-1, 3))
+        self._keep_prefetch = r                   # a page-locked source must outlive the copy
+        self._chk(self.lib.srl_sweep_prefetch(self.h, _ptr(r), len(r)), "srl_sweep_prefetch")
+
+    def sweep_swap(self):
+        self._chk(self.lib.srl_sweep_swap(self.h), "srl_sweep_swap")
 
     def sweep_shard(self):
         b, c, t = C.c_int(), C.c_int(), C.c_int()
@@ -634,6 +646,14 @@ class Lio:
         r = _f64(raw_xyz, (-1, 3))
         self._chk(self.lib.srl_lio_resident_sweep(self.h, _ptr(r), len(r)), "resident_sweep")
         return len(r)
+
+    def prefetch_sweep(self, raw_xyz):
+        r = _f64(raw_xyz, (-1, 3))
+        self._keep_prefetch = r
+        self._chk(self.lib.srl_lio_prefetch_sweep(self.h, _ptr(r), len(r)), "prefetch_sweep")
+
+    def swap_sweep(self):
+        self._chk(self.lib.srl_lio_swap_sweep(self.h), "swap_sweep")
 
     def update_iekf(self, opts, raw_xyz, state, t_last, frame_id=100, log_iters=0, n_resident=None,
                     allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):

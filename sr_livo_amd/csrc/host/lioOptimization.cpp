@@ -86,6 +86,22 @@ int lioOptimization::residentSweep(const double *raw_xyz, int n) {
     return rc;
 }
 
+int lioOptimization::prefetchSweep(const double *raw_xyz, int n) {
+    if (!voxel_map.ctx) return SRL_ERR_NO_DEVICE;
+    const int rc = srl_sweep_prefetch(voxel_map.ctx, raw_xyz, n);
+    prefetched_n = (rc == SRL_OK) ? n : -1;
+    return rc;
+}
+
+int lioOptimization::swapSweep() {
+    if (!voxel_map.ctx) return SRL_ERR_NO_DEVICE;
+    const int rc = srl_sweep_swap(voxel_map.ctx);
+    resident_n = (rc == SRL_OK) ? prefetched_n : -1;
+    sweep_pinned = (rc == SRL_OK);
+    prefetched_n = -1;
+    return rc;
+}
+
 void lioOptimization::fillFrame(cloudFrame *p_frame, srl_frame &f) const {
     const state *cur = p_frame->p_state;
     const state *last_state = all_cloud_frame[p_frame->id - 1]->p_state;        // optimize.cpp:25

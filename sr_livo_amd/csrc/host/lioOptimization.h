@@ -181,6 +181,9 @@ public:
     // pin a sweep in HBM (bench: inputs resident before the timed region): solveIEKF() then runs on it.  updateIEKF()
     // with a keypoint vector always uploads that vector and releases the pin.
     int residentSweep(const double *raw_xyz, int n);
+    // upload the NEXT sweep on the copy stream while solveIEKF() works on the current one; swapSweep() makes it the pinned one
+    int prefetchSweep(const double *raw_xyz, int n);
+    int swapSweep();
     bool sweepPinned(int n) const { return sweep_pinned && resident_n == n; }
     // updateIEKF on the sweep already resident in HBM (no keypoint vector needed)
     optimizeSummary solveIEKF(const icpOptions &cur_icp_options, cloudFrame *p_frame);
@@ -214,6 +217,7 @@ private:
     normal_eq_provider provider = nullptr;
     void *provider_user = nullptr;
     int resident_n = -1;
+    int prefetched_n = -1;
     bool sweep_pinned = false;
 };
 

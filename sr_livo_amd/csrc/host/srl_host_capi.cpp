@@ -214,6 +214,15 @@ int srl_lio_resident_sweep(srl_lio *h, const double *raw_xyz, int n) {
     return h->lio->residentSweep(raw_xyz, n);
 }
 
+int srl_lio_prefetch_sweep(srl_lio *h, const double *raw_xyz, int n) {
+    if (!h || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
+    return h->lio->prefetchSweep(raw_xyz, n);
+}
+int srl_lio_swap_sweep(srl_lio *h) {
+    if (!h) return SRL_ERR_BAD_ARG;
+    return h->lio->swapSweep();
+}
+
 int srl_lio_update_iekf(srl_lio *h, const srl_icp_opts *opts, const double *raw_xyz, int n, double state_io[16],
                         const double t_last[3], int frame_id, double *log, int max_log_iters, int *iters,
                         int *num_residuals_used) {

@@ -153,10 +153,11 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (!ctx) return SRL_OK;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
     if (ctx->comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->comm);
     if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
-                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
+                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
                     ctx->d_tap_offset, ctx->d_gather};
     for (void *b : bufs) if (b) hipFree(b);
     if (ctx->h_out) hipHostFree(ctx->h_out);
@@ -168,6 +169,8 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     ctx->pool_free.clear();
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < srl_ctx::PROF_RING; i++) for (int k = 0; k < 2; k++) if (ctx->ring[i][k]) hipEventDestroy(ctx->ring[i][k]);
+    if (ctx->next_ready) hipEventDestroy(ctx->next_ready);
+    if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return SRL_OK;
@@ -261,6 +264,32 @@ int srl_map_insert(srl_ctx *ctx, const double *world_xyz, int n, double voxel_si
 }
 
 // ------------------------------------------------------------------------------------------ sweep
+namespace {
+// AoS keypoints host -> device staging buffer `d_stage` on stream `st` (no synchronisation): one DMA from page-locked memory,
+// else through the pinned ring (CPU copy of chunk i + 1 overlaps the DMA of chunk i; the caller's buffer is consumed on return)
+int upload_aos(srl_ctx *ctx, const char *src, size_t bytes, double *d_stage, hipStream_t st) {
+    if (srl_is_pinned(src)) {
+        HIPCHK(ctx, hipMemcpyAsync(d_stage, src, bytes, hipMemcpyHostToDevice, st));
+        return SRL_OK;
+    }
+    int rc2 = srl_ring_init(ctx);
+    if (rc2) return rc2;
+    size_t off = 0;
+    while (off < bytes) {
+        const size_t len = std::min(bytes - off, (size_t)srl_ctx::RING_SLOT_BYTES);
+        const int slot = ctx->ring_next++ % srl_ctx::RING_SLOTS;
+        if (ctx->ring_busy[slot]) { HIPCHK(ctx, hipEventSynchronize(ctx->ring_ev[slot])); ctx->ring_busy[slot] = false; }
+        std::memcpy(ctx->h_ring + (size_t)slot * srl_ctx::RING_SLOT_BYTES, src + off, len);
+        HIPCHK(ctx, hipMemcpyAsync(reinterpret_cast<char *>(d_stage) + off, ctx->h_ring + (size_t)slot * srl_ctx::RING_SLOT_BYTES, len,
+                                   hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipEventRecord(ctx->ring_ev[slot], st));
+        ctx->ring_busy[slot] = true;
+        off += len;
+    }
+    return SRL_OK;
+}
+}  // namespace
+
 int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     if (!ctx || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -282,33 +311,58 @@ int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     if (cnt > 0) {
         // stage AoS in the rec buffer (>= 8 doubles per keypoint), transpose to SoA on the device.  Everything is
         // stream-ordered with the solve that follows: no synchronisation here.
-        const char *src = reinterpret_cast<const char *>(raw_xyz + (size_t)b * 3);
-        const size_t bytes = (size_t)cnt * 3 * sizeof(double);
-        if (srl_is_pinned(src)) {
-            // caller's buffer is page-locked (srl_pinned_alloc / srl_host_register): one DMA straight from it.  The caller
-            // must leave it untouched until the next call that returns results (srl_build_residuals) or synchronises.
-            HIPCHK(ctx, hipMemcpyAsync(ctx->d_rec, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-        } else {
-            // pageable memory: through the context's pinned ring, chunk by chunk -- the CPU copy of chunk i + 1 overlaps the
-            // DMA of chunk i, and the caller's buffer is fully consumed when the call returns
-            int rc2 = srl_ring_init(ctx);
-            if (rc2) return rc2;
-            size_t off = 0;
-            while (off < bytes) {
-                const size_t len = std::min(bytes - off, (size_t)srl_ctx::RING_SLOT_BYTES);
-                const int slot = ctx->ring_next++ % srl_ctx::RING_SLOTS;
-                if (ctx->ring_busy[slot]) { HIPCHK(ctx, hipEventSynchronize(ctx->ring_ev[slot])); ctx->ring_busy[slot] = false; }
-                std::memcpy(ctx->h_ring + (size_t)slot * srl_ctx::RING_SLOT_BYTES, src + off, len);
-                HIPCHK(ctx, hipMemcpyAsync(reinterpret_cast<char *>(ctx->d_rec) + off, ctx->h_ring + (size_t)slot * srl_ctx::RING_SLOT_BYTES, len,
-                                           hipMemcpyHostToDevice, ctx->stream));
-                HIPCHK(ctx, hipEventRecord(ctx->ring_ev[slot], ctx->stream));
-                ctx->ring_busy[slot] = true;
-                off += len;
-            }
-        }
+        // (caller's buffer page-locked -- srl_pinned_alloc / srl_host_register: one DMA straight from it, and the caller
+        //  must leave it untouched until the next call that returns results; pageable: through the context's pinned ring)
+        int rcu = upload_aos(ctx, reinterpret_cast<const char *>(raw_xyz + (size_t)b * 3), (size_t)cnt * 3 * sizeof(double), ctx->d_rec, ctx->stream);
+        if (rcu) return rcu;
         HIPCHK(ctx, srl_launch_aos_to_soa(ctx->d_rec, cnt, ctx->d_raw, ctx->d_raw + ctx->sweep_cap, ctx->d_raw + 2 * (size_t)ctx->sweep_cap, ctx->stream));
     }
     return SRL_OK;
+}
+
+// The NEXT sweep, uploaded while the current one is being solved: DMA + SoA transpose run on the context's copy stream
+// into a second sweep buffer; srl_sweep_swap makes it current (the compute stream waits on the upload's event -- the
+// host does not).  With a node that receives sweep k + 1 while it solves sweep k, the H2D hop leaves the critical path.
+int srl_sweep_prefetch(srl_ctx *ctx, const double *raw_xyz, int n) {
+    if (!ctx || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->next_ready, hipEventDisableTiming));
+    }
+    int b = 0, cnt = 0;
+    srl_shard_range(n, ctx->nranks, ctx->rank, &b, &cnt);
+    if (cnt > ctx->next_cap) {
+        const int cap = std::max(cnt, 1024);
+        HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+        int rc = ensure(ctx, ctx->d_raw_next, (size_t)cap * 3);
+        if (rc) return rc;
+        if ((rc = ensure(ctx, ctx->d_stage_next, (size_t)cap * 3))) return rc;
+        ctx->next_cap = cap;
+    }
+    if (cnt > 0) {
+        int rcu = upload_aos(ctx, reinterpret_cast<const char *>(raw_xyz + (size_t)b * 3), (size_t)cnt * 3 * sizeof(double), ctx->d_stage_next, ctx->copy_stream);
+        if (rcu) return rcu;
+        HIPCHK(ctx, srl_launch_aos_to_soa(ctx->d_stage_next, cnt, ctx->d_raw_next, ctx->d_raw_next + ctx->next_cap,
+                                          ctx->d_raw_next + 2 * (size_t)ctx->next_cap, ctx->copy_stream));
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->next_ready, ctx->copy_stream));
+    ctx->next_n = cnt; ctx->next_begin = b; ctx->next_total = n;
+    return SRL_OK;
+}
+
+int srl_sweep_swap(srl_ctx *ctx) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (ctx->next_n < 0) { ctx->err = "srl_sweep_swap: nothing prefetched"; return SRL_ERR_NO_SWEEP; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->next_ready, 0));       // compute waits for the upload; the host does not
+    std::swap(ctx->d_raw, ctx->d_raw_next);
+    std::swap(ctx->sweep_cap, ctx->next_cap);
+    ctx->n = ctx->next_n; ctx->shard_begin = ctx->next_begin; ctx->total_n = ctx->next_total;
+    ctx->next_n = -1;
+    ctx->sweep_loaded = true;
+    ctx->taps_valid = false;
+    return ensure_work(ctx, ctx->n);
 }
 
 int srl_pinned_alloc(size_t bytes, void **out) {

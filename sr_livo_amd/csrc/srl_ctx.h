@@ -32,6 +32,14 @@ struct srl_ctx {
     int search_select_mode = 0;        // srl_debug_set_search_select_mode: selection path of srl_search_neighbors (tests)
     int ablate = 0;                    // srl_debug_set_ablate (profiling tools only; never set by the product)
 
+    // the NEXT sweep (srl_sweep_prefetch / srl_sweep_swap): uploaded on its own stream while the current one is solved
+    double *d_raw_next = nullptr;      // SoA, stride next_cap
+    double *d_stage_next = nullptr;    // AoS staging of the prefetch (d_rec belongs to the running solve)
+    int next_cap = 0;
+    int next_n = -1, next_begin = 0, next_total = 0;   // next_n < 0: nothing prefetched
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t next_ready = nullptr;
+
     // frame-resident pipeline (srl_frame_*)
     double *d_frame_raw = nullptr;     // AoS n x 3
     double *d_frame_world = nullptr;   // AoS n x 3

@@ -155,6 +155,37 @@ def test_fused_final_reduction_equals_the_reduce_kernel(ctx_small, golden, oracl
         ctx.close()
 
 
+def test_prefetched_sweep_is_the_sweep_after_the_swap(ctx_small, golden):
+    """srl_sweep_prefetch uploads the NEXT sweep on the copy stream while the current one is solved; after srl_sweep_swap
+    every result is that of the prefetched sweep, bit for bit -- from pageable and from page-locked sources, interleaved."""
+    f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    A = golden["raw"]
+    B = golden["raw"][::-1].copy()[:1500]                      # a different sweep of a different size
+    ref = {}
+    for name, sw in (("A", A), ("B", B)):
+        ctx_small.sweep_upload(sw)
+        ref[name] = np.array(ctx_small.build_residuals(f, opts)[0].HtH)
+    assert not np.array_equal(ref["A"][:1], ref["B"][:1])
+    pin = srl.PinnedArray(B.shape)
+    pin.array[:] = B
+    ctx_small.sweep_upload(A)
+    cur = "A"
+    for it in range(12):
+        nxt = "B" if cur == "A" else "A"
+        src = A if nxt == "A" else (pin.array if it % 2 else B)
+        ctx_small.sweep_prefetch(src)                          # next sweep in flight ...
+        for _ in range(3):                                     # ... while the current one is solved
+            assert np.array_equal(np.array(ctx_small.build_residuals(f, opts)[0].HtH), ref[cur])
+        ctx_small.sweep_swap()
+        cur = nxt
+        assert np.array_equal(np.array(ctx_small.build_residuals(f, opts)[0].HtH), ref[cur])
+        assert ctx_small.sweep_shard()[2] == (len(A) if cur == "A" else len(B))
+    with pytest.raises(srl.SrlError):
+        ctx_small.sweep_swap()                                 # nothing prefetched
+    pin.close()
+
+
 def test_idempotent_bitwise(ctx_small, golden):
     a = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX)
     b = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], max_num_residuals=INT_MAX)
