@@ -280,8 +280,17 @@ int upload_aos(srl_ctx *ctx, const char *src, size_t bytes, double *d_stage, hip
         const int slot = ctx->ring_next++ % srl_ctx::RING_SLOTS;
         if (ctx->ring_busy[slot]) { HIPCHK(ctx, hipEventSynchronize(ctx->ring_ev[slot])); ctx->ring_busy[slot] = false; }
         std::memcpy(ctx->h_ring + (size_t)slot * srl_ctx::RING_SLOT_BYTES, src + off, len);
-        HIPCHK(ctx, hipMemcpyAsync(reinterpret_cast<char *>(d_stage) + off, ctx->h_ring + (size_t)slot * srl_ctx::RING_SLOT_BYTES, len,
-                                   hipMemcpyHostToDevice, st));
+        {
+            hipError_t e__ = hipMemcpyAsync(reinterpret_cast<char *>(d_stage) + off, ctx->h_ring + (size_t)slot * srl_ctx::RING_SLOT_BYTES, len,
+                                            hipMemcpyHostToDevice, st);
+            if (e__ != hipSuccess) {
+                char buf[256];
+                std::snprintf(buf, sizeof buf, "ring upload: %s (dst %p + %zu, ring %p slot %d, len %zu, stream %p, main stream %p)", hipGetErrorString(e__),
+                              (void *)d_stage, off, (void *)ctx->h_ring, slot, len, (void *)st, (void *)ctx->stream);
+                ctx->err = buf;
+                return SRL_ERR_HIP;
+            }
+        }
         HIPCHK(ctx, hipEventRecord(ctx->ring_ev[slot], st));
         ctx->ring_busy[slot] = true;
         off += len;
@@ -332,13 +341,12 @@ int srl_sweep_prefetch(srl_ctx *ctx, const double *raw_xyz, int n) {
     }
     int b = 0, cnt = 0;
     srl_shard_range(n, ctx->nranks, ctx->rank, &b, &cnt);
-    if (cnt > ctx->next_cap) {
+    if (cnt > ctx->next_cap || cnt > ctx->stage_next_cap) {
         const int cap = std::max(cnt, 1024);
         HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
-        int rc = ensure(ctx, ctx->d_raw_next, (size_t)cap * 3);
-        if (rc) return rc;
-        if ((rc = ensure(ctx, ctx->d_stage_next, (size_t)cap * 3))) return rc;
-        ctx->next_cap = cap;
+        int rc;
+        if (cnt > ctx->next_cap) { if ((rc = ensure(ctx, ctx->d_raw_next, (size_t)cap * 3))) return rc; ctx->next_cap = cap; }
+        if (cnt > ctx->stage_next_cap) { if ((rc = ensure(ctx, ctx->d_stage_next, (size_t)cap * 3))) return rc; ctx->stage_next_cap = cap; }
     }
     if (cnt > 0) {
         int rcu = upload_aos(ctx, reinterpret_cast<const char *>(raw_xyz + (size_t)b * 3), (size_t)cnt * 3 * sizeof(double), ctx->d_stage_next, ctx->copy_stream);

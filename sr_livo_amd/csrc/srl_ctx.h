@@ -35,7 +35,7 @@ struct srl_ctx {
     // the NEXT sweep (srl_sweep_prefetch / srl_sweep_swap): uploaded on its own stream while the current one is solved
     double *d_raw_next = nullptr;      // SoA, stride next_cap
     double *d_stage_next = nullptr;    // AoS staging of the prefetch (d_rec belongs to the running solve)
-    int next_cap = 0;
+    int next_cap = 0, stage_next_cap = 0;      // capacities (points) of d_raw_next / d_stage_next: the sweep buffers swap, the staging does not
     int next_n = -1, next_begin = 0, next_total = 0;   // next_n < 0: nothing prefetched
     hipStream_t copy_stream = nullptr;
     hipEvent_t next_ready = nullptr;
