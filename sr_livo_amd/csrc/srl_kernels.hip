@@ -1354,7 +1354,11 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
 // NaN planarity (optimize.cpp:348-350) is an error only for keypoints the sequential loop reaches (<= last_visited).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a, int mode_in) {
-    __shared__ long long s_chunk[1024];
+    __shared__ long long s_wtot[16];        // accepted residuals per wave (inclusive prefix input)
+    __shared__ double s_rec[256 * 8];       // records of the re-accumulated keypoints (<= one workgroup of the association pass)
+    __shared__ unsigned char s_stat[256];
+    __shared__ int s_wcnt[4];
+    __shared__ int s_first;                 // mode 1: first keypoint with a plane
     __shared__ double s_part[32][SRL_PART_STRIDE];
     __shared__ long long s_tot[4];          // total accepted, sum_pk, (unused), fallback
     __shared__ int s_cut[4];                // cut block, allowed in cut block, last visited local idx, num_res
@@ -1386,20 +1390,25 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
         acc += bi.accepted; pk += bi.sum_pk; fb += bi.num_fallback;
         if (bi.nan_first > 0) { const int g = b * a.kpb + bi.nan_first - 1; nan_min = g < nan_min ? g : nan_min; }
     }
-    s_chunk[tid] = acc;
     if (tid < 4) s_tot[tid] = 0;
-    if (tid == 0) s_nan_min = 0x7fffffff;
+    if (tid == 0) { s_nan_min = 0x7fffffff; s_first = 0x7fffffff; }
     __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    // inclusive prefix of the per-thread accepted counts over the wave (thread t owns blocks [t * per, (t + 1) * per))
+    long long incl = acc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const long long o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+    if (lane == 63) s_wtot[wave] = incl;
     {   // wave-level sums first (integers: order irrelevant), then one LDS atomic per wave and counter
-        long long w0 = acc, w1 = pk, w3 = fb;
+        long long w1 = pk, w3 = fb;
         int w2 = nan_min;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            w0 += __shfl_xor(w0, off); w1 += __shfl_xor(w1, off); w3 += __shfl_xor(w3, off);
+            w1 += __shfl_xor(w1, off); w3 += __shfl_xor(w3, off);
             const int o2 = __shfl_xor(w2, off); w2 = o2 < w2 ? o2 : w2;
         }
-        if ((tid & 63) == 0) {
-            if (w0) atomicAdd((unsigned long long *)&s_tot[0], (unsigned long long)w0);
+        if (lane == 63) {
+            if (incl) atomicAdd((unsigned long long *)&s_tot[0], (unsigned long long)incl);
             if (w1) atomicAdd((unsigned long long *)&s_tot[1], (unsigned long long)w1);
             if (w2 != 0x7fffffff) atomicMin(&s_nan_min, w2);
             if (w3) atomicAdd((unsigned long long *)&s_tot[3], (unsigned long long)w3);
@@ -1407,40 +1416,73 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
     }
     __syncthreads();
 
+    // Where does the sequential loop stop (optimize.cpp:107)?  All 1 024 threads take part: no serial chain of dependent
+    // global loads (round-2 first version: one thread walked chunk sums, block counts and the cut block's status bytes one
+    // load after the other -- 12.8 us for the 70-workgroup prefix pass of the shipped max_num_residuals = 600).
+    const long long total = s_tot[0];
     if (tid == 0) {
-        const long long total = s_tot[0];
-        int cut_block = nb, allowed = 0, last_visited = a.n - 1;
-        long long num_res = total;
-        if (mode == 2) {
-            cut_block = 0; allowed = 0; last_visited = -1; num_res = 0;
-        } else if (mode == 1) {
-            // first keypoint with a plane (status 1 or 2): it is the last one visited, and the only possible residual
-            int k = 0;
-            while (k < a.n && !(a.status[k] == 1 || a.status[k] == 2)) ++k;
-            cut_block = 0; allowed = 0;
-            last_visited = (k < a.n) ? k : a.n - 1;
-            num_res = (k < a.n && a.status[k] == 2) ? 1 : 0;
-        } else if (total >= max_res) {
-            // find the keypoint holding the max_res-th accepted residual (optimize.cpp:107)
-            long long before = 0;
-            int c = 0;
-            while (c < 1024 && before + s_chunk[c] < max_res) { before += s_chunk[c]; ++c; }
-            int b = c * per;
-            while (b < nb && before + a.binfo[b].accepted < max_res) { before += a.binfo[b].accepted; ++b; }
-            cut_block = b;
-            allowed = (int)(max_res - before);
-            int seen = 0;
-            int k = b * a.kpb;
-            const int kend = (k + a.kpb < a.n) ? k + a.kpb : a.n;
-            for (; k < kend; ++k) { if (a.status[k] == 2) { ++seen; if (seen == allowed) break; } }
-            last_visited = k;
-            num_res = max_res;
+        s_cut[0] = nb; s_cut[1] = 0; s_cut[2] = a.n - 1; s_cut[3] = (int)total;          // no cut: everything is visited
+        if (mode == 2) { s_cut[0] = 0; s_cut[2] = -1; s_cut[3] = 0; }
+    }
+    __syncthreads();
+    if (mode == 0 && total >= max_res) {
+        // the thread whose blocks hold the max_res-th accepted residual finds the block (exactly one: the prefix is monotone)
+        long long before = incl - acc;
+        for (int w = 0; w < wave; ++w) before += s_wtot[w];
+        if (before < max_res && before + acc >= max_res) {
+            int b = b0;
+            while (b < b1 && before + a.binfo[b].accepted < max_res) { before += a.binfo[b].accepted; ++b; }
+            s_cut[0] = b;
+            s_cut[1] = (int)(max_res - before);
+            s_cut[3] = (int)max_res;
         }
-        s_cut[0] = cut_block; s_cut[1] = allowed; s_cut[2] = last_visited; s_cut[3] = (int)num_res;
+    } else if (mode == 1) {
+        // first keypoint with a plane (status 1 or 2): it is the last one visited, and the only possible residual
+        for (int base = 0; base < a.n; base += 1024) {
+            const int k = base + tid;
+            const bool hit = k < a.n && (a.status[k] == 1 || a.status[k] == 2);
+            if (hit) atomicMin(&s_first, k);
+            if (__syncthreads_or(hit ? 1 : 0)) break;
+        }
+        if (tid == 0) {
+            const int k = s_first;
+            s_cut[0] = 0; s_cut[1] = 0;
+            s_cut[2] = (k < a.n) ? k : a.n - 1;
+            s_cut[3] = (k < a.n && a.status[k] == 2) ? 1 : 0;
+        }
     }
     __syncthreads();
     const int cut_block = s_cut[0];
+    if (mode == 0 && cut_block < nb) {
+        // the keypoint of the cut block that holds its `allowed`-th accepted residual: one status byte per thread, ballot prefix
+        const int k0 = cut_block * a.kpb;
+        const int kend = (k0 + a.kpb < a.n) ? k0 + a.kpb : a.n;
+        const int allowed = s_cut[1];
+        const int k = k0 + tid;
+        const bool is2 = tid < a.kpb && k < kend && a.status[k] == 2;        // kpb <= 256: waves 0..3
+        const unsigned long long m = __ballot(is2);
+        const int upto = __popcll(m & ((2ull << lane) - 1ull));              // accepted among lanes 0..lane of this wave
+        if (lane == 0 && wave < 4) s_wcnt[wave] = __popcll(m);
+        if (tid == 0) s_cut[2] = kend;                                       // (not reached: the block holds >= allowed accepted keypoints)
+        __syncthreads();
+        if (wave < 4 && is2) {
+            int pre = 0;
+            for (int w = 0; w < wave; ++w) pre += s_wcnt[w];
+            if (pre + upto == allowed) s_cut[2] = k;
+        }
+        __syncthreads();
+    }
     const int last_visited = s_cut[2];
+    // records of the keypoints that are re-accumulated one by one (the cut block up to the stop keypoint; mode 1: the stop
+    // keypoint, nothing before it has a plane): staged in LDS by all threads
+    int nrows = 0;
+    if (mode != 2 && cut_block < nb) {
+        const int row0 = mode == 1 ? last_visited : cut_block * a.kpb;
+        nrows = last_visited - row0 + 1;
+        nrows = nrows < 0 ? 0 : (nrows > 256 ? 256 : nrows);
+        for (int i = tid; i < nrows * 8; i += 1024) s_rec[i] = a.rec[(size_t)row0 * 8 + i];
+        if (tid < nrows) s_stat[tid] = a.status[row0 + tid];
+    }
 
     // deterministic sum of the partials of all blocks strictly before the cut block:
     // part p sums blocks b == p (mod 32) ascending; parts are then added in order 0..31.
@@ -1479,9 +1521,9 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
             if (tid < 21) { int c = tid; int rowlen = 6; while (c >= rowlen) { c -= rowlen; ia++; rowlen--; } ib = ia + c; }
             else if (tid < 27) ia = tid - 21;
             double accd = 0.0;
-            for (int k = cut_block * a.kpb; k <= last_visited; ++k) {
-                if (a.status[k] != 2) continue;
-                const double *r = a.rec + (size_t)k * 8;
+            for (int k = 0; k < nrows; ++k) {
+                if (s_stat[k] != 2) continue;
+                const double *r = s_rec + k * 8;
                 if (tid < 21) accd += r[ia] * r[ib];
                 else if (tid < 27) accd += r[ia] * (r[6] * r[7]);
                 else accd += r[6] * r[6];
