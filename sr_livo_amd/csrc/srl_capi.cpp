@@ -130,6 +130,7 @@ int srl_ctx_create(int device, srl_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return SRL_ERR_NO_DEVICE;
     srl_ctx *ctx = new srl_ctx();
     ctx->device = device;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) ctx->num_cu = cu; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SRL_ERR_NO_DEVICE; }
     if (hipMalloc((void **)&ctx->d_out, sizeof(SrlDevOut)) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_out, sizeof(SrlDevOut)) != hipSuccess ||
@@ -546,13 +547,24 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     //   64k keypoints  16-wave, 2 kernels           52   / 78                    58   / 72     (1 000 small workgroups fused: +14 us)
     const bool single_rank = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
     const bool can_fuse = single_rank && !a.write_rec && a.ablate == 0 && o->max_num_residuals > 0 && ctx->fuse_reduce;
-    const bool fits16 = srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT;
-    // without fusion: 16-wave workgroups only for large sweeps (measured neutral on the kernel there, 4x fewer partials for
-    // the reduce kernel; mid-size sweeps ran 2-6 us slower with them)
-    int wpb = (fits16 && ((kpw == 16 && n_eff >= 256 * 16 * kpw) || (can_fuse && n_eff >= 2048))) ? 16 : 4;
+    // Launch shape.  Sweeps of >= 2 048 keypoints: 16-wave workgroups (one per CU) with the smallest instantiated
+    // keypoints-per-wave count that still places the sweep in ONE round of workgroups -- a wave's serial chain is as short as
+    // the sweep allows and no CU idles while another runs a second workgroup.  Per call, kernel / wall us (tools/shape_sweep.py):
+    //    4 096 keypoints  fused: 4 per wave 25.5 / 31.0 -> 2 per wave 21.5 / 26.8
+    //   24 576 keypoints  fused: 8 per wave (192 workgroups) 36.7 / 45.9 -> 6 per wave (256) 33.4 / 42.4;  two kernels: 4-wave
+    //                     workgroups x 8 per wave 29.2 / 49.6 -> 27.8 / 47.2
+    //   16 384 keypoints  fused: 2 per wave (512 workgroups, two rounds) 37.0 / 42.2 against 4 per wave 28.3 / 33.7
+    // Smaller sweeps, or K too large for the 16-wave LDS footprint: 4-wave workgroups.
+    int wpb = 4;
+    {
+        const int k1 = srl_keypoints_per_wave_one_round(n_eff, ctx->num_cu);
+        if (n_eff >= 2048 && srl_assoc_lds_bytes(K, nb, k1, 16) <= SRL_LDS_LIMIT) { kpw = k1; wpb = 16; }
+    }
     if (ctx->force_kpw) {            // srl_debug_set_launch_shape: tuning experiments only
         kpw = ctx->force_kpw;
-        wpb = (ctx->force_wpb == 16 && srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT) ? 16 : 4;
+        const bool only16 = kpw != 4 && kpw != 8 && kpw != 16;
+        wpb = ((ctx->force_wpb == 16 || only16) && srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT) ? 16 : 4;
+        if (only16 && wpb != 16) kpw = 4;
     }
     const int kpb = kpw * wpb;
     const int nblocks = (n_eff + kpb - 1) / kpb;
@@ -818,7 +830,7 @@ int srl_debug_set_ablate(srl_ctx *ctx, int bits) {
 }
 int srl_debug_set_launch_shape(srl_ctx *ctx, int keypoints_per_wave, int waves_per_workgroup) {
     if (!ctx) return SRL_ERR_BAD_ARG;
-    if (keypoints_per_wave != 0 && keypoints_per_wave != 4 && keypoints_per_wave != 8 && keypoints_per_wave != 16) return SRL_ERR_BAD_ARG;
+    if (keypoints_per_wave != 0 && keypoints_per_wave != 2 && keypoints_per_wave != 3 && keypoints_per_wave != 6 && keypoints_per_wave != 12 && keypoints_per_wave != 4 && keypoints_per_wave != 8 && keypoints_per_wave != 16) return SRL_ERR_BAD_ARG;
     if (waves_per_workgroup != 0 && waves_per_workgroup != 4 && waves_per_workgroup != 16) return SRL_ERR_BAD_ARG;
     ctx->force_kpw = keypoints_per_wave;
     ctx->force_wpb = waves_per_workgroup;

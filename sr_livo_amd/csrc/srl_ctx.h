@@ -38,6 +38,7 @@ struct srl_ctx {
     int next_cap = 0, stage_next_cap = 0;      // capacities (points) of d_raw_next / d_stage_next: the sweep buffers swap, the staging does not
     int next_n = -1, next_begin = 0, next_total = 0;   // next_n < 0: nothing prefetched
     hipStream_t copy_stream = nullptr;
+    int num_cu = 256;                 // compute units of the device (launch-shape policy)
     hipEvent_t next_ready = nullptr;
 
     // frame-resident pipeline (srl_frame_*)

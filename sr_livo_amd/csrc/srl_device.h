@@ -161,6 +161,13 @@ hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpw, int w
 int srl_assoc_lds_bytes(int K, int nb_voxels, int kpw, int wpb);
 // keypoints per wave for a pass over n keypoints: the largest of 4 / 8 / 16 that still yields >= ~4096 waves
 static inline int srl_keypoints_per_wave(int n) { return n <= 16384 ? 4 : (n <= 32768 ? 8 : 16); }
+// ... and for 16-wave workgroups that fuse the final reduction: the smallest instantiated count that still puts the sweep on
+// the chip in ONE round of workgroups (one 16-wave workgroup per CU): a wave's serial chain is as short as the sweep allows
+static inline int srl_keypoints_per_wave_one_round(int n, int num_cu) {
+    const int set[7] = {2, 3, 4, 6, 8, 12, 16};
+    for (int i = 0; i < 7; ++i) if ((long long)16 * set[i] * num_cu >= n) return set[i];
+    return 16;
+}
 #define SRL_LDS_LIMIT (160 * 1024)
 hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s);
 hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, int count_planes, long long *out_total, hipStream_t s);

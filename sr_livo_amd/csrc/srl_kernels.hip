@@ -1658,14 +1658,19 @@ static hipError_t launch_assoc_cfg(const SrlAssocArgs &a, int nb_voxels, hipStre
     if (nb_voxels == 1) return fast ? launch(srl_assoc_kernel<1, 1, KPW, WPB>) : launch(srl_assoc_kernel<1, 0, KPW, WPB>);
     return fast ? launch(srl_assoc_kernel<2, 1, KPW, WPB>) : launch(srl_assoc_kernel<2, 0, KPW, WPB>);
 }
-// kpw = keypoints per wave (16 / 8 / 4), wpb = waves per workgroup (16 / 4): srl_assoc_config
+// kpw = keypoints per wave (16-wave workgroups: 2 / 3 / 4 / 6 / 8 / 12 / 16; 4-wave: 4 / 8 / 16), wpb = waves per workgroup
 hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpw, int wpb, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
     if (wpb == 16) {
+        if (kpw == 2) return launch_assoc_cfg<2, 16>(a, nb_voxels, s);
+        if (kpw == 3) return launch_assoc_cfg<3, 16>(a, nb_voxels, s);
         if (kpw == 4) return launch_assoc_cfg<4, 16>(a, nb_voxels, s);
+        if (kpw == 6) return launch_assoc_cfg<6, 16>(a, nb_voxels, s);
         if (kpw == 8) return launch_assoc_cfg<8, 16>(a, nb_voxels, s);
+        if (kpw == 12) return launch_assoc_cfg<12, 16>(a, nb_voxels, s);
         return launch_assoc_cfg<16, 16>(a, nb_voxels, s);
     }
+    if (kpw != 4 && kpw != 8 && kpw != 16) return hipErrorInvalidConfiguration;   // 4-wave workgroups: phase 2 needs whole waves of 16 keypoints
     if (kpw == 4) return launch_assoc_cfg<4, 4>(a, nb_voxels, s);
     if (kpw == 8) return launch_assoc_cfg<8, 4>(a, nb_voxels, s);
     return launch_assoc_cfg<16, 4>(a, nb_voxels, s);

@@ -6,7 +6,11 @@ sys.path.insert(0, ".")
 import sr_livo_amd as srl
 from sr_livo_amd import capi, synth
 
-for wl in (sys.argv[1:] or ["C1", "C2", "C3", "HEADLINE"]):
+MAX_RES = 2**31 - 1
+args = sys.argv[1:]
+if args and args[0].startswith("--max="):
+    MAX_RES = int(args.pop(0)[6:])
+for wl in (args or ["C1", "C2", "C3", "HEADLINE"]):
     n_kp, map_pts, pattern, seed = synth.CONFIGS[wl]
     cands, L = synth.map_candidates(seed, map_pts)
     sw = synth.make_sweep(seed + 1000, n_kp, L, pattern=pattern)
@@ -14,12 +18,12 @@ for wl in (sys.argv[1:] or ["C1", "C2", "C3", "HEADLINE"]):
     ctx.map_insert(cands)
     ctx.sweep_upload(sw["raw"])
     f = capi.make_frame(sw["q_pred"], sw["t_pred"], sw["t_last"])
-    opts = srl.default_opts(max_num_residuals=2**31 - 1)
+    opts = srl.default_opts(max_num_residuals=MAX_RES)
     res = {}
     for fused in (0, 1):
         ctx.set_fused_reduce(fused)
-        for kpw in (0, 4, 8, 16):
-            for wpb in ((0,) if kpw == 0 else (4, 16)):
+        for kpw in (0, 2, 3, 4, 6, 8, 12, 16):
+            for wpb in ((0,) if kpw == 0 else ((16,) if kpw in (2, 3, 6, 12) else (4, 16))):
                 ctx.set_launch_shape(kpw, wpb)
                 print(wl, 'fused', fused, 'kpw', kpw, 'wpb', wpb, file=sys.stderr, flush=True)
                 for _ in range(5):
