@@ -139,7 +139,7 @@ int srl_ctx_create(int device, srl_ctx **out) {
         delete ctx;
         return SRL_ERR_HIP;
     }
-    if (hipMalloc((void **)&ctx->d_granules, 512 * 64 * 8) != hipSuccess || hipMemset(ctx->d_granules, 0, 512 * 64 * 8) != hipSuccess) { delete ctx; return SRL_ERR_HIP; }
+    if (hipMalloc((void **)&ctx->d_granules, (size_t)SRL_FUSED_MAX_BLOCKS * SRL_ROW_GRANULES * 8) != hipSuccess || hipMemset(ctx->d_granules, 0, (size_t)SRL_FUSED_MAX_BLOCKS * SRL_ROW_GRANULES * 8) != hipSuccess) { delete ctx; return SRL_ERR_HIP; }
     if (hipHostMalloc((void **)&ctx->h_mail, sizeof(SrlMailbox), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         delete ctx;
         return SRL_ERR_HIP;
@@ -158,7 +158,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->comm);
     if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
-                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
+                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
                     ctx->d_tap_offset, ctx->d_gather};
     for (void *b : bufs) if (b) hipFree(b);
     if (ctx->h_out) hipHostFree(ctx->h_out);
@@ -487,7 +487,8 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     a.inf_off = ctx->slab_cap * (unsigned)SRL_SLAB_BYTES;
     // records {J, d, w} + status feed the ordered cut-off (optimize.cpp:107) and the parity taps only: 4 MB of stores per
     // 64k sweep that the throughput configuration (max_num_residuals > number of keypoints) never reads
-    a.write_rec = (ctx->taps || o->max_num_residuals <= 0 || (long long)o->max_num_residuals <= (long long)ctx->total_n) ? 1 : 0;
+    const bool cut_possible_here = o->max_num_residuals <= 0 || (long long)o->max_num_residuals <= (long long)ctx->total_n;
+    a.write_rec = (ctx->taps || cut_possible_here) ? 1 : 0;
     {
         const srl::Quat q(f->q[0], f->q[1], f->q[2], f->q[3]);
         const srl::Mat3 Rn = q.normalized().toRotationMatrix();    // optimize.cpp:35
@@ -546,7 +547,12 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     //   24k keypoints                               30.4 / 47.2                  35.7 / 41.3
     //   64k keypoints  16-wave, 2 kernels           52   / 78                    58   / 72     (1 000 small workgroups fused: +14 us)
     const bool single_rank = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
-    const bool can_fuse = single_rank && !a.write_rec && a.ablate == 0 && o->max_num_residuals > 0 && ctx->fuse_reduce;
+    const bool fuse_base = single_rank && !ctx->taps && a.ablate == 0 && o->max_num_residuals > 0 && ctx->fuse_reduce;
+    const bool can_fuse = fuse_base && !cut_possible_here;
+    // ... and WITH the ordered cut (the shipped max_num_residuals = 600): the finisher also locates the workgroup that holds the
+    // max-th accepted residual and re-accumulates that workgroup's records, which travel as tagged granules like the rows
+    // (small workgroups only: one record granule per finisher thread)
+    bool can_fuse_cut = fuse_base && cut_possible_here;
     // Launch shape.  Sweeps of >= 2 048 keypoints: 16-wave workgroups (one per CU) with the smallest instantiated
     // keypoints-per-wave count that still places the sweep in ONE round of workgroups -- a wave's serial chain is as short as
     // the sweep allows and no CU idles while another runs a second workgroup.  Per call, kernel / wall us (tools/shape_sweep.py):
@@ -585,12 +591,25 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         ring_ev = ctx->ring[ctx->ring_head % srl_ctx::PROF_RING];
     }
 
-    const bool fused = can_fuse && wpb == 16 && nblocks <= 512;
+    can_fuse_cut = can_fuse_cut && wpb == 16 && kpb <= SRL_FUSED_CUT_MAX_KPB && nblocks <= SRL_FUSED_MAX_BLOCKS;
+    const bool fused = (can_fuse && wpb == 16 && nblocks <= SRL_FUSED_MAX_BLOCKS) || can_fuse_cut;
     const unsigned long long seq_now = ++ctx->seq;
     if (fused) {
         a.granules = ctx->d_granules;
         a.mailbox = ctx->h_mail;
         a.seq = seq_now;
+    }
+    if (can_fuse_cut) {
+        const size_t need = (size_t)nblocks * kpb * 16;
+        if (need > ctx->rec_granule_cap) {
+            int rcg;
+            if ((rcg = ensure(ctx, ctx->d_rec_granules, need))) return rcg;
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_rec_granules, 0, need * sizeof(unsigned long long), ctx->stream));   // no stale tag can match
+            ctx->rec_granule_cap = need;
+        }
+        a.rec_granules = ctx->d_rec_granules;
+        a.cut_max = o->max_num_residuals;
+        a.write_rec = 0;                                    // nobody reads the global records: the finisher has the granules
     }
 
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));

@@ -76,6 +76,8 @@ struct srl_ctx {
     SrlDevOut *h_out = nullptr;        // pinned
     long long *d_count = nullptr;
     long long *h_count = nullptr;      // pinned
+    unsigned long long *d_rec_granules = nullptr;   // fused ordered cut: 16 tagged granules per keypoint (the record), grown on demand
+    size_t rec_granule_cap = 0;
     unsigned long long *d_granules = nullptr;   // published rows of the fused final reduction: 512 workgroups x 64 granules
     int force_kpw = 0, force_wpb = 0;  // srl_debug_set_launch_shape (0 = automatic)
     bool fuse_reduce = true;           // srl_debug_set_fused_reduce(0): always run the separate reduce kernel (A/B, tests)

@@ -32,6 +32,9 @@
 #define SRL_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define SRL_TABLE_FACTOR 4u   // hash slots per voxel capacity (load <= 0.25: a 2-slot probe almost always resolves)
 #define SRL_PART_STRIDE 32
+#define SRL_ROW_GRANULES 128  // published row of a workgroup (fused final reduction): 64 granules = 32 doubles, 8 = acceptance mask of <= 256 keypoints
+#define SRL_FUSED_MAX_BLOCKS 512
+#define SRL_FUSED_CUT_MAX_KPB 64   // fused ordered cut: the finisher re-reads one workgroup's records, one granule per thread
 
 struct SrlMapSlot {
     unsigned long long key;
@@ -108,7 +111,9 @@ struct SrlAssocArgs {
     int ablate;             // debug only (env SRL_ABLATE): bit0 skip phase 2, bit1 stop after compaction, bit2 stop after probe, bit3 skip probe
     // fused final reduction (single rank, no ordered cut possible, no taps): the last workgroup to finish sums the block
     // partials and publishes the result itself -- no second kernel, no kernel boundary on the per-iteration critical path
-    unsigned long long *granules;   // nblocks x 64 tagged 8-byte granules {epoch, 32-bit half}: the published rows (null = not fused)
+    unsigned long long *granules;   // nblocks x SRL_ROW_GRANULES tagged 8-byte granules {epoch, 32-bit payload}: the published rows (null = not fused)
+    unsigned long long *rec_granules;   // fused ORDERED CUT: per keypoint 16 tagged granules = the record {J[6], distance, weight} (else null)
+    long long cut_max;              // fused ordered cut: max_num_residuals (> 0), the sequential loop's budget (optimize.cpp:107); 0 = no cut possible
     SrlMailbox *mailbox;        // host-mapped result mailbox
     unsigned long long seq;     // launch sequence number published with the result
     // outputs

@@ -1167,6 +1167,22 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         }
     }
 
+    if (b.rec_granules != nullptr && p2_wave) {
+        // fused ordered cut (4.2): the record {J[6], distance, weight} of every keypoint of this workgroup travels as 16 tagged
+        // granules (sub-lane s holds doubles 2s, 2s + 1 = granules 4s .. 4s + 3); zeros unless accepted
+        typedef __attribute__((address_space(1))) unsigned long long gu64r;
+        double v0 = (sl == 0) ? J[0] : ((sl == 1) ? J[2] : ((sl == 2) ? J[4] : dist));
+        double v1 = (sl == 0) ? J[1] : ((sl == 1) ? J[3] : ((sl == 2) ? J[5] : weight));
+        if (status != 2) { v0 = 0.0; v1 = 0.0; }
+        const unsigned long long tag = (unsigned long long)(unsigned)b.seq << 32;
+        const unsigned long long b0 = (unsigned long long)__double_as_longlong(v0), b1 = (unsigned long long)__double_as_longlong(v1);
+        gu64r *dst = (gu64r *)(b.rec_granules + ((size_t)blockIdx.x * KPB + kl) * 16 + 4 * sl);
+        __hip_atomic_store(dst + 0, tag | (b0 & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, tag | (b0 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 2, tag | (b1 & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 3, tag | (b1 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
     // ---- wave partial of H^T H (21 upper-tri), H^T h (6), loss (1).  Every accepted keypoint leaves the row
     // {J[0..5], h, distance} in LDS (zeros otherwise); lane c < 28 then owns component c and walks the 16 keypoints in
     // order -- two LDS reads, one multiply, one add each, no cross-lane traffic, fixed summation order.
@@ -1213,6 +1229,13 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
                 // first NaN keypoint of these 16 as 1 + index inside the workgroup (quad q = keypoint w2 * 16 + q)
                 s_winfo[w2 * 8 + 2] = nan_mask ? 1 + w2 * 16 + ((int)__builtin_ctzll(nan_mask) >> 2) : 0;
                 s_winfo[w2 * 8 + 4] = __popcll(pln_mask);
+                // accepted keypoints of these 16 as a 16-bit mask (ballot bits sit at lanes 4q: gather every 4th bit)
+                unsigned long long x = acc_mask & 0x1111111111111111ull;
+                x = (x | (x >> 3)) & 0x0303030303030303ull;
+                x = (x | (x >> 6)) & 0x000F000F000F000Full;
+                x = (x | (x >> 12)) & 0x000000FF000000FFull;
+                x = (x | (x >> 24)) & 0xFFFFull;
+                s_winfo[w2 * 8 + 5] = (int)x;
             }
         }
     }
@@ -1263,17 +1286,189 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         } else if (tid < 32) {
             int acc = 0, pk = 0, nanf = 0, fb = 0;
             for (int w = 0; w < WPB; ++w) fb += s_winfo[w * 8 + 3];
-            for (int w = 0; w < P2W; ++w) { acc += s_winfo[w * 8 + 0]; pk += s_winfo[w * 8 + 1]; nanf |= s_winfo[w * 8 + 2]; }
-            v = tid == 28 ? (double)acc : (tid == 29 ? (double)(unsigned)pk : (tid == 30 ? (nanf ? 1.0 : 0.0) : (double)fb));
+            // nanf: 1 + index inside the workgroup of its first NaN-planarity keypoint (slots are in keypoint order), 0 = none
+            for (int w = 0; w < P2W; ++w) { acc += s_winfo[w * 8 + 0]; pk += s_winfo[w * 8 + 1]; if (nanf == 0) nanf = s_winfo[w * 8 + 2]; }
+            v = tid == 28 ? (double)acc : (tid == 29 ? (double)(unsigned)pk : (tid == 30 ? (double)nanf : (double)fb));
         }
         // lane l publishes granule l of the row: half l >> 5 of component l & 31
         const double vs = __shfl(v, tid & 31);
         const unsigned long long bits = (unsigned long long)__double_as_longlong(vs);
         const unsigned half = (tid < 32) ? (unsigned)bits : (unsigned)(bits >> 32);
-        __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * 64 + tid), ((unsigned long long)epoch << 32) | half,
+        __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * SRL_ROW_GRANULES + tid), ((unsigned long long)epoch << 32) | half,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (tid < 72 && b.cut_max > 0) {
+        // granules 64..71: which keypoints of this workgroup were accepted (bit i = keypoint i), 32 per granule
+        const int j = tid - 64;
+        unsigned word = 0u;
+        if (2 * j < P2W) word |= (unsigned)s_winfo[(2 * j) * 8 + 5];
+        if (2 * j + 1 < P2W) word |= (unsigned)s_winfo[(2 * j + 1) * 8 + 5] << 16;
+        __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * SRL_ROW_GRANULES + tid), ((unsigned long long)epoch << 32) | word,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (blockIdx.x != gridDim.x - 1) return;
+    if (b.cut_max > 0) {
+        // ---- finisher WITH the ordered cut (optimize.cpp:107: the sequential loop stops at the max-th accepted residual).
+        // (a) every thread t < #workgroups reads the counters of row t; a prefix over the accepted counts finds the workgroup c that
+        // holds the max-th accepted residual and how many of its residuals still count; (b) rows r < c are summed in the same
+        // fixed order as without a cut (counters over all rows); (c) workgroup c's acceptance mask gives the stop keypoint and
+        // its records -- re-read as tagged granules, one per thread -- are re-accumulated in keypoint order up to it.
+        // Same results as srl_reduce_kernel on the same launch shape (tests/test_gpu_parity.py runs both).
+        if constexpr (KPB <= SRL_FUSED_CUT_MAX_KPB && WPB == 16) {
+            constexpr int NT = 64 * WPB, NPART = NT / 32, INF = 8;
+            __syncthreads();
+            double *s_part = reinterpret_cast<double *>(smem);                           // [NPART][32]
+            double *s_recd = reinterpret_cast<double *>(smem + NPART * 32 * 8);          // [KPB][8]
+            long long *s_wacc = reinterpret_cast<long long *>(smem + NPART * 32 * 8 + SRL_FUSED_CUT_MAX_KPB * 64);   // [WPB]
+            int *s_i = reinterpret_cast<int *>(smem + NPART * 32 * 8 + SRL_FUSED_CUT_MAX_KPB * 64 + WPB * 8);      // bad, c, allowed, pos, nan_min, -, -, -, mask[8]
+            const int nbk = (int)gridDim.x;
+            const long long cut_max = b.cut_max;
+            if (tid == 0) { s_i[0] = 0; s_i[1] = nbk; s_i[2] = 0; s_i[3] = -1; s_i[4] = 0x7fffffff; }
+            __syncthreads();
+            bool timed_out = false;
+            auto ld = [](const unsigned long long *p) { return __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            auto fresh = [epoch](unsigned long long x) { return (unsigned)(x >> 32) == epoch; };
+            auto as_double = [](unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
+            // (a) four granules per thread, requested together (every poll round is one memory round trip, not four)
+            long long my_acc = 0;
+            if (tid < nbk) {
+                const unsigned long long *row = b.granules + (size_t)tid * SRL_ROW_GRANULES;
+                unsigned long long x0, x1, x2, x3;
+                unsigned spins = 0;
+                for (;;) {
+                    x0 = ld(row + 28); x1 = ld(row + 60); x2 = ld(row + 30); x3 = ld(row + 62);
+                    if (fresh(x0) && fresh(x1) && fresh(x2) && fresh(x3)) break;
+                    if (++spins > (1u << 18)) { timed_out = true; x0 = x1 = x2 = x3 = 0ull; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                my_acc = (long long)as_double((unsigned)x0, (unsigned)x1);
+                const int nanf = (int)as_double((unsigned)x2, (unsigned)x3);
+                if (nanf > 0) atomicMin(&s_i[4], tid * KPB + nanf - 1);
+            }
+            long long incl = my_acc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const long long o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+            if (lane == 63) s_wacc[wave] = incl;
+            __syncthreads();
+            {
+                long long before = incl - my_acc, total = 0;
+                for (int w = 0; w < WPB; ++w) { const long long t = s_wacc[w]; total += t; if (w < wave) before += t; }
+                if (total >= cut_max && tid < nbk && before < cut_max && before + my_acc >= cut_max) {
+                    s_i[1] = tid;
+                    s_i[2] = (int)(cut_max - before);
+                }
+            }
+            __syncthreads();
+            const int c = s_i[1];
+            const bool cut = c < nbk;
+            // (c) workgroup c's acceptance mask and records: requested here, looked at after the row sums below (same round trip)
+            const unsigned long long *p_rec = b.rec_granules + (size_t)(cut ? c : 0) * KPB * 16 + (tid < KPB * 16 ? tid : 0);
+            const unsigned long long *p_msk = b.granules + (size_t)(cut ? c : 0) * SRL_ROW_GRANULES + 64 + (tid & 7);
+            unsigned long long x_rec = 0ull, x_msk = 0ull;
+            if (cut) { x_rec = ld(p_rec); x_msk = ld(p_msk); }
+            // (b)
+            const int comp = tid & 31, part = tid >> 5;
+            double s0 = 0.0;
+            for (int r0 = part; r0 < nbk; r0 += NPART * INF) {
+                unsigned lo[INF], hi[INF];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < INF; ++k) {
+                        const int r = r0 + NPART * k;
+                        if (r < nbk && (comp >= 28 || r < c)) {
+                            const unsigned long long x0 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * SRL_ROW_GRANULES + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long x1 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * SRL_ROW_GRANULES + 32 + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && (unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch;
+                            lo[k] = (unsigned)x0; hi[k] = (unsigned)x1;
+                        } else { lo[k] = 0u; hi[k] = 0u; }
+                    }
+                    if (ok) break;
+                    if (++spins > (1u << 18)) { timed_out = true; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+#pragma unroll
+                for (int k = 0; k < INF; ++k) s0 += as_double(lo[k], hi[k]);
+            }
+            if (cut) {
+                unsigned spins = 0;
+                while (!(fresh(x_rec) && fresh(x_msk))) {
+                    if (++spins > (1u << 18)) { timed_out = true; x_rec = 0ull; x_msk = 0ull; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                    x_rec = ld(p_rec); x_msk = ld(p_msk);
+                }
+                if (tid < 8) s_i[8 + tid] = (int)(unsigned)x_msk;
+                const unsigned hi = __shfl_down((unsigned)x_rec, 1);            // granule 2d + half of keypoint tid >> 4
+                if (tid < KPB * 16 && (tid & 1) == 0) s_recd[tid >> 1] = as_double((unsigned)x_rec, hi);
+            }
+            if (timed_out) atomicOr(&s_i[0], 1);
+            s_part[part * 32 + comp] = s0;
+            __syncthreads();
+            if (tid < 32) {
+                double sum = s_part[tid];
+                for (int p = 1; p < NPART; ++p) sum += s_part[p * 32 + tid];
+                if (tid < 28 && cut) {
+                    // the stop keypoint: the `allowed`-th accepted one of workgroup c
+                    int need = s_i[2], pos = -1;
+                    for (int w = 0; w < 8 && pos < 0; ++w) {
+                        unsigned m = (unsigned)s_i[8 + w];
+                        const int pc = __popc(m);
+                        if (need > pc) { need -= pc; continue; }
+                        for (int k = 1; k < need; ++k) m &= m - 1u;
+                        pos = w * 32 + (int)__builtin_ctz(m);
+                    }
+                    if (tid == 0) s_i[3] = pos;
+                    int ia = 0, ib = 0;
+                    if (tid < 21) { int cc = tid; int rowlen = 6; while (cc >= rowlen) { cc -= rowlen; ia++; rowlen--; } ib = ia + cc; }
+                    else if (tid < 27) ia = tid - 21;
+                    // keypoints that were not accepted published all-zero records: they add +0.0, i.e. nothing, so the walk needs no
+                    // mask test and its LDS reads do not depend on anything (the same sum as srl_reduce_kernel's, which skips them)
+                    double accd = 0.0;
+                    if (tid < 21) {
+#pragma unroll 8
+                        for (int k = 0; k <= pos; ++k) accd += s_recd[k * 8 + ia] * s_recd[k * 8 + ib];
+                    } else if (tid < 27) {
+#pragma unroll 8
+                        for (int k = 0; k <= pos; ++k) accd += s_recd[k * 8 + ia] * (s_recd[k * 8 + 6] * s_recd[k * 8 + 7]);
+                    } else {
+#pragma unroll 8
+                        for (int k = 0; k <= pos; ++k) accd += s_recd[k * 8 + 6] * s_recd[k * 8 + 6];
+                    }
+                    sum += accd;
+                }
+                s_part[tid] = sum;
+            }
+            __syncthreads();
+            SrlDevOut *out = &b.mailbox->out;
+            auto put_f = [](double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+            if (tid < 21) {
+                int ia = 0, cc = tid, rowlen = 6;
+                while (cc >= rowlen) { cc -= rowlen; ia++; rowlen--; }
+                const int ib = ia + cc;
+                put_f(&out->HtH[ia * 6 + ib], s_part[tid]);
+                if (ib != ia) put_f(&out->HtH[ib * 6 + ia], s_part[tid]);
+            } else if (tid < 27) {
+                put_f(&out->Hth[tid - 21], s_part[tid]);
+            } else if (tid == 27) {
+                put_f(&out->loss, s_part[27]);
+            } else if (tid == 32) {
+                const long long last_visited = cut ? (long long)c * KPB + s_i[3] : (long long)b.n - 1;
+                put_f(&out->d_num_res, cut ? (double)cut_max : s_part[28]);
+                put_f(&out->d_total_accepted, s_part[28]);
+                put_f(&out->d_sum_pk, s_part[29]);
+                put_f(&out->d_nan, (long long)s_i[4] <= last_visited ? 1.0 : 0.0);   // NaN planarity only counts for visited keypoints
+                put_f(&out->d_fallback, s_part[31]);
+                put_f(&out->d_visited, (double)(last_visited + 1));
+                __hip_atomic_store(&out->last_visited, last_visited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&out->pad, s_i[0] ? 0x7117ll : 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // time-out marker
+            }
+            if (tid < 64) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (tid == 0) __hip_atomic_store(&b.mailbox->seq, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
     {
         // deterministic: part p sums rows p, p + NPART, ... ascending; parts are then added in order
         constexpr int NT = 64 * WPB, NPART = NT / 32, INF = 8;
@@ -1294,8 +1489,8 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
                 for (int k = 0; k < INF; ++k) {
                     const int r = r0 + NPART * k;
                     if (r < nbk) {
-                        const unsigned long long x0 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * 64 + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long x1 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * 64 + 32 + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long x0 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * SRL_ROW_GRANULES + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long x1 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * SRL_ROW_GRANULES + 32 + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ok = ok && (unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch;
                         lo[k] = (unsigned)x0; hi[k] = (unsigned)x1;
                     } else { lo[k] = 0u; hi[k] = 0u; }

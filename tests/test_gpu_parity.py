@@ -490,6 +490,42 @@ def test_nan_planarity_raises_through_the_class_surface(golden):
         lio.close()
 
 
+@pytest.mark.parametrize("n,kpw", [(4096, 0), (7000, 0), (4096, 4)])
+def test_fused_ordered_cut_equals_the_two_kernel_path_and_the_oracle(oracle_lib, scene100k, n, kpw):
+    """Finite max_num_residuals on sweeps of >= 2 048 keypoints: the last workgroup of the association kernel applies the
+    sequential loop's cut itself (optimize.cpp:107) from published rows, acceptance masks and record granules.  Against
+    the separate reduce kernel on the same launch (srl_debug_set_fused_reduce(0)) and against the oracle, for budgets that
+    stop in the first workgroup, in the middle, on the very last accepted keypoint, and not at all."""
+    m = scene100k["map"]
+    sw = synth.make_sweep(77, n, scene100k["L"], pattern="livox")
+    o_all = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=INT_MAX), sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"])
+    total = int(o_all["neq"].num_residuals)
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(*m.export())
+        ctx.sweep_upload(sw["raw"])
+        ctx.set_launch_shape(kpw, 16 if kpw else 0)
+        f = capi.make_frame(sw["q_pred"], sw["t_pred"], sw["t_last"])
+        for max_res in (1, 2, 31, 32, 33, 600, 1000, total - 1, total, min(total + 1, n)):
+            opts = srl.default_opts(max_num_residuals=max_res)
+            ctx.set_fused_reduce(1)
+            a, rca = ctx.build_residuals(f, opts)
+            a2, _ = ctx.build_residuals(f, opts)
+            ctx.set_fused_reduce(0)
+            b, rcb = ctx.build_residuals(f, opts)
+            ctx.set_fused_reduce(1)
+            o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=max_res), sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"])
+            assert rca == rcb == 0
+            for x in (a, b):
+                assert x.num_residuals == o["neq"].num_residuals == min(max_res, total), max_res
+                assert x.last_visited == o["neq"].num_visited - 1, max_res
+                assert rel(np.array(x.HtH).reshape(6, 6), o["HtH"]) < TIGHT and rel(np.array(x.Hth), o["Hth"]) < TIGHT, max_res
+            assert np.array_equal(np.array(a.HtH), np.array(a2.HtH)) and np.array_equal(np.array(a.Hth), np.array(a2.Hth))   # deterministic
+            assert rel(np.array(a.HtH), np.array(b.HtH)) < 1e-13 and abs(a.loss_sum - b.loss_sum) <= 1e-13 * abs(b.loss_sum)
+    finally:
+        ctx.close()
+
+
 # ----------------------------------------------------------------------------- max_num_residuals <= 0, empty sweeps
 def test_class_default_max_num_residuals_stops_at_the_first_keypoint_with_a_plane(oracle_lib, oracle_backend, golden):
     """optimize.cpp:107 sits behind the `continue` of :78-79: with max_num_residuals = -1 the loop passes over keypoints
