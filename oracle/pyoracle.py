@@ -1,7 +1,8 @@
 """ctypes binding of the CPU ORACLE (oracle/liboracle.so or oracle/_ref/liboracle_tsl.so).
 
 TEST INFRASTRUCTURE ONLY -- import from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
-leg, never from the product package (see oracle/srl_oracle.h).  PARITY UNPINNED by the reference.
+leg, never from the product package (see oracle/srl_oracle.h).  Pinned bitwise against the reference's own translation
+units (oracle/pyref.py, tests/test_reference_tu.py).
 """
 import ctypes as C
 import os

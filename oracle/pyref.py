@@ -2,8 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY (same rule as oracle/pyoracle.py: tests/, tools/ and the golden generators may import it, the
 product package may not).  The library is built by `make -C oracle refpath` from /root/reference/src/{optimize,
-eskfEstimator,utility,state,cloudMap}.cpp compiled where they lie, against the stand-in third-party headers of
-oracle/ref_shim/ (see oracle/ref_harness.cpp).  It exists in the build container and travels to the GPU box as a prebuilt
+lioOptimization,eskfEstimator,utility,state,cloudMap,parameters}.cpp compiled where they lie, against the stand-in
+third-party headers of oracle/ref_shim/ (see oracle/ref_harness.cpp).  It exists in the build container and travels to the GPU box as a prebuilt
 file; where it is missing, `available()` is False and the tests that need it skip.
 """
 import ctypes as C
@@ -61,6 +61,22 @@ def load():
     lib.ref_angular_distance_so3.argtypes = [dp]; lib.ref_angular_distance_so3.restype = C.c_double
     lib.ref_so3_to_rot.argtypes = [dp, dp]; lib.ref_so3_to_quat.argtypes = [dp, dp]; lib.ref_rot_to_so3.argtypes = [dp, dp]
     lib.ref_derivative_s2.argtypes = [dp, dp]
+    lib.ref_param_set_num.argtypes = [C.c_char_p, dp, C.c_int]
+    lib.ref_param_set_str.argtypes = [C.c_char_p, C.c_char_p]
+    lib.ref_node_create.argtypes = [C.c_int]; lib.ref_node_create.restype = p
+    lib.ref_node_destroy.argtypes = [p]
+    lib.ref_node_push_imu.argtypes = [p, C.c_double, dp, dp]
+    lib.ref_node_push_image_time.argtypes = [p, C.c_double]
+    lib.ref_node_push_points.argtypes = [p, p, p, C.c_int]
+    lib.ref_node_run.argtypes = [p, dp]; lib.ref_node_run.restype = C.c_int
+    lib.ref_node_last_frame_info.argtypes = [p, dp, dp, ip]; lib.ref_node_last_frame_info.restype = C.c_int
+    lib.ref_node_last_frame_points.argtypes = [p, p, p, p, p, p, p]
+    lib.ref_node_eskf_get.argtypes = [p, dp, dp]
+    lib.ref_node_map_num_voxels.argtypes = [p]; lib.ref_node_map_num_voxels.restype = C.c_int
+    lib.ref_node_map_export.argtypes = [p, C.c_int, p, p, p]; lib.ref_node_map_export.restype = C.c_int
+    lib.ref_node_add_points_to_map.argtypes = [p, p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int]; lib.ref_node_add_points_to_map.restype = C.c_int
+    lib.ref_node_state_initialization.argtypes = [p, C.c_int, C.c_int, dp, dp, dp, dp, dp]
+    lib.ref_node_make_point_timestamp.argtypes = [p, p, C.c_int, C.c_double, C.c_double, p, p, p]; lib.ref_node_make_point_timestamp.restype = C.c_int
     _lib = lib
     return lib
 
@@ -245,3 +261,112 @@ def rot_to_so3(R):
 
 def derivative_s2(g):
     B = np.zeros(6); load().ref_derivative_s2(_dp(_f64(g)), _dp(B)); return B.reshape(3, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the node (src/lioOptimization.cpp): its own constructor / readParameters / imuHandler / getMeasurements / run / process
+MOTION_COMPENSATION = {0: "IMU", 1: "CONSTANT_VELOCITY"}                 # utility.h:82-86 <- readParameters' strings
+INITIALIZATION = {0: "INIT_IMU", 1: "INIT_CONSTANT_VELOCITY"}            # utility.h:88-92
+
+
+def set_params(num=None, strs=None, clear=True):
+    """Fill the stand-in parameter server the node's readParameters() (src/lioOptimization.cpp:249-349) reads."""
+    lib = load()
+    if clear:
+        lib.ref_param_clear()
+    for k, v in (num or {}).items():
+        a = _f64(np.atleast_1d(v))
+        lib.ref_param_set_num(k.encode(), _dp(a), len(a))
+    for k, v in (strs or {}).items():
+        lib.ref_param_set_str(k.encode(), str(v).encode())
+
+
+def params_from_options(oo, icp, gravity=(0.0, 0.0, 9.81)):
+    """odometry options dict (as tests/replay_reference.py takes it) + OrcOpts -> parameter names of the reference's yaml."""
+    num = {"common/gravity_acc": gravity,
+           "imu_parameter/acc_cov": oo["acc_cov"], "imu_parameter/gyr_cov": oo["gyr_cov"],
+           "imu_parameter/b_acc_cov": oo["b_acc_cov"], "imu_parameter/b_gyr_cov": oo["b_gyr_cov"]}
+    for k in ("init_voxel_size", "init_sample_voxel_size", "init_num_frames", "voxel_size", "sample_voxel_size", "max_num_points_in_voxel",
+              "min_distance_points"):
+        num["odometry_options/" + k] = oo[k]
+    for k in ("threshold_voxel_occupancy", "size_voxel_map", "num_iters_icp", "min_number_neighbors", "voxel_neighborhood", "power_planarity",
+              "max_number_neighbors", "max_dist_to_plane_icp", "threshold_orientation_norm", "threshold_translation_norm", "max_num_residuals",
+              "weight_alpha", "weight_neighborhood"):
+        num["icp_options/" + k] = getattr(icp, k)
+    num["icp_options/debug_print"] = 0
+    strs = {"odometry_options/motion_compensation": MOTION_COMPENSATION[oo["motion_compensation"]],
+            "odometry_options/initialization": INITIALIZATION.get(oo["initialization"], "NONE")}
+    return num, strs
+
+
+class Node:
+    def __init__(self, point_time_enable=True):
+        self.lib = load()
+        reset_globals()
+        self.h = C.c_void_p(self.lib.ref_node_create(int(bool(point_time_enable))))
+
+    def close(self):
+        if self.h:
+            self.lib.ref_node_destroy(self.h)
+            self.h = None
+        reset_globals()
+
+    def push_imu(self, t, acc, gyr):
+        for ti, a, g in zip(_f64(t), _f64(acc, (-1, 3)), _f64(gyr, (-1, 3))):
+            self.lib.ref_node_push_imu(self.h, float(ti), _dp(np.ascontiguousarray(a)), _dp(np.ascontiguousarray(g)))
+
+    def push_image_time(self, t):
+        self.lib.ref_node_push_image_time(self.h, float(t))
+
+    def push_points(self, raw, timestamp):
+        r = _f64(raw, (-1, 3)); ts = _f64(timestamp)
+        self.lib.ref_node_push_points(self.h, _vp(r), _vp(ts), len(r))
+
+    def run(self):
+        info = np.zeros(8)
+        rc = self.lib.ref_node_run(self.h, _dp(info))
+        return dict(rc=rc, index_frame=int(info[0]), initial_flag=bool(info[1]), window=int(info[2]), last_frame_id=int(info[3]),
+                    points_left=int(info[4]), map_points=int(info[5]), map_voxels=int(info[6]), current_time=float(info[7]))
+
+    def last_frame(self):
+        st = np.zeros(16); tm = np.zeros(2); fid = C.c_int()
+        n = self.lib.ref_node_last_frame_info(self.h, _dp(st), _dp(tm), C.byref(fid))
+        if n < 0:
+            return None
+        raw = np.zeros((n, 3)); pt = np.zeros((n, 3)); imu = np.zeros((n, 3)); al = np.zeros(n); rel = np.zeros(n); ts = np.zeros(n)
+        if n:
+            self.lib.ref_node_last_frame_points(self.h, _vp(raw), _vp(pt), _vp(imu), _vp(al), _vp(rel), _vp(ts))
+        return dict(state=st, time_sweep_begin=tm[0], time_sweep_end=tm[1], frame_id=fid.value, raw_point=raw, point=pt, imu_point=imu,
+                    alpha_time=al, relative_time=rel, timestamp=ts)
+
+    def eskf(self):
+        s = np.zeros(19); P = np.zeros(289)
+        self.lib.ref_node_eskf_get(self.h, _dp(s), _dp(P))
+        return s, P.reshape(17, 17)
+
+    def map_export(self, cap=20):
+        V = self.lib.ref_node_map_num_voxels(self.h)
+        keys = np.zeros((V, 3), dtype=np.int16); counts = np.zeros(V, dtype=np.int32); xyz = np.zeros((V, cap, 3), dtype=np.float32)
+        self.lib.ref_node_map_export(self.h, cap, _vp(keys), _vp(counts), _vp(xyz))
+        return keys, counts, xyz
+
+    def add_points_to_map(self, world, voxel_size=1.0, cap=20, min_dist=0.15, min_num_points=0):
+        w = _f64(world, (-1, 3))
+        return self.lib.ref_node_add_points_to_map(self.h, _vp(w), len(w), voxel_size, cap, min_dist, min_num_points)
+
+    def state_initialization(self, index_frame, initial_flag, prev2, prev1, eskf_q=(1, 0, 0, 0), eskf_t=(0, 0, 0)):
+        out = np.zeros(7)
+        self.lib.ref_node_state_initialization(self.h, int(index_frame), int(bool(initial_flag)), _dp(_f64(prev2)), _dp(_f64(prev1)),
+                                               _dp(_f64(eskf_q)), _dp(_f64(eskf_t)), _dp(out))
+        return out[0:4].copy(), out[4:7].copy()
+
+    def make_point_timestamp(self, timestamp, time_begin, time_end):
+        ts = _f64(timestamp)
+        rel = np.zeros_like(ts); alpha = np.zeros_like(ts); keep = np.zeros(len(ts), dtype=np.int32)
+        m = self.lib.ref_node_make_point_timestamp(self.h, _vp(ts), len(ts), float(time_begin), float(time_end), _vp(rel), _vp(alpha), _vp(keep))
+        return rel[:m], alpha[:m], keep[:m]
+
+
+def map_as_dict(keys, counts, xyz):
+    """{voxel key: points in slot order} -- container iteration order does not matter for equality."""
+    return {tuple(int(c) for c in k): xyz[i, : counts[i]].copy() for i, k in enumerate(keys)}

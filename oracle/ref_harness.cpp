@@ -1,15 +1,20 @@
 // oracle/ref_harness.cpp -- C ABI around the REFERENCE'S OWN translation units (TEST INFRASTRUCTURE ONLY).
 //
-// oracle/_ref/libref_path.so = this file + /root/reference/src/{optimize,eskfEstimator,utility,state,cloudMap}.cpp compiled
-// WHERE THEY LIE (never copied) against the stand-in third-party headers of oracle/ref_shim/ and the real vendored
-// tsl::robin_map (recipe: oracle/Makefile, target `refpath`).  What runs behind every ref_* entry point is therefore the
-// reference's source: lioOptimization::buildPlaneResiduals / updateIEKF / searchNeighbors / computeNeighborhoodDistribution
-// / optimize (src/optimize.cpp), eskfEstimator (src/eskfEstimator.cpp), gridSampling / subSampleFrame / transformPoint /
-// distortFrameBy* / transformAllImuPoint / AngularDistance (src/utility.cpp), numType (include/utility.h), rgbPoint
-// (src/cloudMap.cpp).  Ours are only (a) the third-party arithmetic (oracle/ref_shim/Eigen/Core: Eigen is absent from
-// this image) and (b) the two constructors below, which the reference defines in src/lioOptimization.cpp next to its ROS
-// node code (not compilable here).  The ABI mirrors oracle/srl_oracle.h (same layouts: row-major matrices, quaternions
-// w,x,y,z) so tests/test_reference_tu.py can run the restatement and the reference side by side.
+// oracle/_ref/libref_path.so = this file + /root/reference/src/{optimize,lioOptimization,eskfEstimator,utility,state,
+// cloudMap,parameters}.cpp compiled WHERE THEY LIE (never copied) against the stand-in third-party headers of
+// oracle/ref_shim/ and the real vendored tsl::robin_map (recipe: oracle/Makefile, target `refpath`).  What runs behind every
+// ref_* entry point is therefore the reference's source: lioOptimization::buildPlaneResiduals / updateIEKF / searchNeighbors
+// / computeNeighborhoodDistribution / optimize (src/optimize.cpp); the node itself -- constructor, readParameters,
+// imuHandler, getMeasurements, run, process, stateInitialization, makePointTimestamp, buildFrame, stateEstimation,
+// addPointToMap / addPointsToMap (src/lioOptimization.cpp); eskfEstimator (src/eskfEstimator.cpp); gridSampling /
+// subSampleFrame / transformPoint / distortFrameBy* / transformAllImuPoint / AngularDistance (src/utility.cpp); numType
+// (include/utility.h); rgbPoint (src/cloudMap.cpp).  Ours are only (a) the third-party arithmetic (oracle/ref_shim/Eigen/
+// Core: Eigen is absent from this image), (b) inert ROS / PCL / OpenCV stand-ins (publishers drop their messages, images
+// are empty, parameters come from a stand-in parameter server the tests fill), and (c) no-op definitions of the sensor
+// decoder (src/cloudProcessing.cpp) and of the vision stage's entry points, both out of scope: the harness
+// puts decoded points straight into the node's point_buffer, exactly where cloudProcessing would.
+// The ABI mirrors oracle/srl_oracle.h (row-major matrices, quaternions w,x,y,z) so tests/test_reference_tu.py can run the
+// restatement and the reference side by side.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -36,21 +41,49 @@
 #undef private
 #undef protected
 
-// ---- the two definitions the reference keeps in src/lioOptimization.cpp (ROS node file, not compiled) ----
-// src/lioOptimization.cpp:3-8
-cloudFrame::cloudFrame(std::vector<point3D> &point_frame_, state *p_state_) {
-    point_frame.insert(point_frame.end(), point_frame_.begin(), point_frame_.end());
-    p_state = p_state_;
+// ---- out-of-scope collaborators of the node, defined as no-ops so that src/lioOptimization.cpp links ----
+// sensor decoder (src/cloudProcessing.cpp needs the ROS / Livox message layouts): the tests hand over decoded points
+cloudProcessing::cloudProcessing() {
+    lidar_type = LIVOX; N_SCANS = 6; SCAN_RATE = 10; time_unit = US; time_interval_sweep = 0.1; time_unit_scale = 1.e-3; blind = 0.01;
+    given_offset_time = true; point_filter_num = 1; sweep_id = 0; delta_cut_time = 0.0; last_end_time = 0.0;
+    R_imu_lidar = Eigen::Matrix3d::Identity(); t_imu_lidar = Eigen::Vector3d::Zero();
 }
-// src/lioOptimization.cpp:211-... reads ROS parameters and allocates the ROS side; the harness sets what the path reads
-lioOptimization::lioOptimization() {
-    cloud_pro = nullptr;
-    eskf_pro = nullptr;
-    img_pro = nullptr;
-    index_frame = 1;
-    laser_point_cov = 0.001;
-    R_imu_lidar = Eigen::Matrix3d::Identity();
-    t_imu_lidar = Eigen::Vector3d::Zero();
+void cloudProcessing::setLidarType(int para) { lidar_type = para; }
+void cloudProcessing::setNumScans(int para) { N_SCANS = para; }
+void cloudProcessing::setScanRate(int para) { SCAN_RATE = para; time_interval_sweep = 1 / double(SCAN_RATE); }   // src/cloudProcessing.cpp:38-42
+void cloudProcessing::setTimeUnit(int para) { time_unit = para; }
+void cloudProcessing::setBlind(double para) { blind = para; }
+void cloudProcessing::setExtrinR(Eigen::Matrix3d &R) { R_imu_lidar = R; }
+void cloudProcessing::setExtrinT(Eigen::Vector3d &t) { t_imu_lidar = t; }
+void cloudProcessing::setUseFeature(bool) {}
+void cloudProcessing::setPointFilterNum(int para) { point_filter_num = para; }
+void cloudProcessing::process(const sensor_msgs::PointCloud2::ConstPtr &, std::queue<point3D> &) {}
+void cloudProcessing::livoxHandler(const livox_ros_driver::CustomMsg::ConstPtr &, std::queue<point3D> &) {}
+// vision stage (oracle/ref_shim/local/imageProcessing.h)
+imageProcessing::imageProcessing() { map_tracker = new rgbMapTracker(); }
+void imageProcessing::setImageWidth(int &) {}
+void imageProcessing::setImageHeight(int &) {}
+void imageProcessing::setCameraIntrinsic(std::vector<double> &) {}
+void imageProcessing::setCameraDistCoeffs(std::vector<double> &) {}
+void imageProcessing::setExtrinR(Eigen::Matrix3d &) {}
+void imageProcessing::setExtrinT(Eigen::Vector3d &) {}
+Eigen::Matrix3d imageProcessing::getCameraIntrinsic() { return Eigen::Matrix3d::Identity(); }
+void imageProcessing::process(voxelHashMap &, cloudFrame *) {}
+void imageProcessing::printParameter() {}
+
+// what a launch file would provide and readParameters() cannot default (vec3FromArray / mat33FromArray index their arrays)
+static void ensure_default_params() {
+    auto &n = ros::standin::num_params();
+    auto &s = ros::standin::str_params();
+    auto put = [&](const char *k, std::vector<double> v) { if (!n.count(k)) n[k] = v; };
+    put("common/gravity_acc", {0.0, 0.0, 9.81});
+    put("extrinsic_parameter/extrinsic_t_imu_lidar", {0, 0, 0});
+    put("extrinsic_parameter/extrinsic_R_imu_lidar", {1, 0, 0, 0, 1, 0, 0, 0, 1});
+    put("extrinsic_parameter/extrinsic_t_imu_camera", {0, 0, 0});
+    put("extrinsic_parameter/extrinsic_R_imu_camera", {1, 0, 0, 0, 1, 0, 0, 0, 1});
+    put("camera_parameter/camera_intrinsic", {1, 0, 0, 0, 1, 0, 0, 0, 1});
+    put("camera_parameter/camera_dist_coeffs", {0, 0, 0, 0, 0});
+    if (!s.count("output_path")) s["output_path"] = "/nonexistent_srl_ref_output";     // recordSinglePose appends to files there: must not exist
 }
 
 namespace {
@@ -83,7 +116,9 @@ inline icpOptions to_opts(const orc_icp_opts *o) {
 }
 
 // the node object plus the two frames the path dereferences (all_cloud_frame[p_frame->id - 1] and p_frame)
+struct ParamGuard { ParamGuard() { ensure_default_params(); } };
 struct Node {
+    ParamGuard guard;                     // before the node's constructor reads its parameters
     lioOptimization lio;
     state last_state, cur_state;
     std::vector<point3D> no_points;
@@ -145,7 +180,7 @@ uint64_t ref_voxel_hash(int16_t x, int16_t y, int16_t z) { return (uint64_t)std:
 // out_xyz: up to K x 3 (ascending by distance, as returned), out_voxel: K x 3 shorts (the `voxels` out-parameter)
 int ref_search_neighbors(ref_map *m, const double p[3], int nb_voxels_visited, double size_voxel_map, int max_num_neighbors,
                          int threshold_voxel_capacity, double *out_xyz, int16_t *out_voxel) {
-    Node node;
+    static Node node;                         // searchNeighbors reads no member
     std::vector<voxel> voxels;
     auto nb = node.lio.searchNeighbors(m->map, v3(p), nb_voxels_visited, size_voxel_map, max_num_neighbors, threshold_voxel_capacity,
                                        out_voxel ? &voxels : nullptr);
@@ -158,7 +193,7 @@ int ref_search_neighbors(ref_map *m, const double p[3], int nb_voxels_visited, d
 
 // ---- lioOptimization::computeNeighborhoodDistribution (src/optimize.cpp:316-353).  Returns 0, -1 when it throws ----
 int ref_neighborhood(const double *pts, int n, double center[3], double normal[3], double cov[9], double *a2D) {
-    Node node;
+    static Node node;                         // computeNeighborhoodDistribution reads no member
     std::vector<Eigen::Vector3d, Eigen::aligned_allocator<Eigen::Vector3d>> points;
     for (int i = 0; i < n; i++) points.push_back(v3(pts + 3 * (size_t)i));
     try {
@@ -294,6 +329,7 @@ int ref_update_iekf(ref_map *m, ref_eskf *e, const orc_icp_opts *o, const double
     node.lio.R_imu_lidar = m3(R_il);
     node.lio.t_imu_lidar = v3(t_il);
     node.lio.laser_point_cov = laser_point_cov;
+    delete node.lio.eskf_pro;
     node.lio.eskf_pro = &e->e;
     node.cur_frame.frame_id = frame_id;
     node.cur_state.rotation = Eigen::Quaterniond(state_io[0], state_io[1], state_io[2], state_io[3]);
@@ -328,6 +364,7 @@ int ref_optimize(ref_map *m, ref_eskf *e, const orc_icp_opts *o, const double *f
     node.lio.R_imu_lidar = m3(R_il);
     node.lio.t_imu_lidar = v3(t_il);
     node.lio.laser_point_cov = laser_point_cov;
+    delete node.lio.eskf_pro;
     node.lio.eskf_pro = &e->e;
     node.lio.voxel_map = m->map;
     node.cur_frame.frame_id = frame_id;
@@ -427,5 +464,163 @@ void ref_so3_to_rot(const double w[3], double R[9]) { Eigen::Matrix3d m = numTyp
 void ref_so3_to_quat(const double w[3], double q[4]) { Eigen::Quaterniond r = numType::so3ToQuat(v3(w)); q[0] = r.w(); q[1] = r.x(); q[2] = r.y(); q[3] = r.z(); }
 void ref_rot_to_so3(const double R[9], double w[3]) { Eigen::Vector3d r = numType::rotationToSo3(m3(R)); w[0] = r[0]; w[1] = r[1]; w[2] = r[2]; }
 void ref_derivative_s2(const double g[3], double B[6]) { Eigen::Matrix<double, 3, 2> b = numType::derivativeS2(v3(g)); for (int i = 0; i < 3; i++) for (int j = 0; j < 2; j++) B[2 * i + j] = b(i, j); }
+
+// =====================================================================================================================
+// The node itself (src/lioOptimization.cpp): constructed by its own constructor from the stand-in parameter server, fed
+// through its own imuHandler and buffers, advanced by its own run().
+// =====================================================================================================================
+void ref_param_clear(void) { ros::standin::num_params().clear(); ros::standin::str_params().clear(); }
+void ref_param_set_num(const char *name, const double *v, int n) { ros::standin::num_params()[name] = std::vector<double>(v, v + n); }
+void ref_param_set_str(const char *name, const char *v) { ros::standin::str_params()[name] = v; }
+
+struct ref_node { ParamGuard guard; lioOptimization lio; };
+
+// point_time_enable: what cloudProcessing derives from the message fields (given_offset_time, src/cloudProcessing.cpp:228-233)
+ref_node *ref_node_create(int point_time_enable) {
+    std::streambuf *old = std::cout.rdbuf(nullptr);
+    ref_node *n = new ref_node();
+    std::cout.rdbuf(old);
+    n->lio.cloud_pro->given_offset_time = point_time_enable != 0;
+    // uninitialised Eigen members of eskfEstimator upstream (include/eskfEstimator.h:21-28): zero, like the restatement
+    eskfEstimator &e = *n->lio.eskf_pro;
+    e.acc_cov = Eigen::Vector3d::Zero(); e.gyr_cov = Eigen::Vector3d::Zero();
+    e.acc_0 = Eigen::Vector3d::Zero(); e.gyr_0 = Eigen::Vector3d::Zero(); e.acc_1 = Eigen::Vector3d::Zero(); e.gyr_1 = Eigen::Vector3d::Zero();
+    e.lxly = Eigen::Matrix<double, 3, 2>::Zero(); e.time_first_imu = 0.0; e.dt = 0.0;
+    return n;
+}
+void ref_node_destroy(ref_node *n) { delete n; }
+
+// sensor_msgs::Imu through the node's own imuHandler (src/lioOptimization.cpp:606-626)
+void ref_node_push_imu(ref_node *n, double t, const double acc[3], const double gyr[3]) {
+    sensor_msgs::Imu::Ptr msg(new sensor_msgs::Imu());
+    msg->header.stamp = ros::Time().fromSec(t);
+    msg->linear_acceleration.x = acc[0]; msg->linear_acceleration.y = acc[1]; msg->linear_acceleration.z = acc[2];
+    msg->angular_velocity.x = gyr[0]; msg->angular_velocity.y = gyr[1]; msg->angular_velocity.z = gyr[2];
+    n->lio.imuHandler(msg);
+}
+// what imageHandler leaves behind (src/lioOptimization.cpp:628-641): an (empty) image and its time stamp
+void ref_node_push_image_time(ref_node *n, double t) {
+    n->lio.img_buffer.push(cv::Mat());
+    n->lio.time_img_buffer.push(t);
+    n->lio.last_time_img = t;
+}
+// decoded LiDAR points as cloudProcessing::livoxHandler queues them (src/cloudProcessing.cpp:139-146):
+// raw_point, point = raw_point, timestamp, alpha_time = 0
+void ref_node_push_points(ref_node *n, const double *raw_xyz, const double *timestamp, int count) {
+    for (int i = 0; i < count; i++) {
+        point3D p;
+        p.raw_point = v3(raw_xyz + 3 * (size_t)i);
+        p.point = p.raw_point;
+        p.imu_point = Eigen::Vector3d::Zero();
+        p.timestamp = timestamp[i];
+        p.relative_time = 0.0;
+        p.alpha_time = 0.0;
+        n->lio.point_buffer.push(p);
+    }
+}
+// one call of lioOptimization::run() (src/lioOptimization.cpp:1427-1584).  info: index_frame, initial_flag, #frames in the
+// window, frames ever built (all_cloud_frame.back()->frame_id), points left in point_buffer, map points, map voxels.
+// Returns 0, or -2 when computeNeighborhoodDistribution threw.
+int ref_node_run(ref_node *n, double info[8]) {
+    std::streambuf *old = std::cout.rdbuf(nullptr);
+    std::streambuf *olde = std::cerr.rdbuf(nullptr);
+    int rc = 0;
+    try { n->lio.run(); } catch (const std::runtime_error &) { rc = -2; }
+    std::cout.rdbuf(old);
+    std::cerr.rdbuf(olde);
+    lioOptimization &l = n->lio;
+    info[0] = l.index_frame; info[1] = initial_flag ? 1 : 0; info[2] = (double)l.all_cloud_frame.size();
+    info[3] = l.all_cloud_frame.empty() ? 0 : l.all_cloud_frame.back()->frame_id;
+    info[4] = (double)l.point_buffer.size(); info[5] = (double)l.mapSize(l.voxel_map); info[6] = (double)l.voxel_map.size();
+    info[7] = l.current_time;
+    return rc;
+}
+// the newest frame of the window: state16 (q wxyz, t, v, ba, bg), times (sweep begin, sweep end), frame_id, #points
+int ref_node_last_frame_info(ref_node *n, double state16[16], double times[2], int *frame_id) {
+    if (n->lio.all_cloud_frame.empty()) return -1;
+    cloudFrame *f = n->lio.all_cloud_frame.back();
+    const state &s = *f->p_state;
+    state16[0] = s.rotation.w(); state16[1] = s.rotation.x(); state16[2] = s.rotation.y(); state16[3] = s.rotation.z();
+    for (int i = 0; i < 3; i++) { state16[4 + i] = s.translation[i]; state16[7 + i] = s.velocity[i]; state16[10 + i] = s.ba[i]; state16[13 + i] = s.bg[i]; }
+    times[0] = f->time_sweep_begin; times[1] = f->time_sweep_end;
+    *frame_id = f->frame_id;
+    return (int)f->point_frame.size();
+}
+// its points: raw_point, point, imu_point (n x 3 each), alpha_time, relative_time, timestamp (n each)
+void ref_node_last_frame_points(ref_node *n, double *raw, double *point, double *imu_point, double *alpha, double *rel, double *ts) {
+    cloudFrame *f = n->lio.all_cloud_frame.back();
+    for (size_t i = 0; i < f->point_frame.size(); i++) {
+        const point3D &p = f->point_frame[i];
+        for (int c = 0; c < 3; c++) { raw[3 * i + c] = p.raw_point[c]; point[3 * i + c] = p.point[c]; imu_point[3 * i + c] = p.imu_point[c]; }
+        alpha[i] = p.alpha_time; rel[i] = p.relative_time; ts[i] = p.timestamp;
+    }
+}
+void ref_node_eskf_get(ref_node *n, double s[19], double P[289]) {
+    eskfEstimator &e = *n->lio.eskf_pro;
+    const Eigen::Vector3d p = e.getTranslation(), v = e.getVelocity(), ba = e.getBa(), bg = e.getBg(), g = e.getGravity();
+    const Eigen::Quaterniond q = e.getRotation();
+    for (int i = 0; i < 3; i++) { s[i] = p[i]; s[7 + i] = v[i]; s[10 + i] = ba[i]; s[13 + i] = bg[i]; s[16 + i] = g[i]; }
+    s[3] = q.w(); s[4] = q.x(); s[5] = q.y(); s[6] = q.z();
+    const Eigen::Matrix<double, 17, 17> c = e.getCovariance();
+    for (int i = 0; i < 17; i++) for (int j = 0; j < 17; j++) P[17 * i + j] = c(i, j);
+}
+// the LiDAR voxel map, in the container's iteration order: keys (V x 3), counts (V), xyz (V x cap x 3 f32); returns V
+int ref_node_map_num_voxels(ref_node *n) { return (int)n->lio.voxel_map.size(); }
+int ref_node_map_export(ref_node *n, int cap, int16_t *keys, int32_t *counts, float *xyz) {
+    int v = 0;
+    for (auto it = n->lio.voxel_map.begin(); it != n->lio.voxel_map.end(); ++it, ++v) {
+        keys[3 * v] = it->first.x; keys[3 * v + 1] = it->first.y; keys[3 * v + 2] = it->first.z;
+        auto &block = it.value();
+        counts[v] = block.NumPoints();
+        for (int s = 0; s < block.NumPoints() && s < cap; s++) {
+            const Eigen::Vector3d p = block.points[s].getPosition();
+            float *o = xyz + ((size_t)v * cap + s) * 3;
+            o[0] = (float)p[0]; o[1] = (float)p[1]; o[2] = (float)p[2];
+        }
+    }
+    return v;
+}
+// lioOptimization::addPointsToMap (src/lioOptimization.cpp:520-554) -> addPointToMap (:399-446) on world points, in order
+int ref_node_add_points_to_map(ref_node *n, const double *world_xyz, int count, double voxel_size, int max_num_points_in_voxel,
+                               double min_distance_points, int min_num_points) {
+    lioOptimization &l = n->lio;
+    state st;
+    std::vector<point3D> pts((size_t)count);
+    for (int i = 0; i < count; i++) { pts[i].point = v3(world_xyz + 3 * (size_t)i); pts[i].raw_point = pts[i].point; pts[i].imu_point = pts[i].point; }
+    cloudFrame frame(pts, &st);
+    frame.time_sweep_end = 1.0 + (double)l.voxel_map.size();     // only read by the colour map's bookkeeping
+    const size_t before = l.mapSize(l.voxel_map);
+    l.addPointsToMap(l.voxel_map, &frame, voxel_size, max_num_points_in_voxel, min_distance_points, min_num_points, false);
+    return (int)(l.mapSize(l.voxel_map) - before);
+}
+// lioOptimization::stateInitialization (src/lioOptimization.cpp:895-990).  prev2 / prev1 = (q wxyz, t) of
+// all_cloud_frame[size-2] / [size-1]; the node's `initialization` comes from the parameter server
+void ref_node_state_initialization(ref_node *n, int index_frame, int initial_flag_, const double prev2[7], const double prev1[7],
+                                   const double eskf_q[4], const double eskf_t[3], double out[7]) {
+    lioOptimization &l = n->lio;
+    state s2, s1, cur;
+    s2.rotation = Eigen::Quaterniond(prev2[0], prev2[1], prev2[2], prev2[3]); s2.translation = v3(prev2 + 4);
+    s1.rotation = Eigen::Quaterniond(prev1[0], prev1[1], prev1[2], prev1[3]); s1.translation = v3(prev1 + 4);
+    std::vector<point3D> none;
+    cloudFrame f2(none, &s2), f1(none, &s1);
+    std::vector<cloudFrame *> saved = l.all_cloud_frame;
+    l.all_cloud_frame.clear(); l.all_cloud_frame.push_back(&f2); l.all_cloud_frame.push_back(&f1);
+    const int saved_index = l.index_frame; const bool saved_flag = initial_flag;
+    l.index_frame = index_frame; initial_flag = initial_flag_ != 0;
+    l.eskf_pro->setRotation(Eigen::Quaterniond(eskf_q[0], eskf_q[1], eskf_q[2], eskf_q[3])); l.eskf_pro->setTranslation(v3(eskf_t));
+    l.stateInitialization(&cur);
+    out[0] = cur.rotation.w(); out[1] = cur.rotation.x(); out[2] = cur.rotation.y(); out[3] = cur.rotation.z();
+    for (int i = 0; i < 3; i++) out[4 + i] = cur.translation[i];
+    l.all_cloud_frame = saved; l.index_frame = saved_index; initial_flag = saved_flag;
+}
+// lioOptimization::makePointTimestamp (src/lioOptimization.cpp:786-819): returns the number of points kept; keep_index (n)
+int ref_node_make_point_timestamp(ref_node *n, const double *timestamp, int count, double time_begin, double time_end,
+                                  double *relative_time, double *alpha_time, int32_t *keep_index) {
+    std::vector<point3D> sweep((size_t)count);
+    for (int i = 0; i < count; i++) { sweep[i].timestamp = timestamp[i]; sweep[i].index_frame = i; sweep[i].raw_point = Eigen::Vector3d::Zero(); sweep[i].point = sweep[i].raw_point; sweep[i].imu_point = sweep[i].raw_point; }
+    n->lio.makePointTimestamp(sweep, time_begin, time_end);
+    for (size_t i = 0; i < sweep.size(); i++) { relative_time[i] = sweep[i].relative_time; alpha_time[i] = sweep[i].alpha_time; keep_index[i] = sweep[i].index_frame; }
+    return (int)sweep.size();
+}
 
 }  // extern "C"

@@ -1,4 +1,4 @@
-// NOT the Livox driver: declaration-only stand-in (see ros/ros.h).
+// NOT the Livox driver: inert stand-in (see ros/ros.h).
 #pragma once
-#include <memory>
-namespace livox_ros_driver { struct CustomMsg { typedef std::shared_ptr<const CustomMsg> ConstPtr; }; }
+#include <ros/ros.h>
+namespace livox_ros_driver { struct CustomMsg { typedef std::shared_ptr<const CustomMsg> ConstPtr; std_msgs::Header header; }; }

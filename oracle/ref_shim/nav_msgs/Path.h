@@ -1,3 +1,4 @@
-// NOT ROS: declaration-only stand-ins (see ros/ros.h).
+// NOT ROS: inert stand-ins (see ros/ros.h in this directory tree).
 #pragma once
-namespace nav_msgs { struct Path {}; }
+#include <geometry_msgs/Vector3.h>
+namespace nav_msgs { struct Path { std_msgs::Header header; std::vector<geometry_msgs::PoseStamped> poses; }; }

@@ -1,8 +1,9 @@
 // srl_oracle.cpp -- CPU ORACLE (test infrastructure, NOT product code; see srl_oracle.h).
 //
 // Line-by-line restatement of the SR-LIVO LIO scan-matching hot path.  Every function cites
-// the reference file:line (relative to /root/reference) it follows.  PARITY UNPINNED by the
-// reference's own tests (it has none for this path) -- see the header of srl_oracle.h.
+// the reference file:line (relative to /root/reference) it follows.  The reference has no tests for this
+// path; the restatement is pinned BITWISE against the reference's own translation units compiled in place
+// (oracle/_ref/libref_path.so, tests/test_reference_tu.py) -- see the header of srl_oracle.h.
 //
 // Third-party arithmetic that is NOT under /root/reference (Eigen 3.3.x, unpinned; libstdc++)
 // is restated from its published algorithms:

@@ -5,15 +5,20 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and there
  * only as the checker / the timed CPU baseline -- never as the thing shipped.
  *
- * PARITY UNPINNED: the reference (ZikangYuan/sr_livo) ships no tests, golden vectors or
- * fixtures for this path and its own sources cannot be compiled
- * here (Eigen/ROS/PCL/OpenCV/Ceres absent).  The oracle is a line-by-line restatement of
+ * PINNED AGAINST THE REFERENCE'S OWN SOURCE: the reference (ZikangYuan/sr_livo) ships no tests, golden vectors or
+ * fixtures for this path and its build needs Eigen/ROS/PCL/OpenCV/Ceres, which are absent
+ * here -- but src/{optimize,lioOptimization,eskfEstimator,utility,state,cloudMap,parameters}.cpp compile where they lie
+ * against stand-in third-party headers (oracle/ref_shim/, oracle/ref_harness.cpp -> oracle/_ref/libref_path.so), and
+ * tests/test_reference_tu.py requires this restatement to equal that library BITWISE (residual fields, neighbour lists on
+ * tied distances, solved state and covariance, the whole node's run() over 40 sweeps, the final map).  What is restated
+ * rather than compiled is the third-party arithmetic only (Eigen 3.3.7's SelfAdjointEigenSolver and PartialPivLU inverse:
+ * orc_eigen337.h; quaternion helpers; product / reduction order).  The oracle restates
  *   src/optimize.cpp:18-448, include/cloudMap.h:37-184, src/cloudMap.cpp:5-29,
- *   src/lioOptimization.cpp:400-446,520-554,574-581, src/eskfEstimator.cpp:3-21,166-230,
- *   include/utility.h:191-331, src/utility.cpp:146-153
- * pinned instead by (1) an independent NumPy implementation in tests/, (2) analytic cases,
- * (3) the known-answer values of SURVEY.md Appendix D, and (4) a build against the real
- * vendored tsl::robin_map (oracle/_ref/, see oracle/Makefile).
+ *   src/lioOptimization.cpp:400-446,520-554,574-581,786-990, src/eskfEstimator.cpp:3-21,43-230,
+ *   include/utility.h:191-331, src/utility.cpp:146-332
+ * and is additionally checked by (1) an independent NumPy implementation in tests/, (2) analytic cases, (3) the
+ * known-answer values of SURVEY.md Appendix D, and (4) a build against the real vendored tsl::robin_map
+ * (oracle/_ref/liboracle_tsl.so, see oracle/Makefile).
  *
  * All matrices are ROW-MAJOR in this ABI.  Quaternions are (w, x, y, z).
  */

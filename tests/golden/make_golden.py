@@ -2,10 +2,12 @@
 
     python tests/golden/make_golden.py
 
-PARITY UNPINNED: the reference ships no golden vectors for this path and cannot be compiled here
-(SURVEY.md 8(c)), so these vectors are outputs of oracle/ (the line-by-line restatement), built
-against the real vendored tsl::robin_map when /root/reference is present.  They pin the oracle
-against regressions and travel to the GPU box, where the HIP path is compared with them.
+The reference ships no golden vectors for this path; these vectors are outputs of oracle/ (the
+line-by-line restatement), built against the real vendored tsl::robin_map when /root/reference is present, with
+per-keypoint detail (ids, status, taps) the reference's interfaces do not expose.  Their reference-side counterpart is
+golden_ref_tu.npz (make_golden_ref.py): outputs of the reference's OWN translation units compiled in place, on the same
+scenes -- tests/test_reference_tu.py requires the two to agree bitwise.  Both travel to the GPU box, where the HIP path
+is compared with them.
 The symmetric eigen-solver is the oracle's restatement of Eigen 3.3.7's algorithm (eig3_eigen_ql).
 """
 import os

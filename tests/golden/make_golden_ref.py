@@ -2,10 +2,11 @@
 
     make -C oracle refpath && python tests/golden/make_golden_ref.py
 
-oracle/_ref/libref_path.so is /root/reference/src/{optimize,eskfEstimator,utility,state,cloudMap}.cpp compiled where they
-lie (oracle/ref_harness.cpp, oracle/Makefile); every array written here is an output of lioOptimization::
-buildPlaneResiduals / updateIEKF / searchNeighbors / optimize, eskfEstimator::predict / observe / tryInit, gridSampling,
-distortFrameBy*, transformAllImuPoint as the reference wrote them.  Third-party arithmetic (Eigen is absent from the image)
+oracle/_ref/libref_path.so is /root/reference/src/{optimize,lioOptimization,eskfEstimator,utility,state,cloudMap,
+parameters}.cpp compiled where they lie (oracle/ref_harness.cpp, oracle/Makefile); every array written here is an output of
+lioOptimization::buildPlaneResiduals / updateIEKF / searchNeighbors / optimize, and -- the `run*` arrays -- of the node's own
+constructor / readParameters / imuHandler / getMeasurements / run / process / buildFrame / stateEstimation / addPointsToMap
+on a 40-sweep sequence, as the reference wrote them.  Third-party arithmetic (Eigen is absent from the image)
 is the stand-in of oracle/ref_shim/Eigen/Core -- see its header for what that means for low-order bits.
 The inputs are those of golden_small.npz (same scenes), so the two files are read side by side:
   * tests/test_reference_tu.py (CPU): the oracle must reproduce these vectors BITWISE (also on the GPU box, where neither
@@ -37,6 +38,44 @@ def one_pass(rm, opts, raw, q, t, t_last, frame_id, prefix, data):
     data[f"{prefix}_ref_num_residuals"] = r["num_residuals"]
     data[f"{prefix}_ref_loss"] = r["loss"]
     return r
+
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from replay_reference import REPLAY_OO, REPLAY_SEQ, replay_inputs  # noqa: E402
+
+
+def replay(data):
+    """lioOptimization's own constructor / readParameters / imuHandler / getMeasurements / run / process / buildFrame /
+    stateEstimation / addPointsToMap (src/lioOptimization.cpp) on a 40-sweep sequence: per processed frame the solved state,
+    the filter, the frame size and the map size; at the end the map."""
+    st, parts, _ = replay_inputs()
+    for mc in (1, 0):
+        oo = dict(REPLAY_OO, motion_compensation=mc)
+        icp = po.default_opts(max_num_residuals=REPLAY_SEQ["max_num_residuals"])
+        pr.set_params(*pr.params_from_options(oo, icp))
+        node = pr.Node(True)
+        node.push_imu(st["imu_t"], st["imu_acc"], st["imu_gyr"])
+        node.push_points(st["pts_raw"], st["pts_timestamp"])
+        for t in st["image_times"]:
+            node.push_image_time(t)
+        rows = []
+        for i in range(len(parts)):
+            before = node.run()
+            assert before["rc"] == 0
+            f = node.last_frame()
+            if f is None or (rows and f["frame_id"] == rows[-1]["frame_id"]):
+                continue
+            s, P = node.eskf()
+            rows.append(dict(measurement=i, frame_id=f["frame_id"], state=f["state"], eskf_state=s, eskf_cov=P, frame_points=len(f["raw_point"]),
+                             map_points=before["map_points"], raw_sum=f["raw_point"].sum(0), point_sum=f["point"].sum(0), imu_sum=f["imu_point"].sum(0)))
+        k, c, x = node.map_export()
+        order = np.lexsort((k[:, 2], k[:, 1], k[:, 0]))
+        pre = f"run{mc}"
+        for name in ("measurement", "frame_id", "state", "eskf_state", "eskf_cov", "frame_points", "map_points", "raw_sum", "point_sum", "imu_sum"):
+            data[f"{pre}_{name}"] = np.array([r[name] for r in rows])
+        data[f"{pre}_map_keys"] = k[order]; data[f"{pre}_map_counts"] = c[order]; data[f"{pre}_map_xyz"] = x[order]
+        node.close()
+        print(pre, "frames", len(rows), "first processed at measurement", rows[0]["measurement"], "map points", rows[-1]["map_points"], "voxels", len(k))
 
 
 def main():
@@ -74,6 +113,7 @@ def main():
         data[f"{name}_ref_neighbors"] = nbr
         data[f"{name}_ref_num_neighbors"] = cnt
         print(name, "residuals", r["num_residuals"])
+    replay(data)
     path = os.path.join(HERE, "golden_ref_tu.npz")
     np.savez_compressed(path, **data)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")

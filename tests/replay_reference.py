@@ -135,3 +135,58 @@ class OracleReplay:
                 f = self.frames.pop(0); self.trajectory.append((f["time_sweep_end"], f["state"][4:7].copy(), f["state"][0:4].copy()))
         self.last = info
         return info
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sensor STREAMS for the reference's own node (oracle/pyref.Node: imuHandler + buffers + run()), and the same streams cut
+# into `Measurements` the way lioOptimization::getMeasurements does (src/lioOptimization.cpp:666-784, the branch taken when
+# an image closes the sweep), for the drivers that take one measurement at a time (OracleReplay above, the product's
+# runMeasurement).
+def streams_from_sequence(meas, image_offset=0.0013):
+    """synth.make_sequence output -> (imu_t, imu_acc, imu_gyr, pts_raw, pts_timestamp, image_times): one continuous IMU
+    stream, one continuous point stream, one image a little after every synthetic sweep end (so that the sample that
+    straddles the image time is interpolated, src/lioOptimization.cpp:1456-1473,1534-1566)."""
+    imu_t = np.concatenate([m["imu_t"] for m in meas]); imu_acc = np.concatenate([m["imu_acc"] for m in meas]); imu_gyr = np.concatenate([m["imu_gyr"] for m in meas])
+    pts = np.concatenate([m["pts_raw"] for m in meas]); ts = np.concatenate([m["pts_timestamp"] for m in meas])
+    order = np.argsort(ts, kind="stable")
+    images = np.array([m["time_frame"] + image_offset for m in meas[:-1]])          # the last sweep has no data behind its image
+    assert np.all(np.diff(imu_t) > 0)
+    return dict(imu_t=imu_t, imu_acc=imu_acc, imu_gyr=imu_gyr, pts_raw=pts[order], pts_timestamp=ts[order], image_times=images)
+
+
+def partition_like_get_measurements(st, sweep_interval=0.1):
+    """getMeasurements restated on arrays: for every image, the IMU samples before it plus the first one at / behind it (which
+    stays queued for the next measurement too), the points before it; time_sweep = (previous cut, image - previous cut)."""
+    out = []
+    last = st["imu_t"][0]                               # imuHandler: last_get_measurement = first IMU stamp
+    i0 = 0; p0 = 0
+    for t_img in st["image_times"]:
+        assert not (last + sweep_interval < t_img - 0.5 * sweep_interval), "the no-image branch is not exercised here"
+        assert st["pts_timestamp"][-1] > t_img and st["imu_t"][-1] > t_img
+        i1 = int(np.searchsorted(st["imu_t"], t_img, side="left"))          # stamps < t_img are popped ...
+        sel = slice(i0, i1 + 1)                                             # ... and the front is appended without popping
+        p1 = int(np.searchsorted(st["pts_timestamp"], t_img, side="left"))
+        if p1 > p0:
+            out.append(dict(time_frame=t_img, imu_t=st["imu_t"][sel], imu_acc=st["imu_acc"][sel], imu_gyr=st["imu_gyr"][sel],
+                            pts_raw=st["pts_raw"][p0:p1], pts_timestamp=st["pts_timestamp"][p0:p1], time_sweep_begin=last,
+                            time_sweep_offset=t_img - last))
+        i0 = i1; p0 = p1
+        last = t_img
+    return out
+
+
+# the replay sequence of tests/golden/golden_ref_tu.npz (`run0_*` / `run1_*`: motion compensation IMU / CONSTANT_VELOCITY)
+REPLAY_OO = dict(init_voxel_size=0.2, init_sample_voxel_size=1.0, init_num_frames=6, num_for_initialization=10, voxel_size=0.2,
+                 sample_voxel_size=1.5, max_num_points_in_voxel=20, min_distance_points=0.1, initialization=0,
+                 point_time_enable=1, acc_cov=0.1, gyr_cov=0.1, b_acc_cov=1e-4, b_gyr_cov=1e-4)
+REPLAY_SEQ = dict(map_seed=555, map_target=60_000, seq_seed=31, n_moving=7, n_pts=6000, max_num_residuals=600)
+
+
+def replay_inputs():
+    """The sensor streams of the replay goldens (regenerated from seeds wherever they are needed), the same streams cut
+    into measurements the way getMeasurements does, and the ground-truth poses."""
+    from sr_livo_amd import synth
+    _, L = synth.map_candidates(REPLAY_SEQ["map_seed"], REPLAY_SEQ["map_target"])
+    meas, gt, _ = synth.make_sequence(REPLAY_SEQ["seq_seed"], REPLAY_SEQ["n_moving"], REPLAY_SEQ["n_pts"], L)
+    st = streams_from_sequence(meas)
+    return st, partition_like_get_measurements(st), gt

@@ -90,6 +90,72 @@ def check_pass_against(g, ref, prefix, tol=TIGHT, well_posed=None):
         assert rel(g["neq"].loss_sum, ref[f"{prefix}_one_loss"]) < tol
 
 
+# ----------------------------------------------------------------------------- vs the reference's own translation units
+@pytest.fixture(scope="module")
+def gref():
+    """tests/golden/golden_ref_tu.npz: outputs of /root/reference/src/optimize.cpp & co. compiled in place
+    (oracle/_ref/libref_path.so, tests/golden/make_golden_ref.py) on the scenes of golden_small.npz."""
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ref_tu.npz"), allow_pickle=False))
+
+
+def check_pass_against_reference_tu(g, gref, prefix, raw, tol=TIGHT, ok=None):
+    """The reference returns the accepted residuals as a list in push order (plane_residuals, optimize.cpp:100-103): the
+    device's accepted keypoints, in keypoint order, must be that list."""
+    acc = g["status"] == 2
+    if ok is None:
+        ok = np.ones(int(acc.sum()), bool)
+    assert int(acc.sum()) == len(gref[f"{prefix}_ref_distance"]) == g["neq"].num_residuals == int(gref[f"{prefix}_ref_num_residuals"])
+    assert g["neq"].success == int(gref[f"{prefix}_ref_success"])
+    assert np.array_equal(raw[acc], gref[f"{prefix}_ref_location"])            # the same keypoints, not just as many
+    for key in ("normal", "weight", "norm_offset", "distance", "jacobian"):
+        assert rel(g[key][acc][ok], gref[f"{prefix}_ref_{key}"][ok]) < tol, key
+    if ok.all():
+        assert rel(g["neq"].loss_sum, float(gref[f"{prefix}_ref_loss"])) < tol
+
+
+@pytest.mark.parametrize("prefix,frame_id,max_res", [("full", 100, INT_MAX), ("cut600", 100, 600), ("init", 5, INT_MAX), ("neg1", 100, -1)])
+def test_one_pass_matches_reference_tu_golden(ctx_small, golden, gref, prefix, frame_id, max_res):
+    g = gpu_pass(ctx_small, golden["raw"], golden["q_pred"], golden["t_pred"], golden["t_last"], frame_id=frame_id, max_num_residuals=max_res)
+    check_pass_against_reference_tu(g, gref, prefix, golden["raw"])
+
+
+@pytest.mark.parametrize("prefix,frame_id,max_res", [("full", 100, INT_MAX), ("cut600", 100, 600), ("init", 5, INT_MAX), ("neg1", 100, -1)])
+def test_full_solve_matches_reference_tu_golden(golden, gref, prefix, frame_id, max_res):
+    """updateIEKF of the reference's src/optimize.cpp:133-314 (compiled in place) vs the device path + host algebra."""
+    with srl.Lio(0) as lio:
+        lio.ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        lio.eskf_set_state(golden[f"{prefix}_eskf_state0"])
+        lio.eskf_set_cov(golden[f"{prefix}_eskf_cov0"])
+        opts = srl.default_opts(max_num_residuals=max_res)
+        r = lio.update_iekf(opts, golden["raw"], golden[f"{prefix}_state0"], golden["t_last"], frame_id=frame_id, log_iters=20)
+        assert (r["rc"] == 0) == (int(gref[f"{prefix}_ref_solve_rc"]) == 1)
+        assert r["num_residuals"] == int(gref[f"{prefix}_ref_solve_num_residuals"])
+        assert rel(r["state"], gref[f"{prefix}_ref_solve_state"]) < TIGHT
+        assert rel(lio.eskf_get_state(), gref[f"{prefix}_ref_solve_eskf_state"]) < TIGHT
+        assert rel(lio.eskf_get_cov(), gref[f"{prefix}_ref_solve_eskf_cov"]) < 1e-8
+
+
+@pytest.mark.parametrize("prefix,kw,frame_id", [("tie", {}, 100), ("tie5", dict(max_number_neighbors=5, min_number_neighbors=5), 100), ("tieinit", {}, 5)])
+def test_tie_scene_neighbours_match_reference_tu_golden(golden, gref, prefix, kw, frame_id):
+    """Neighbour lists on the tie scene = what the real std::priority_queue inside the reference's searchNeighbors left
+    (src/optimize.cpp:394-422, compiled in place): coordinates of the device's ids, in order, bit for bit."""
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(golden["tie_map_keys"], golden["tie_map_counts"], golden["tie_map_xyz"])
+        g = gpu_pass(ctx, golden["tie_raw"], golden["tie_q"], golden["tie_t"], golden["tie_t_last"], frame_id=frame_id, max_num_residuals=INT_MAX, **kw)
+    finally:
+        ctx.close()
+    flat = golden["tie_map_xyz"].reshape(-1, 3)
+    cnt = gref[f"{prefix}_ref_num_neighbors"]
+    assert np.array_equal((g["ids"] >= 0).sum(axis=1), cnt)
+    for i in range(len(cnt)):
+        assert np.array_equal(flat[g["ids"][i, : cnt[i]]], gref[f"{prefix}_ref_neighbors"][i, : cnt[i]]), i
+    # exact-plane lattice neighbourhoods: the normal is well determined only where the eigen-gap is (see eigen_gap)
+    acc = g["status"] == 2
+    gap = eigen_gap(g["ids"], golden["tie_map_xyz"])
+    check_pass_against_reference_tu(g, gref, prefix, golden["tie_raw"], tol=1e-6, ok=(gap[acc] > 1e-6))
+
+
 # ----------------------------------------------------------------------------- one pass vs golden
 @pytest.mark.parametrize("prefix,frame_id,max_res", [("full", 100, INT_MAX), ("cut600", 100, 600), ("init", 5, INT_MAX), ("neg1", 100, -1)])
 def test_one_pass_matches_golden(ctx_small, golden, prefix, frame_id, max_res):
@@ -1333,6 +1399,47 @@ def test_frame_undistort_matches_oracle(oracle_lib, oracle_backend, mode):
             ctx.frame_take(np.array([n], dtype=np.int32))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("mc", [capi.MC_CONSTANT_VELOCITY, capi.MC_IMU])
+def test_replay_driver_matches_the_reference_node_golden(gref, mc):
+    """golden `run{mc}_*` (tests/golden/make_golden_ref.py): the reference's OWN node -- src/lioOptimization.cpp compiled in
+    place: constructor, readParameters, imuHandler, getMeasurements, run, process, buildFrame, stateEstimation, optimize,
+    addPointsToMap -- fed 40 sweeps of sensor streams.  The product's replay driver gets the same streams cut into
+    measurements the way getMeasurements cuts them: frame sizes, residual-driven poses, filter and the final map."""
+    from replay_reference import REPLAY_OO, REPLAY_SEQ, replay_inputs
+    st, parts, gt = replay_inputs()
+    oo = dict(REPLAY_OO, motion_compensation=mc)
+    icp_p = srl.default_opts(max_num_residuals=REPLAY_SEQ["max_num_residuals"])
+    pre = f"run{mc}"
+    lio = srl.Lio(0)
+    try:
+        lio.set_initial_flag(False)
+        lio.set_odometry_options(icp=icp_p, **oo)
+        row = 0
+        for i, ms in enumerate(parts):
+            got = lio.run_measurement(ms["time_frame"], ms["imu_t"], ms["imu_acc"], ms["imu_gyr"], ms["pts_raw"], ms["pts_timestamp"],
+                                      ms["time_sweep_begin"], ms["time_sweep_offset"])
+            assert got["rc"] == 0
+            if not got["processed"]:
+                continue
+            assert i == int(gref[f"{pre}_measurement"][row]) and got["success"]
+            assert got["frame_points"] == int(gref[f"{pre}_frame_points"][row])
+            assert rel(got["state"], gref[f"{pre}_state"][row]) < TIGHT
+            assert rel(lio.eskf_get_state(), gref[f"{pre}_eskf_state"][row]) < TIGHT
+            assert rel(lio.eskf_get_cov(), gref[f"{pre}_eskf_cov"][row]) < 1e-8
+            assert lio.map_size() == int(gref[f"{pre}_map_points"][row])
+            f = lio.last_frame()
+            assert rel(f["raw_point"].sum(0), gref[f"{pre}_raw_sum"][row]) < 1e-11 and rel(f["point"].sum(0), gref[f"{pre}_point_sum"][row]) < TIGHT
+            row += 1
+        assert row == len(gref[f"{pre}_measurement"]) == 9
+        k, c, x = lio.ctx.map_download()
+        order = np.lexsort((k[:, 2], k[:, 1], k[:, 0]))
+        assert np.array_equal(k[order], gref[f"{pre}_map_keys"]) and np.array_equal(c[order], gref[f"{pre}_map_counts"])
+        assert np.array_equal(x[order], gref[f"{pre}_map_xyz"])
+    finally:
+        lio.set_initial_flag(False)
+        lio.close()
 
 
 @pytest.mark.parametrize("mc", [capi.MC_CONSTANT_VELOCITY, capi.MC_IMU])

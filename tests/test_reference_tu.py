@@ -1,7 +1,7 @@
 """The oracle against the REFERENCE'S OWN translation units (CPU; row (c) of SURVEY.md 8).
 
-oracle/_ref/libref_path.so = /root/reference/src/{optimize,eskfEstimator,utility,state,cloudMap}.cpp compiled where they lie
-behind a C ABI (oracle/ref_harness.cpp; third-party headers the image lacks are the stand-ins of oracle/ref_shim/, the voxel
+oracle/_ref/libref_path.so = /root/reference/src/{optimize,lioOptimization,eskfEstimator,utility,state,cloudMap,parameters}.cpp
+compiled where they lie behind a C ABI (oracle/ref_harness.cpp; third-party headers the image lacks are the stand-ins of oracle/ref_shim/, the voxel
 map is the real vendored tsl::robin_map).  Two kinds of tests:
 
   * golden: tests/golden/golden_ref_tu.npz holds outputs of that library on the scenes of golden_small.npz
@@ -10,7 +10,9 @@ map is the real vendored tsl::robin_map).  Two kinds of tests:
   * live (skipped where the prebuilt library is absent): restatement and reference side by side on more inputs --
     searchNeighbors on the tie scene (the neighbour list the real std::priority_queue leaves), computeNeighborhoodDistribution
     incl. the NaN throw, eskfEstimator::predict / observe / tryInit, gridSampling, transformPoint, distortFrameBy*,
-    transformAllImuPoint, numType helpers, optimize(), km-scale coordinates, the truncation seam, empty sweeps.
+    transformAllImuPoint, numType helpers, optimize(), km-scale coordinates, the truncation seam, empty sweeps, and the node
+    itself: its own constructor / readParameters / imuHandler / getMeasurements / run / process / buildFrame / stateEstimation
+    / addPointsToMap on 40 sweeps of sensor streams, stateInitialization, makePointTimestamp.
 
 Bitwise everywhere: with the same third-party arithmetic underneath, the restatement and the reference's source must not
 differ in a single operation.
@@ -350,3 +352,135 @@ def test_far_coordinates_and_truncation_seam_bitwise(oracle_backend):
         r = rm.build_plane_residuals(opts, raw, sw["q_pred"], t_pred, t_last)
         assert_pass_equals(o, r)
         assert o["neq"].num_residuals > 300
+
+
+# ============================================================================== the node itself (src/lioOptimization.cpp)
+def _sorted_map(keys, counts, xyz):
+    order = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
+    return keys[order], counts[order], xyz[order]
+
+
+@pytest.mark.parametrize("mc", [1, 0])
+def test_oracle_replay_reproduces_the_reference_node_run_bitwise(gref, oracle_backend, mc):
+    """golden `run{mc}_*`: the reference's own node -- constructor, readParameters, imuHandler, getMeasurements, run, process,
+    stateInitialization, buildFrame (mt19937_64 shuffles, subSampleFrame), stateEstimation, optimize, addPointsToMap -- fed 40
+    sweeps of sensor streams.  The same loop restated on the oracle's pieces (tests/replay_reference.py) must give the same
+    poses, filter, frames and final map, bit for bit."""
+    from replay_reference import REPLAY_OO, REPLAY_SEQ, OracleReplay, replay_inputs
+    st, parts, gt = replay_inputs()
+    oo = dict(REPLAY_OO, motion_compensation=mc)
+    ref = OracleReplay(po, oracle_backend, oo, po.default_opts(max_num_residuals=REPLAY_SEQ["max_num_residuals"]))
+    pre = f"run{mc}"
+    row = 0
+    for i, ms in enumerate(parts):
+        out = ref.run_measurement(ms)
+        if out is None:
+            continue
+        assert i == int(gref[f"{pre}_measurement"][row]) and ref.frames[-1]["frame_id"] == int(gref[f"{pre}_frame_id"][row])
+        f = ref.frames[-1]
+        assert np.array_equal(f["state"], gref[f"{pre}_state"][row])
+        assert np.array_equal(ref.e.get_state(), gref[f"{pre}_eskf_state"][row]) and np.array_equal(ref.e.get_cov(), gref[f"{pre}_eskf_cov"][row])
+        assert len(f["raw"]) == int(gref[f"{pre}_frame_points"][row]) and ref.m.size() == int(gref[f"{pre}_map_points"][row])
+        assert np.array_equal(f["raw"].sum(0), gref[f"{pre}_raw_sum"][row]) and np.array_equal(f["point"].sum(0), gref[f"{pre}_point_sum"][row])
+        assert np.array_equal(f["imu_point"].sum(0), gref[f"{pre}_imu_sum"][row])
+        row += 1
+    assert row == len(gref[f"{pre}_measurement"]) == 9
+    k, c, x = _sorted_map(*ref.m.export())
+    assert np.array_equal(k, gref[f"{pre}_map_keys"]) and np.array_equal(c, gref[f"{pre}_map_counts"]) and np.array_equal(x, gref[f"{pre}_map_xyz"])
+    # and the estimate follows the motion (odometry frame = first sensor pose)
+    assert np.linalg.norm(ref.frames[-1]["state"][4:7] - gt[len(parts) - 1][1]) < 0.08
+
+
+@live
+@pytest.mark.parametrize("mc,init", [(1, 0), (0, 0), (1, 1)])
+def test_reference_node_run_live(oracle_backend, mc, init):
+    """The same comparison against the live library with full frame contents (and INIT_CONSTANT_VELOCITY)."""
+    from replay_reference import REPLAY_OO, REPLAY_SEQ, OracleReplay, replay_inputs
+    st, parts, _ = replay_inputs()
+    oo = dict(REPLAY_OO, motion_compensation=mc, initialization=init)
+    icp = po.default_opts(max_num_residuals=REPLAY_SEQ["max_num_residuals"])
+    pr.set_params(*pr.params_from_options(oo, icp))
+    node = pr.Node(True)
+    try:
+        node.push_imu(st["imu_t"], st["imu_acc"], st["imu_gyr"])
+        node.push_points(st["pts_raw"], st["pts_timestamp"])
+        for t in st["image_times"]:
+            node.push_image_time(t)
+        ref = OracleReplay(po, oracle_backend, oo, icp)
+        processed = 0
+        for ms in parts:
+            want = ref.run_measurement(ms)
+            info = node.run()
+            assert info["rc"] == 0 and info["index_frame"] == ref.index_frame and info["initial_flag"] == ref.initial_flag
+            assert info["map_points"] == ref.m.size()
+            if want is None:
+                continue
+            processed += 1
+            f = node.last_frame(); fo = ref.frames[-1]
+            assert f["frame_id"] == fo["frame_id"] and f["time_sweep_end"] == fo["time_sweep_end"]
+            for a, b in ((f["state"], fo["state"]), (f["raw_point"], fo["raw"]), (f["imu_point"], fo["imu_point"]), (f["point"], fo["point"])):
+                assert np.array_equal(a, b)
+            s, P = node.eskf()
+            assert np.array_equal(s, ref.e.get_state()) and np.array_equal(P, ref.e.get_cov())
+        assert processed == 9
+        do = pr.map_as_dict(*ref.m.export()); dr = pr.map_as_dict(*node.map_export())
+        assert set(do) == set(dr) and all(np.array_equal(do[k], dr[k]) for k in do)
+    finally:
+        node.close()
+        pr.set_params()
+
+
+@live
+def test_add_points_to_map_is_the_reference_insert(oracle_backend):
+    """lioOptimization::addPointsToMap -> addPointToMap (src/lioOptimization.cpp:399-446,520-554): batches, full voxels, the
+    minimum-distance rule against residents and earlier points of the same batch, min_num_points > 0, +-20 km."""
+    pts, L = synth.map_candidates(556, 80_000)
+    rng = np.random.default_rng(4)
+    for off, min_num in ((np.zeros(3), 0), (np.array([20000.0, -20000.0, 150.0]), 0), (np.zeros(3), 3)):
+        pr.set_params()
+        node = pr.Node(True)
+        om = po.Map(oracle_backend)
+        try:
+            for b in range(5):
+                chunk = pts[rng.permutation(len(pts))[:20_000]] + off
+                mn = min_num if b >= 2 else 0
+                a = om.add_points(chunk, voxel_size=1.0, cap=20, min_dist=0.1, min_num_points=mn)
+                r = node.add_points_to_map(chunk, voxel_size=1.0, cap=20, min_dist=0.1, min_num_points=mn)
+                assert a == r and a > 0
+            do = pr.map_as_dict(*om.export()); dr = pr.map_as_dict(*node.map_export())
+            assert set(do) == set(dr) and all(np.array_equal(do[k], dr[k]) for k in do)
+            assert max(len(v) for v in do.values()) == 20                 # some voxels filled up
+        finally:
+            node.close()
+
+
+@live
+def test_state_initialization_and_point_timestamps_are_the_reference_members(oracle_backend):
+    rng = np.random.default_rng(8)
+    for init in (0, 1):        # the `else` arm (copy the last pose) cannot be selected through readParameters: an unknown string keeps the default
+        pr.set_params(strs={"odometry_options/initialization": pr.INITIALIZATION.get(init, "NONE")})
+        node = pr.Node(True)
+        try:
+            for index_frame in (1, 2, 3, 4, 25):
+                for flag in (False, True):
+                    p2 = np.r_[synth.quat_from_rotvec(rng.normal(0, 0.3, 3)), rng.normal(0, 2, 3)]
+                    p1 = np.r_[synth.quat_from_rotvec(rng.normal(0, 0.3, 3)), rng.normal(0, 2, 3)]
+                    eq = synth.quat_from_rotvec(rng.normal(0, 0.3, 3)); et = rng.normal(0, 2, 3)
+                    qo, to = po.state_initialization(index_frame, init, flag, p2, p1, eq, et, backend=oracle_backend)
+                    qr, tr = node.state_initialization(index_frame, flag, p2, p1, eq, et)
+                    assert np.array_equal(qo, qr) and np.array_equal(to, tr), (init, index_frame, flag)
+        finally:
+            node.close()
+    ts = np.sort(rng.uniform(99.9, 100.25, 5000)); ts[10] = 100.0; ts[-10] = 100.2
+    for enable in (True, False):
+        pr.set_params()
+        node = pr.Node(enable)
+        try:
+            rel_o, al_o, keep_o = po.make_point_timestamp(ts, 100.0, 100.2, enable, backend=oracle_backend)
+            rel_r, al_r, keep_r = node.make_point_timestamp(ts, 100.0, 100.2)
+            assert np.array_equal(np.flatnonzero(keep_o), keep_r)
+            assert np.array_equal(rel_o[keep_o], rel_r) and np.array_equal(al_o[keep_o], al_r)
+            assert (len(keep_r) == len(ts)) == enable
+        finally:
+            node.close()
+    pr.set_params()
