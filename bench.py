@@ -23,6 +23,7 @@ The JSON line also carries
   configs      : every BASELINE configuration (C1..C4), the headline at the shipped max_num_residuals = 600 and the
                  init mode (frame_id < 20: r = 2, >= 16 iterations), each with kernel time, roofline fraction, rate, parity
   cpu_baseline / cpu_baseline_all_cores : the CPU oracle, single thread like the reference and OpenMP over all host cores.
+  cpu_baseline_reference_tu : the same solve through the reference's OWN src/optimize.cpp (oracle/_ref/libref_path.so, prebuilt).
 The oracle is used ONLY for those legs and for the parity figures printed next to the timings.
 """
 import argparse
@@ -200,6 +201,14 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         return ent
     finally:
         lio.close()
+
+
+def eo_last_cov(po, backend, omap, oo, prior_state, prior_cov, sweep, state0, frame_id):
+    """covariance the oracle leaves after the same solve (for the bitwise oracle-vs-reference-TU flag of the bench line)"""
+    eo = po.Eskf(backend)
+    eo.set_state(prior_state); eo.set_cov(prior_cov)
+    po.update_iekf(omap, eo, oo, sweep["raw"], state0, sweep["t_last"], frame_id=frame_id)
+    return eo.get_cov()
 
 
 def main():
@@ -518,6 +527,35 @@ def main():
                                          "speedup_over_1_core": cpu_s / cpu_all}
         out["parity"] = {"state_rel_err_vs_oracle": state_err, "iterations_gpu": iters, "iterations_oracle": ou["rc"],
                          "residuals_gpu": r["num_residuals"], "residuals_oracle": ou["num_residuals"]}
+        # the reference's OWN translation units (oracle/_ref/libref_path.so = /root/reference/src/optimize.cpp & co. compiled in
+        # place against stand-in third-party headers; prebuilt, travels with the tree): the same solve through
+        # lioOptimization::updateIEKF as the reference wrote it.  Checker + baseline only.
+        try:
+            from oracle import pyref as pr
+            if pr.available():
+                rmap = pr.Map.from_oracle(omap)
+                rtimes, ru, re_ = [], None, None
+                t_start = time.perf_counter()
+                while len(rtimes) < 3 and (time.perf_counter() - t_start) < 12.0:
+                    re_ = pr.Eskf()
+                    re_.set_state(prior_state); re_.set_cov(prior_cov)
+                    tc = time.perf_counter()
+                    ru = pr.update_iekf(rmap, re_, oo, sweep["raw"], state0, sweep["t_last"], frame_id=args.frame_id)
+                    rtimes.append(time.perf_counter() - tc)
+                ref_s = float(np.median(rtimes))
+                out["cpu_baseline_reference_tu"] = {
+                    "value": 1.0 / ref_s, "unit": "sweeps/s", "cores": 1, "kind": "reference",
+                    "sample": f"{len(rtimes)} full solves of the same sweep and map through the reference's own lioOptimization::updateIEKF "
+                              f"(src/optimize.cpp compiled in place; third-party arithmetic = the stand-in Eigen of oracle/ref_shim, so this is "
+                              f"not an Eigen-vectorised build); single thread",
+                    "ms_per_solve": ref_s * 1e3}
+                out["parity"]["state_rel_err_vs_reference_tu"] = rel(r["state"], ru["state"])
+                out["parity"]["oracle_equals_reference_tu_bitwise"] = bool(np.array_equal(ou["state"], ru["state"]) and
+                                                                           np.array_equal(re_.get_cov(), eo_last_cov(po, backend, omap, oo, prior_state, prior_cov, sweep, state0, args.frame_id)))
+                out["parity"]["residuals_reference_tu"] = ru["num_residuals"]
+                del rmap
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline_reference_tu"] = {"error": repr(e)}
         del omap
     lio.close()
 
