@@ -122,7 +122,8 @@ def test_one_pass_matches_reference_tu_golden(ctx_small, golden, gref, prefix, f
 @pytest.mark.parametrize("prefix,frame_id,max_res", [("full", 100, INT_MAX), ("cut600", 100, 600), ("init", 5, INT_MAX), ("neg1", 100, -1)])
 def test_full_solve_matches_reference_tu_golden(golden, gref, prefix, frame_id, max_res):
     """updateIEKF of the reference's src/optimize.cpp:133-314 (compiled in place) vs the device path + host algebra."""
-    with srl.Lio(0) as lio:
+    lio = srl.Lio(0)
+    try:
         lio.ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
         lio.eskf_set_state(golden[f"{prefix}_eskf_state0"])
         lio.eskf_set_cov(golden[f"{prefix}_eskf_cov0"])
@@ -133,6 +134,8 @@ def test_full_solve_matches_reference_tu_golden(golden, gref, prefix, frame_id, 
         assert rel(r["state"], gref[f"{prefix}_ref_solve_state"]) < TIGHT
         assert rel(lio.eskf_get_state(), gref[f"{prefix}_ref_solve_eskf_state"]) < TIGHT
         assert rel(lio.eskf_get_cov(), gref[f"{prefix}_ref_solve_eskf_cov"]) < 1e-8
+    finally:
+        lio.close()
 
 
 @pytest.mark.parametrize("prefix,kw,frame_id", [("tie", {}, 100), ("tie5", dict(max_number_neighbors=5, min_number_neighbors=5), 100), ("tieinit", {}, 5)])

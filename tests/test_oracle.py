@@ -1,9 +1,10 @@
 """Pins the CPU oracle (oracle/srl_oracle.cpp) on a CPU-only box.
 
-The reference ships no tests / golden vectors for this path (PARITY UNPINNED), so the
-oracle is pinned by: the known-answer values probed from the reference's own definitions (SURVEY.md
-Appendix D), analytic cases, an independent NumPy/SciPy re-implementation (tests/np_reference.py), the
-build against the real vendored tsl::robin_map (oracle/_ref), and the committed golden vectors.
+The reference ships no tests / golden vectors for this path.  The oracle is pinned bitwise against
+the reference's own translation units compiled in place (tests/test_reference_tu.py); this file holds the checks
+that do not need them: the known-answer values probed from the reference's own definitions,
+analytic cases, an independent NumPy/SciPy re-implementation (tests/np_reference.py), the build against the real
+vendored tsl::robin_map (oracle/_ref), and the committed golden vectors.
 """
 import os
 
