@@ -373,6 +373,21 @@ __device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, cons
     return nv_a | (nv_b << 8);
 }
 
+// where the selected neighbours go: the workgroup's neighbour planes in LDS (and the parity tap)
+struct LdsSink {
+    float *col;         // &nbx[0][kl]; planes x | y | z, each K rows of `row` floats
+    int row;            // KPW + 1
+    int plane;          // K * row
+    int *tap_ids;       // global row or null
+    __device__ __forceinline__ void put(int rank, float x, float y, float z, unsigned id) {
+        float *p = col + rank * row;
+        p[0] = x;
+        p[plane] = y;
+        p[2 * plane] = z;
+        if (tap_ids) tap_ids[rank] = (int)id;
+    }
+};
+
 // ---- fast exact top-K, FP32 prefilter variant (default for r = 1) -----------------------------------
 // Only the ~25 survivors of a conservative FP32 threshold are ever evaluated in FP64:
 //   pass 1  : coalesced 12-B loads (all rounds in flight), d2f = |p - fl32(q)|^2 in FP32 (FMA allowed: it
@@ -384,6 +399,7 @@ __device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, cons
 //   exact   : lane i < c evaluates survivor i's d2 in FP64 with the reference's operation order
 //             ((dx*dx + dy*dy) + dz*dz, no FMA), strict rank by counting, clash check, emit from registers.
 struct alignas(16) SurvRec { float x, y, z; int code; };
+#define SRL_PAIR_MAX_ROUNDS 4          // keypoint pairs with at most this many candidate rounds each are selected with both in flight
 
 __device__ __forceinline__ float d2_f32(float px, float py, float pz, float qx, float qy, float qz) {
 #pragma clang fp contract(fast)
@@ -455,17 +471,15 @@ __device__ __forceinline__ int finish_survivors(double qx, double qy, double qz,
     return SEL_DONE;
 }
 
-// R = compile-time number of candidate rounds (3 voxels each): straight-line code, arrays stay in registers
-template <int R, class Sink>
-__device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
-                                                  const unsigned char *slabs, unsigned inf_off, int K, void *scratch, int lane,
-                                                  const LaneRole &role, Sink &sink, int &total_out, int ablate) {
-    const float kInfF = __builtin_huge_valf();
-    const float qxf = qf[0], qyf = qf[1], qzf = qf[2];      // FP32 query and margin coefficients, prepared in phase 0
-    float px[R], py[R], pz[R];
+// R = compile-time number of candidate rounds (3 voxels each): straight-line code, arrays stay in registers.
+// cand_issue puts every round's coalesced 12-B load in flight; cand_select consumes them.  They are separate so that a keypoint
+// PAIR can have both keypoints' loads in flight before the first one is worked on (select_pair_f32_r): the second keypoint's
+// L2 / MALL round trip then hides behind the first one's bisection and FP64 finish.
+template <int R>
+__device__ __forceinline__ void cand_issue(const VoxEnt *vox, const unsigned char *slabs, unsigned inf_off, const LaneRole &role,
+                                           float (&px)[R], float (&py)[R], float (&pz)[R], int &total_out) {
     // all voxel entries (branch-free LDS reads; the list is zero-filled up to 27 entries), then every round's
     // coalesced 12-B load, all in flight before the first use.
-    (void)nv;
     VoxEnt ve[R];
     const int cbase = role.c0 < 3 ? role.c0 : 0;
 #pragma unroll
@@ -488,41 +502,36 @@ __device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz
         const float *p = reinterpret_cast<const float *>(slabs + off[j]);
         px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
     }
-    float d2f[R];
-    float lmin = kInfF;
+    total_out = total;
+}
+
+// FP32 distances of one keypoint's rounds and their per-lane minimum
+template <int R>
+__device__ __forceinline__ float cand_d2f(const float (&px)[R], const float (&py)[R], const float (&pz)[R], const float *qf, float (&d2f)[R]) {
+    const float qxf = qf[0], qyf = qf[1], qzf = qf[2];      // FP32 query, prepared in phase 0
+    float lmin = __builtin_huge_valf();
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         d2f[j] = d2_f32(px[j], py[j], pz[j], qxf, qyf, qzf);
         lmin = fminf(lmin, d2f[j]);
     }
-    total_out = total;
-
-    const unsigned v = __float_as_uint(lmin);
-    unsigned lo = 0;
-#pragma unroll
-    for (int bit = 30; bit >= 18; --bit) {
-        const unsigned trial = lo | (1u << bit);
-        const int cnt = __popcll(__ballot(v < trial));
-        lo = (cnt < K) ? trial : lo;
-    }
+    return lmin;
+}
+// FP32 error model: a = abs error of fl32(q) per axis; per-axis difference error <= a + u*|d|; sum of
+// squares (3 terms, FMA or not) adds <= 4u relative.  For d2, d2f <= T:  |d2f - d2| <= m(T) with
+//   m(T) = 4 a sqrt(T) + 8 u T + 4 a^2   (u = 2^-24), evaluated at T = 2 tau_f + 1e-6 with sqrt(T) replaced by
+//   its upper bound (T + 1) / 2 (AM-GM; no transcendental), and doubled: linear in tau_f, coefficients from phase 0.
+// Fewer than K candidates: every candidate survives (FLT_MAX; empty lanes hold +inf and never pass).
+__device__ __forceinline__ float thr_from_bisection(unsigned lo, const float *qf) {
     const float tau_f = __uint_as_float(lo | 0x3FFFFu);   // >= K candidates have d2f <= tau_f (if that many exist)
-    // FP32 error model: a = abs error of fl32(q) per axis; per-axis difference error <= a + u*|d|; sum of
-    // squares (3 terms, FMA or not) adds <= 4u relative.  For d2, d2f <= T:  |d2f - d2| <= m(T) with
-    //   m(T) = 4 a sqrt(T) + 8 u T + 4 a^2   (u = 2^-24), evaluated at T = 2 tau_f + 1e-6 with sqrt(T) replaced by
-    //   its upper bound (T + 1) / 2 (AM-GM; no transcendental), and doubled: linear in tau_f, coefficients from phase 0.
-    // Fewer than K candidates: every candidate survives (FLT_MAX; empty lanes hold +inf and never pass).
     float thr = 3.4028235e38f;
-    if (tau_f < kInfF) thr = qf[3] + qf[4] * tau_f;      // (tau + 2 m(2 tau + 1e-6)) (1 + eps), linear in tau
-
-    SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));            // [64], 16-B aligned
-    unsigned long long svm[R];
-    int c = 0;
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        svm[j] = __ballot(d2f[j] <= thr);
-        c += __popcll(svm[j]);
-    }
-    if (c > 64) return SEL_OVERFLOW;       // checked before anything is written: the stores below need no clamp
+    if (tau_f < __builtin_huge_valf()) thr = qf[3] + qf[4] * tau_f;      // (tau + 2 m(2 tau + 1e-6)) (1 + eps), linear in tau
+    return thr;
+}
+// survivors of all rounds, compacted in visit order into recs[0 ..)
+template <int R>
+__device__ __forceinline__ void cand_compact(const float (&px)[R], const float (&py)[R], const float (&pz)[R], const float (&d2f)[R], float thr,
+                                             const unsigned long long (&svm)[R], const LaneRole &role, SurvRec *recs) {
     const int code0 = (role.c0 << 5) | role.slot;
     int base = 0;
 #pragma unroll
@@ -535,8 +544,150 @@ __device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz
             base += __popcll(svm[j]);
         }
     }
+}
+
+template <int R, class Sink>
+__device__ __forceinline__ int cand_select(const float (&px)[R], const float (&py)[R], const float (&pz)[R], double qx, double qy, double qz,
+                                           const float *qf, const VoxEnt *vox, int K, void *scratch, int lane, const LaneRole &role, Sink &sink,
+                                           int ablate) {
+    float d2f[R];
+    const unsigned v = __float_as_uint(cand_d2f<R>(px, py, pz, qf, d2f));
+    unsigned lo = 0;
+#pragma unroll
+    for (int bit = 30; bit >= 18; --bit) {
+        const unsigned trial = lo | (1u << bit);
+        const int cnt = __popcll(__ballot(v < trial));
+        lo = (cnt < K) ? trial : lo;
+    }
+    const float thr = thr_from_bisection(lo, qf);
+    SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));            // [64], 16-B aligned
+    unsigned long long svm[R];
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        svm[j] = __ballot(d2f[j] <= thr);
+        c += __popcll(svm[j]);
+    }
+    if (c > 64) return SEL_OVERFLOW;       // checked before anything is written: the stores below need no clamp
+    cand_compact<R>(px, py, pz, d2f, thr, svm, role, recs);
     if (ablate & 2) return SEL_DONE;
     return finish_survivors(qx, qy, qz, c, vox, K, scratch, lane, sink);
+}
+
+template <int R, class Sink>
+__device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz, const float *qf, int nv, const VoxEnt *vox,
+                                                  const unsigned char *slabs, unsigned inf_off, int K, void *scratch, int lane,
+                                                  const LaneRole &role, Sink &sink, int &total_out, int ablate) {
+    (void)nv;
+    float px[R], py[R], pz[R];
+    cand_issue<R>(vox, slabs, inf_off, role, px, py, pz, total_out);
+    return cand_select<R>(px, py, pz, qx, qy, qz, qf, vox, K, scratch, lane, role, sink, ablate);
+}
+
+// FP64 finish of a keypoint PAIR with at most 32 survivors each (the usual case: ~25): half-wave h works on keypoint h --
+// lane (h, i) evaluates survivor i of its keypoint exactly and counts the 32 keys of its own keypoint below it.  Same
+// arithmetic, ranks and tie rule as finish_survivors; the fixed part (LDS round trips, rank filing, tie check, emission)
+// is paid once per pair instead of once per keypoint.  Scratch: recs[64] (A: 0..31, B: 32..63) | keys[64] | sorted[64].
+// Needs K <= 31 (rank K is filed too).  Returns done_a | done_b << 8.
+__device__ __forceinline__ int finish_pair(const double *qa, const double *qb, int ca, int cb, const VoxEnt *vox, int K, void *scratch, int lane,
+                                           const LdsSink &sink_a, const LdsSink &sink_b) {
+    SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));
+    double *keys = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024);
+    double *sorted = keys + 64;
+    __builtin_amdgcn_wave_barrier();
+    const int h = lane >> 5, i = lane & 31;
+    const int c = h ? cb : ca;
+    const bool act = i < c;
+    const double *q = h ? qb : qa;
+    SurvRec me;
+    me.x = me.y = me.z = 0.0f; me.code = 0;
+    double my = __builtin_huge_val();
+    if (act) {
+        me = recs[lane];
+        const double dx = (double)me.x - q[0];
+        const double dy = (double)me.y - q[1];
+        const double dz = (double)me.z - q[2];
+        my = (dx * dx + dy * dy) + dz * dz;          // the reference's evaluation order (optimize.cpp:394-395)
+    }
+    keys[lane] = my;                                  // slots >= c hold +inf and never count
+    sorted[lane] = __builtin_nan("");                 // "nobody holds this rank", both keypoints
+    __builtin_amdgcn_wave_barrier();
+    const double2 *kp = reinterpret_cast<const double2 *>(keys + 32 * h);
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double2 kk = kp[j];
+        rank += (kk.x < my) ? 1 : 0;
+        rank += (kk.y < my) ? 1 : 0;
+    }
+    const bool win = act && rank < K;
+    if (act && rank <= K) sorted[32 * h + rank] = my;
+    __builtin_amdgcn_wave_barrier();
+    bool bad = false;
+    if (i >= 1 && i <= K && i < c) bad = !(sorted[32 * h + i] > sorted[32 * h + i - 1] * SRL_NEAR_TIE);
+    const unsigned long long bm = __ballot(bad);
+    const bool tie_a = (unsigned)bm != 0u, tie_b = (unsigned)(bm >> 32) != 0u;
+    if (win && !(h ? tie_b : tie_a)) {
+        const VoxEnt ve = vox[32 * h + (me.code >> 5)];
+        LdsSink s = sink_a;
+        if (h) { s.col = sink_b.col; s.tap_ids = sink_b.tap_ids; }
+        s.put(rank, me.x, me.y, me.z, ve.slab * SRL_CAP + ((unsigned)me.code & 31u));
+    }
+    __builtin_amdgcn_wave_barrier();
+    return (tie_a ? SEL_TIE : SEL_DONE) | ((tie_b ? SEL_TIE : SEL_DONE) << 8);
+}
+
+// Both keypoints of a pair with R rounds each (R = the larger of the two round counts: the shorter list is zero-filled, its
+// extra rounds read the all-inf slab).  The two keypoints' loads are in flight together, their bisections run as two
+// independent dependency chains in the same instruction stream, and -- when both have at most 32 survivors -- one FP64
+// finish serves both (finish_pair).  Returns done_a | done_b << 8.
+template <int R>
+__device__ __forceinline__ int select_pair_f32_r(const double *qa, const double *qb, const float *qfa, const float *qfb, const VoxEnt *vox,
+                                                 const unsigned char *slabs, unsigned inf_off, int K, void *scratch, int lane,
+                                                 const LaneRole &role, LdsSink &sink_a, LdsSink &sink_b, int &total_a, int &total_b, int ablate) {
+    float ax[R], ay[R], az[R], bx[R], by[R], bz[R];
+    cand_issue<R>(vox, slabs, inf_off, role, ax, ay, az, total_a);
+    cand_issue<R>(vox + 32, slabs, inf_off, role, bx, by, bz, total_b);
+    float da[R], db[R];
+    const unsigned va = __float_as_uint(cand_d2f<R>(ax, ay, az, qfa, da));
+    const unsigned vb = __float_as_uint(cand_d2f<R>(bx, by, bz, qfb, db));
+    unsigned lo_a = 0, lo_b = 0;
+#pragma unroll
+    for (int bit = 30; bit >= 18; --bit) {
+        const unsigned ta = lo_a | (1u << bit), tb = lo_b | (1u << bit);
+        const int cnt_a = __popcll(__ballot(va < ta));
+        const int cnt_b = __popcll(__ballot(vb < tb));
+        lo_a = (cnt_a < K) ? ta : lo_a;
+        lo_b = (cnt_b < K) ? tb : lo_b;
+    }
+    const float thr_a = thr_from_bisection(lo_a, qfa), thr_b = thr_from_bisection(lo_b, qfb);
+    unsigned long long sa[R], sb[R];
+    int ca = 0, cb = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        sa[j] = __ballot(da[j] <= thr_a);
+        sb[j] = __ballot(db[j] <= thr_b);
+        ca += __popcll(sa[j]);
+        cb += __popcll(sb[j]);
+    }
+    SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));
+    if (ca <= 32 && cb <= 32 && K <= 31 && !(ablate & (2 | 512))) {
+        cand_compact<R>(ax, ay, az, da, thr_a, sa, role, recs);
+        cand_compact<R>(bx, by, bz, db, thr_b, sb, role, recs + 32);
+        return finish_pair(qa, qb, ca, cb, vox, K, scratch, lane, sink_a, sink_b);
+    }
+    // one after the other through the single-keypoint finish (more than 32 survivors, K = 32, or a debug switch)
+    int done_a = SEL_OVERFLOW, done_b = SEL_OVERFLOW;
+    if (ca <= 64) {
+        cand_compact<R>(ax, ay, az, da, thr_a, sa, role, recs);
+        done_a = (ablate & 2) ? SEL_DONE : finish_survivors(qa[0], qa[1], qa[2], ca, vox, K, scratch, lane, sink_a);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (cb <= 64) {
+        cand_compact<R>(bx, by, bz, db, thr_b, sb, role, recs);
+        done_b = (ablate & 2) ? SEL_DONE : finish_survivors(qb[0], qb[1], qb[2], cb, vox + 32, K, scratch, lane, sink_b);
+    }
+    return done_a | (done_b << 8);
 }
 
 template <class Sink>
@@ -836,19 +987,6 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, i
     return L;
 }
 
-struct LdsSink {
-    float *col;         // &nbx[0][kl]; planes x | y | z, each K rows of `row` floats
-    int row;            // KPW + 1
-    int plane;          // K * row
-    int *tap_ids;       // global row or null
-    __device__ __forceinline__ void put(int rank, float x, float y, float z, unsigned id) {
-        float *p = col + rank * row;
-        p[0] = x;
-        p[plane] = y;
-        p[2 * plane] = z;
-        if (tap_ids) tap_ids[rank] = (int)id;
-    }
-};
 
 // butterfly add inside groups of 4 lanes (sub-lanes of one keypoint): all 4 lanes end with the same bits
 __device__ __forceinline__ double quad_sum(double v) {
@@ -991,23 +1129,36 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
                 const ProbeReq creq = preq;
                 if (!(a.ablate & 32)) preq = probe_issue(s_kv, 2 * (nxt < npairs ? nxt : npairs), role, a.table, a.table_mask, lane);
                 const int nv_pair = __builtin_amdgcn_readfirstlane((a.ablate & 8) ? 0 : probe_finish(creq, a.thr_cap, a.table, a.table_mask, vox, lane));
+                auto file = [&](int kl, int done, int total) {        // lane 0: result of one keypoint
+                    if (done == SEL_DONE) {
+                        s_nfound[kl] = total < a.K ? total : a.K;
+                        s_ncand[kl] = total;
+                    } else {
+                        s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)(kl | (done == SEL_TIE ? 0x8000 : 0));
+                    }
+                };
+                const int r_a = ((nv_pair & 0xFF) + 2) / 3, r_b = ((nv_pair >> 8) + 2) / 3;
+                const int r_max = r_a > r_b ? r_a : r_b;
+                if (2 * cur + 1 < n_here && r_max <= SRL_PAIR_MAX_ROUNDS && !(a.ablate & (4 | 256))) {
+                    // both keypoints exist and their candidate rounds fit in registers together: B's loads fly while A is selected
+                    const int kl = 2 * cur;
+                    LdsSink sink_a = make_sink(kl), sink_b = make_sink(kl + 1);
+                    int total_a = 0, total_b = 0, done;
+                    if (r_max <= 3) done = select_pair_f32_r<3>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, a.slabs, a.inf_off, a.K, surv, lane, role, sink_a, sink_b, total_a, total_b, a.ablate);
+                    else done = select_pair_f32_r<4>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, a.slabs, a.inf_off, a.K, surv, lane, role, sink_a, sink_b, total_a, total_b, a.ablate);
+                    if (lane == 0) { file(kl, done & 0xFF, total_a); file(kl + 1, done >> 8, total_b); }
+                } else {
 #pragma nounroll
-                for (int h = 0; h < 2; ++h) {
-                    const int kl = 2 * cur + h;
-                    if (kl >= n_here) break;
-                    const int nv_fast = h ? (nv_pair >> 8) : (nv_pair & 0xFF);
-                    const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
-                    LdsSink sink = make_sink(kl);
-                    int total = nv_fast;
-                    int done = SEL_DONE;
-                    if (!(a.ablate & 4)) done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv_fast, vox + 32 * h, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
-                    if (lane == 0) {
-                        if (done == SEL_DONE) {
-                            s_nfound[kl] = total < a.K ? total : a.K;
-                            s_ncand[kl] = total;
-                        } else {
-                            s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)(kl | (done == SEL_TIE ? 0x8000 : 0));
-                        }
+                    for (int h = 0; h < 2; ++h) {
+                        const int kl = 2 * cur + h;
+                        if (kl >= n_here) break;
+                        const int nv_fast = h ? (nv_pair >> 8) : (nv_pair & 0xFF);
+                        const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
+                        LdsSink sink = make_sink(kl);
+                        int total = nv_fast;
+                        int done = SEL_DONE;
+                        if (!(a.ablate & 4)) done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv_fast, vox + 32 * h, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
+                        if (lane == 0) file(kl, done, total);
                     }
                 }
                 cur = nxt;
