@@ -1214,45 +1214,53 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
 #else
     const SrlAssocArgs &b = a;
 #endif
-    // ---------------- phase 2: plane fit + residual + Jacobian for this wave's 16 keypoints, 4 lanes each.
-    // Sub-lane s accumulates neighbours s, s+4, ...; quad butterflies make the sums identical in the 4 lanes,
-    // which then run the (scalar) eigen-solve / weights redundantly and split the 28 H^T H / H^T h / loss
-    // products between them (7 each) before the sum over keypoints.
-    // Phase 2 always runs with full waves: the workgroup's KPB keypoints fill P2W = KPB / 16 waves (16 keypoints x 4 lanes);
-    // with KPW < 16 the remaining waves have nothing to do here (before, every wave ran the ~800 instructions of this phase
-    // with 4 * KPW of its 64 lanes).  Which waves work rotates with the workgroup index, so that the phase-2 waves of the
-    // workgroups sharing a CU sit on different SIMDs.
-    constexpr int P2W = KPB / 16;
+    // ---------------- phase 2: plane fit + residual + Jacobian.  LPK lanes per keypoint: ONE when the workgroup has at least
+    // 48 keypoints (its KPB keypoints then fill ceil(KPB / 64) waves and the other waves have nothing to do here), two / four
+    // for workgroups of 32 / 16 keypoints (one wave either way; the lanes of a keypoint split its neighbours and butterfly the
+    // sums, so the serial chain stays short where there is nothing to amortise).  Until round 2 every keypoint had four
+    // lanes that ran the scalar part -- eigen-decomposition, weights, gate, Jacobian: most of this phase -- redundantly, so 16
+    // keypoints cost a wave ~800 instructions: 16 waves x 800 per 256 keypoints against 4 x ~700 now (headline: -3 us).
+    // Which waves work rotates with the workgroup index, so that the phase-2 waves of workgroups sharing a CU sit on
+    // different SIMDs.  With one lane per keypoint the neighbour-plane reads are conflict-free and the barycentre / scatter
+    // sums run sequentially over the neighbours, the reference's own order (optimize.cpp:320-337).
+    constexpr int LPK = KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4);                         // lanes per keypoint
+    constexpr int KP2 = 64 / LPK;                                                   // keypoints per phase-2 wave
+    constexpr int P2W = (KPB + KP2 - 1) / KP2;
     const int w2 = (wave + WPB - (int)(blockIdx.x % WPB)) % WPB;                    // phase-2 slot of this wave
     const bool p2_wave = w2 < P2W;
-    const int klw = lane >> 2, sl = lane & 3;                                      // keypoint inside this wave's 16
-    const int kl = (p2_wave ? w2 : 0) * 16 + klw;                                   // ... and inside the workgroup
-    const bool owner_lane = p2_wave;
+    const int klw = lane / LPK, sl = lane % LPK;                                    // keypoint inside this wave, sub-lane
+    const int kl = (p2_wave ? w2 : 0) * KP2 + klw;                                  // keypoint inside the workgroup
+    const bool owner_lane = p2_wave && kl < KPB;
     const int g = owner_lane ? bbase_kp + kl : b.n;
+    // sum over the LPK lanes of a keypoint (butterfly: all of them end with the same bits)
+    auto lpk_sum = [](double v) {
+        if (LPK >= 2) v += __shfl_xor(v, 1);
+        if (LPK >= 4) v += __shfl_xor(v, 2);
+        return v;
+    };
     int status = 3;
     bool nan_bad = false;
     double J[6] = {0, 0, 0, 0, 0, 0};
     double dist = 0.0, weight = 0.0;
-    const int nf = s_nfound[kl];
+    const int nf = owner_lane ? s_nfound[kl] : 0;
     if (g < b.n) status = 0;
     const bool fit = (g < b.n) && (nf >= b.min_nb) && !(b.ablate & 1);
-    // the butterflies need all four sub-lanes of a quad active together: `fit` is uniform inside a quad
     if (fit) {
 #pragma clang fp contract(fast)      // plane fit / weights / Jacobian are tolerance-bound (1e-9 vs the oracle): products may fuse
         const D3 p_imu = d3(s_pimu[kl * 3 + 0], s_pimu[kl * 3 + 1], s_pimu[kl * 3 + 2]);
         const D3 p_w = d3(s_pw[kl * 3 + 0], s_pw[kl * 3 + 1], s_pw[kl * 3 + 2]);
         // barycenter (optimize.cpp:320-325)
         D3 bc = d3(0, 0, 0);
-        for (int i = sl; i < nf; i += 4) {
+        for (int i = sl; i < nf; i += LPK) {
             const float *p = s_nb + i * NB_ROW + kl;
             bc = add(bc, d3((double)p[0], (double)p[nb_plane], (double)p[2 * nb_plane]));
         }
-        bc = d3(quad_sum(bc.x), quad_sum(bc.y), quad_sum(bc.z));
+        bc = d3(lpk_sum(bc.x), lpk_sum(bc.y), lpk_sum(bc.z));
         const double icnt = rcp_nr((double)nf);
         bc = d3(bc.x * icnt, bc.y * icnt, bc.z * icnt);
         // scatter matrix, upper triangle (optimize.cpp:328-337)
         double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-        for (int i = sl; i < nf; i += 4) {
+        for (int i = sl; i < nf; i += LPK) {
             const float *p = s_nb + i * NB_ROW + kl;
             const double ex = (double)p[0] - bc.x, ey = (double)p[nb_plane] - bc.y, ez = (double)p[2 * nb_plane] - bc.z;
             c00 += ex * ex; c01 += ex * ey; c02 += ex * ez;
@@ -1260,8 +1268,8 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             c22 += ez * ez;
         }
         double C[3][3];
-        C[0][0] = quad_sum(c00); C[0][1] = quad_sum(c01); C[0][2] = quad_sum(c02);
-        C[1][1] = quad_sum(c11); C[1][2] = quad_sum(c12); C[2][2] = quad_sum(c22);
+        C[0][0] = lpk_sum(c00); C[0][1] = lpk_sum(c01); C[0][2] = lpk_sum(c02);
+        C[1][1] = lpk_sum(c11); C[1][2] = lpk_sum(c12); C[2][2] = lpk_sum(c22);
         C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
         double ev[3];
         D3 nrm;
@@ -1304,49 +1312,49 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             J[3] = s0 * weight; J[4] = s1 * weight; J[5] = s2 * weight;
         }
     }
-    if (g < b.n && b.write_rec) {
-        // per-keypoint record {J[6], distance, weight} (ordered cut-off path + taps): the four lanes of a quad hold
-        // identical values, so sub-lane s stores doubles 2s, 2s+1 -- one fully coalesced 16-B store per lane
-        // (1 KB per wave) instead of eight scattered 8-B stores.
+    if (g < b.n && b.write_rec && sl == 0) {
+        // per-keypoint record {J[6], distance, weight} (ordered cut-off path + taps; never on the throughput path)
+        double2 *r = reinterpret_cast<double2 *>(b.rec + (size_t)g * 8);
         double2 v;
-        v.x = (sl == 0) ? J[0] : ((sl == 1) ? J[2] : ((sl == 2) ? J[4] : dist));
-        v.y = (sl == 0) ? J[1] : ((sl == 1) ? J[3] : ((sl == 2) ? J[5] : weight));
-        *reinterpret_cast<double2 *>(b.rec + (size_t)g * 8 + 2 * sl) = v;
-        if (sl == 0) {
-            b.status[g] = (unsigned char)status;
-            if (b.tap_ncand) b.tap_ncand[g] = s_ncand[kl];
+        v.x = J[0]; v.y = J[1]; r[0] = v;
+        v.x = J[2]; v.y = J[3]; r[1] = v;
+        v.x = J[4]; v.y = J[5]; r[2] = v;
+        v.x = dist; v.y = weight; r[3] = v;
+        b.status[g] = (unsigned char)status;
+        if (b.tap_ncand) b.tap_ncand[g] = s_ncand[kl];
+    }
+
+    if (b.rec_granules != nullptr && owner_lane && sl == 0) {
+        // fused ordered cut (4.2): the record {J[6], distance, weight} of every keypoint of this workgroup travels as 16 tagged
+        // granules (double d = granules 2d, 2d + 1); zeros unless accepted -- also for the keypoints behind the end of the sweep
+        typedef __attribute__((address_space(1))) unsigned long long gu64r;
+        const bool accd = status == 2;
+        const double rec8[8] = {J[0], J[1], J[2], J[3], J[4], J[5], dist, weight};
+        const unsigned long long tag = (unsigned long long)(unsigned)b.seq << 32;
+        gu64r *dst = (gu64r *)(b.rec_granules + ((size_t)blockIdx.x * KPB + kl) * 16);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const unsigned long long bits = accd ? (unsigned long long)__double_as_longlong(rec8[d]) : 0ull;
+            __hip_atomic_store(dst + 2 * d, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 2 * d + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 
-    if (b.rec_granules != nullptr && p2_wave) {
-        // fused ordered cut (4.2): the record {J[6], distance, weight} of every keypoint of this workgroup travels as 16 tagged
-        // granules (sub-lane s holds doubles 2s, 2s + 1 = granules 4s .. 4s + 3); zeros unless accepted
-        typedef __attribute__((address_space(1))) unsigned long long gu64r;
-        double v0 = (sl == 0) ? J[0] : ((sl == 1) ? J[2] : ((sl == 2) ? J[4] : dist));
-        double v1 = (sl == 0) ? J[1] : ((sl == 1) ? J[3] : ((sl == 2) ? J[5] : weight));
-        if (status != 2) { v0 = 0.0; v1 = 0.0; }
-        const unsigned long long tag = (unsigned long long)(unsigned)b.seq << 32;
-        const unsigned long long b0 = (unsigned long long)__double_as_longlong(v0), b1 = (unsigned long long)__double_as_longlong(v1);
-        gu64r *dst = (gu64r *)(b.rec_granules + ((size_t)blockIdx.x * KPB + kl) * 16 + 4 * sl);
-        __hip_atomic_store(dst + 0, tag | (b0 & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, tag | (b0 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 2, tag | (b1 & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 3, tag | (b1 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
-    // ---- wave partial of H^T H (21 upper-tri), H^T h (6), loss (1).  Every accepted keypoint leaves the row
-    // {J[0..5], h, distance} in LDS (zeros otherwise); lane c < 28 then owns component c and walks the 16 keypoints in
-    // order -- two LDS reads, one multiply, one add each, no cross-lane traffic, fixed summation order.
+    // ---- wave partial of H^T H (21 upper-tri), H^T h (6), loss (1).  Every keypoint of the wave leaves the row
+    // {J[0..5], h, distance} in LDS (zeros unless accepted); lane c < 28 then owns component c and walks the KP2 rows in
+    // keypoint order -- two LDS reads, one multiply, one add each, no cross-lane traffic, fixed summation order.
     if (p2_wave) {
-        double *s_row = reinterpret_cast<double *>(surv);            // [16][8], phase-1 scratch is free now
+        // KP2 rows x 8 doubles per phase-2 wave in the per-wave regions of phase 1 (free behind the barrier above)
+        static_assert(P2W * KP2 * 64 <= WPB * (64 * 8 + SRL_WAVE_SCRATCH), "phase-2 rows must fit in the phase-1 per-wave regions");
+        double *s_row = reinterpret_cast<double *>(smem + L.off_wave) + w2 * (KP2 * 8);
         const bool accd = status == 2;
-        if (owner_lane && sl < 2) {
-            // sub-lane 0 stores J[0..3], sub-lane 1 stores J[4], J[5], h, distance (optimize.cpp:169,104)
-            const double h = dist * weight;
+        if (sl == 0) {
+            const double h = dist * weight;                      // optimize.cpp:169
             double4 v;
-            v.x = sl == 0 ? J[0] : J[4]; v.y = sl == 0 ? J[1] : J[5]; v.z = sl == 0 ? J[2] : h; v.w = sl == 0 ? J[3] : dist;
-            if (!accd) { v.x = 0.0; v.y = 0.0; v.z = 0.0; v.w = 0.0; }
-            *reinterpret_cast<double4 *>(s_row + klw * 8 + 4 * sl) = v;
+            v.x = accd ? J[0] : 0.0; v.y = accd ? J[1] : 0.0; v.z = accd ? J[2] : 0.0; v.w = accd ? J[3] : 0.0;
+            *reinterpret_cast<double4 *>(s_row + klw * 8) = v;
+            v.x = accd ? J[4] : 0.0; v.y = accd ? J[5] : 0.0; v.z = accd ? h : 0.0; v.w = accd ? dist : 0.0;
+            *reinterpret_cast<double4 *>(s_row + klw * 8 + 4) = v;
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < 28) {
@@ -1360,16 +1368,34 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             } else if (lane < 27) { ia = lane - 21; ib = 6; }
             else { ia = 7; ib = 7; }
             double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc += s_row[k * 8 + ia] * s_row[k * 8 + ib];
+#pragma unroll 16
+            for (int k = 0; k < KP2; ++k) acc += s_row[k * 8 + ia] * s_row[k * 8 + ib];
             s_wpart[w2 * 32 + lane] = acc;
         }
     }
     {
+        // one bit per keypoint: the ballot has the keypoint's bit at lane klw * LPK
+        auto per_keypoint = [](unsigned long long m) {
+            if (LPK == 2) {
+                m &= 0x5555555555555555ull;
+                m = (m | (m >> 1)) & 0x3333333333333333ull;
+                m = (m | (m >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+                m = (m | (m >> 4)) & 0x00FF00FF00FF00FFull;
+                m = (m | (m >> 8)) & 0x0000FFFF0000FFFFull;
+                m = (m | (m >> 16)) & 0x00000000FFFFFFFFull;
+            } else if (LPK == 4) {
+                m &= 0x1111111111111111ull;
+                m = (m | (m >> 3)) & 0x0303030303030303ull;
+                m = (m | (m >> 6)) & 0x000F000F000F000Full;
+                m = (m | (m >> 12)) & 0x000000FF000000FFull;
+                m = (m | (m >> 24)) & 0xFFFFull;
+            }
+            return m;
+        };
         const unsigned long long acc_mask = __ballot(status == 2 && sl == 0);
         const unsigned long long nan_mask = __ballot(nan_bad);
         const unsigned long long pln_mask = __ballot((status == 1 || status == 2) && sl == 0);
-        int pk = (p2_wave && lane < 16 && bbase_kp + w2 * 16 + lane < b.n) ? s_ncand[w2 * 16 + lane] : 0;
+        int pk = (g < b.n && sl == 0) ? s_ncand[kl] : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
         if (lane == 0) {
@@ -1377,16 +1403,13 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             if (p2_wave) {                                       // phase-2 results, filed under the phase-2 slot
                 s_winfo[w2 * 8 + 0] = __popcll(acc_mask);
                 s_winfo[w2 * 8 + 1] = pk;
-                // first NaN keypoint of these 16 as 1 + index inside the workgroup (quad q = keypoint w2 * 16 + q)
-                s_winfo[w2 * 8 + 2] = nan_mask ? 1 + w2 * 16 + ((int)__builtin_ctzll(nan_mask) >> 2) : 0;
+                // first NaN keypoint of this wave as 1 + index inside the workgroup
+                s_winfo[w2 * 8 + 2] = nan_mask ? 1 + w2 * KP2 + (int)__builtin_ctzll(nan_mask) / LPK : 0;
                 s_winfo[w2 * 8 + 4] = __popcll(pln_mask);
-                // accepted keypoints of these 16 as a 16-bit mask (ballot bits sit at lanes 4q: gather every 4th bit)
-                unsigned long long x = acc_mask & 0x1111111111111111ull;
-                x = (x | (x >> 3)) & 0x0303030303030303ull;
-                x = (x | (x >> 6)) & 0x000F000F000F000Full;
-                x = (x | (x >> 12)) & 0x000000FF000000FFull;
-                x = (x | (x >> 24)) & 0xFFFFull;
-                s_winfo[w2 * 8 + 5] = (int)x;
+                // accepted keypoints of this wave (bit i = keypoint w2 * KP2 + i), as two 32-bit words
+                const unsigned long long km = per_keypoint(acc_mask);
+                s_winfo[w2 * 8 + 5] = (int)(unsigned)km;
+                s_winfo[w2 * 8 + 6] = (int)(unsigned)(km >> 32);
             }
         }
     }
@@ -1451,8 +1474,16 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         // granules 64..71: which keypoints of this workgroup were accepted (bit i = keypoint i), 32 per granule
         const int j = tid - 64;
         unsigned word = 0u;
-        if (2 * j < P2W) word |= (unsigned)s_winfo[(2 * j) * 8 + 5];
-        if (2 * j + 1 < P2W) word |= (unsigned)s_winfo[(2 * j + 1) * 8 + 5] << 16;
+        if (KP2 >= 32) {
+            const int w = (32 * j) / KP2;
+            if (w < P2W) word = (unsigned)s_winfo[w * 8 + 5 + (((32 * j) % KP2) >> 5)];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 32 / KP2; ++t) {
+                const int w = (32 * j) / KP2 + t;
+                if (w < P2W) word |= (unsigned)s_winfo[w * 8 + 5] << (t * KP2);
+            }
+        }
         __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * SRL_ROW_GRANULES + tid), ((unsigned long long)epoch << 32) | word,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
