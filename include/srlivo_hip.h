@@ -175,6 +175,13 @@ int srl_frame_commit(srl_ctx *ctx, const double q[4], const double t[3], const d
  * of updateIEKF (:235,:239).  One call per ESIKF iteration.  With a communicator the result is
  * all-reduced (RCCL) and identical on every rank.  Returns SRL_OK even when out->success == 0. */
 int srl_build_residuals(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts *opts, srl_normal_eq *out);
+/* The same call with a host callback that runs ONCE while the kernels are in flight (after the launches are enqueued,
+ * before the result is awaited): updateIEKF's part of the 17-dim algebra that does not depend on H_x -- the prior error
+ * state, the covariance projection and the first of the two 17x17 inverses, src/optimize.cpp:172-234 -- fits there, so
+ * only the second inverse and the gain (src/optimize.cpp:235-244) remain behind the kernel.  fn may be NULL. */
+typedef void (*srl_overlap_fn)(void *user);
+int srl_build_residuals_overlap(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts *opts, srl_normal_eq *out,
+                                srl_overlap_fn fn, void *user);
 
 /* enable/disable the per-keypoint parity taps written by srl_build_residuals (off by default) */
 int srl_set_taps(srl_ctx *ctx, int enable);

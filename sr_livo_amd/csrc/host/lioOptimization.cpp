@@ -115,13 +115,14 @@ void lioOptimization::fillFrame(cloudFrame *p_frame, srl_frame &f) const {
     f.frame_id = p_frame->frame_id;
 }
 
-int lioOptimization::normalEquations(const icpOptions &o, cloudFrame *p_frame, srl_normal_eq &neq) {
+int lioOptimization::normalEquations(const icpOptions &o, cloudFrame *p_frame, srl_normal_eq &neq, void (*while_running)(void *), void *user) {
     srl_frame f;
     fillFrame(p_frame, f);
     const srl_icp_opts abi = o.toAbi();
     if (provider) return provider(&f, &abi, &neq, provider_user);
     if (!voxel_map.ctx) return SRL_ERR_NO_DEVICE;
-    return srl_build_residuals(voxel_map.ctx, &f, &abi, &neq);
+    // while_running: host work that does not need the normal equations, run beside the kernels
+    return srl_build_residuals_overlap(voxel_map.ctx, &f, &abi, &neq, while_running, user);
 }
 
 // ---------------------------------------------------------------- optimize.cpp:18-131
@@ -220,35 +221,38 @@ optimizeSummary lioOptimization::solveIEKF(const icpOptions &cur_icp_options, cl
     iteration_log.clear();
     last_num_iterations = 0;
 
+    // covariance projection helpers (optimize.cpp:220-232): rows then columns of the so3 / S2 blocks
+    auto left3 = [](Mat17 &dst, const Mat3 &J, const Mat17 &src) {
+        for (int j = 0; j < 17; j++) { const Vec3 c = J * src.block<3, 1>(3, j); dst.setBlock<3, 1>(3, j, c); }
+    };
+    auto left2 = [](Mat17 &dst, const Mat2 &J, const Mat17 &src) {
+        for (int j = 0; j < 17; j++) { const Vec2 c = J * src.block<2, 1>(15, j); dst.setBlock<2, 1>(15, j, c); }
+    };
+    auto right3 = [](Mat17 &dst, const Mat3 &J, const Mat17 &src) {
+        const Mat3 Jt = J.transpose();
+        for (int j = 0; j < 17; j++) { const srl::Mat<1, 3> r = src.block<1, 3>(j, 3) * Jt; dst.setBlock<1, 3>(j, 3, r); }
+    };
+    auto right2 = [](Mat17 &dst, const Mat2 &J, const Mat17 &src) {
+        const Mat2 Jt = J.transpose();
+        for (int j = 0; j < 17; j++) { const srl::Mat<1, 2> r = src.block<1, 2>(j, 15) * Jt; dst.setBlock<1, 2>(j, 15, r); }
+    };
+
     for (int i = -1; i < max_num_iter; i++) {
-        // buildPlaneResiduals + H_x^T H_x + H_x^T h (optimize.cpp:153-170,235,239) on the device
-        srl_normal_eq neq;
-        std::memset(&neq, 0, sizeof neq);
-        const int rc = normalEquations(cur_icp_options, p_frame, neq);
-        if (rc == SRL_ERR_NAN_PLANARITY) throw std::runtime_error("error");      // optimize.cpp:348-350
-        check(voxel_map.ctx, rc, "srl_build_residuals");
-        summary.num_residuals_used = neq.num_residuals;
-        if (!neq.success) {                                                      // optimize.cpp:110-123,155-156
-            std::stringstream ss_out;
-            ss_out << "[Optimization] Error : not enough keypoints selected in ct-icp !" << std::endl;
-            ss_out << "[Optimization] number_of_residuals : " << neq.num_residuals << std::endl;
-            summary.success = false;
-            summary.error_log = ss_out.str();
-            return summary;
-        }
-        summary.success = true;
-        summary.error_log.clear();
-        last_num_iterations++;
-
-        srl::Mat<6, 6> HTH;
-        srl::Mat<6, 1> HTh;
-        for (int a = 0; a < 36; a++) HTH.a[a] = neq.HtH[a];
-        for (int a = 0; a < 6; a++) HTh.a[a] = neq.Hth[a];
-
+        // Everything of this iteration that does NOT depend on H_x -- the prior error state (optimize.cpp:172-211), the
+        // covariance projection (:220-232) and the first 17x17 inverse (:234) -- runs on the host WHILE the kernels of this
+        // iteration are in flight (srl_build_residuals_overlap): the same operations on the same values, only earlier.
+        Vec3 d_so3, so3_dg;
+        Mat32 B_x_predict;
+        Vec17 d_x, d_x_new;
+        Mat3 J_k_so3;
+        Mat2 J_k_s2;
+        Mat17 covariance, temp;
+        bool prior_done = false;
+        auto prior = [&]() {
         // prior error state (optimize.cpp:172-211)
         const Vec3 d_p = eskf_pro->getTranslation() - p_predict;
         const Quat d_q = q_predict.inverse() * eskf_pro->getRotation();
-        const Vec3 d_so3 = numType::quatToSo3(d_q);
+        d_so3 = numType::quatToSo3(d_q);
         const Vec3 d_v = eskf_pro->getVelocity() - v_predict;
         const Vec3 d_ba = eskf_pro->getBa() - ba_predict;
         const Vec3 d_bg = eskf_pro->getBg() - bg_predict;
@@ -268,21 +272,20 @@ optimizeSummary lioOptimization::solveIEKF(const icpOptions &cur_icp_options, cl
             const Mat3 skew = numType::skewSymmetric(crs);
             R_dg = Mat3::Identity() + skew + ((skew * skew) * (1.0 - dotv)) / (crs[0] * crs[0] + crs[1] * crs[1] + crs[2] * crs[2]);
         }
-        const Vec3 so3_dg = numType::rotationToSo3(R_dg);
-        const Mat32 B_x_predict = numType::derivativeS2(g_predict);
+        so3_dg = numType::rotationToSo3(R_dg);
+        B_x_predict = numType::derivativeS2(g_predict);
         const Vec2 d_g = B_x_predict.transpose() * so3_dg;
 
-        Vec17 d_x;
         for (int a = 0; a < 3; a++) {
             d_x[a] = d_p[a]; d_x[3 + a] = d_so3[a]; d_x[6 + a] = d_v[a]; d_x[9 + a] = d_ba[a]; d_x[12 + a] = d_bg[a];
         }
         d_x[15] = d_g[0];
         d_x[16] = d_g[1];
 
-        Mat3 J_k_so3 = Mat3::Identity() - 0.5 * numType::skewSymmetric(d_so3);
-        Mat2 J_k_s2 = Mat2::Identity() + ((0.5 * B_x_predict.transpose()) * numType::skewSymmetric(so3_dg)) * B_x_predict;
+        J_k_so3 = Mat3::Identity() - 0.5 * numType::skewSymmetric(d_so3);
+        J_k_s2 = Mat2::Identity() + ((0.5 * B_x_predict.transpose()) * numType::skewSymmetric(so3_dg)) * B_x_predict;
 
-        Vec17 d_x_new = d_x;
+        d_x_new = d_x;
         {
             const Vec3 t3 = J_k_so3 * d_so3;
             const Vec2 t2 = J_k_s2 * d_g;
@@ -292,29 +295,42 @@ optimizeSummary lioOptimization::solveIEKF(const icpOptions &cur_icp_options, cl
         }
 
         // covariance projection (optimize.cpp:220-232): rows then columns of the so3 / S2 blocks
-        Mat17 covariance = eskf_pro->getCovariance();
-        auto left3 = [](Mat17 &dst, const Mat3 &J, const Mat17 &src) {
-            for (int j = 0; j < 17; j++) { const Vec3 c = J * src.block<3, 1>(3, j); dst.setBlock<3, 1>(3, j, c); }
-        };
-        auto left2 = [](Mat17 &dst, const Mat2 &J, const Mat17 &src) {
-            for (int j = 0; j < 17; j++) { const Vec2 c = J * src.block<2, 1>(15, j); dst.setBlock<2, 1>(15, j, c); }
-        };
-        auto right3 = [](Mat17 &dst, const Mat3 &J, const Mat17 &src) {
-            const Mat3 Jt = J.transpose();
-            for (int j = 0; j < 17; j++) { const srl::Mat<1, 3> r = src.block<1, 3>(j, 3) * Jt; dst.setBlock<1, 3>(j, 3, r); }
-        };
-        auto right2 = [](Mat17 &dst, const Mat2 &J, const Mat17 &src) {
-            const Mat2 Jt = J.transpose();
-            for (int j = 0; j < 17; j++) { const srl::Mat<1, 2> r = src.block<1, 2>(j, 15) * Jt; dst.setBlock<1, 2>(j, 15, r); }
-        };
+        covariance = eskf_pro->getCovariance();
         { Mat17 s = covariance; left3(covariance, J_k_so3, s); }
         { Mat17 s = covariance; left2(covariance, J_k_s2, s); }
         { Mat17 s = covariance; right3(covariance, J_k_so3, s); }
         { Mat17 s = covariance; right2(covariance, J_k_s2, s); }
-
-        // Kalman gain pieces (optimize.cpp:234-244)
-        Mat17 temp, temp_inv;
+        // first half of the Kalman gain (optimize.cpp:234)
         srl::inverse<17>(covariance / laser_point_cov, temp);
+        prior_done = true;
+        };
+        // buildPlaneResiduals + H_x^T H_x + H_x^T h (optimize.cpp:153-170,235,239) on the device
+        srl_normal_eq neq;
+        std::memset(&neq, 0, sizeof neq);
+        const int rc = normalEquations(cur_icp_options, p_frame, neq, [](void *u) { (*static_cast<decltype(prior) *>(u))(); }, &prior);
+        if (rc == SRL_ERR_NAN_PLANARITY) throw std::runtime_error("error");      // optimize.cpp:348-350
+        check(voxel_map.ctx, rc, "srl_build_residuals");
+        summary.num_residuals_used = neq.num_residuals;
+        if (!neq.success) {                                                      // optimize.cpp:110-123,155-156
+            std::stringstream ss_out;
+            ss_out << "[Optimization] Error : not enough keypoints selected in ct-icp !" << std::endl;
+            ss_out << "[Optimization] number_of_residuals : " << neq.num_residuals << std::endl;
+            summary.success = false;
+            summary.error_log = ss_out.str();
+            return summary;
+        }
+        summary.success = true;
+        summary.error_log.clear();
+        last_num_iterations++;
+
+        srl::Mat<6, 6> HTH;
+        srl::Mat<6, 1> HTh;
+        for (int a = 0; a < 36; a++) HTH.a[a] = neq.HtH[a];
+        for (int a = 0; a < 6; a++) HTh.a[a] = neq.Hth[a];
+        if (!prior_done) prior();      // provider / early paths that did not run it beside the kernels
+
+        // Kalman gain pieces (optimize.cpp:235-244; `temp` = (covariance / laser_point_cov)^-1 comes from prior())
+        Mat17 temp_inv;
         for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) temp(a, b) += HTH(a, b);
         srl::inverse<17>(temp, temp_inv);
 

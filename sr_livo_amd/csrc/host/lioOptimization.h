@@ -212,7 +212,7 @@ public:
     int last_num_iterations = 0;
 
 private:
-    int normalEquations(const icpOptions &o, cloudFrame *p_frame, srl_normal_eq &neq);
+    int normalEquations(const icpOptions &o, cloudFrame *p_frame, srl_normal_eq &neq, void (*while_running)(void *) = nullptr, void *user = nullptr);
     void fillFrame(cloudFrame *p_frame, srl_frame &f) const;
     normal_eq_provider provider = nullptr;
     void *provider_user = nullptr;

@@ -669,6 +669,12 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     if (!fused) HIPCHK(ctx, srl_launch_reduce(ra, mode, ctx->stream));
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     const auto t_enq = std::chrono::steady_clock::now();
+    // everything is enqueued: the caller's H-independent host work runs now, beside the kernels (srl_build_residuals_overlap)
+    if (ctx->overlap_fn) {
+        void (*fn)(void *) = ctx->overlap_fn;
+        ctx->overlap_fn = nullptr;                 // once per call, in the first pass
+        fn(ctx->overlap_user);
+    }
 
     // the one exchange step: sum of the normal equations over the point-range shards
     const int n_red = 36 + 6 + 1 + 6;   // HtH, Hth, loss, 6 counters carried as doubles (incl. visited keypoints)
@@ -946,6 +952,16 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     int rc = build_residuals_pass(ctx, f, o, out, n_eff);
     if ((rc == SRL_OK || rc == SRL_ERR_NAN_PLANARITY) && n_eff < ctx->n && out->num_residuals < o->max_num_residuals)
         rc = build_residuals_pass(ctx, f, o, out, ctx->n);
+    return rc;
+}
+
+int srl_build_residuals_overlap(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, srl_normal_eq *out, srl_overlap_fn fn, void *user) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    ctx->overlap_fn = fn;
+    ctx->overlap_user = user;
+    const int rc = srl_build_residuals(ctx, f, o, out);
+    ctx->overlap_fn = nullptr;                     // an early return (no sweep, empty sweep, bad argument) never ran it
+    ctx->overlap_user = nullptr;
     return rc;
 }
 

@@ -31,6 +31,8 @@ struct srl_ctx {
     bool sweep_loaded = false;         // a sweep (possibly empty) has been uploaded / selected
     int search_select_mode = 0;        // srl_debug_set_search_select_mode: selection path of srl_search_neighbors (tests)
     int ablate = 0;                    // srl_debug_set_ablate (profiling tools only; never set by the product)
+    void (*overlap_fn)(void *) = nullptr;   // srl_build_residuals_overlap: host work to run while the kernels are in flight
+    void *overlap_user = nullptr;
 
     // the NEXT sweep (srl_sweep_prefetch / srl_sweep_swap): uploaded on its own stream while the current one is solved
     double *d_raw_next = nullptr;      // SoA, stride next_cap
