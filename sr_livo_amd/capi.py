@@ -118,6 +118,7 @@ def load_library():
         "srl_host_unregister": ([p], C.c_int),
         "srl_comm_backend_info": ([C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_build_residuals": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq)], C.c_int),
+        "srl_build_residuals_overlap": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq), p, p], C.c_int),
         "srl_set_taps": ([p, C.c_int], C.c_int),
         "srl_fetch_neighbors": ([p, p, p, p], C.c_int),
         "srl_fetch_residuals": ([p, p, p, p, p, p, p], C.c_int),
@@ -417,6 +418,14 @@ class Context:
     def build_residuals(self, frame, opts, allow=(SRL_ERR_NAN_PLANARITY,)):
         out = NormalEq()
         rc = self._chk(self.lib.srl_build_residuals(self.h, C.byref(frame), C.byref(opts), C.byref(out)), "srl_build_residuals", ok=allow)
+        return out, rc
+
+    def build_residuals_overlap(self, frame, opts, fn, allow=(SRL_ERR_NAN_PLANARITY,)):
+        """srl_build_residuals with a host callback (a Python callable without arguments) run while the kernels are in flight."""
+        out = NormalEq()
+        cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _u: fn())
+        rc = self._chk(self.lib.srl_build_residuals_overlap(self.h, C.byref(frame), C.byref(opts), C.byref(out), cb, None),
+                       "srl_build_residuals_overlap", ok=allow)
         return out, rc
 
     def fetch_neighbors(self, K=20):

@@ -1490,3 +1490,23 @@ def test_replay_driver_matches_reference_loop(oracle_lib, oracle_backend, mc):
     finally:
         lio.set_initial_flag(False)
         lio.close()
+
+
+def test_build_residuals_overlap_runs_the_callback_once_beside_the_kernel(ctx_small, golden):
+    """srl_build_residuals_overlap: same result as srl_build_residuals, the callback runs exactly once per call (also when the
+    finite-max_num_residuals prefix pass has to be repeated over the whole sweep), and never for an empty sweep."""
+    f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+    ctx_small.sweep_upload(golden["raw"])
+    for max_res in (INT_MAX, 600, 2000):
+        opts = srl.default_opts(max_num_residuals=max_res)
+        a, _ = ctx_small.build_residuals(f, opts)
+        calls = []
+        b, rc = ctx_small.build_residuals_overlap(f, opts, lambda: calls.append(1))
+        assert rc == 0 and len(calls) == 1
+        assert np.array_equal(np.array(a.HtH), np.array(b.HtH)) and np.array_equal(np.array(a.Hth), np.array(b.Hth))
+        assert a.num_residuals == b.num_residuals and a.last_visited == b.last_visited
+    ctx_small.sweep_upload(np.zeros((0, 3)))
+    calls = []
+    b, rc = ctx_small.build_residuals_overlap(f, srl.default_opts(), lambda: calls.append(1))
+    assert rc == 0 and b.num_residuals == 0 and not calls
+    ctx_small.sweep_upload(golden["raw"])
