@@ -3,8 +3,10 @@ updateIEKF solve by
     QL   the oracle with the restated Eigen 3.3.7 SelfAdjointEigenSolver (what the reference executes),
     JAC  the oracle with the independent FP64 cyclic Jacobi solver,
     GPU  the HIP path through the C-ABI (closed-form eigen-decomposition in the kernel),
-and the maximum deviations between them (relative to the field's largest magnitude unless noted).
-Bounds the Eigen-boundary uncertainty of the unpinned oracle: how far can results move with the eigen-solver.
+    REF  the reference's OWN translation units (oracle/_ref/libref_path.so: src/optimize.cpp & co. compiled in place against
+         stand-in third-party headers; prebuilt) -- where that library travelled with the tree,
+and the maximum deviations between them (relative to the field's largest magnitude unless noted).  QL vs REF must be
+bitwise (`ref_tu.*_bitwise`); QL vs JAC bounds how far results can move with the eigen-solver.
 
     python tools/parity_report.py [CONFIG ...] > gpurun_out/parity_report.json
 """
@@ -18,6 +20,7 @@ sys.path.insert(0, ".")
 import sr_livo_amd as srl  # noqa: E402
 from sr_livo_amd import capi, synth  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
+from oracle import pyref as pr  # noqa: E402
 
 INT_MAX = 2**31 - 1
 
@@ -57,6 +60,7 @@ def one_config(name, sample=None):
     lio = srl.Lio(0)
     lio.add_points_to_map(pts)
     rep = {"config": name, "keypoints": len(sw["raw"]), "map_points": int(m.size()), "map_voxels": int(m.num_voxels())}
+    rm = pr.Map.from_oracle(m) if pr.available() else None
     for label, frame_id, max_res in (("r1_all", 100, INT_MAX), ("r1_cut600", 100, 600), ("init_r2", 5, INT_MAX)):
         if label == "init_r2" and len(sw["raw"]) > 70000:
             continue
@@ -91,6 +95,18 @@ def one_config(name, sample=None):
                       "state": {"QL_vs_JAC": rel(u_q["state"], u_j["state"]), "GPU_vs_QL": rel(gs["state"], u_q["state"]), "GPU_vs_JAC": rel(gs["state"], u_j["state"])},
                       "eskf_state": {"QL_vs_JAC": rel(es_q, es_j), "GPU_vs_QL": rel(lio.eskf_get_state(), es_q)},
                       "covariance": {"QL_vs_JAC": rel(P_q, P_j), "GPU_vs_QL": rel(lio.eskf_get_cov(), P_q)}}
+        if rm is not None:
+            # the reference's own buildPlaneResiduals / updateIEKF on the same inputs: the restatement must equal it bit for bit
+            rr = rm.build_plane_residuals(oo, sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"], frame_id=frame_id)
+            re_ = pr.Eskf(); re_.set_state(s0); re_.set_cov(P0)
+            ru = pr.update_iekf(rm, re_, oo2, sw["raw"], st, sw["t_last"], frame_id=frame_id)
+            one_bitwise = bool(rr["rc"] == int(acc.sum()) and all(np.array_equal(o_q[k][acc], rr[k]) for k in ("normal", "jacobian", "norm_offset", "distance", "weight"))
+                               and np.array_equal(o_q["point_world"], rr["point_world"]) and o_q["neq"].loss_sum == rr["loss"])
+            r["ref_tu"] = {"one_pass_bitwise": one_bitwise, "residuals": int(rr["num_residuals"]),
+                           "solve_state_bitwise": bool(np.array_equal(u_q["state"], ru["state"])),
+                           "solve_covariance_bitwise": bool(np.array_equal(P_q, re_.get_cov())),
+                           "GPU_vs_REF_state": rel(gs["state"], ru["state"]),
+                           "GPU_vs_REF_jacobian": rel(g["jacobian"][acc], rr["jacobian"]), "GPU_vs_REF_distance": rel(g["distance"][acc], rr["distance"])}
         rep[label] = r
     rep["seconds"] = round(time.time() - t0, 1)
     lio.close()
@@ -115,6 +131,10 @@ def main():
                 worst[pair]["HtH"] = max(worst[pair].get("HtH", 0.0), c[lab]["HtH"][pair])
                 worst[pair]["solve_state"] = max(worst[pair].get("solve_state", 0.0), c[lab]["solve"]["state"][pair])
     out["worst_over_all_configs"] = worst
+    refs = [c[lab]["ref_tu"] for c in out["configs"] for lab in ("r1_all", "r1_cut600", "init_r2") if lab in c and "ref_tu" in c[lab]]
+    if refs:
+        out["oracle_equals_reference_tu_bitwise_everywhere"] = bool(all(x["one_pass_bitwise"] and x["solve_state_bitwise"] and x["solve_covariance_bitwise"] for x in refs))
+        out["worst_GPU_vs_reference_tu"] = {k: max(x[k] for x in refs) for k in ("GPU_vs_REF_state", "GPU_vs_REF_jacobian", "GPU_vs_REF_distance")}
     print(json.dumps(out, indent=1))
 
 
