@@ -30,10 +30,13 @@ int main() { return (p_cnd && p_sn && p_opt && p_bpr && p_upd) ? 0 : 1; }
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
-def test_reference_signatures_compile_with_eigen_on_the_include_path(tmp_path):
+@pytest.mark.parametrize("eigen_dir", [os.path.join("tests", "stub_eigen"), os.path.join("oracle", "ref_shim")])
+def test_reference_signatures_compile_with_eigen_on_the_include_path(tmp_path, eigen_dir):
+    """eigen_dir: the minimal stand-in of this test, and the fuller stand-in Eigen the reference's own translation units are
+    compiled against (oracle/ref_shim/Eigen/Core) -- the same header must serve both."""
     src = tmp_path / "surface.cpp"
     src.write_text(SRC)
-    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-I", ROOT, "-I", os.path.join(ROOT, "tests", "stub_eigen"), "-I", "/opt/rocm/include", str(src)]
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-I", ROOT, "-I", os.path.join(ROOT, eigen_dir), "-I", "/opt/rocm/include", str(src)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     # and without Eigen on the path the same header still compiles (the srl:: surface only)
