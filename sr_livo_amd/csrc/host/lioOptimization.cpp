@@ -330,11 +330,11 @@ optimizeSummary lioOptimization::solveIEKF(const icpOptions &cur_icp_options, cl
         if (!prior_done) prior();      // provider / early paths that did not run it beside the kernels
 
         // Kalman gain pieces (optimize.cpp:235-244; `temp` = (covariance / laser_point_cov)^-1 comes from prior())
-        Mat17 temp_inv;
         for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) temp(a, b) += HTH(a, b);
-        srl::inverse<17>(temp, temp_inv);
-
-        const srl::Mat<17, 6> Tl = temp_inv.block<17, 6>(0, 0);
+        // temp_inv = temp.inverse() is only ever read through temp_inv.block<17, 6>(0, 0) (optimize.cpp:237-242): its first six
+        // columns, solved alone, carry the same bits as in the full inverse
+        srl::Mat<17, 6> Tl;
+        srl::inverse_cols<17, 6>(temp, Tl);
         const Vec17 K_h = Tl * HTh;              // temp_inv.block<17,6>(0,0) * H_x^T * h, with H_x^T h reduced on the device
         Mat17 K_x = Mat17::Zero();
         K_x.setBlock<17, 6>(0, 0, Tl * HTH);

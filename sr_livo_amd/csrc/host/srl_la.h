@@ -137,8 +137,11 @@ inline Vec3 Quat::operator*(const Vec3 &v) const {
 }
 
 // Matrix<double,N,N>::inverse() for N > 4: PartialPivLU, then solve against the identity
-template <int N>
-bool inverse(const Mat<N, N> &A, Mat<N, N> &Ainv) {
+// inverse_cols<N, M>: the first M columns of that inverse.  Every column of the inverse is the solution of L U x = P e_c, solved
+// independently of the others, so the first M columns computed alone carry the same bits as the same columns of the full
+// inverse -- updateIEKF only ever reads temp_inv.block<17, 6>(0, 0) of its second inverse (src/optimize.cpp:237-242).
+template <int N, int M>
+bool inverse_cols(const Mat<N, N> &A, Mat<N, M> &Ainv) {
     double lu[N][N];
     int perm[N];
     for (int i = 0; i < N; i++) { perm[i] = i; for (int j = 0; j < N; j++) lu[i][j] = A(i, j); }
@@ -158,25 +161,27 @@ bool inverse(const Mat<N, N> &A, Mat<N, N> &Ainv) {
     // j = 0, 1, ... of the column-by-column loop (same rounding, bit for bit), but the N columns are N independent
     // chains the CPU can overlap -- a single column is one long dependent chain of subtractions (latency-bound: the two
     // 17 x 17 inverses of an ESIKF iteration cost 9 us that way, 2 us this way).
-    double Y[N][N];
+    double Y[N][M];
     for (int i = 0; i < N; i++) {
-        for (int c = 0; c < N; c++) Y[i][c] = (perm[i] == c) ? 1.0 : 0.0;
+        for (int c = 0; c < M; c++) Y[i][c] = (perm[i] == c) ? 1.0 : 0.0;
         for (int j = 0; j < i; j++) {
             const double f = lu[i][j];
-            for (int c = 0; c < N; c++) Y[i][c] -= f * Y[j][c];
+            for (int c = 0; c < M; c++) Y[i][c] -= f * Y[j][c];
         }
     }
     for (int i = N - 1; i >= 0; i--) {
         for (int j = i + 1; j < N; j++) {
             const double f = lu[i][j];
-            for (int c = 0; c < N; c++) Y[i][c] -= f * Y[j][c];
+            for (int c = 0; c < M; c++) Y[i][c] -= f * Y[j][c];
         }
         const double d = lu[i][i];
-        for (int c = 0; c < N; c++) Y[i][c] = Y[i][c] / d;
+        for (int c = 0; c < M; c++) Y[i][c] = Y[i][c] / d;
     }
-    for (int i = 0; i < N; i++) for (int c = 0; c < N; c++) Ainv(i, c) = Y[i][c];
+    for (int i = 0; i < N; i++) for (int c = 0; c < M; c++) Ainv(i, c) = Y[i][c];
     return true;
 }
+template <int N>
+bool inverse(const Mat<N, N> &A, Mat<N, N> &Ainv) { return inverse_cols<N, N>(A, Ainv); }
 
 // Eigen::SelfAdjointEigenSolver<Matrix3d> as the reference uses it (src/optimize.cpp:339-346): constructed from a
 // symmetric 3x3, then eigenvalues() ascending and eigenvectors().col(i).  Follows Eigen 3.3.7's iterative path

@@ -1,5 +1,6 @@
 """Host-side logic of the product that runs without a GPU: the C++ mirror of eskfEstimator and of the
 ESIKF update (sr_livo_amd/csrc/host), driven through the srl_lio handles, against the CPU oracle."""
+import os
 import numpy as np
 import pytest
 
@@ -200,3 +201,39 @@ def test_state_initialization_matches_oracle_and_rotation_algebra():
                 else:
                     assert np.array_equal(q, q1) and np.array_equal(t, t1)
     lio.set_initial_flag(False)
+
+
+def test_inverse_cols_equals_the_columns_of_the_full_inverse_bitwise(tmp_path):
+    """updateIEKF's second 17x17 inverse is only read through temp_inv.block<17,6>(0,0) (optimize.cpp:237-242); the host mirror
+    solves those six columns alone (srl::inverse_cols<17,6>).  Compiled check on the header itself: same bits as the full inverse."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    src = tmp_path / "inv.cpp"
+    src.write_text(r'''
+#include "sr_livo_amd/csrc/host/srl_la.h"
+#include <cstdio>
+#include <cstring>
+#include <random>
+int main() {
+    std::mt19937_64 rng(7);
+    std::normal_distribution<double> nd(0.0, 1.0);
+    for (int trial = 0; trial < 200; trial++) {
+        srl::Mat<17, 17> B, A, full;
+        for (int i = 0; i < 17; i++) for (int j = 0; j < 17; j++) B(i, j) = nd(rng);
+        for (int i = 0; i < 17; i++) for (int j = 0; j < 17; j++) { double s = (i == j) ? 1e-3 * (1 + trial) : 0.0; for (int k = 0; k < 17; k++) s += B(i, k) * B(j, k); A(i, j) = s; }
+        if (trial % 3 == 0) { for (int j = 0; j < 17; j++) { double t = A(2, j); A(2, j) = A(11, j); A(11, j) = t; } }   // force row pivoting
+        srl::Mat<17, 6> cols;
+        if (!srl::inverse<17>(A, full) || !srl::inverse_cols<17, 6>(A, cols)) return 2;
+        for (int i = 0; i < 17; i++) for (int c = 0; c < 6; c++) { double a = full(i, c), b = cols(i, c); if (std::memcmp(&a, &b, 8) != 0) { std::printf("mismatch %d %d %d\n", trial, i, c); return 1; } }
+    }
+    return 0;
+}
+''')
+    exe = tmp_path / "inv"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I", root, str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
