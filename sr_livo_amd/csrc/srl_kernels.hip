@@ -4,17 +4,19 @@
 // neighbour sets are bit-identical.
 //
 // Kernel map:
-//   srl_assoc_kernel<NB>   buildPlaneResiduals (optimize.cpp:18-131) for 64 keypoints per workgroup:
-//        phase 0  thread/keypoint : transformKeypoints (optimize.cpp:30-40, :83)
-//        phase 1  wave/keypoint   : searchNeighbors (optimize.cpp:365-426) -- (2r+1)^3 hash probes
-//                                   by lanes, occupied voxels compacted by ballot/mbcnt into LDS,
-//                                   candidates streamed 64 per round (coalesced 12-B loads from the
-//                                   256-B slabs), exact top-K by {f32 threshold from a 64-lane
-//                                   bitonic sort of per-lane minima -> ballot compaction of the
-//                                   survivors into LDS -> FP64 rank-by-counting}
-//        phase 2  thread/keypoint : computeNeighborhoodDistribution (optimize.cpp:316-353), weights,
+//   srl_assoc_kernel<NB, FAST, KPW, WPB>   buildPlaneResiduals (optimize.cpp:18-131), KPW x WPB keypoints per workgroup:
+//        phase 0  thread/keypoint : transformKeypoints (optimize.cpp:30-40, :83), voxel key, FP32 prefilter constants
+//        phase 1  wave/keypoint pair : searchNeighbors (optimize.cpp:365-426) -- (2r+1)^3 hash probes by lanes (one
+//                                   keypoint per half-wave, issued one pair ahead), occupied voxels compacted by
+//                                   ballot/mbcnt into LDS, candidates 60 per round (coalesced 12-B loads from the 256-B
+//                                   slabs, both keypoints' rounds in flight together), exact top-K by {FP32 distances ->
+//                                   13-step ballot bisection on the per-lane minima -> conservative threshold -> ballot
+//                                   compaction of the ~25 survivors into LDS -> FP64 rank-by-counting, one finish per
+//                                   pair -> tie check -> libstdc++ heap replay when distances tie}
+//        phase 2  lane/keypoint   : computeNeighborhoodDistribution (optimize.cpp:316-353), weights,
 //                                   plane, signed distance gate, Jacobian (optimize.cpp:42-53,85-105),
-//                                   then an in-order H^T H / H^T h partial per workgroup.
+//                                   then an in-order H^T H / H^T h partial per workgroup;
+//        fused final reduction (last workgroup of the grid), with or without the ordered cut (optimize.cpp:107).
 //   srl_reduce_kernel      the sequential early-exit (optimize.cpp:107) as an ordered prefix cut +
 //                          the deterministic final reduction of the partials (optimize.cpp:235,239).
 //   srl_search_kernel<NB>  searchNeighbors for a batch of world points (parity / API surface).
@@ -987,21 +989,6 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, i
     return L;
 }
 
-
-// butterfly add inside groups of 4 lanes (sub-lanes of one keypoint): all 4 lanes end with the same bits
-__device__ __forceinline__ double quad_sum(double v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    return v;
-}
-// sum over the 16 keypoints of a wave for a value held per (keypoint, sub-lane): lanes with equal sub-lane
-__device__ __forceinline__ double kp_sum(double v) {
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
 
 // FAST: 0 = general path only, 1 = FP32-prefilter fast path (r = 1: keypoint pairs, rounds in registers; r = 2: looped)
 // WPB = waves per workgroup: 16 (one workgroup per CU; every wave of a SIMD belongs to it) or 4 (when the 16-wave LDS

@@ -484,3 +484,36 @@ def test_state_initialization_and_point_timestamps_are_the_reference_members(ora
         finally:
             node.close()
     pr.set_params()
+
+
+@live
+@pytest.mark.parametrize("pos,max_res,expect_throw", [(100, INT_MAX, True), (100, 600, True), (1500, 600, False), (1500, INT_MAX, True),
+                                                      (2047, 2040, False), (0, -1, True), (5, -1, False)])
+def test_nan_planarity_throw_is_visited_only_in_the_reference(golden, oracle_backend, pos, max_res, expect_throw):
+    """The reference throws std::runtime_error("error") at optimize.cpp:348-350 only for keypoints its sequential loop reaches
+    before the break at :107 (and, with max_num_residuals <= 0, before the first keypoint that has a plane).  Same scene and
+    cases as the GPU test of that name: the reference's own throw, the oracle's nan_error and -- in test_gpu_parity.py -- the
+    device's SRL_ERR_NAN_PLANARITY must agree case by case."""
+    keys = np.concatenate([golden["map_keys"], np.array([[300, 300, 30]], np.int16)])
+    counts = np.concatenate([golden["map_counts"], np.array([20], np.int32)])
+    xyz = np.concatenate([golden["map_xyz"], np.full((1, 20, 3), [300.5, 300.5, 30.5], np.float32)])       # 20 IDENTICAL points
+    om = po.Map(oracle_backend); om.import_(keys, counts, xyz)
+    rm = pr.Map(keys, counts, xyz)
+    raw = golden["raw"].copy()
+    R = synth.quat_to_rot(golden["q_pred"] / np.linalg.norm(golden["q_pred"]))
+    raw[pos] = R.T @ (np.array([300.5, 300.5, 30.45]) - golden["t_pred"])       # lands next to the degenerate voxel
+    opts = po.default_opts(max_num_residuals=max_res)
+    o = om.build_plane_residuals(opts, raw, golden["q_pred"], golden["t_pred"], golden["t_last"])
+    r = rm.build_plane_residuals(opts, raw, golden["q_pred"], golden["t_pred"], golden["t_last"])
+    assert (r["rc"] == -2) == expect_throw == bool(o["neq"].nan_error)
+    if not expect_throw:
+        assert_pass_equals(o, r)
+    # and through updateIEKF: the solve aborts (-2) or runs to the same state
+    e = po.Eskf(oracle_backend); e.set_state(golden["full_eskf_state0"]); e.set_cov(golden["full_eskf_cov0"])
+    re_ = pr.Eskf(); re_.set_state(golden["full_eskf_state0"]); re_.set_cov(golden["full_eskf_cov0"])
+    u = po.update_iekf(om, e, opts, raw, golden["full_state0"], golden["t_last"])
+    ru = pr.update_iekf(rm, re_, opts, raw, golden["full_state0"], golden["t_last"])
+    if expect_throw:
+        assert u["rc"] == -2 and ru["rc"] == -2
+    else:
+        assert (u["rc"] > 0) == (ru["rc"] == 1) and np.array_equal(u["state"], ru["state"])
