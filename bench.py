@@ -212,6 +212,31 @@ def eo_last_cov(po, backend, omap, oo, prior_state, prior_cov, sweep, state0, fr
     return eo.get_cov()
 
 
+def pin_to_gpu_numa_node(device_index):
+    """Run this process on the CPUs of the NUMA node the GPU hangs off (2-socket hosts: the mailbox read and the doorbell
+    write of every ESIKF iteration otherwise cross the socket interconnect -- measured +3 us per iteration, tools/numa_probe.py).
+    Standard placement for a latency-bound host loop; INTEGRATION.md says the same for the node.  Never fatal."""
+    info = {"pinned": False}
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device_index)
+        path = f"/sys/bus/pci/devices/{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(open(path + "/numa_node").read().strip())
+        cpulist = open(path + "/local_cpulist").read().strip()
+        cpus = set()
+        for part in cpulist.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        info.update(numa_node=node, local_cpulist=cpulist)
+        if node >= 0 and cpus:
+            os.sched_setaffinity(0, cpus)
+            info["pinned"] = True
+    except Exception as e:  # noqa: BLE001
+        info["error"] = repr(e)
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +251,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration array (C1..C4, headline@600, init mode)")
     ap.add_argument("--select-mode", type=int, default=0)
     ap.add_argument("--no-fused-reduce", action="store_true", help="A/B: always run the separate reduce kernel")
+    ap.add_argument("--no-numa-pin", action="store_true", help="A/B: do not pin the process to the GPU-local NUMA node")
     ap.add_argument("--no-aux-legs", action="store_true",
                     help="only the timed configuration runs on the GPU (profiling: no association-only / PCIe legs in the trace)")
     ap.add_argument("--force-comm", action="store_true",
@@ -241,6 +267,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
+    pin_info = {"pinned": False, "disabled": True} if args.no_numa_pin else pin_to_gpu_numa_node(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:
         import datetime
@@ -466,6 +493,8 @@ def main():
                              "whole_iteration": ms_per_step * 1e3 / max(iters, 1),
                              "note": "first three: extra solves after the timed region with full event profiling (adds ~20 us/iter); "
                                      "whole_iteration: the timed region"},
+        "host_placement": dict(pin_info, what="the process runs on the CPUs of the GPU's NUMA node (sched_setaffinity from "
+                               "/sys/bus/pci/devices/<gpu>/local_cpulist); on the other socket every ESIKF iteration costs ~3 us more"),
         "pcie_inclusive_sweeps_per_s": rates["pinned"],
         "pcie": {"from_pinned_host_memory_sweeps_per_s": rates["pinned"], "from_pageable_host_memory_sweeps_per_s": rates["pageable"],
                  "pipelined_prefetch_sweeps_per_s": rates["pipelined"], "median_based": medians, "solves_per_leg": n_pcie, "steps_over_1ms": stalls,
