@@ -214,24 +214,20 @@ def eo_last_cov(po, backend, omap, oo, prior_state, prior_cov, sweep, state0, fr
 
 def pin_to_gpu_numa_node(device_index):
     """Run this process on the CPUs of the NUMA node the GPU hangs off (2-socket hosts: the mailbox read and the doorbell
-    write of every ESIKF iteration otherwise cross the socket interconnect -- measured +3 us per iteration, tools/numa_probe.py).
-    Standard placement for a latency-bound host loop; INTEGRATION.md says the same for the node.  Never fatal."""
+    write of every ESIKF iteration otherwise cross the socket interconnect -- measured +3 us per iteration, tools/numa_probe.py)
+    through the library's own helper, srl_thread_pin_to_gpu_numa (the main thread is pinned before any other thread exists, so
+    the whole process follows).  Standard placement for a latency-bound host loop; INTEGRATION.md says the same for the node.
+    Never fatal."""
     info = {"pinned": False}
     try:
-        import torch
-        p = torch.cuda.get_device_properties(device_index)
-        path = f"/sys/bus/pci/devices/{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
-        node = int(open(path + "/numa_node").read().strip())
-        cpulist = open(path + "/local_cpulist").read().strip()
-        cpus = set()
-        for part in cpulist.split(","):
-            a, _, b = part.partition("-")
-            cpus.update(range(int(a), int(b or a) + 1))
-        cpus &= os.sched_getaffinity(0)
-        info.update(numa_node=node, local_cpulist=cpulist)
-        if node >= 0 and cpus:
-            os.sched_setaffinity(0, cpus)
-            info["pinned"] = True
+        import sr_livo_amd as srl
+        ctx = srl.Context(device_index)
+        try:
+            node = ctx.pin_thread_to_gpu_numa()
+        finally:
+            ctx.close()
+        if node is not None:
+            info.update(pinned=True, numa_node=int(node), cpus=len(os.sched_getaffinity(0)))
     except Exception as e:  # noqa: BLE001
         info["error"] = repr(e)
     return info
@@ -493,7 +489,7 @@ def main():
                              "whole_iteration": ms_per_step * 1e3 / max(iters, 1),
                              "note": "first three: extra solves after the timed region with full event profiling (adds ~20 us/iter); "
                                      "whole_iteration: the timed region"},
-        "host_placement": dict(pin_info, what="the process runs on the CPUs of the GPU's NUMA node (sched_setaffinity from "
+        "host_placement": dict(pin_info, what="the process runs on the CPUs of the GPU's NUMA node (srl_thread_pin_to_gpu_numa: "
                                "/sys/bus/pci/devices/<gpu>/local_cpulist); on the other socket every ESIKF iteration costs ~3 us more"),
         "pcie_inclusive_sweeps_per_s": rates["pinned"],
         "pcie": {"from_pinned_host_memory_sweeps_per_s": rates["pinned"], "from_pageable_host_memory_sweeps_per_s": rates["pageable"],

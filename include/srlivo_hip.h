@@ -119,6 +119,13 @@ int srl_pinned_alloc(size_t bytes, void **out);
 int srl_pinned_free(void *p);
 int srl_host_register(void *p, size_t bytes);
 int srl_host_unregister(void *p);
+/* Thread placement helper for the node's estimation thread (the reference runs it as the ROS node's main thread,
+ * src/lioOptimization.cpp:1587-1611): restricts the CALLING thread to the CPUs of the NUMA node the context's GPU hangs off
+ * (/sys/bus/pci/devices/<gpu>/local_cpulist).  The solve is a latency-bound host loop -- one mailbox read and one doorbell
+ * write per ESIKF iteration --, and from the other socket of a two-socket host every iteration costs ~3 us more.  Optional;
+ * returns SRL_ERR_UNSUPPORTED when the topology cannot be read (nothing is changed then).  *numa_node (may be NULL) receives
+ * the node. */
+int srl_thread_pin_to_gpu_numa(srl_ctx *ctx, int *numa_node);
 /* The NEXT sweep while the current one is being solved (a node receives sweep k + 1 during the solve of sweep k):
  * srl_sweep_prefetch uploads it on the context's copy stream into a second sweep buffer and returns at once; the current
  * sweep stays valid.  srl_sweep_swap makes the prefetched sweep current -- the compute stream waits for the upload's event,

@@ -112,6 +112,7 @@ def load_library():
         "srl_sweep_shard": ([p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_sweep_prefetch": ([p, p, C.c_int], C.c_int),
         "srl_sweep_swap": ([p], C.c_int),
+        "srl_thread_pin_to_gpu_numa": ([p, C.POINTER(C.c_int)], C.c_int),
         "srl_pinned_alloc": ([C.c_size_t, C.POINTER(p)], C.c_int),
         "srl_pinned_free": ([p], C.c_int),
         "srl_host_register": ([p, C.c_size_t], C.c_int),
@@ -427,6 +428,12 @@ class Context:
         rc = self._chk(self.lib.srl_build_residuals_overlap(self.h, C.byref(frame), C.byref(opts), C.byref(out), cb, None),
                        "srl_build_residuals_overlap", ok=allow)
         return out, rc
+
+    def pin_thread_to_gpu_numa(self):
+        """restrict the calling thread to the CPUs of the GPU's NUMA node; returns the node, or None when the topology is unreadable"""
+        node = C.c_int(-1)
+        rc = self.lib.srl_thread_pin_to_gpu_numa(self.h, C.byref(node))
+        return node.value if rc == 0 else None
 
     def fetch_neighbors(self, K=20):
         _, n, _ = self.sweep_shard()

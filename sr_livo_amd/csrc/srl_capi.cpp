@@ -8,6 +8,7 @@
 #include "srl_heap.h"
 
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <chrono>
@@ -372,6 +373,38 @@ int srl_sweep_swap(srl_ctx *ctx) {
     ctx->sweep_loaded = true;
     ctx->taps_valid = false;
     return ensure_work(ctx, ctx->n);
+}
+
+int srl_thread_pin_to_gpu_numa(srl_ctx *ctx, int *numa_node) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (numa_node) *numa_node = -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, ctx->device) != hipSuccess) { (void)hipGetLastError(); return SRL_ERR_UNSUPPORTED; }
+    for (char *c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');     // sysfs spells the address in lower case
+    const std::string base = std::string("/sys/bus/pci/devices/") + bus;
+    int node = -1;
+    if (FILE *f = std::fopen((base + "/numa_node").c_str(), "r")) { if (std::fscanf(f, "%d", &node) != 1) node = -1; std::fclose(f); }
+    char list[1024] = {0};
+    if (FILE *f = std::fopen((base + "/local_cpulist").c_str(), "r")) { if (!std::fgets(list, (int)sizeof list, f)) list[0] = 0; std::fclose(f); }
+    if (node < 0 || !list[0]) return SRL_ERR_UNSUPPORTED;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return SRL_ERR_UNSUPPORTED;
+    int any = 0;
+    for (const char *p = list; *p && *p != '\n';) {           // "0-63,128-191"
+        char *end = nullptr;
+        const long a = std::strtol(p, &end, 10);
+        long b = a;
+        if (end == p) break;
+        p = end;
+        if (*p == '-') { b = std::strtol(p + 1, &end, 10); p = end; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET((int)c, &allowed)) { CPU_SET((int)c, &want); any = 1; }
+        if (*p == ',') ++p;
+    }
+    if (!any) return SRL_ERR_UNSUPPORTED;                     // the caller's own affinity excludes that node: leave it alone
+    if (sched_setaffinity(0, sizeof want, &want) != 0) return SRL_ERR_UNSUPPORTED;
+    if (numa_node) *numa_node = node;
+    return SRL_OK;
 }
 
 int srl_pinned_alloc(size_t bytes, void **out) {

@@ -1510,3 +1510,25 @@ def test_build_residuals_overlap_runs_the_callback_once_beside_the_kernel(ctx_sm
     b, rc = ctx_small.build_residuals_overlap(f, srl.default_opts(), lambda: calls.append(1))
     assert rc == 0 and b.num_residuals == 0 and not calls
     ctx_small.sweep_upload(golden["raw"])
+
+
+def test_thread_pin_to_gpu_numa_restricts_the_calling_thread_to_the_local_cpus():
+    """srl_thread_pin_to_gpu_numa: the calling thread ends up on CPUs of the NUMA node the call names (or the call reports
+    SRL_ERR_UNSUPPORTED and changes nothing); the affinity is restored afterwards."""
+    before = os.sched_getaffinity(0)
+    ctx = srl.Context(0)
+    try:
+        node = ctx.pin_thread_to_gpu_numa()
+        after = os.sched_getaffinity(0)
+        if node is None:
+            assert after == before
+        else:
+            assert node >= 0 and after and after <= before
+            local = set()
+            for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+                a, _, b = part.partition("-")
+                local.update(range(int(a), int(b or a) + 1))
+            assert after <= local
+    finally:
+        os.sched_setaffinity(0, before)
+        ctx.close()
