@@ -284,7 +284,11 @@ int srl_debug_device_sqrt(srl_ctx *ctx, const double *in, int n, double *out);
 int srl_debug_block_times(srl_ctx *ctx, double *out, int max_blocks, int *nblocks);
 int srl_set_profiling(srl_ctx *ctx, int mode);     /* 0 off (default); 1 full: four events + a sync per call (kernel, reduce,
                                                       * device total, host splits); 2 light: one event pair around the association
-                                                      * kernel, read back lazily (calls / sum_assoc_ms / sum_algorithmic_bytes only).
+                                                      * kernel, read back lazily (calls / sum_assoc_ms / sum_algorithmic_bytes only);
+                                                      * 3 host stamps only, no events: sum_host_launch_us = the launch call,
+                                                      * sum_host_wait_us = enqueued -> result (incl. the overlap callback),
+                                                      * sum_host_total_us = the whole call, sum_assoc_ms / sum_reduce_ms = argument
+                                                      * preparation / launch returned -> everything enqueued (tools/host_hop_probe.py).
                                                       * Switching on resets the sums. */
 
 #ifdef __cplusplus

@@ -462,7 +462,7 @@ int drain_ring(srl_ctx *ctx, bool all) {
 }  // namespace
 
 int srl_set_profiling(srl_ctx *ctx, int enable) {
-    if (!ctx || enable < 0 || enable > 2) return SRL_ERR_BAD_ARG;
+    if (!ctx || enable < 0 || enable > 3) return SRL_ERR_BAD_ARG;
     if (ctx->profiling == 2) { int rc = drain_ring(ctx, true); if (rc) return rc; }
     ctx->profiling = enable;
     if (ctx->profiling) std::memset(&ctx->timing, 0, sizeof ctx->timing);
@@ -647,7 +647,9 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
 
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (prof_light) HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
+    const auto t_prep = std::chrono::steady_clock::now();
     HIPCHK(ctx, srl_launch_assoc(a, nb, kpw, wpb, ctx->stream));
+    const auto t_launched = std::chrono::steady_clock::now();
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if (prof_light) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_head++; }
 
@@ -784,6 +786,15 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         const double pk_share = (ctx->nranks > 1 && ctx->total_n > 0) ? r.d_sum_pk * ((double)ctx->n / (double)ctx->total_n) : r.d_sum_pk;
         ctx->timing.algorithmic_bytes = per_kp * (long long)n_eff + (long long)(12.0 * pk_share);
         if (prof || prof_light) { ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes; ctx->timing.sum_keypoints += prof_light ? n_eff : 0; }
+    }
+    if (ctx->profiling == 3) {
+        // host stamps only (no events): argument preparation, the launch call itself, the wait for the result
+        ctx->timing.calls += 1;
+        ctx->timing.sum_host_launch_us += std::chrono::duration<double, std::micro>(t_launched - t_prep).count();
+        ctx->timing.sum_host_wait_us += std::chrono::duration<double, std::micro>(t_res - t_enq).count();
+        ctx->timing.sum_host_total_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count();
+        ctx->timing.sum_assoc_ms += std::chrono::duration<double, std::milli>(t_prep - t_entry).count();      // argument preparation (ms)
+        ctx->timing.sum_reduce_ms += std::chrono::duration<double, std::milli>(t_enq - t_launched).count();  // launch returned -> everything enqueued + overlap callback (ms)
     }
     if (out->nan_error) { ctx->err = "NaN planarity"; return SRL_ERR_NAN_PLANARITY; }
     return SRL_OK;
