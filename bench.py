@@ -162,13 +162,21 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
             rc, it, nr = solve()
             if rc:
                 raise RuntimeError(f"{name}: update_iekf status {rc}")
-        lio.ctx.set_profiling(2)
+        # timed region: no events on the stream (the light profiling's event pair costs ~1.5 us per launch); per-solve stamps
+        # on the host besides the total, so that one scheduling hiccup in a region of a few milliseconds shows as what it is
         torch.cuda.synchronize()
+        per = np.empty(steps)
         t = time.perf_counter()
-        for _ in range(steps):
+        for k in range(steps):
+            tk = time.perf_counter()
             rc, it, nr = solve()
+            per[k] = time.perf_counter() - tk
         torch.cuda.synchronize()
         el = time.perf_counter() - t
+        # kernel time of the same solves: a second pass with one event pair around every association launch
+        lio.ctx.set_profiling(2)
+        for _ in range(min(steps, 20)):
+            solve()
         tim = lio.ctx.timing()
         lio.ctx.set_profiling(0)
         calls = max(tim.calls, 1)
@@ -179,7 +187,7 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         lio.ctx.set_fused_reduce(0)
         solve()
         lio.ctx.set_profiling(2)
-        for _ in range(max(3, steps // 2)):
+        for _ in range(min(max(3, steps // 2), 20)):
             solve()
         tu = lio.ctx.timing()
         lio.ctx.set_profiling(0)
@@ -188,6 +196,7 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         ent = {"name": name, "workload": f"{workload}: {n_kp} keypoints ({pattern}), {lio.map_size()}-pt map, max_num_residuals={max_res}, frame_id={frame_id}"
                                          f" (r={2 if frame_id < 20 else 1})",
                "sweeps_per_s": steps / el, "ms_per_solve": el / steps * 1e3, "esikf_iterations": it, "ms_per_esikf_iter": el / steps * 1e3 / max(it, 1),
+               "steps": steps, "ms_per_solve_median": float(np.median(per)) * 1e3, "ms_per_solve_max": float(per.max()) * 1e3,
                "residuals_used": nr, "assoc_kernel_us": assoc_ms * 1e3, "assoc_launches": tim.calls,
                "keypoints_per_launch": tim.sum_keypoints / calls, "algorithmic_MB_per_launch": bytes_per_launch / 1e6,
                "hbm_roofline_frac": bytes_per_launch / (assoc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if assoc_ms > 0 else None,
@@ -597,8 +606,9 @@ def main():
             backend = "tsl" if os.path.exists(po.LIB_TSL) else "plain"
             threads = min(os.cpu_count() or 1, 64)
         del cands
-        plan = [("C1", "C1", INT_MAX, 100, 20), ("C2", "C2", INT_MAX, 100, 20), ("C3", "C3", INT_MAX, 100, 20),
-                ("C4", "C4", INT_MAX, 100, 10), ("HEADLINE@600", "HEADLINE", 600, 100, 20), ("INIT(frame_id=5)", "HEADLINE", INT_MAX, 5, 3)]
+        # small configurations get enough solves that the timed region spans tens of milliseconds
+        plan = [("C1", "C1", INT_MAX, 100, 200), ("C2", "C2", INT_MAX, 100, 200), ("C3", "C3", INT_MAX, 100, 200),
+                ("C4", "C4", INT_MAX, 100, 20), ("HEADLINE@600", "HEADLINE", 600, 100, 200), ("INIT(frame_id=5)", "HEADLINE", INT_MAX, 5, 6)]
         cfgs = []
         for name, wl, mr, fid, st in plan:
             try:
