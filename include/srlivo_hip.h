@@ -37,7 +37,8 @@ typedef enum srl_status {
     SRL_ERR_NO_SWEEP = -6,
     SRL_ERR_COMM = -7,          /* RCCL failure */
     SRL_ERR_NAN_PLANARITY = -8, /* optimize.cpp:348-350: a2D is NaN -> the reference throws std::runtime_error("error") */
-    SRL_ERR_NOT_ENOUGH_RESIDUALS = -9  /* optimize.cpp:110-123: summary.success = false */
+    SRL_ERR_NOT_ENOUGH_RESIDUALS = -9, /* optimize.cpp:110-123: summary.success = false */
+    SRL_ERR_RETRY_PER_ITERATION = -10  /* srl_solve_iekf: run this solve through srl_build_residuals (nothing was changed) */
 } srl_status;
 
 typedef struct srl_ctx srl_ctx;
@@ -189,6 +190,45 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts
 typedef void (*srl_overlap_fn)(void *user);
 int srl_build_residuals_overlap(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts *opts, srl_normal_eq *out,
                                 srl_overlap_fn fn, void *user);
+
+/* ------------------------------------------------------------------ one launch per solve
+ * replaces: the whole loop of lioOptimization::updateIEKF (optimize.cpp:133-314) on the sweep resident in HBM -- every
+ * buildPlaneResiduals pass (optimize.cpp:153), the 17-dim update (optimize.cpp:172-261), the step guard (:248-251), the
+ * convergence rule (:263-270) and the posterior covariance (:272-310) -- in ONE persistent kernel: the workgroups stay
+ * resident across the ESIKF iterations, the finishing workgroup sums the normal equations, one of its waves runs the
+ * 17-dim algebra in FP64 with the host mirror's operation order (csrc/srl_iekf_wave.h) and publishes the next pose to the
+ * other workgroups.  No kernel launch, no PCIe round trip and no host arithmetic between iterations.
+ *   frame      pose prior of the sweep (p_frame->p_state), t_last, extrinsics, frame_id -- as for srl_build_residuals
+ *   state      eskfEstimator's p(3) q(wxyz) v(3) ba(3) bg(3) g(3) at entry (= the "predict" values of optimize.cpp:138-143);
+ *              on return the filter state after the last observe() (optimize.cpp:253), also p_frame->p_state (:255-261)
+ *   covariance eskfEstimator's 17 x 17 covariance, row-major; replaced by the posterior when res->covariance_updated
+ *   log        optional, per pass HtH(36) Hth(6) d_x(17) num_residuals loss = 61 doubles (host memory, max_log_iters rows)
+ * Returns SRL_OK with res->verdict in {SRL_IEKF_DONE, SRL_IEKF_DONE_NO_COV, SRL_IEKF_FAIL_RESIDUALS} (the last one is
+ * optimizeSummary.success = false, optimize.cpp:110-123: state as left by the passes before it), SRL_ERR_NAN_PLANARITY
+ * (optimize.cpp:348-350), or SRL_ERR_RETRY_PER_ITERATION: this configuration or this solve has to go through
+ * srl_build_residuals (sharded context, taps, max_num_residuals <= 0, a keypoint prefix that turned out too short for a
+ * finite max_num_residuals, a workgroup that did not report in time); state and covariance are untouched then and
+ * lioOptimization::updateIEKF of the host mirror does exactly that. */
+typedef enum srl_iekf_verdict {
+    SRL_IEKF_CONTINUE = 0, SRL_IEKF_DONE = 1, SRL_IEKF_DONE_NO_COV = 2, SRL_IEKF_FAIL_RESIDUALS = 3, SRL_IEKF_NAN = 4,
+    SRL_IEKF_TIMEOUT = 5, SRL_IEKF_PREFIX_SHORT = 6, SRL_IEKF_SINGULAR = 7
+} srl_iekf_verdict;
+typedef struct srl_iekf_result {
+    int32_t verdict;              /* srl_iekf_verdict */
+    int32_t iterations;           /* passes that delivered normal equations (optimizeSummary.success) */
+    int32_t covariance_updated;   /* optimize.cpp:272-310 ran */
+    int32_t launches;             /* kernel launches this solve cost (1) */
+    srl_normal_eq last;           /* normal equations of the last pass */
+} srl_iekf_result;
+int srl_solve_iekf(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts *opts, double laser_point_cov,
+                   double state[19], double covariance[289], srl_iekf_result *res, double *log, int max_log_iters);
+/* debug / parity hook: the one-wave algebra of that kernel (csrc/srl_iekf_wave.h: the same source, instantiated for an
+ * emulated wave of 64 lanes) run on the HOST around normal equations delivered by `fn` -- lets the CPU tests compare the
+ * kernel's arithmetic with the host mirror's updateIEKF bit for bit.  No GPU.  Same state / covariance / log conventions. */
+typedef int (*srl_neq_fn)(const srl_frame *frame, const srl_icp_opts *opts, srl_normal_eq *out, void *user);
+int srl_debug_iekf_wave_solve(const srl_frame *frame, const srl_icp_opts *opts, double laser_point_cov, double state[19],
+                              double covariance[289], srl_neq_fn fn, void *user, srl_iekf_result *res, double *log,
+                              int max_log_iters);
 
 /* enable/disable the per-keypoint parity taps written by srl_build_residuals (off by default) */
 int srl_set_taps(srl_ctx *ctx, int enable);

@@ -18,6 +18,7 @@ SRL_ERR_NO_DEVICE = -1
 SRL_ERR_COMM = -7
 SRL_ERR_NAN_PLANARITY = -8
 SRL_ERR_NOT_ENOUGH_RESIDUALS = -9
+SRL_ERR_RETRY_PER_ITERATION = -10
 SRL_COMM_ID_BYTES = 128
 
 
@@ -49,6 +50,14 @@ class NormalEq(C.Structure):
     _fields_ = [("HtH", C.c_double * 36), ("Hth", C.c_double * 6), ("loss_sum", C.c_double),
                 ("num_residuals", C.c_int32), ("success", C.c_int32), ("sum_candidates", C.c_int64),
                 ("last_visited", C.c_int64), ("nan_error", C.c_int32), ("num_fallback", C.c_int32)]
+
+
+class IekfResult(C.Structure):
+    _fields_ = [("verdict", C.c_int32), ("iterations", C.c_int32), ("covariance_updated", C.c_int32), ("launches", C.c_int32),
+                ("last", NormalEq)]
+
+
+IEKF_CONTINUE, IEKF_DONE, IEKF_DONE_NO_COV, IEKF_FAIL_RESIDUALS, IEKF_NAN, IEKF_TIMEOUT, IEKF_PREFIX_SHORT, IEKF_SINGULAR = range(8)
 
 
 class Timing(C.Structure):
@@ -120,6 +129,9 @@ def load_library():
         "srl_comm_backend_info": ([C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_build_residuals": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq)], C.c_int),
         "srl_build_residuals_overlap": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq), p, p], C.c_int),
+        "srl_solve_iekf": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.c_double, dp, dp, C.POINTER(IekfResult), p, C.c_int], C.c_int),
+        "srl_debug_iekf_wave_solve": ([C.POINTER(Frame), C.POINTER(IcpOpts), C.c_double, dp, dp, PROVIDER_FN, p, C.POINTER(IekfResult),
+                                       p, C.c_int], C.c_int),
         "srl_set_taps": ([p, C.c_int], C.c_int),
         "srl_fetch_neighbors": ([p, p, p, p], C.c_int),
         "srl_fetch_residuals": ([p, p, p, p, p, p, p], C.c_int),
@@ -247,6 +259,23 @@ def heap_topk(distances, K):
     if n < 0:
         raise SrlError(n, "srl_debug_heap_topk")
     return out[:n].copy()
+
+
+def iekf_wave_solve(frame, opts, laser_point_cov, state19, cov, provider, log_iters=0):
+    """srl_debug_iekf_wave_solve: the persistent kernel's one-wave ESIKF algebra (csrc/srl_iekf_wave.h) run on the host
+    around normal equations from provider(frame, opts, out) -> status.  Returns dict(rc, verdict, iterations, state, cov, log)."""
+    def _p(fp, op, outp, _user):
+        return int(provider(fp.contents, op.contents, outp.contents))
+    cb = PROVIDER_FN(_p)
+    st = _f64(state19).copy()
+    P = _f64(cov).ravel().copy()
+    res = IekfResult()
+    log = np.zeros((max(log_iters, 1), 61)) if log_iters else None
+    rc = load_library().srl_debug_iekf_wave_solve(C.byref(frame), C.byref(opts), float(laser_point_cov), _dptr(st), _dptr(P), cb, None,
+                                                  C.byref(res), _ptr(log) if log is not None else None, int(log_iters))
+    return dict(rc=rc, verdict=res.verdict, iterations=res.iterations, covariance_updated=res.covariance_updated, state=st,
+                cov=P.reshape(17, 17), num_residuals=res.last.num_residuals,
+                log=None if log is None else log[: min(res.iterations, log_iters)])
 
 
 class PinnedArray:

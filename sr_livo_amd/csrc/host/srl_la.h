@@ -9,30 +9,39 @@
 #include <cmath>
 #include <cstring>
 
+// The same fixed-size algebra also runs inside the persistent ESIKF kernel (csrc/srl_iekf_wave.h): in a HIP translation
+// unit every function below is __host__ __device__, elsewhere the marker is empty.
+#if defined(__HIP__)
+#include <hip/hip_runtime.h>
+#define SRL_HD __host__ __device__
+#else
+#define SRL_HD
+#endif
+
 namespace srl {
 
 template <int R, int C>
 struct Mat {
     double a[R * C];
-    double &operator()(int i, int j) { return a[i * C + j]; }
-    double operator()(int i, int j) const { return a[i * C + j]; }
-    double &operator()(int i) { return a[i]; }
-    double operator()(int i) const { return a[i]; }
-    double &operator[](int i) { return a[i]; }
-    double operator[](int i) const { return a[i]; }
-    static Mat Zero() { Mat m; for (int i = 0; i < R * C; i++) m.a[i] = 0.0; return m; }
-    static Mat Identity() { Mat m = Zero(); for (int i = 0; i < (R < C ? R : C); i++) m(i, i) = 1.0; return m; }
-    Mat<C, R> transpose() const { Mat<C, R> t; for (int i = 0; i < R; i++) for (int j = 0; j < C; j++) t(j, i) = (*this)(i, j); return t; }
-    double x() const { return a[0]; }
-    double y() const { return a[1]; }
-    double z() const { return a[2]; }
-    double squaredNorm() const { double s = a[0] * a[0]; for (int i = 1; i < R * C; i++) s += a[i] * a[i]; return s; }
-    double norm() const { return std::sqrt(squaredNorm()); }
-    double dot(const Mat &o) const { double s = a[0] * o.a[0]; for (int i = 1; i < R * C; i++) s += a[i] * o.a[i]; return s; }
-    void normalize() { double z = squaredNorm(); if (z > 0.0) { double n = std::sqrt(z); for (int i = 0; i < R * C; i++) a[i] /= n; } }
-    Mat normalized() const { Mat m = *this; m.normalize(); return m; }
-    template <int BR, int BC> Mat<BR, BC> block(int r0, int c0) const { Mat<BR, BC> b; for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) b(i, j) = (*this)(r0 + i, c0 + j); return b; }
-    template <int BR, int BC> void setBlock(int r0, int c0, const Mat<BR, BC> &b) { for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) (*this)(r0 + i, c0 + j) = b(i, j); }
+    SRL_HD double &operator()(int i, int j) { return a[i * C + j]; }
+    SRL_HD double operator()(int i, int j) const { return a[i * C + j]; }
+    SRL_HD double &operator()(int i) { return a[i]; }
+    SRL_HD double operator()(int i) const { return a[i]; }
+    SRL_HD double &operator[](int i) { return a[i]; }
+    SRL_HD double operator[](int i) const { return a[i]; }
+    SRL_HD static Mat Zero() { Mat m; for (int i = 0; i < R * C; i++) m.a[i] = 0.0; return m; }
+    SRL_HD static Mat Identity() { Mat m = Zero(); for (int i = 0; i < (R < C ? R : C); i++) m(i, i) = 1.0; return m; }
+    SRL_HD Mat<C, R> transpose() const { Mat<C, R> t; for (int i = 0; i < R; i++) for (int j = 0; j < C; j++) t(j, i) = (*this)(i, j); return t; }
+    SRL_HD double x() const { return a[0]; }
+    SRL_HD double y() const { return a[1]; }
+    SRL_HD double z() const { return a[2]; }
+    SRL_HD double squaredNorm() const { double s = a[0] * a[0]; for (int i = 1; i < R * C; i++) s += a[i] * a[i]; return s; }
+    SRL_HD double norm() const { return std::sqrt(squaredNorm()); }
+    SRL_HD double dot(const Mat &o) const { double s = a[0] * o.a[0]; for (int i = 1; i < R * C; i++) s += a[i] * o.a[i]; return s; }
+    SRL_HD void normalize() { double z = squaredNorm(); if (z > 0.0) { double n = std::sqrt(z); for (int i = 0; i < R * C; i++) a[i] /= n; } }
+    SRL_HD Mat normalized() const { Mat m = *this; m.normalize(); return m; }
+    template <int BR, int BC> SRL_HD Mat<BR, BC> block(int r0, int c0) const { Mat<BR, BC> b; for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) b(i, j) = (*this)(r0 + i, c0 + j); return b; }
+    template <int BR, int BC> SRL_HD void setBlock(int r0, int c0, const Mat<BR, BC> &b) { for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) (*this)(r0 + i, c0 + j) = b(i, j); }
 };
 
 using Vec3 = Mat<3, 1>;
@@ -43,16 +52,16 @@ using Mat32 = Mat<3, 2>;
 using Vec17 = Mat<17, 1>;
 using Mat17 = Mat<17, 17>;
 
-inline Vec3 vec3(double x, double y, double z) { Vec3 v; v.a[0] = x; v.a[1] = y; v.a[2] = z; return v; }
+SRL_HD inline Vec3 vec3(double x, double y, double z) { Vec3 v; v.a[0] = x; v.a[1] = y; v.a[2] = z; return v; }
 
-template <int R, int C> Mat<R, C> operator+(const Mat<R, C> &x, const Mat<R, C> &y) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = x.a[i] + y.a[i]; return r; }
-template <int R, int C> Mat<R, C> operator-(const Mat<R, C> &x, const Mat<R, C> &y) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = x.a[i] - y.a[i]; return r; }
-template <int R, int C> Mat<R, C> operator-(const Mat<R, C> &x) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = -x.a[i]; return r; }
-template <int R, int C> Mat<R, C> operator*(const Mat<R, C> &x, double s) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = x.a[i] * s; return r; }
-template <int R, int C> Mat<R, C> operator*(double s, const Mat<R, C> &x) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = s * x.a[i]; return r; }
-template <int R, int C> Mat<R, C> operator/(const Mat<R, C> &x, double s) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = x.a[i] / s; return r; }
+template <int R, int C> SRL_HD Mat<R, C> operator+(const Mat<R, C> &x, const Mat<R, C> &y) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = x.a[i] + y.a[i]; return r; }
+template <int R, int C> SRL_HD Mat<R, C> operator-(const Mat<R, C> &x, const Mat<R, C> &y) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = x.a[i] - y.a[i]; return r; }
+template <int R, int C> SRL_HD Mat<R, C> operator-(const Mat<R, C> &x) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = -x.a[i]; return r; }
+template <int R, int C> SRL_HD Mat<R, C> operator*(const Mat<R, C> &x, double s) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = x.a[i] * s; return r; }
+template <int R, int C> SRL_HD Mat<R, C> operator*(double s, const Mat<R, C> &x) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = s * x.a[i]; return r; }
+template <int R, int C> SRL_HD Mat<R, C> operator/(const Mat<R, C> &x, double s) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = x.a[i] / s; return r; }
 template <int R, int K, int C>
-Mat<R, C> operator*(const Mat<R, K> &x, const Mat<K, C> &y) {
+SRL_HD Mat<R, C> operator*(const Mat<R, K> &x, const Mat<K, C> &y) {
     Mat<R, C> r;
     for (int i = 0; i < R; i++)
         for (int j = 0; j < C; j++) {
@@ -62,35 +71,35 @@ Mat<R, C> operator*(const Mat<R, K> &x, const Mat<K, C> &y) {
         }
     return r;
 }
-inline Vec3 cross(const Vec3 &a, const Vec3 &b) {
+SRL_HD inline Vec3 cross(const Vec3 &a, const Vec3 &b) {
     return vec3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
 }
 
 // Eigen::Quaterniond restated (w,x,y,z)
 struct Quat {
     double w, x, y, z;
-    Quat() : w(1), x(0), y(0), z(0) {}
-    Quat(double w_, double x_, double y_, double z_) : w(w_), x(x_), y(y_), z(z_) {}
-    static Quat Identity() { return Quat(1, 0, 0, 0); }
-    double squaredNorm() const { return ((x * x + y * y) + z * z) + w * w; }
-    Quat normalized() const {
+    SRL_HD Quat() : w(1), x(0), y(0), z(0) {}
+    SRL_HD Quat(double w_, double x_, double y_, double z_) : w(w_), x(x_), y(y_), z(z_) {}
+    SRL_HD static Quat Identity() { return Quat(1, 0, 0, 0); }
+    SRL_HD double squaredNorm() const { return ((x * x + y * y) + z * z) + w * w; }
+    SRL_HD Quat normalized() const {
         double n2 = squaredNorm();
         if (n2 > 0.0) { double n = std::sqrt(n2); return Quat(w / n, x / n, y / n, z / n); }
         return *this;
     }
-    void normalize() { *this = normalized(); }
-    Quat inverse() const {
+    SRL_HD void normalize() { *this = normalized(); }
+    SRL_HD Quat inverse() const {
         double n2 = squaredNorm();
         if (n2 > 0.0) return Quat(w / n2, -x / n2, -y / n2, -z / n2);
         return Quat(0, 0, 0, 0);
     }
-    Quat operator*(const Quat &b) const {
+    SRL_HD Quat operator*(const Quat &b) const {
         return Quat(w * b.w - x * b.x - y * b.y - z * b.z, w * b.x + x * b.w + y * b.z - z * b.y,
                     w * b.y + y * b.w + z * b.x - x * b.z, w * b.z + z * b.w + x * b.y - y * b.x);
     }
     // Quaternion * Vector3 (Eigen's _transformVector: two cross products, not a matrix product)
-    Vec3 operator*(const Vec3 &v) const;
-    Mat3 toRotationMatrix() const {
+    SRL_HD Vec3 operator*(const Vec3 &v) const;
+    SRL_HD Mat3 toRotationMatrix() const {
         const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
         const double twx = tx * w, twy = ty * w, twz = tz * w;
         const double txx = tx * x, txy = ty * x, txz = tz * x;
@@ -101,7 +110,7 @@ struct Quat {
         r(2, 0) = txz - twy; r(2, 1) = tyz + twx; r(2, 2) = 1.0 - (txx + tyy);
         return r;
     }
-    static Quat fromRotationMatrix(const Mat3 &m) {   // Shepperd
+    SRL_HD static Quat fromRotationMatrix(const Mat3 &m) {   // Shepperd
         Quat q;
         double t = m(0, 0) + m(1, 1) + m(2, 2);
         if (t > 0.0) {
@@ -129,7 +138,7 @@ struct Quat {
     }
 };
 
-inline Vec3 Quat::operator*(const Vec3 &v) const {
+SRL_HD inline Vec3 Quat::operator*(const Vec3 &v) const {
     const Vec3 qv = vec3(x, y, z);
     Vec3 uv = cross(qv, v);
     uv = uv + uv;
@@ -141,7 +150,7 @@ inline Vec3 Quat::operator*(const Vec3 &v) const {
 // independently of the others, so the first M columns computed alone carry the same bits as the same columns of the full
 // inverse -- updateIEKF only ever reads temp_inv.block<17, 6>(0, 0) of its second inverse (src/optimize.cpp:237-242).
 template <int N, int M>
-bool inverse_cols(const Mat<N, N> &A, Mat<N, M> &Ainv) {
+SRL_HD bool inverse_cols(const Mat<N, N> &A, Mat<N, M> &Ainv) {
     double lu[N][N];
     int perm[N];
     for (int i = 0; i < N; i++) { perm[i] = i; for (int j = 0; j < N; j++) lu[i][j] = A(i, j); }
@@ -181,7 +190,7 @@ bool inverse_cols(const Mat<N, N> &A, Mat<N, M> &Ainv) {
     return true;
 }
 template <int N>
-bool inverse(const Mat<N, N> &A, Mat<N, N> &Ainv) { return inverse_cols<N, N>(A, Ainv); }
+SRL_HD bool inverse(const Mat<N, N> &A, Mat<N, N> &Ainv) { return inverse_cols<N, N>(A, Ainv); }
 
 // Eigen::SelfAdjointEigenSolver<Matrix3d> as the reference uses it (src/optimize.cpp:339-346): constructed from a
 // symmetric 3x3, then eigenvalues() ascending and eigenvectors().col(i).  Follows Eigen 3.3.7's iterative path

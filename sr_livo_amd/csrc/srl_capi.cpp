@@ -6,6 +6,7 @@
 #include "srl_device.h"
 #include "srl_hash.h"
 #include "srl_heap.h"
+#include "srl_iekf_wave.h"
 
 #include <hip/hip_runtime.h>
 #include <sched.h>
@@ -101,6 +102,7 @@ const char *srl_status_str(int s) {
         case SRL_ERR_COMM: return "RCCL error";
         case SRL_ERR_NAN_PLANARITY: return "NaN planarity (optimize.cpp:348-350 throws)";
         case SRL_ERR_NOT_ENOUGH_RESIDUALS: return "not enough residuals (optimize.cpp:110)";
+        case SRL_ERR_RETRY_PER_ITERATION: return "solve not run by the persistent kernel: go through srl_build_residuals";
         default: return "unknown status";
     }
 }
@@ -938,6 +940,69 @@ int srl_debug_device_sqrt(srl_ctx *ctx, const double *in, int n, double *out) {
     HIPCHK(ctx, hipMemcpyAsync(out, b.as<double>(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SRL_OK;
+}
+
+// ---- the persistent kernel's one-wave ESIKF algebra on the host (emulated wave of 64 lanes; csrc/srl_iekf_wave.h) ----
+static void iekf_consts_from(const srl_frame *f, const srl_icp_opts *o, double laser_point_cov, const double state[19], srlw::IekfConsts &K) {
+    std::memcpy(K.pred, state, sizeof K.pred);
+    K.laser_point_cov = laser_point_cov;
+    K.thr_translation = o->threshold_translation_norm;
+    K.thr_orientation = o->threshold_orientation_norm;
+    K.frame_id = f->frame_id;
+    K.max_num_iter = f->frame_id < o->init_num_frames ? std::max(15, o->num_iters_icp) : o->num_iters_icp;   // optimize.cpp:135-136
+}
+static void iekf_log_row(double *log, int row, const srl_normal_eq &neq, const double *d_x) {
+    double *L = log + (size_t)row * 61;
+    std::memcpy(L, neq.HtH, 36 * sizeof(double));
+    std::memcpy(L + 36, neq.Hth, 6 * sizeof(double));
+    std::memcpy(L + 42, d_x, 17 * sizeof(double));
+    L[59] = (double)neq.num_residuals;
+    L[60] = neq.loss_sum;
+}
+int srl_debug_iekf_wave_solve(const srl_frame *frame, const srl_icp_opts *o, double laser_point_cov, double state[19],
+                              double covariance[289], srl_neq_fn fn, void *user, srl_iekf_result *res, double *log,
+                              int max_log_iters) {
+    if (!frame || !o || !state || !covariance || !fn || !res) return SRL_ERR_BAD_ARG;
+    using namespace srlw;
+    IekfConsts K;
+    iekf_consts_from(frame, o, laser_point_cov, state, K);
+    static thread_local IekfShared sh;
+    std::memcpy(sh.state, state, sizeof sh.state);
+    sh.singular = 0;
+    srl_frame f = *frame;
+    std::memset(res, 0, sizeof *res);
+    double cov_out[289];
+    int verdict = IEKF_CONTINUE;
+    for (int iter = 0; iter <= K.max_num_iter && verdict == IEKF_CONTINUE; iter++) {
+        iekf_prior<HostWave>(K, covariance, sh);
+        srl_normal_eq neq;
+        std::memset(&neq, 0, sizeof neq);
+        const int rc = fn(&f, o, &neq, user);
+        res->last = neq;
+        if (rc == SRL_ERR_NAN_PLANARITY) { verdict = IEKF_NAN; break; }
+        if (rc != SRL_OK) return rc;
+        if (!neq.success) { verdict = IEKF_FAIL_RESIDUALS; break; }
+        res->iterations++;
+        std::memcpy(sh.HtH, neq.HtH, sizeof sh.HtH);
+        std::memcpy(sh.Hth, neq.Hth, sizeof sh.Hth);
+        verdict = iekf_update<HostWave>(K, iter, sh, cov_out);
+        if (log && iter < max_log_iters) iekf_log_row(log, iter, neq, sh.d_x);
+        if (sh.singular) { verdict = IEKF_SINGULAR; break; }
+        // the pose of the next pass is the filter's (optimize.cpp:255-256)
+        f.q[0] = sh.state[3]; f.q[1] = sh.state[4]; f.q[2] = sh.state[5]; f.q[3] = sh.state[6];
+        f.t[0] = sh.state[0]; f.t[1] = sh.state[1]; f.t[2] = sh.state[2];
+    }
+    res->verdict = verdict;
+    if (verdict == IEKF_SINGULAR) return SRL_ERR_RETRY_PER_ITERATION;
+    std::memcpy(state, sh.state, sizeof sh.state);
+    if (verdict == IEKF_DONE) { std::memcpy(covariance, cov_out, sizeof cov_out); res->covariance_updated = 1; }
+    return verdict == IEKF_NAN ? SRL_ERR_NAN_PLANARITY : SRL_OK;
+}
+
+int srl_solve_iekf(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts *o, double laser_point_cov, double state[19],
+                   double covariance[289], srl_iekf_result *res, double *log, int max_log_iters) {
+    (void)ctx; (void)frame; (void)o; (void)laser_point_cov; (void)state; (void)covariance; (void)res; (void)log; (void)max_log_iters;
+    return SRL_ERR_RETRY_PER_ITERATION;
 }
 
 void srl_shard_range(int n, int nranks, int rank, int *begin, int *count) {
