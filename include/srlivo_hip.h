@@ -217,7 +217,7 @@ typedef struct srl_iekf_result {
     int32_t verdict;              /* srl_iekf_verdict */
     int32_t iterations;           /* passes that delivered normal equations (optimizeSummary.success) */
     int32_t covariance_updated;   /* optimize.cpp:272-310 ran */
-    int32_t launches;             /* kernel launches this solve cost (1) */
+    int32_t observed;             /* observe() calls (optimize.cpp:253): > 0 means the frame's pose is now the filter's (:255-261) */
     srl_normal_eq last;           /* normal equations of the last pass */
 } srl_iekf_result;
 int srl_solve_iekf(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts *opts, double laser_point_cov,
@@ -227,8 +227,14 @@ int srl_solve_iekf(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts *opt
  * kernel's arithmetic with the host mirror's updateIEKF bit for bit.  No GPU.  Same state / covariance / log conventions. */
 typedef int (*srl_neq_fn)(const srl_frame *frame, const srl_icp_opts *opts, srl_normal_eq *out, void *user);
 int srl_debug_iekf_wave_solve(const srl_frame *frame, const srl_icp_opts *opts, double laser_point_cov, double state[19],
-                              double covariance[289], srl_neq_fn fn, void *user, srl_iekf_result *res, double *log,
-                              int max_log_iters);
+                              double covariance[289], srl_neq_fn fn, void *user, int exact_lu, srl_iekf_result *res,
+                              double *log, int max_log_iters);
+/* Which form of the second inverse (optimize.cpp:237) srl_solve_iekf's kernel uses: 0 (default) the Schur-complement form
+ * -- the H-independent 11 x 11 block is eliminated while the sweep is associated, a symmetric positive definite 6 x 6
+ * system is left behind the reduction (csrc/srl_iekf_wave.h, ~1e-10 relative to the LU form) --, 1 the reference form:
+ * both 17 x 17 inverses by partial-pivot LU in the host mirror's operation order (bitwise equal to it up to the device's
+ * sin / cos / acos). */
+int srl_debug_set_iekf_exact_lu(srl_ctx *ctx, int exact_lu);
 
 /* enable/disable the per-keypoint parity taps written by srl_build_residuals (off by default) */
 int srl_set_taps(srl_ctx *ctx, int enable);

@@ -53,7 +53,7 @@ class NormalEq(C.Structure):
 
 
 class IekfResult(C.Structure):
-    _fields_ = [("verdict", C.c_int32), ("iterations", C.c_int32), ("covariance_updated", C.c_int32), ("launches", C.c_int32),
+    _fields_ = [("verdict", C.c_int32), ("iterations", C.c_int32), ("covariance_updated", C.c_int32), ("observed", C.c_int32),
                 ("last", NormalEq)]
 
 
@@ -130,8 +130,9 @@ def load_library():
         "srl_build_residuals": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq)], C.c_int),
         "srl_build_residuals_overlap": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq), p, p], C.c_int),
         "srl_solve_iekf": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.c_double, dp, dp, C.POINTER(IekfResult), p, C.c_int], C.c_int),
-        "srl_debug_iekf_wave_solve": ([C.POINTER(Frame), C.POINTER(IcpOpts), C.c_double, dp, dp, PROVIDER_FN, p, C.POINTER(IekfResult),
-                                       p, C.c_int], C.c_int),
+        "srl_debug_iekf_wave_solve": ([C.POINTER(Frame), C.POINTER(IcpOpts), C.c_double, dp, dp, PROVIDER_FN, p, C.c_int,
+                                       C.POINTER(IekfResult), p, C.c_int], C.c_int),
+        "srl_debug_set_iekf_exact_lu": ([p, C.c_int], C.c_int),
         "srl_set_taps": ([p, C.c_int], C.c_int),
         "srl_fetch_neighbors": ([p, p, p, p], C.c_int),
         "srl_fetch_residuals": ([p, p, p, p, p, p, p], C.c_int),
@@ -166,6 +167,8 @@ def load_library():
         "srl_lio_last_error": ([p], C.c_char_p),
         "srl_lio_set_extrinsics": ([p, dp, dp], C.c_int),
         "srl_lio_set_laser_point_cov": ([p, C.c_double], C.c_int),
+        "srl_lio_set_persistent_solve": ([p, C.c_int], C.c_int),
+        "srl_lio_last_solve_launches": ([p, C.POINTER(C.c_int)], C.c_int),
         "srl_lio_eskf_get_state": ([p, dp], C.c_int),
         "srl_lio_eskf_set_state": ([p, dp], C.c_int),
         "srl_lio_eskf_get_cov": ([p, dp], C.c_int),
@@ -261,7 +264,7 @@ def heap_topk(distances, K):
     return out[:n].copy()
 
 
-def iekf_wave_solve(frame, opts, laser_point_cov, state19, cov, provider, log_iters=0):
+def iekf_wave_solve(frame, opts, laser_point_cov, state19, cov, provider, log_iters=0, exact_lu=True):
     """srl_debug_iekf_wave_solve: the persistent kernel's one-wave ESIKF algebra (csrc/srl_iekf_wave.h) run on the host
     around normal equations from provider(frame, opts, out) -> status.  Returns dict(rc, verdict, iterations, state, cov, log)."""
     def _p(fp, op, outp, _user):
@@ -272,7 +275,7 @@ def iekf_wave_solve(frame, opts, laser_point_cov, state19, cov, provider, log_it
     res = IekfResult()
     log = np.zeros((max(log_iters, 1), 61)) if log_iters else None
     rc = load_library().srl_debug_iekf_wave_solve(C.byref(frame), C.byref(opts), float(laser_point_cov), _dptr(st), _dptr(P), cb, None,
-                                                  C.byref(res), _ptr(log) if log is not None else None, int(log_iters))
+                                                  1 if exact_lu else 0, C.byref(res), _ptr(log) if log is not None else None, int(log_iters))
     return dict(rc=rc, verdict=res.verdict, iterations=res.iterations, covariance_updated=res.covariance_updated, state=st,
                 cov=P.reshape(17, 17), num_residuals=res.last.num_residuals,
                 log=None if log is None else log[: min(res.iterations, log_iters)])
@@ -486,6 +489,21 @@ class Context:
         self._chk(self.lib.srl_search_neighbors(self.h, _ptr(q), len(q), nb, size, K, thr, _ptr(ids), _ptr(xyz), _ptr(nf)), "srl_search_neighbors")
         return ids, xyz, nf
 
+    def solve_iekf(self, frame, opts, laser_point_cov, state19, cov, log_iters=0, allow=(SRL_ERR_NAN_PLANARITY, SRL_ERR_RETRY_PER_ITERATION)):
+        """srl_solve_iekf: the whole updateIEKF loop in one persistent kernel on the resident sweep."""
+        st = _f64(state19).copy()
+        P = _f64(cov).ravel().copy()
+        res = IekfResult()
+        log = np.zeros((max(log_iters, 1), 61)) if log_iters else None
+        rc = self._chk(self.lib.srl_solve_iekf(self.h, C.byref(frame), C.byref(opts), float(laser_point_cov), _dptr(st), _dptr(P),
+                                               C.byref(res), _ptr(log) if log is not None else None, int(log_iters)), "solve_iekf", ok=allow)
+        return dict(rc=rc, verdict=res.verdict, iterations=res.iterations, covariance_updated=res.covariance_updated,
+                    observed=res.observed, state=st, cov=P.reshape(17, 17), num_residuals=res.last.num_residuals, neq=res.last,
+                    log=None if log is None else log[: min(res.iterations, log_iters)])
+
+    def set_iekf_exact_lu(self, on):
+        self._chk(self.lib.srl_debug_set_iekf_exact_lu(self.h, 1 if on else 0), "set_iekf_exact_lu")
+
     def set_launch_shape(self, kpw, wpb):
         self._chk(self.lib.srl_debug_set_launch_shape(self.h, int(kpw), int(wpb)), "srl_debug_set_launch_shape")
 
@@ -622,6 +640,14 @@ class Lio:
 
     def set_extrinsics(self, R_il, t_il):
         self._chk(self.lib.srl_lio_set_extrinsics(self.h, _dptr(_f64(R_il).ravel()), _dptr(_f64(t_il))), "set_extrinsics")
+
+    def set_persistent_solve(self, on):
+        self._chk(self.lib.srl_lio_set_persistent_solve(self.h, 1 if on else 0), "set_persistent_solve")
+
+    def last_solve_launches(self):
+        n = C.c_int()
+        self._chk(self.lib.srl_lio_last_solve_launches(self.h, C.byref(n)), "last_solve_launches")
+        return n.value
 
     def set_laser_point_cov(self, c):
         self._chk(self.lib.srl_lio_set_laser_point_cov(self.h, float(c)), "set_laser_point_cov")

@@ -210,6 +210,10 @@ public:
     bool record_iterations = false;
     std::vector<iterationLog> iteration_log;
     int last_num_iterations = 0;
+    // updateIEKF as ONE persistent kernel (srl_solve_iekf) where the configuration allows; false: always one
+    // srl_build_residuals call per ESIKF iteration with the 17-dim algebra on the host (the reference form, A/B, tests)
+    bool persistent_solve = true;
+    int last_solve_launches = 0;       // kernel launches the last solve cost: 1, or one per pass
 
 private:
     int normalEquations(const icpOptions &o, cloudFrame *p_frame, srl_normal_eq &neq, void (*while_running)(void *) = nullptr, void *user = nullptr);

@@ -110,31 +110,39 @@ struct Quat {
         r(2, 0) = txz - twy; r(2, 1) = tyz + twx; r(2, 2) = 1.0 - (txx + tyy);
         return r;
     }
+    // the branch of Shepperd's method for a non-positive trace, largest diagonal element I (static indices: the same
+    // operations as Eigen's run-time i, j, k form, and no indexed local array in device code)
+    template <int I>
+    SRL_HD static Quat shepperdDiag(const Mat3 &m) {
+        constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+        double t = std::sqrt(m(I, I) - m(J, J) - m(K, K) + 1.0);
+        const double vi = 0.5 * t;
+        t = 0.5 / t;
+        const double w = (m(K, J) - m(J, K)) * t;
+        const double vj = (m(J, I) + m(I, J)) * t;
+        const double vk = (m(K, I) + m(I, K)) * t;
+        if (I == 0) return Quat(w, vi, vj, vk);
+        if (I == 1) return Quat(w, vk, vi, vj);
+        return Quat(w, vj, vk, vi);
+    }
     SRL_HD static Quat fromRotationMatrix(const Mat3 &m) {   // Shepperd
-        Quat q;
         double t = m(0, 0) + m(1, 1) + m(2, 2);
         if (t > 0.0) {
+            Quat q;
             t = std::sqrt(t + 1.0);
             q.w = 0.5 * t;
             t = 0.5 / t;
             q.x = (m(2, 1) - m(1, 2)) * t;
             q.y = (m(0, 2) - m(2, 0)) * t;
             q.z = (m(1, 0) - m(0, 1)) * t;
-        } else {
-            int i = 0;
-            if (m(1, 1) > m(0, 0)) i = 1;
-            if (m(2, 2) > m(i, i)) i = 2;
-            const int j = (i + 1) % 3, k = (j + 1) % 3;
-            t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0);
-            double v[3];
-            v[i] = 0.5 * t;
-            t = 0.5 / t;
-            q.w = (m(k, j) - m(j, k)) * t;
-            v[j] = (m(j, i) + m(i, j)) * t;
-            v[k] = (m(k, i) + m(i, k)) * t;
-            q.x = v[0]; q.y = v[1]; q.z = v[2];
+            return q;
         }
-        return q;
+        int i = 0;
+        if (m(1, 1) > m(0, 0)) i = 1;
+        if (m(2, 2) > m(i == 1 ? 1 : 0, i == 1 ? 1 : 0)) i = 2;
+        if (i == 0) return shepperdDiag<0>(m);
+        if (i == 1) return shepperdDiag<1>(m);
+        return shepperdDiag<2>(m);
     }
 };
 

@@ -148,6 +148,13 @@ int srl_ctx_create(int device, srl_ctx **out) {
         return SRL_ERR_HIP;
     }
     std::memset(ctx->h_mail, 0, sizeof(SrlMailbox));
+    if (hipHostMalloc((void **)&ctx->h_solve, sizeof(SrlSolveMailbox), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->h_solve_log, (size_t)SRL_SOLVE_LOG_ROWS * 61 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_pose_granules, 64 * 8) != hipSuccess || hipMemset(ctx->d_pose_granules, 0, 64 * 8) != hipSuccess) {
+        delete ctx;
+        return SRL_ERR_HIP;
+    }
+    std::memset(ctx->h_solve, 0, sizeof(SrlSolveMailbox));
     for (int i = 0; i < 4; i++) hipEventCreate(&ctx->ev[i]);
     *out = ctx;
     return SRL_OK;
@@ -162,11 +169,13 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
                     ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
-                    ctx->d_tap_offset, ctx->d_gather};
+                    ctx->d_tap_offset, ctx->d_gather, ctx->d_pose_granules};
     for (void *b : bufs) if (b) hipFree(b);
     if (ctx->h_out) hipHostFree(ctx->h_out);
     if (ctx->h_count) hipHostFree(ctx->h_count);
     if (ctx->h_mail) hipHostFree(ctx->h_mail);
+    if (ctx->h_solve) hipHostFree(ctx->h_solve);
+    if (ctx->h_solve_log) hipHostFree(ctx->h_solve_log);
     if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
     if (ctx->h_ring) { hipHostFree(ctx->h_ring); for (int i = 0; i < srl_ctx::RING_SLOTS; i++) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]); }
     for (auto &b : ctx->pool_free) hipFree(b.p);
@@ -497,10 +506,8 @@ int srl_get_timing(srl_ctx *ctx, srl_timing *t) {
 
 // ------------------------------------------------------------------------------------------ hot path
 // one association + reduction pass over the first n_eff keypoints of this rank's shard (n_eff == ctx->n: all of them)
-static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, srl_normal_eq *out, int n_eff) {
-    const auto t_entry = std::chrono::steady_clock::now();
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-
+// the kernel arguments both forms of the pass share (one-shot kernel per ESIKF iteration / persistent solve)
+static int prepare_assoc_args(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, int n_eff, SrlAssocArgs &a, int &nb_out) {
     // init-mode switches (optimize.cpp:21-23)
     const bool init_mode = f->frame_id < o->init_num_frames;
     const int nb = init_mode ? 2 : o->voxel_neighborhood;
@@ -510,7 +517,6 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     if (K < 1 || K > SRL_MAX_NEIGHBORS) { ctx->err = "max_number_neighbors must be in [1,32]"; return SRL_ERR_UNSUPPORTED; }
     if (!(o->size_voxel_map > 0.0)) return SRL_ERR_BAD_ARG;
 
-    SrlAssocArgs a;
     std::memset(&a, 0, sizeof a);
     a.raw_x = ctx->d_raw;
     a.raw_y = ctx->d_raw + ctx->sweep_cap;
@@ -556,6 +562,18 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     a.status = ctx->d_status;
     a.partials = ctx->d_partials;
     a.binfo = ctx->d_binfo;
+    nb_out = nb;
+    return SRL_OK;
+}
+
+static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, srl_normal_eq *out, int n_eff) {
+    const auto t_entry = std::chrono::steady_clock::now();
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    SrlAssocArgs a;
+    int nb = 1;
+    { const int rca = prepare_assoc_args(ctx, f, o, n_eff, a, nb); if (rca) return rca; }
+    const int K = o->max_number_neighbors;
+    const bool cut_possible_here = o->max_num_residuals <= 0 || (long long)o->max_num_residuals <= (long long)ctx->total_n;
     ctx->taps_valid = false;
     if (ctx->taps) {
         int rc = ensure_taps(ctx, ctx->n, K);
@@ -912,6 +930,11 @@ int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable) {
     ctx->fuse_reduce = enable != 0;
     return SRL_OK;
 }
+int srl_debug_set_iekf_exact_lu(srl_ctx *ctx, int exact_lu) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    ctx->iekf_exact_lu = exact_lu != 0;
+    return SRL_OK;
+}
 int srl_debug_set_search_select_mode(srl_ctx *ctx, int select_mode) {
     if (!ctx || select_mode < 0 || select_mode > 5) return SRL_ERR_BAD_ARG;
     ctx->search_select_mode = select_mode;
@@ -960,7 +983,7 @@ static void iekf_log_row(double *log, int row, const srl_normal_eq &neq, const d
     L[60] = neq.loss_sum;
 }
 int srl_debug_iekf_wave_solve(const srl_frame *frame, const srl_icp_opts *o, double laser_point_cov, double state[19],
-                              double covariance[289], srl_neq_fn fn, void *user, srl_iekf_result *res, double *log,
+                              double covariance[289], srl_neq_fn fn, void *user, int exact_lu, srl_iekf_result *res, double *log,
                               int max_log_iters) {
     if (!frame || !o || !state || !covariance || !fn || !res) return SRL_ERR_BAD_ARG;
     using namespace srlw;
@@ -969,12 +992,14 @@ int srl_debug_iekf_wave_solve(const srl_frame *frame, const srl_icp_opts *o, dou
     static thread_local IekfShared sh;
     std::memcpy(sh.state, state, sizeof sh.state);
     sh.singular = 0;
+    sh.observed = 0;
     srl_frame f = *frame;
     std::memset(res, 0, sizeof *res);
     double cov_out[289];
     int verdict = IEKF_CONTINUE;
     for (int iter = 0; iter <= K.max_num_iter && verdict == IEKF_CONTINUE; iter++) {
-        iekf_prior<HostWave>(K, covariance, sh);
+        if (exact_lu) iekf_prior<HostWave, false>(K, covariance, sh);
+        else iekf_prior<HostWave, true>(K, covariance, sh);
         srl_normal_eq neq;
         std::memset(&neq, 0, sizeof neq);
         const int rc = fn(&f, o, &neq, user);
@@ -985,7 +1010,7 @@ int srl_debug_iekf_wave_solve(const srl_frame *frame, const srl_icp_opts *o, dou
         res->iterations++;
         std::memcpy(sh.HtH, neq.HtH, sizeof sh.HtH);
         std::memcpy(sh.Hth, neq.Hth, sizeof sh.Hth);
-        verdict = iekf_update<HostWave>(K, iter, sh, cov_out);
+        verdict = exact_lu ? iekf_update<HostWave, false>(K, iter, sh, cov_out) : iekf_update<HostWave, true>(K, iter, sh, cov_out);
         if (log && iter < max_log_iters) iekf_log_row(log, iter, neq, sh.d_x);
         if (sh.singular) { verdict = IEKF_SINGULAR; break; }
         // the pose of the next pass is the filter's (optimize.cpp:255-256)
@@ -993,16 +1018,137 @@ int srl_debug_iekf_wave_solve(const srl_frame *frame, const srl_icp_opts *o, dou
         f.t[0] = sh.state[0]; f.t[1] = sh.state[1]; f.t[2] = sh.state[2];
     }
     res->verdict = verdict;
+    res->observed = sh.observed;
     if (verdict == IEKF_SINGULAR) return SRL_ERR_RETRY_PER_ITERATION;
     std::memcpy(state, sh.state, sizeof sh.state);
     if (verdict == IEKF_DONE) { std::memcpy(covariance, cov_out, sizeof cov_out); res->covariance_updated = 1; }
     return verdict == IEKF_NAN ? SRL_ERR_NAN_PLANARITY : SRL_OK;
 }
 
-int srl_solve_iekf(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts *o, double laser_point_cov, double state[19],
+// ---- one launch per solve: the whole loop of updateIEKF (optimize.cpp:133-314) in the persistent kernel
+int srl_solve_iekf(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, double laser_point_cov, double state[19],
                    double covariance[289], srl_iekf_result *res, double *log, int max_log_iters) {
-    (void)ctx; (void)frame; (void)o; (void)laser_point_cov; (void)state; (void)covariance; (void)res; (void)log; (void)max_log_iters;
-    return SRL_ERR_RETRY_PER_ITERATION;
+    if (!ctx || !f || !o || !state || !covariance || !res) return SRL_ERR_BAD_ARG;
+    if (!ctx->d_table) return SRL_ERR_NO_MAP;
+    if (!ctx->sweep_loaded) return SRL_ERR_NO_SWEEP;
+    std::memset(res, 0, sizeof *res);
+    // what the persistent kernel does not cover goes through srl_build_residuals (the caller's loop): shards, taps, debug
+    // ablations, max_num_residuals <= 0 (the stop-at-the-first-plane quirk), empty sweeps, the general selection paths
+    const bool single = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
+    const bool fast_sel = o->select_mode == 0 || o->select_mode == 4;
+    if (!single || ctx->taps || ctx->ablate != 0 || o->max_num_residuals <= 0 || ctx->total_n <= 0 || !fast_sel || !ctx->fuse_reduce ||
+        ctx->force_kpw != 0 || ctx->profiling == 1)
+        return SRL_ERR_RETRY_PER_ITERATION;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // finite max_num_residuals: the sequential loop never looks past the max-th accepted keypoint, so only a prefix that
+    // almost surely contains it is associated (as srl_build_residuals does); if a pass finds it too short the kernel stops
+    // with IEKF_PREFIX_SHORT and the caller repeats the solve per iteration
+    const bool cut_possible = (long long)o->max_num_residuals <= (long long)ctx->total_n;
+    int n_eff = ctx->n;
+    if (cut_possible) {
+        const long long pre = ((4LL * o->max_num_residuals + 2048 + 63) / 64) * 64;
+        if (pre < (long long)ctx->n) n_eff = (int)pre;
+    }
+    SrlAssocArgs a;
+    int nb = 1;
+    { const int rca = prepare_assoc_args(ctx, f, o, n_eff, a, nb); if (rca) return rca; }
+    const int K = o->max_number_neighbors;
+    const int kpw = srl_keypoints_per_wave_one_round(n_eff, ctx->num_cu);
+    if (srl_solve_lds_bytes(K, nb, kpw) > SRL_LDS_LIMIT) return SRL_ERR_RETRY_PER_ITERATION;
+    const int kpb = 16 * kpw;
+    const int ntiles = (n_eff + kpb - 1) / kpb;
+    if (cut_possible && (kpb > SRL_FUSED_CUT_MAX_KPB || ntiles > ctx->num_cu)) return SRL_ERR_RETRY_PER_ITERATION;   // the fused ordered cut needs one small tile per workgroup
+    const int grid = std::min(ntiles, ctx->num_cu);          // every workgroup resident: one 16-wave workgroup per compute unit at most
+    a.write_rec = 0;
+    a.granules = ctx->d_granules;
+    a.mailbox = ctx->h_mail;                                  // unused by the persistent kernel (its result goes to h_solve)
+    if (cut_possible) {
+        const size_t need = (size_t)ntiles * kpb * 16;
+        if (need > ctx->rec_granule_cap) {
+            int rcg;
+            if ((rcg = ensure(ctx, ctx->d_rec_granules, need))) return rcg;
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_rec_granules, 0, need * sizeof(unsigned long long), ctx->stream));
+            ctx->rec_granule_cap = need;
+        }
+        a.rec_granules = ctx->d_rec_granules;
+        a.cut_max = o->max_num_residuals;
+    }
+    SrlSolveArgs sv;
+    std::memset(&sv, 0, sizeof sv);
+    iekf_consts_from(f, o, laser_point_cov, state, sv.K);
+    std::memcpy(sv.state0, state, sizeof sv.state0);
+    std::memcpy(sv.cov0, covariance, sizeof sv.cov0);
+    sv.pose_granules = ctx->d_pose_granules;
+    sv.mailbox = ctx->h_solve;
+    const int log_rows = log ? std::min(max_log_iters, SRL_SOLVE_LOG_ROWS) : 0;
+    sv.log = log_rows > 0 ? ctx->h_solve_log : nullptr;
+    sv.max_log = log_rows;
+    sv.min_residuals = o->min_number_neighbors;
+    sv.ntiles = ntiles;
+    sv.prefix = (cut_possible && n_eff < ctx->n) ? 1 : 0;
+    sv.exact_lu = ctx->iekf_exact_lu ? 1 : 0;
+    // one epoch per pass: rows and pose granules of pass i carry seq + i
+    const unsigned long long seq0 = ctx->seq + 1;
+    ctx->seq += (unsigned long long)sv.K.max_num_iter + 2;
+    a.seq = seq0;
+    ctx->last_nblocks = grid;
+    hipEvent_t *ring_ev = nullptr;
+    if (ctx->profiling == 2) {
+        if (ctx->ring_head - ctx->ring_tail >= (unsigned)srl_ctx::PROF_RING) { int rc = drain_ring(ctx, true); if (rc) return rc; }
+        ring_ev = ctx->ring[ctx->ring_head % srl_ctx::PROF_RING];
+        HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
+    }
+    HIPCHK(ctx, srl_launch_solve(a, sv, nb, kpw, grid, ctx->stream));
+    if (ring_ev) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_head++; }
+    {
+        volatile unsigned long long *seqp = &ctx->h_solve->seq;
+        unsigned long long spins = 0;
+        while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq0) {
+            if ((++spins & 0xFFFFF) == 0) {
+                const hipError_t qe = hipStreamQuery(ctx->stream);
+                if (qe != hipSuccess && qe != hipErrorNotReady) { ctx->err = std::string("solve kernel: ") + hipGetErrorString(qe); return SRL_ERR_HIP; }
+                if (qe == hipSuccess && __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq0) {
+                    // every workgroup left without a verdict from the finishing one (its bounded waits ran out)
+                    ctx->err = "solve kernel finished without publishing";
+                    return SRL_ERR_RETRY_PER_ITERATION;
+                }
+            }
+        }
+    }
+    const SrlSolveMailbox &mb = *ctx->h_solve;
+    res->verdict = (int32_t)mb.verdict;
+    res->iterations = (int32_t)mb.iterations;
+    res->covariance_updated = (int32_t)mb.covariance_updated;
+    res->observed = (int32_t)mb.observed;
+    {
+        const SrlDevOut &r = mb.last;
+        std::memcpy(res->last.HtH, r.HtH, sizeof res->last.HtH);
+        std::memcpy(res->last.Hth, r.Hth, sizeof res->last.Hth);
+        res->last.loss_sum = r.loss;
+        res->last.num_residuals = (int32_t)(r.d_num_res + 0.5);
+        res->last.success = res->last.num_residuals >= o->min_number_neighbors ? 1 : 0;
+        res->last.sum_candidates = (int64_t)(r.d_sum_pk + 0.5);
+        res->last.last_visited = (int64_t)(r.d_visited + 0.5) - 1;
+        res->last.nan_error = r.d_nan > 0.5 ? 1 : 0;
+        res->last.num_fallback = (int32_t)(r.d_fallback + 0.5);
+        const long long side = 2 * nb + 1;
+        ctx->timing.algorithmic_bytes = (24 + 12 * side * side * side) * (long long)n_eff + (long long)(12.0 * r.d_sum_pk);
+        if (ctx->profiling == 2) { ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes * std::max(1, res->iterations); ctx->timing.sum_keypoints += (long long)n_eff * std::max(1, res->iterations); }
+    }
+    ctx->last_K = K;
+    ctx->last_nb = nb;
+    ctx->taps_valid = false;
+    switch (res->verdict) {
+        case srlw::IEKF_DONE: case srlw::IEKF_DONE_NO_COV: case srlw::IEKF_FAIL_RESIDUALS: break;
+        case srlw::IEKF_NAN: ctx->err = "NaN planarity"; return SRL_ERR_NAN_PLANARITY;
+        case srlw::IEKF_PREFIX_SHORT: ctx->err = "solve kernel: the keypoint prefix held fewer accepted residuals than max_num_residuals"; return SRL_ERR_RETRY_PER_ITERATION;
+        case srlw::IEKF_TIMEOUT: ctx->err = "solve kernel: a workgroup's row did not arrive in time"; return SRL_ERR_RETRY_PER_ITERATION;
+        default: ctx->err = "solve kernel: singular normal equations"; return SRL_ERR_RETRY_PER_ITERATION;
+    }
+    std::memcpy(state, mb.state, sizeof(double) * 19);
+    if (res->covariance_updated) std::memcpy(covariance, mb.cov, sizeof(double) * 289);
+    if (log_rows > 0) std::memcpy(log, ctx->h_solve_log, (size_t)std::min(log_rows, res->iterations) * 61 * sizeof(double));
+    return SRL_OK;
 }
 
 void srl_shard_range(int n, int nranks, int rank, int *begin, int *count) {

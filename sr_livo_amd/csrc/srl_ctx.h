@@ -84,6 +84,12 @@ struct srl_ctx {
     int force_kpw = 0, force_wpb = 0;  // srl_debug_set_launch_shape (0 = automatic)
     bool fuse_reduce = true;           // srl_debug_set_fused_reduce(0): always run the separate reduce kernel (A/B, tests)
     SrlMailbox *h_mail = nullptr;      // host-mapped fine-grained mailbox the reduce kernel publishes into
+    // persistent solve (srl_solve_iekf): result mailbox and per-pass log in host-mapped memory, the pose hand-over granules
+    SrlSolveMailbox *h_solve = nullptr;
+    double *h_solve_log = nullptr;     // SRL_SOLVE_LOG_ROWS x 61 doubles
+    unsigned long long *d_pose_granules = nullptr;
+    bool iekf_exact_lu = false;        // srl_debug_set_iekf_exact_lu
+    bool solve_lds_opted = false;
     unsigned long long seq = 0;
 
     // taps
@@ -123,6 +129,8 @@ struct srl_ctx {
     srl_timing timing = {};
     int last_nb = 1;
 };
+
+#define SRL_SOLVE_LOG_ROWS 32
 
 #define HIPCHK(ctx, call)                                                                      \
     do {                                                                                       \

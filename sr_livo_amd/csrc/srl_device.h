@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "srl_iekf_wave.h"
+
 #define SRL_CAP 20
 #define SRL_SLAB_BYTES 256
 #define SRL_MAX_SLABS 16777215u      // slab * 256 + slot offset must fit 32 bits (kernels address slabs with 32-bit byte offsets)
@@ -129,6 +131,35 @@ struct SrlAssocArgs {
     double *tap_offset;     // n
 };
 
+// ---- persistent solve (one launch per updateIEKF, optimize.cpp:133-314): second kernel argument, behind SrlAssocArgs ----
+struct SrlSolveMailbox {       // host-mapped (fine-grained): what the finishing workgroup leaves when the loop ends
+    double state[19];          // the filter after the last observe(): p q(wxyz) v ba bg g
+    double cov[289];           // posterior covariance (valid when covariance_updated)
+    SrlDevOut last;            // normal equations of the last pass
+    long long verdict;         // srlw::IEKF_*
+    long long iterations;      // passes that delivered normal equations
+    long long covariance_updated;
+    long long observed;        // observe() calls (optimize.cpp:253)
+    unsigned long long seq;    // = launch sequence number once everything above is complete
+    unsigned long long pad[7];
+};
+#define SRL_POSE_DOUBLES 22    // what the finishing workgroup hands to the others after a pass: Rn[9] R[9] t[3] verdict
+struct SrlSolveArgs {
+    srlw::IekfConsts K;
+    double state0[19];         // eskfEstimator state at entry
+    double cov0[289];          // its covariance, row-major
+    unsigned long long *pose_granules;   // 2 * SRL_POSE_DOUBLES tagged granules {epoch, 32-bit half}
+    SrlSolveMailbox *mailbox;
+    double *log;               // host-mapped: 61 doubles per pass (HtH Hth d_x num_residuals loss), or null
+    int max_log;
+    int min_residuals;         // min_number_neighbors: fewer accepted residuals fail the solve (optimize.cpp:110)
+    int ntiles;                // tiles of KPW x 16 keypoints; workgroup b takes tiles b, b + gridDim, ...
+    int prefix;                // finite max_num_residuals: only a prefix of the shard is associated (too few accepted -> the host repeats)
+    int exact_lu;              // 1: both 17 x 17 inverses by partial-pivot LU in the host's order; 0: the Schur-complement form (srl_iekf_wave.h)
+    int pad;
+};
+static_assert(sizeof(SrlAssocArgs) + sizeof(SrlSolveArgs) <= 4096, "both structs travel in the kernarg segment");
+
 struct SrlReduceArgs {
     const double *rec;
     const unsigned char *status;
@@ -164,6 +195,9 @@ struct SrlSearchArgs {
 // launchers (srl_kernels.hip)
 hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpw, int wpb, hipStream_t s);
 int srl_assoc_lds_bytes(int K, int nb_voxels, int kpw, int wpb);
+// persistent solve: 16-wave workgroups, `grid` of them (<= compute units: every workgroup must be resident)
+hipError_t srl_launch_solve(const SrlAssocArgs &a, const SrlSolveArgs &sv, int nb_voxels, int kpw, int grid, hipStream_t s);
+int srl_solve_lds_bytes(int K, int nb_voxels, int kpw);
 // keypoints per wave for a pass over n keypoints: the largest of 4 / 8 / 16 that still yields >= ~4096 waves
 static inline int srl_keypoints_per_wave(int n) { return n <= 16384 ? 4 : (n <= 32768 ? 8 : 16); }
 // ... and for 16-wave workgroups that fuse the final reduction: the smallest instantiated count that still puts the sweep on

@@ -59,7 +59,11 @@ struct IekfShared {
     double d_x_new[17];      // projected prior error state (optimize.cpp:213-218)
     double HtH[36], Hth[6];  // normal equations of this iteration (filled by the reduction)
     double d_x[17];          // last step (log / posterior)
+    double F[17 * 6];        // fast form: covariance[:, 0:6] * covariance[0:6, 0:6]^-1
+    double RG[36];           // fast form: laser_point_cov * covariance[0:6, 0:6]^-1
     int singular;
+    int observed;            // observe() calls so far (optimize.cpp:253): the frame's pose is the filter's from the first one on
+    int passes;              // passes that delivered normal equations (the kernel's loop bookkeeping)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -90,13 +94,24 @@ struct DevWave {
         const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, false);
         return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
-    static __device__ __forceinline__ double wave_max17(VD v) {
-        v = fmax(v, dpp<0xB1>(v));      // quad_perm [1,0,3,2]
-        v = fmax(v, dpp<0x4E>(v));      // quad_perm [2,3,0,1]
-        v = fmax(v, dpp<0x141>(v));     // row_half_mirror
-        v = fmax(v, dpp<0x140>(v));     // row_mirror
-        return fmax(bcast(v, 0), bcast(v, 16));
+    static __device__ __forceinline__ double vmax(double a, double b) {      // one v_max_f64 (no NaN canonicalisation around it)
+        double r;
+        asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
     }
+    static __device__ __forceinline__ double wave_max17(VD v) {
+        v = vmax(v, dpp<0xB1>(v));      // quad_perm [1,0,3,2]
+        v = vmax(v, dpp<0x4E>(v));      // quad_perm [2,3,0,1]
+        v = vmax(v, dpp<0x141>(v));     // row_half_mirror
+        v = vmax(v, dpp<0x140>(v));     // row_mirror
+        return vmax(bcast(v, 0), bcast(v, 16));
+    }
+    // Register pressure: every loop below is fully unrolled and nothing orders the LDS reads / broadcasts of a later row
+    // behind the arithmetic of an earlier one -- left alone the scheduler issues all of them first and spills.  `after`
+    // makes a pointer / value opaque and dependent on a result of the step before: what is read through it stays behind.
+    static __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
+    static __device__ __forceinline__ const double *after(const double *p, VD dep) { asm volatile("" : "+v"(p) : "v"(dep)); return p; }
+    static __device__ __forceinline__ VD after_v(VD v, VD dep) { asm volatile("" : "+v"(v) : "v"(dep)); return v; }
     static __device__ __forceinline__ unsigned long long ballot(VB p) { return __ballot(p); }
     static __device__ __forceinline__ VD sel(VB c, VD a, VD b) { return c ? a : b; }
     static __device__ __forceinline__ VI sel_i(VB c, VI a, VI b) { return c ? a : b; }
@@ -139,6 +154,9 @@ struct HostWave {
     static void st(double *base, const VI &idx, const VD &v, const VB &m) { for (int l = 0; l < 64; l++) if (m.v[l]) base[idx.v[l]] = v.v[l]; }
     static double ldu(const double *p) { return *p; }
     static void barrier() {}
+    static void fence() {}
+    static const double *after(const double *p, const VD &) { return p; }
+    static VD after_v(const VD &v, const VD &) { return v; }
 };
 #define SRLW_BIN(op)                                                                                                                   \
     inline HostWave::VD operator op(const HostWave::VD &a, const HostWave::VD &b) { HostWave::VD r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] op b.v[l]; return r; } \
@@ -208,6 +226,7 @@ SRL_HD inline bool wave_inverse_cols(typename W::VD (&r)[17], double *sh_u, doub
 #pragma unroll
             for (int c = 0; c < M; c++) yy[c] = yy[c] - f * W::bcast(yy[c], p_lane);          // Y[i][c] -= lu[i][k] * Y[k][c]
         });
+        W::fence();
     }
     // U and the forward-substituted right-hand sides by position, then one lane per right-hand side
     const VI base = pos * 17;
@@ -222,9 +241,10 @@ SRL_HD inline bool wave_inverse_cols(typename W::VD (&r)[17], double *sh_u, doub
     for (int i = 0; i < 17; i++) x[i] = W::ld(sh_y, cl + i * 17);
 #pragma unroll
     for (int i = 16; i >= 0; i--) {
+        const double *urow = W::after(sh_u + i * 17, x[i < 16 ? i + 1 : 16]);      // row i of U is read once row i + 1 is done
 #pragma unroll
-        for (int j = i + 1; j < 17; j++) x[i] = x[i] - W::ldu(sh_u + i * 17 + j) * x[j];
-        x[i] = x[i] / W::ldu(sh_u + i * 17 + i);
+        for (int j = i + 1; j < 17; j++) x[i] = x[i] - W::ldu(urow + j) * x[j];
+        x[i] = x[i] / W::ldu(urow + i);
     }
     W::barrier();
     return ok;
@@ -236,16 +256,19 @@ template <class W, int NC>
 SRL_HD inline void wave_left3(typename W::VD *dst, const srl::Mat3 &J, const typename W::VD *src, int row0) {
     typedef typename W::VD VD;
     const typename W::VI lane = W::lane();
-    const typename W::VB m0 = lane == row0, m1 = lane == row0 + 1, m2 = lane == row0 + 2;
+    const typename W::VB m0 = lane == row0, m1 = lane == row0 + 1;
     const VD j0 = W::sel(m0, W::splat(J(0, 0)), W::sel(m1, W::splat(J(1, 0)), W::splat(J(2, 0))));
     const VD j1 = W::sel(m0, W::splat(J(0, 1)), W::sel(m1, W::splat(J(1, 1)), W::splat(J(2, 1))));
     const VD j2 = W::sel(m0, W::splat(J(0, 2)), W::sel(m1, W::splat(J(1, 2)), W::splat(J(2, 2))));
     const typename W::VB mine = (lane >= row0) && (lane < row0 + 3);
+    VD prev = j0;
 #pragma unroll
     for (int j = 0; j < NC; j++) {
-        const double b0 = W::bcast(src[j], row0), b1 = W::bcast(src[j], row0 + 1), b2 = W::bcast(src[j], row0 + 2);
+        const VD sj = W::after_v(src[j], prev);
+        const double b0 = W::bcast(sj, row0), b1 = W::bcast(sj, row0 + 1), b2 = W::bcast(sj, row0 + 2);
         const VD v = (j0 * b0 + j1 * b1) + j2 * b2;
         dst[j] = W::sel(mine, v, dst[j]);
+        prev = v;
     }
 }
 template <class W, int NC>
@@ -256,11 +279,14 @@ SRL_HD inline void wave_left2(typename W::VD *dst, const srl::Mat2 &J, const typ
     const VD j0 = W::sel(m0, W::splat(J(0, 0)), W::splat(J(1, 0)));
     const VD j1 = W::sel(m0, W::splat(J(0, 1)), W::splat(J(1, 1)));
     const typename W::VB mine = (lane >= row0) && (lane < row0 + 2);
+    VD prev = j0;
 #pragma unroll
     for (int j = 0; j < NC; j++) {
-        const double b0 = W::bcast(src[j], row0), b1 = W::bcast(src[j], row0 + 1);
+        const VD sj = W::after_v(src[j], prev);
+        const double b0 = W::bcast(sj, row0), b1 = W::bcast(sj, row0 + 1);
         const VD v = j0 * b0 + j1 * b1;
         dst[j] = W::sel(mine, v, dst[j]);
+        prev = v;
     }
 }
 // dst(i, c0 .. c0+2) = src(i, c0 .. c0+2) * J^T for every row (optimize.cpp:222,300): in-lane
@@ -277,6 +303,56 @@ SRL_HD inline void wave_right2(typename W::VD *dst, const srl::Mat2 &J, const ty
     const VD s0 = src[c0], s1 = src[c0 + 1];
 #pragma unroll
     for (int c = 0; c < 2; c++) dst[c0 + c] = s0 * J(c, 0) + s1 * J(c, 1);
+}
+
+// ---- the FAST form of the second inverse ------------------------------------------------------------------------------
+// updateIEKF only ever reads temp_inv.block<17,6>(0,0) of temp = (C / R)^-1 with temp[0:6,0:6] += H (optimize.cpp:234-242;
+// C = projected covariance, R = laser_point_cov, H = H_x^T H_x).  By the block-inverse (Schur complement) identity
+//     temp_inv[:, 0:6] = F * (R * G + H)^-1,        G = C66^-1,   F = C[:, 0:6] * G        (C66 = C[0:6, 0:6])
+// -- F and R G do not depend on H and are prepared while the sweep is associated; behind the reduction only a symmetric
+// positive definite 6 x 6 system is left (Cholesky, no pivoting), ~1/10 of the instructions of the 17 x 17 LU.  Same
+// matrix, different operation order: agrees with the LU form to ~1e-10 relative (tests/test_iekf_wave.py bounds it), which
+// is why the LU form stays as the pinned reference form (bitwise equal to the host mirror) and this one is a mode.
+//
+// Cholesky factor of the SPD 6 x 6 matrix whose row i sits in a[0..5] of lane i < 6 (lower triangle read):
+// L(c, k), c >= k, packed at c (c + 1) / 2 + k, and 1 / L(c, c) -- wave-uniform values.
+template <class W>
+SRL_HD inline void wave_chol6(typename W::VD (&a)[6], double (&L)[21], double (&inv_d)[6]) {
+    typedef typename W::VD VD;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const double d = std::sqrt(W::bcast(a[j], j));
+        const double id = 1.0 / d;
+        L[j * (j + 1) / 2 + j] = d;
+        inv_d[j] = id;
+        const VD lij = a[j] * id;                          // column j of L (rows i > j)
+#pragma unroll
+        for (int c = j + 1; c < 6; c++) {
+            const double lcj = W::bcast(lij, c);
+            L[c * (c + 1) / 2 + j] = lcj;
+            a[c] = a[c] - lij * lcj;                       // trailing update of column c (rows i >= c are read later)
+        }
+    }
+}
+// z (L L^T) = f for one right-hand side per lane (row vectors of 6)
+template <class W>
+SRL_HD inline void wave_solve6(const double (&L)[21], const double (&inv_d)[6], const typename W::VD (&f)[6], typename W::VD (&z)[6]) {
+    typedef typename W::VD VD;
+    VD w[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        VD s = f[c];
+#pragma unroll
+        for (int k = 0; k < c; k++) s = s - w[k] * L[c * (c + 1) / 2 + k];
+        w[c] = s * inv_d[c];
+    }
+#pragma unroll
+    for (int c = 5; c >= 0; c--) {
+        VD s = w[c];
+#pragma unroll
+        for (int k = c + 1; k < 6; k++) s = s - z[k] * L[k * (k + 1) / 2 + c];
+        z[c] = s * inv_d[c];
+    }
 }
 
 struct IekfState {
@@ -311,7 +387,7 @@ struct IekfState {
 // prior(): optimize.cpp:172-234 (host/lioOptimization.cpp:251-306).  P = covariance at loop entry, row-major (any memory).
 // Leaves sh.cov (projected covariance), sh.temp = (covariance / R)^-1, sh.d_x_new.
 // ---------------------------------------------------------------------------------------------------------------------
-template <class W>
+template <class W, bool FAST = false>
 SRL_HD inline void iekf_prior(const IekfConsts &K, const double *P, IekfShared &sh) {
     typedef typename W::VD VD;
     typedef typename W::VI VI;
@@ -369,6 +445,25 @@ SRL_HD inline void iekf_prior(const IekfConsts &K, const double *P, IekfShared &
     wave_right2<W>(c, J_k_s2, c, 15);
 #pragma unroll
     for (int j = 0; j < 17; j++) W::st(sh.cov, rbase + j, c[j], row);
+    if constexpr (FAST) {
+        // F = C[:, 0:6] C66^-1 and R G = R C66^-1 (see wave_chol6)
+        VD a[6], f[6], z[6];
+        double L[21], inv_d[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { a[j] = c[j]; f[j] = c[j]; }
+        wave_chol6<W>(a, L, inv_d);
+        wave_solve6<W>(L, inv_d, f, z);
+#pragma unroll
+        for (int j = 0; j < 6; j++) W::st(sh.F, W::sel_i(row, lane, W::spl_i(0)) * 6 + j, z[j], row);
+#pragma unroll
+        for (int j = 0; j < 6; j++) f[j] = W::sel(lane == j, W::splat(K.laser_point_cov), W::splat(0.0));
+        wave_solve6<W>(L, inv_d, f, z);
+        const typename W::VB top = lane < 6;
+#pragma unroll
+        for (int j = 0; j < 6; j++) W::st(sh.RG, W::sel_i(top, lane, W::spl_i(0)) * 6 + j, z[j], top);
+        W::barrier();
+        return;
+    }
     // temp = (covariance / laser_point_cov).inverse() (optimize.cpp:234)
 #pragma unroll
     for (int j = 0; j < 17; j++) c[j] = c[j] / K.laser_point_cov;
@@ -387,7 +482,7 @@ SRL_HD inline void iekf_prior(const IekfConsts &K, const double *P, IekfShared &
 // iter = the reference's loop index i + 1 (0 .. max_num_iter).  Returns IEKF_CONTINUE / IEKF_DONE / IEKF_DONE_NO_COV;
 // on IEKF_DONE cov_out (row-major, any memory) receives the posterior covariance.  sh.state is the filter.
 // ---------------------------------------------------------------------------------------------------------------------
-template <class W>
+template <class W, bool FAST = false>
 SRL_HD inline int iekf_update(const IekfConsts &K, int iter, IekfShared &sh, double *cov_out) {
     typedef typename W::VD VD;
     typedef typename W::VI VI;
@@ -398,30 +493,42 @@ SRL_HD inline int iekf_update(const IekfConsts &K, int iter, IekfShared &sh, dou
     const VB row = lane < 17;
     const VI rl = W::sel_i(row, lane, W::spl_i(0));
     const VI rbase = rl * 17;
-    // temp.block<6,6>(0,0) += H^T H (optimize.cpp:235-236), temp_inv.block<17,6>(0,0) (optimize.cpp:237)
-    VD t[17];
-#pragma unroll
-    for (int j = 0; j < 17; j++) t[j] = W::ld(sh.temp, rbase + j);
-    {
+    VD tl[6];                // row `lane` of temp_inv.block<17,6>(0,0)
+    if constexpr (FAST) {
+        // (R G + H) = L L^T, then temp_inv[i, 0:6] = F[i, :] (R G + H)^-1
+        VD a[6], f[6];
         const VB top = lane < 6;
         const VI hb = W::sel_i(top, lane, W::spl_i(0)) * 6;
 #pragma unroll
-        for (int j = 0; j < 6; j++) t[j] = W::sel(top, t[j] + W::ld(sh.HtH, hb + j), t[j]);
-    }
-    VD x[17];
-    const bool ok = wave_inverse_cols<W, 6>(t, sh.scr, sh.scr + 289, x);
-    if (!ok) sh.singular = 1;
-    {
-        const VB col = lane < 6;
-        const VI cl = W::sel_i(col, lane, W::spl_i(0));
-#pragma unroll
-        for (int i = 0; i < 17; i++) W::st(sh.scr, cl + i * 6, x[i], col);
+        for (int j = 0; j < 6; j++) { a[j] = W::ld(sh.RG, hb + j) + W::ld(sh.HtH, hb + j); f[j] = W::ld(sh.F, rl * 6 + j); }
+        double L[21], inv_d[6];
+        wave_chol6<W>(a, L, inv_d);
+        wave_solve6<W>(L, inv_d, f, tl);
+    } else {
+        // temp.block<6,6>(0,0) += H^T H (optimize.cpp:235-236), temp_inv.block<17,6>(0,0) (optimize.cpp:237)
+        VD t[17];
+    #pragma unroll
+        for (int j = 0; j < 17; j++) t[j] = W::ld(sh.temp, rbase + j);
+        {
+            const VB top = lane < 6;
+            const VI hb = W::sel_i(top, lane, W::spl_i(0)) * 6;
+    #pragma unroll
+            for (int j = 0; j < 6; j++) t[j] = W::sel(top, t[j] + W::ld(sh.HtH, hb + j), t[j]);
+        }
+        VD x[17];
+        const bool ok = wave_inverse_cols<W, 6>(t, sh.scr, sh.scr + 289, x);
+        if (!ok) sh.singular = 1;
+        {
+            const VB col = lane < 6;
+            const VI cl = W::sel_i(col, lane, W::spl_i(0));
+    #pragma unroll
+            for (int i = 0; i < 17; i++) W::st(sh.scr, cl + i * 6, x[i], col);
+            W::barrier();
+        }
+    #pragma unroll
+        for (int k = 0; k < 6; k++) tl[k] = W::ld(sh.scr, rl * 6 + k);
         W::barrier();
     }
-    VD tl[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) tl[k] = W::ld(sh.scr, rl * 6 + k);
-    W::barrier();
     // K_h = temp_inv.block<17,6>(0,0) * H^T h ; K_x.block<17,6>(0,0) = temp_inv.block<17,6>(0,0) * H^T H (optimize.cpp:239-242)
     VD kh = tl[0] * W::ldu(sh.Hth + 0);
 #pragma unroll
@@ -429,9 +536,10 @@ SRL_HD inline int iekf_update(const IekfConsts &K, int iter, IekfShared &sh, dou
     VD kx[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        VD s = tl[0] * W::ldu(sh.HtH + j);
+        const double *hcol = W::after(sh.HtH + j, j ? kx[j ? j - 1 : 0] : kh);
+        VD s = tl[0] * W::ldu(hcol);
 #pragma unroll
-        for (int k = 1; k < 6; k++) s = s + tl[k] * W::ldu(sh.HtH + k * 6 + j);
+        for (int k = 1; k < 6; k++) s = s + tl[k] * W::ldu(hcol + k * 6);
         kx[j] = s;
     }
     // d_x = - K_h + (K_x - I) * d_x_new (optimize.cpp:244)
@@ -449,6 +557,12 @@ SRL_HD inline int iekf_update(const IekfConsts &K, int iter, IekfShared &sh, dou
     double d_x[17];
 #pragma unroll
     for (int a = 0; a < 17; a++) { d_x[a] = W::bcast(dxv, a); sh.d_x[a] = d_x[a]; }
+    if constexpr (FAST) {
+        // R G + H not positive definite (never for a covariance and a Gram matrix; NaN input): the square roots say so
+        bool bad = false;
+        for (int a = 0; a < 17; a++) bad = bad || !(d_x[a] == d_x[a]);
+        if (bad) sh.singular = 1;
+    }
 
     IekfState st;
     st.load(sh.state);
@@ -460,6 +574,7 @@ SRL_HD inline int iekf_update(const IekfConsts &K, int iter, IekfShared &sh, dou
         return last ? IEKF_DONE_NO_COV : IEKF_CONTINUE;
     st.observe(d_x);                                                              // optimize.cpp:253
     st.store(sh.state);
+    sh.observed = sh.observed + 1;
     bool converage = false;
     if (K.frame_id > 1 && dx_p.norm() < K.thr_translation && srlivo::AngularDistance(dx_r) < K.thr_orientation) converage = true;
     if (!(converage || last)) return IEKF_CONTINUE;
@@ -487,12 +602,15 @@ SRL_HD inline int iekf_update(const IekfConsts &K, int iter, IekfShared &sh, dou
     wave_left3<W, 6>(kx, J_k_so3, kx, 3);
     wave_left2<W, 6>(kx, J_k_s2, kx, 15);
     // covariance = covariance_new - K_x.block<17,6>(0,0) * covariance.block<6,17>(0,0)
+    VD prev = kx[0];
 #pragma unroll
     for (int j = 0; j < 17; j++) {
-        VD s = kx[0] * W::bcast(cov[j], 0);
+        const VD cj = W::after_v(cov[j], prev);            // column j's six broadcasts stay behind column j - 1's result
+        VD s = kx[0] * W::bcast(cj, 0);
 #pragma unroll
-        for (int k = 1; k < 6; k++) s = s + kx[k] * W::bcast(cov[j], k);
-        W::st(cov_out, rbase + j, cnew[j] - s, row);
+        for (int k = 1; k < 6; k++) s = s + kx[k] * W::bcast(cj, k);
+        prev = cnew[j] - s;
+        W::st(cov_out, rbase + j, prev, row);
     }
     W::barrier();
     return IEKF_DONE;

@@ -960,8 +960,9 @@ struct LdsLayout {
     int off_nb, off_pw, off_pimu, off_qf, off_kv, off_nfound, off_ncand, off_next, off_defer;
     int off_wave, wave_bytes, off_vox, off_scratch;     // per-wave: off_wave + w * wave_bytes + {off_vox, off_scratch}
     int off_wpart, off_winfo, total;
+    int off_pose, off_out, off_iekf, off_rowacc;      // persistent solve only
 };
-__host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, int wpb) {
+__host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, int wpb, int persist = 0) {
     const int kpb = wpb * kpw;
     LdsLayout L;
     // stride = 17 (mod 32): the K winner lanes of one keypoint and the (keypoint, sub-lane) readers of phase 2 spread over the banks
@@ -985,6 +986,14 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, i
     o += wpb * w;
     L.off_wpart = o;   o += wpb * 32 * 8;
     L.off_winfo = o;   o += wpb * 8 * 4;
+    L.off_pose = L.off_out = L.off_iekf = L.off_rowacc = o;
+    if (persist) {
+        // the pose of the running pass (+ verdict), the finishing workgroup's normal equations and its filter / matrices
+        L.off_pose = o;   o += up16(SRL_POSE_DOUBLES * 8);
+        L.off_out = o;    o += up16((int)sizeof(SrlDevOut));
+        L.off_iekf = o;   o += up16((int)sizeof(srlw::IekfShared));
+        L.off_rowacc = o; o += 32 * 8;                      // this workgroup's row, summed over its tiles
+    }
     L.total = o;
     return L;
 }
@@ -997,11 +1006,33 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, i
 // pair counter of phase 1 evens that out (workgroups 45..48 us).  The kernel itself is not shorter for it -- a CU is busy
 // (instruction issue + LDS) for the same ~47 us either way, tools/block_times.py -- but the reduce kernel sums 256
 // partials instead of 1 024 and a short sweep needs fewer workgroups to fill the chip.
-template <int NB, int FAST, int KPW, int WPB>
-__global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_SIMD) srl_assoc_kernel(const SrlAssocArgs a) {
+// The 17-dim update of the persistent solve as two real functions (not inlined: their registers and their code stay out of
+// the association loop's allocation).  sv = the solve arguments in the kernarg segment, lds_off = byte offset of the
+// finishing workgroup's IekfShared in LDS (the address space is re-established here, so the accesses are ds_ instructions).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) srlw::IekfShared *IekfLdsPtr;
+__device__ __attribute__((noinline)) void dev_iekf_prior(const SrlSolveArgs *sv, unsigned lds_off) {
+    srlw::IekfShared &sh = *(srlw::IekfShared *)(IekfLdsPtr)(size_t)lds_off;
+    const srlw::IekfConsts K = sv->K;
+    if (sv->exact_lu) srlw::iekf_prior<srlw::DevWave, false>(K, sv->cov0, sh);
+    else srlw::iekf_prior<srlw::DevWave, true>(K, sv->cov0, sh);
+}
+__device__ __attribute__((noinline)) int dev_iekf_update(const SrlSolveArgs *sv, int iter, unsigned lds_off) {
+    srlw::IekfShared &sh = *(srlw::IekfShared *)(IekfLdsPtr)(size_t)lds_off;
+    const srlw::IekfConsts K = sv->K;
+    return sv->exact_lu ? srlw::iekf_update<srlw::DevWave, false>(K, iter, sh, sh.temp) : srlw::iekf_update<srlw::DevWave, true>(K, iter, sh, sh.temp);
+}
+#endif
+
+// PERSIST = 1: the persistent solve (srl_solve_kernel below) -- the same three phases inside the ESIKF loop of
+// optimize.cpp:147-312: every workgroup walks its tiles of KPB keypoints, publishes ONE row per pass, the last workgroup
+// of the grid sums the rows, one of its waves runs the 17-dim update (srl_iekf_wave.h) and hands the next pose (or the
+// verdict that ends the loop) to the others as tagged granules.  The pose then comes from LDS, not from the kernarg.
+template <int NB, int FAST, int KPW, int WPB, int PERSIST>
+__device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile, const bool do_prior) {
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayout L = lds_layout(a.K, NB, KPW, WPB);
+    const LdsLayout L = lds_layout(A.K, NB, KPW, WPB, PERSIST);
     const int NB_ROW = L.nb_row;
     const int tid = threadIdx.x;
     const int lane = lane_id();
@@ -1009,7 +1040,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     // workgroup-level keypoint arrays: any wave may search any keypoint pair of the workgroup (phase 1 hands pairs out
     // dynamically), phase 2 then takes the KPW keypoints of its own quarter
     float *s_nb = reinterpret_cast<float *>(smem + L.off_nb);
-    const int nb_plane = a.K * NB_ROW;
+    const int nb_plane = A.K * NB_ROW;
     double *s_pw = reinterpret_cast<double *>(smem + L.off_pw);
     double *s_pimu = reinterpret_cast<double *>(smem + L.off_pimu);
     float *s_qf = reinterpret_cast<float *>(smem + L.off_qf);
@@ -1024,10 +1055,16 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     double *s_wpart = reinterpret_cast<double *>(smem + L.off_wpart);     // [4][32]
     int *s_winfo = reinterpret_cast<int *>(smem + L.off_winfo);           // [WPB][8]: accepted, sum_pk, 1 + first NaN keypoint, fallback, planes
 
-    const int bbase_kp = blockIdx.x * KPB;                                // first keypoint of this workgroup
+    const long long dbg_t0 = (!PERSIST && (A.ablate & 128)) ? (long long)wall_clock64() : 0;   // debug: workgroup start (100 MHz clock)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
+    typedef const __attribute__((address_space(4))) SrlSolveArgs *SolveargPtr;
+#endif
+    double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);       // persistent solve: Rn[9] | R[9] | t[3] of the running pass
+    srlw::IekfShared *s_iekf = reinterpret_cast<srlw::IekfShared *>(smem + L.off_iekf);
+    int n_fallback = 0;
+    const int bbase_kp = tile * KPB;                                      // first keypoint of this tile
     const int wbase_kp = bbase_kp + wave * KPW;                           // first keypoint of this wave's quarter (phases 0 and 2)
-    if (a.ablate & 16) return;                                            // debug: launch/drain floor
-    const long long dbg_t0 = (a.ablate & 128) ? (long long)wall_clock64() : 0;   // debug: workgroup start (100 MHz clock)
 
     // ---------------- phase 0: transformKeypoints (optimize.cpp:30-40), location (optimize.cpp:83), voxel key
     if (tid < 4) s_next[tid] = 0;
@@ -1035,10 +1072,11 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         const int kq = wave * KPW + lane;                                  // index inside the workgroup
         const int g = wbase_kp + lane;
         D3 p_imu = d3(0, 0, 0), p_w = d3(0, 0, 0);
-        if (g < a.n) {
-            const D3 raw = d3(a.raw_x[g], a.raw_y[g], a.raw_z[g]);
-            p_imu = add(matvec(a.R_il, raw), d3(a.t_il[0], a.t_il[1], a.t_il[2]));
-            p_w = add(matvec(a.Rn, p_imu), d3(a.t[0], a.t[1], a.t[2]));
+        if (g < A.n) {
+            const D3 raw = d3(A.raw_x[g], A.raw_y[g], A.raw_z[g]);
+            p_imu = add(matvec(A.R_il, raw), d3(A.t_il[0], A.t_il[1], A.t_il[2]));
+            if constexpr (PERSIST) p_w = add(matvec(s_pose, p_imu), d3(s_pose[18], s_pose[19], s_pose[20]));
+            else p_w = add(matvec(A.Rn, p_imu), d3(A.t[0], A.t[1], A.t[2]));
         }
         s_pw[kq * 3 + 0] = p_w.x; s_pw[kq * 3 + 1] = p_w.y; s_pw[kq * 3 + 2] = p_w.z;
         s_pimu[kq * 3 + 0] = p_imu.x; s_pimu[kq * 3 + 1] = p_imu.y; s_pimu[kq * 3 + 2] = p_imu.z;
@@ -1059,10 +1097,10 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         }
         // static_cast<short>(point / size_voxel_map): truncation toward zero (optimize.cpp:372-374)
         // (x / 1.0 == x exactly: the shipped size_voxel_map = 1.0 skips three FP64 divisions)
-        const bool unit = a.size_voxel == 1.0;
-        s_kv[kq * 4 + 0] = (int)(short)(int)(unit ? p_w.x : p_w.x / a.size_voxel);
-        s_kv[kq * 4 + 1] = (int)(short)(int)(unit ? p_w.y : p_w.y / a.size_voxel);
-        s_kv[kq * 4 + 2] = (int)(short)(int)(unit ? p_w.z : p_w.z / a.size_voxel);
+        const bool unit = A.size_voxel == 1.0;
+        s_kv[kq * 4 + 0] = (int)(short)(int)(unit ? p_w.x : p_w.x / A.size_voxel);
+        s_kv[kq * 4 + 1] = (int)(short)(int)(unit ? p_w.y : p_w.y / A.size_voxel);
+        s_kv[kq * 4 + 2] = (int)(short)(int)(unit ? p_w.z : p_w.z / A.size_voxel);
         s_nfound[kq] = 0;
         s_ncand[kq] = 0;
     } else if (wave == WPB - 1 && lane < KPW + 2) {
@@ -1071,17 +1109,27 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     }
     __syncthreads();
 
+    // ---------------- persistent solve: the H-independent half of the 17-dim update (optimize.cpp:172-234) on the last
+    // wave of the finishing workgroup, before it joins the pair loop below (the other 15 waves start on the pairs)
+    if constexpr (PERSIST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (do_prior && wave == WPB - 1) {
+            SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
+            asm volatile("" : "+s"(sp));
+            dev_iekf_prior((const SrlSolveArgs *)sp, (unsigned)(size_t)(IekfLdsPtr)s_iekf);
+        }
+#endif
+    }
     // ---------------- phase 1: searchNeighbors, the whole wave on one keypoint at a time
-    int n_fallback = 0;
     {
-        const int left = a.n - bbase_kp;
+        const int left = A.n - bbase_kp;
         const int n_here = __builtin_amdgcn_readfirstlane(left < KPB ? left : KPB);   // keypoints of this workgroup that exist
         auto make_sink = [&](int kl) {
             LdsSink sink;
             sink.col = s_nb + kl;
             sink.row = NB_ROW;
             sink.plane = nb_plane;
-            sink.tap_ids = a.tap_ids ? (a.tap_ids + (size_t)(bbase_kp + kl) * a.K) : nullptr;
+            sink.tap_ids = A.tap_ids ? (A.tap_ids + (size_t)(bbase_kp + kl) * A.K) : nullptr;
             return sink;
         };
         // general path for one keypoint (own hash probes; tie = replay the reference's heap directly)
@@ -1089,11 +1137,11 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
             LdsSink sink = make_sink(kl);
             int total = 0, fb = 0;
-            const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, vox, lane);
-            select_topk(qx, qy, qz, nv, vox, a.slabs, a.K, tie ? 5 : a.select_mode, surv, lane, sink, total, fb);
+            const int nv = probe_voxels<NB>(qx, qy, qz, A.size_voxel, A.thr_cap, A.table, A.table_mask, vox, lane);
+            select_topk(qx, qy, qz, nv, vox, A.slabs, A.K, tie ? 5 : A.select_mode, surv, lane, sink, total, fb);
             n_fallback += (NB == 1) ? 1 : fb;      // r = 1: anything off the fast path counts as a fallback
             if (lane == 0) {
-                s_nfound[kl] = total < a.K ? total : a.K;
+                s_nfound[kl] = total < A.K ? total : A.K;
                 s_ncand[kl] = total;
             }
         };
@@ -1110,15 +1158,15 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             auto take = [&]() { int p = 0; if (lane == 0) p = atomicAdd(s_next, 1); return __builtin_amdgcn_readfirstlane(p); };
             int cur = take();
             ProbeReq preq;
-            if (!(a.ablate & 32)) preq = probe_issue(s_kv, 2 * (cur < npairs ? cur : npairs), role, a.table, a.table_mask, lane);
+            if (!(A.ablate & 32)) preq = probe_issue(s_kv, 2 * (cur < npairs ? cur : npairs), role, A.table, A.table_mask, lane);
             while (cur < npairs) {
                 const int nxt = take();
                 const ProbeReq creq = preq;
-                if (!(a.ablate & 32)) preq = probe_issue(s_kv, 2 * (nxt < npairs ? nxt : npairs), role, a.table, a.table_mask, lane);
-                const int nv_pair = __builtin_amdgcn_readfirstlane((a.ablate & 8) ? 0 : probe_finish(creq, a.thr_cap, a.table, a.table_mask, vox, lane));
+                if (!(A.ablate & 32)) preq = probe_issue(s_kv, 2 * (nxt < npairs ? nxt : npairs), role, A.table, A.table_mask, lane);
+                const int nv_pair = __builtin_amdgcn_readfirstlane((A.ablate & 8) ? 0 : probe_finish(creq, A.thr_cap, A.table, A.table_mask, vox, lane));
                 auto file = [&](int kl, int done, int total) {        // lane 0: result of one keypoint
                     if (done == SEL_DONE) {
-                        s_nfound[kl] = total < a.K ? total : a.K;
+                        s_nfound[kl] = total < A.K ? total : A.K;
                         s_ncand[kl] = total;
                     } else {
                         s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)(kl | (done == SEL_TIE ? 0x8000 : 0));
@@ -1126,13 +1174,13 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
                 };
                 const int r_a = ((nv_pair & 0xFF) + 2) / 3, r_b = ((nv_pair >> 8) + 2) / 3;
                 const int r_max = r_a > r_b ? r_a : r_b;
-                if (2 * cur + 1 < n_here && r_max <= SRL_PAIR_MAX_ROUNDS && !(a.ablate & (4 | 256))) {
+                if (2 * cur + 1 < n_here && r_max <= SRL_PAIR_MAX_ROUNDS && !(A.ablate & (4 | 256))) {
                     // both keypoints exist and their candidate rounds fit in registers together: B's loads fly while A is selected
                     const int kl = 2 * cur;
                     LdsSink sink_a = make_sink(kl), sink_b = make_sink(kl + 1);
                     int total_a = 0, total_b = 0, done;
-                    if (r_max <= 3) done = select_pair_f32_r<3>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, a.slabs, a.inf_off, a.K, surv, lane, role, sink_a, sink_b, total_a, total_b, a.ablate);
-                    else done = select_pair_f32_r<4>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, a.slabs, a.inf_off, a.K, surv, lane, role, sink_a, sink_b, total_a, total_b, a.ablate);
+                    if (r_max <= 3) done = select_pair_f32_r<3>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, A.K, surv, lane, role, sink_a, sink_b, total_a, total_b, A.ablate);
+                    else done = select_pair_f32_r<4>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, A.K, surv, lane, role, sink_a, sink_b, total_a, total_b, A.ablate);
                     if (lane == 0) { file(kl, done & 0xFF, total_a); file(kl + 1, done >> 8, total_b); }
                 } else {
 #pragma nounroll
@@ -1144,7 +1192,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
                         LdsSink sink = make_sink(kl);
                         int total = nv_fast;
                         int done = SEL_DONE;
-                        if (!(a.ablate & 4)) done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv_fast, vox + 32 * h, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total, a.ablate);
+                        if (!(A.ablate & 4)) done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv_fast, vox + 32 * h, A.slabs, A.inf_off, A.K, surv, lane, role, sink, total, A.ablate);
                         if (lane == 0) file(kl, done, total);
                     }
                 }
@@ -1156,15 +1204,15 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             auto take = [&]() { int p = 0; if (lane == 0) p = atomicAdd(s_next, 1); return __builtin_amdgcn_readfirstlane(p); };
             for (int kl = take(); kl < n_here; kl = take()) {
                 const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
-                const int nv = probe_voxels<NB>(qx, qy, qz, a.size_voxel, a.thr_cap, a.table, a.table_mask, vox, lane);
+                const int nv = probe_voxels<NB>(qx, qy, qz, A.size_voxel, A.thr_cap, A.table, A.table_mask, vox, lane);
                 if (lane < 3) { VoxEnt z; z.slab = 0u; z.count = 0u; vox[nv + lane] = z; }      // branch-free reads up to 3 * rounds
                 __builtin_amdgcn_wave_barrier();
                 LdsSink sink = make_sink(kl);
                 int total = 0;
-                const int done = select_topk_f32_loop(qx, qy, qz, s_qf + kl * 8, nv, vox, a.slabs, a.inf_off, a.K, surv, lane, role, sink, total);
+                const int done = select_topk_f32_loop(qx, qy, qz, s_qf + kl * 8, nv, vox, A.slabs, A.inf_off, A.K, surv, lane, role, sink, total);
                 if (lane == 0) {
                     if (done == SEL_DONE) {
-                        s_nfound[kl] = total < a.K ? total : a.K;
+                        s_nfound[kl] = total < A.K ? total : A.K;
                         s_ncand[kl] = total;
                     } else {
                         s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)(kl | (done == SEL_TIE ? 0x8000 : 0));
@@ -1190,16 +1238,15 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     }
     __syncthreads();
 
-    if (a.ablate & 64) return;                                            // debug: phase 0 + loop skeleton only
+    if (!PERSIST && (A.ablate & 64)) return true;                              // debug: phase 0 + loop skeleton only
     // Phase 2 re-reads its parameters from the kernarg segment through a laundered pointer: kept live across phase 1
     // they cost ~70 SGPRs and pushed the selection loop into SGPR spills (v_readlane / v_writelane).
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
-    KernargPtr bp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();     // the struct is the kernel's only argument
+    KernargPtr bp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();     // the struct is the kernel's first argument
     asm volatile("" : "+s"(bp));
     const __attribute__((address_space(4))) SrlAssocArgs &b = *bp;
 #else
-    const SrlAssocArgs &b = a;
+    const SrlAssocArgs &b = A;
 #endif
     // ---------------- phase 2: plane fit + residual + Jacobian.  LPK lanes per keypoint: ONE when the workgroup has at least
     // 48 keypoints (its KPB keypoints then fill ceil(KPB / 64) waves and the other waves have nothing to do here), two / four
@@ -1276,7 +1323,13 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         weight = b.lambda_w * w_plan + b.lambda_n * exp(-sqrt(dot3(dq, dq)) * rcp_nr(b.nbr_scale));   // optimize.cpp:87-88
         const D3 nv = normalized3_fast(nrm);                       // optimize.cpp:93
         const double off = -dot3(nv, nn0);                         // optimize.cpp:94
-        const D3 pe = add(matvec(b.R, p_imu), d3(b.t[0], b.t[1], b.t[2]));
+        // the residual uses the un-normalised rotation (optimize.cpp:95,101); persistent solve: the pose block of this pass
+        double Rm[9], tv[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rm[i] = PERSIST ? s_pose[9 + i] : b.R[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tv[i] = PERSIST ? s_pose[18 + i] : b.t[i];
+        const D3 pe = add(matvec(Rm, p_imu), d3(tv[0], tv[1], tv[2]));
         dist = dot3(nv, pe) + off;                                 // optimize.cpp:95
         status = 1;
         if (b.tap_normal && sl == 0) {
@@ -1289,9 +1342,9 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             J[0] = nv.x * weight; J[1] = nv.y * weight; J[2] = nv.z * weight;
             // - n^T * R * skew(p_imu) * weight, left to right (optimize.cpp:101)
             const double m0 = -nv.x, m1 = -nv.y, m2 = -nv.z;
-            const double r0 = (m0 * b.R[0] + m1 * b.R[3]) + m2 * b.R[6];
-            const double r1 = (m0 * b.R[1] + m1 * b.R[4]) + m2 * b.R[7];
-            const double r2 = (m0 * b.R[2] + m1 * b.R[5]) + m2 * b.R[8];
+            const double r0 = (m0 * Rm[0] + m1 * Rm[3]) + m2 * Rm[6];
+            const double r1 = (m0 * Rm[1] + m1 * Rm[4]) + m2 * Rm[7];
+            const double r2 = (m0 * Rm[2] + m1 * Rm[5]) + m2 * Rm[8];
             // skew(p) = [[0,-pz,py],[pz,0,-px],[-py,px,0]]
             const double s0 = (r0 * 0.0 + r1 * p_imu.z) + r2 * (-p_imu.y);
             const double s1 = (r0 * (-p_imu.z) + r1 * 0.0) + r2 * p_imu.x;
@@ -1402,6 +1455,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
     }
     __syncthreads();
 
+    if constexpr (!PERSIST) {
     if ((b.ablate & 128) && (tid == 28 || tid == 29 || tid == 30))        // debug: start / end stamps of this workgroup in the spare slots
         b.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] =
             (tid == 28) ? (double)dbg_t0 : ((tid == 29) ? (double)(long long)wall_clock64() : (double)__builtin_amdgcn_s_getreg(6164) /* XCC_ID */);
@@ -1424,57 +1478,38 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
         }
         b.binfo[blockIdx.x] = bi;
     }
-    if (b.granules == nullptr) return;
-
-    // ---------------- fused final reduction: every workgroup publishes its row, the LAST workgroup of the grid finishes.
-    // Row = 28 partial sums + {accepted, candidates visited, NaN flag, off-fast-path keypoints} carried as doubles.
-    // Hand-off across the 8 XCDs (private L2s) in the "data is the flag" form of guide G16 (R2): every double travels as
-    // two 8-byte granules {epoch, 32-bit half}, stored write-through at agent scope -- ONE store instruction per workgroup,
-    // no drain, no counter, no fence; the finisher re-reads the granules it needs (agent-scope loads) until every tag
-    // carries this launch's epoch, then sums the rows in a fixed order.  (Round-2 first version: drained row + two-level
-    // arrival counters = three dependent memory round trips behind the last workgroup, +5.6 us on the 64k launch.)
-    // A stale granule has an older epoch (the epoch is the context's launch sequence number), so nothing is reset
-    // between launches.  The finisher only waits for results every other workgroup produces without it: no co-residency
-    // assumption; its spin is bounded (time-out marker in the mailbox, the host turns it into an error).
-    typedef __attribute__((address_space(1))) unsigned long long gu64;
-    const unsigned epoch = (unsigned)b.seq;
-    if (tid < 64) {
-        double v = 0.0;
-        if (tid < 28) {
-            v = s_wpart[tid];
-#pragma unroll
-            for (int w = 1; w < P2W; ++w) v += s_wpart[w * 32 + tid];
-        } else if (tid < 32) {
-            int acc = 0, pk = 0, nanf = 0, fb = 0;
-            for (int w = 0; w < WPB; ++w) fb += s_winfo[w * 8 + 3];
-            // nanf: 1 + index inside the workgroup of its first NaN-planarity keypoint (slots are in keypoint order), 0 = none
-            for (int w = 0; w < P2W; ++w) { acc += s_winfo[w * 8 + 0]; pk += s_winfo[w * 8 + 1]; if (nanf == 0) nanf = s_winfo[w * 8 + 2]; }
-            v = tid == 28 ? (double)acc : (tid == 29 ? (double)(unsigned)pk : (tid == 30 ? (double)nanf : (double)fb));
-        }
-        // lane l publishes granule l of the row: half l >> 5 of component l & 31
-        const double vs = __shfl(v, tid & 31);
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(vs);
-        const unsigned half = (tid < 32) ? (unsigned)bits : (unsigned)(bits >> 32);
-        __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * SRL_ROW_GRANULES + tid), ((unsigned long long)epoch << 32) | half,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (tid < 72 && b.cut_max > 0) {
-        // granules 64..71: which keypoints of this workgroup were accepted (bit i = keypoint i), 32 per granule
-        const int j = tid - 64;
-        unsigned word = 0u;
-        if (KP2 >= 32) {
-            const int w = (32 * j) / KP2;
-            if (w < P2W) word = (unsigned)s_winfo[w * 8 + 5 + (((32 * j) % KP2) >> 5)];
-        } else {
-#pragma unroll
-            for (int t = 0; t < 32 / KP2; ++t) {
-                const int w = (32 * j) / KP2 + t;
-                if (w < P2W) word |= (unsigned)s_winfo[w * 8 + 5] << (t * KP2);
-            }
-        }
-        __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * SRL_ROW_GRANULES + tid), ((unsigned long long)epoch << 32) | word,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b.granules == nullptr) return true;
     }
-    if (blockIdx.x != gridDim.x - 1) return;
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The finishing workgroup: sums the published rows (with the ordered cut of optimize.cpp:107 when max_num_residuals can
+// bind) and leaves the normal equations -- one-shot kernel: in the host mailbox; persistent solve: in its LDS, where its
+// last wave runs the 17-dim update and hands the next pose / the verdict to the other workgroups.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KPW, int WPB, int NBV, int PERSIST>
+__device__ __forceinline__ void finish_rows(const int iter, const unsigned epoch) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KPB = WPB * KPW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
+    typedef const __attribute__((address_space(4))) SrlSolveArgs *SolveargPtr;
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    KernargPtr bq = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(bq));
+    const __attribute__((address_space(4))) SrlAssocArgs &b = *bq;
+    const LdsLayout L = lds_layout(b.K, NBV, KPW, WPB, PERSIST);
+    const int tid = threadIdx.x;
+    const int lane = lane_id();
+    const int wave = tid >> 6;
+    double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);
+    SrlDevOut *s_out = reinterpret_cast<SrlDevOut *>(smem + L.off_out);
+    srlw::IekfShared *s_iekf = reinterpret_cast<srlw::IekfShared *>(smem + L.off_iekf);
+    // where the finishing workgroup leaves the normal equations: the host mailbox (system-scope stores), or -- persistent
+    // solve -- its own LDS, for the wave that runs the 17-dim update
+    auto put_f = [](double *p, double x) { if constexpr (PERSIST) *p = x; else __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto put_i = [](long long *p, long long x) { if constexpr (PERSIST) *p = x; else __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     if (b.cut_max > 0) {
         // ---- finisher WITH the ordered cut (optimize.cpp:107: the sequential loop stops at the max-th accepted residual).
         // (a) every thread t < #workgroups reads the counters of row t; a prefix over the accepted counts finds the workgroup c that
@@ -1608,8 +1643,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
                 s_part[tid] = sum;
             }
             __syncthreads();
-            SrlDevOut *out = &b.mailbox->out;
-            auto put_f = [](double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+            SrlDevOut *out = PERSIST ? s_out : &b.mailbox->out;
             if (tid < 21) {
                 int ia = 0, cc = tid, rowlen = 6;
                 while (cc >= rowlen) { cc -= rowlen; ia++; rowlen--; }
@@ -1628,17 +1662,18 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
                 put_f(&out->d_nan, (long long)s_i[4] <= last_visited ? 1.0 : 0.0);   // NaN planarity only counts for visited keypoints
                 put_f(&out->d_fallback, s_part[31]);
                 put_f(&out->d_visited, (double)(last_visited + 1));
-                __hip_atomic_store(&out->last_visited, last_visited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&out->pad, s_i[0] ? 0x7117ll : 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // time-out marker
+                put_i(&out->last_visited, last_visited);
+                put_i(&out->pad, s_i[0] ? 0x7117ll : 0ll);      // time-out marker
             }
+            if constexpr (!PERSIST) {
             if (tid < 64) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (tid == 0) __hip_atomic_store(&b.mailbox->seq, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            }
         }
-        return;
-    }
-    {
+        if constexpr (!PERSIST) return;
+    } else {
         // deterministic: part p sums rows p, p + NPART, ... ascending; parts are then added in order
         constexpr int NT = 64 * WPB, NPART = NT / 32, INF = 8;
         __syncthreads();                                                   // phase-2 LDS reads are done: smem is free
@@ -1680,8 +1715,7 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             s_part[tid] = sum;                                             // row 0 = the totals
         }
         __syncthreads();
-        SrlDevOut *out = &b.mailbox->out;
-        auto put_f = [](double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+        SrlDevOut *out = PERSIST ? s_out : &b.mailbox->out;
         if (tid < 21) {
             int ia = 0, c = tid, rowlen = 6;
             while (c >= rowlen) { c -= rowlen; ia++; rowlen--; }
@@ -1699,14 +1733,288 @@ __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_
             put_f(&out->d_nan, s_part[30] > 0.0 ? 1.0 : 0.0);              // every keypoint is visited
             put_f(&out->d_fallback, s_part[31]);
             put_f(&out->d_visited, (double)b.n);
-            __hip_atomic_store(&out->last_visited, (long long)b.n - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&out->pad, *s_bad ? 0x7117ll : 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // time-out marker
+            put_i(&out->last_visited, (long long)b.n - 1);
+            put_i(&out->pad, *s_bad ? 0x7117ll : 0ll);          // time-out marker
         }
+        if constexpr (!PERSIST) {
         if (tid < 64) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every mailbox writer sits in wave 0
             if (tid == 0) __hip_atomic_store(&b.mailbox->seq, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        }
     }
+    if constexpr (PERSIST) {
+        using namespace srlw;
+        SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
+        asm volatile("" : "+s"(sp));
+        __syncthreads();                                               // s_out is complete
+        if (wave == WPB - 1) {
+            int verdict;
+            const int obs_before = s_iekf->observed;
+            const int num_res = (int)(s_out->d_num_res + 0.5);
+            if (s_out->pad != 0) verdict = IEKF_TIMEOUT;
+            else if (s_out->d_nan > 0.5) verdict = IEKF_NAN;                                     // optimize.cpp:348-350
+            else if (sp->prefix && (long long)num_res < b.cut_max) verdict = IEKF_PREFIX_SHORT;  // nothing can be concluded from the prefix
+            else if (num_res < sp->min_residuals) verdict = IEKF_FAIL_RESIDUALS;                 // optimize.cpp:110-123
+            else {
+                s_iekf->passes = s_iekf->passes + 1;
+                if (lane < 36) s_iekf->HtH[lane] = s_out->HtH[lane];
+                if (lane < 6) s_iekf->Hth[lane] = s_out->Hth[lane];
+                DevWave::barrier();
+                verdict = dev_iekf_update((const SrlSolveArgs *)sp, iter, (unsigned)(size_t)(IekfLdsPtr)s_iekf);
+                if (s_iekf->singular) verdict = IEKF_SINGULAR;
+                if (sp->log != nullptr && iter < sp->max_log && lane < 61) {
+                    // per-pass log row: HtH(36) Hth(6) d_x(17) num_residuals loss
+                    const double x = lane < 36 ? s_out->HtH[lane] : (lane < 42 ? s_out->Hth[lane - 36] : (lane < 59 ? s_iekf->d_x[lane - 42] : (lane == 59 ? (double)num_res : s_out->loss)));
+                    __hip_atomic_store(sp->log + (size_t)iter * 61 + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            // the pose of the next pass is the filter's once observe() has run (optimize.cpp:253-256; a guarded pass leaves
+            // p_frame->p_state alone): Rn = R(q.normalized()), R = R(q) as the host computes them for the one-shot kernel
+            if (verdict == IEKF_CONTINUE && s_iekf->observed != obs_before) {
+                const srl::Quat q(s_iekf->state[3], s_iekf->state[4], s_iekf->state[5], s_iekf->state[6]);
+                const srl::Mat3 Rn = q.normalized().toRotationMatrix();
+                const srl::Mat3 R = q.toRotationMatrix();
+                if (lane == 0) {
+                    for (int i = 0; i < 9; ++i) { s_pose[i] = Rn.a[i]; s_pose[9 + i] = R.a[i]; }
+                    for (int i = 0; i < 3; ++i) s_pose[18 + i] = s_iekf->state[i];
+                }
+            }
+            if (lane == 0) s_pose[21] = (double)verdict;
+            DevWave::barrier();
+            if (lane < 2 * SRL_POSE_DOUBLES) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(s_pose[lane >> 1]);
+                const unsigned half = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+                __hip_atomic_store((gu64 *)(sp->pose_granules + lane), ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (verdict != IEKF_CONTINUE) {
+                // the loop is over: filter, posterior covariance, the last normal equations and the summary go to the host
+                SrlSolveMailbox *mb = sp->mailbox;
+                if (lane < 19) __hip_atomic_store(&mb->state[lane], s_iekf->state[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (verdict == IEKF_DONE)
+                    for (int i = lane; i < 289; i += 64) __hip_atomic_store(&mb->cov[i], s_iekf->temp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                {
+                    constexpr int NW = (int)(sizeof(SrlDevOut) / 8);
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(s_out);
+                    unsigned long long *dst = reinterpret_cast<unsigned long long *>(&mb->last);
+                    if (lane < NW) __hip_atomic_store(dst + lane, src[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (lane == 0) {
+                    __hip_atomic_store(&mb->verdict, (long long)verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&mb->iterations, (long long)s_iekf->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&mb->covariance_updated, verdict == IEKF_DONE ? 1ll : 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&mb->observed, (long long)s_iekf->observed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&mb->seq, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+#endif
+}
+// the persistent solve calls it as a real function, from the waves of the finishing workgroup only (16 of 4 096: the
+// callee-saved registers it spills cost nothing, and its registers stay out of the association loop's allocation)
+template <int NB, int KPW>
+__device__ __attribute__((noinline)) void finish_rows_call(const int iter, const unsigned epoch) { finish_rows<KPW, 16, NB, 1>(iter, epoch); }
+
+template <int NB, int FAST, int KPW, int WPB, int PERSIST>
+__device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
+    constexpr int KPB = WPB * KPW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    if (a.ablate & 16) return;                                            // debug: launch/drain floor
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
+    typedef const __attribute__((address_space(4))) SrlSolveArgs *SolveargPtr;
+#endif
+    // The LDS carve.  Persistent solve: re-derived from a freshly read max_number_neighbors wherever it is needed -- kept in
+    // registers across the tiles its dozen offsets, like everything else that outlives a tile, come out of the selection
+    // loop's budget (the one-shot kernel runs at 123 of 128 VGPRs and 102 of 102 SGPRs; two SGPR spill registers more and
+    // the loop spills its candidate rounds).
+    auto carve = [&]() -> LdsLayout {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (PERSIST) {
+            KernargPtr q = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(q));
+            return lds_layout(q->K, NB, KPW, WPB, PERSIST);
+        }
+#endif
+        return lds_layout(a.K, NB, KPW, WPB, PERSIST);
+    };
+    if constexpr (PERSIST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // ---- persistent solve: pose block of the first pass, the finishing workgroup's filter
+        const LdsLayout L = carve();
+        double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);       // Rn[9] | R[9] | t[3] | verdict of the pass before
+        srlw::IekfShared *s_iekf = reinterpret_cast<srlw::IekfShared *>(smem + L.off_iekf);
+        SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
+        const bool fin = blockIdx.x == gridDim.x - 1;
+        if (tid < 9) { s_pose[tid] = a.Rn[tid]; s_pose[9 + tid] = a.R[tid]; }
+        if (tid < 3) s_pose[18 + tid] = a.t[tid];
+        if (fin && tid < 19) s_iekf->state[tid] = sp->state0[tid];
+        if (fin && tid == 19) { s_iekf->singular = 0; s_iekf->observed = 0; s_iekf->passes = 0; }
+#endif
+        __syncthreads();
+    }
+  for (int iter = 0;; ++iter) {                                           // ESIKF passes (PERSIST == 0: one trip, every path returns)
+    double row_v = 0.0;                                                   // one-shot kernel, tid < 32: component tid of this workgroup's row
+    if constexpr (PERSIST) {                                              // persistent solve: the row lives in LDS across the tiles
+        const LdsLayout L = carve();
+        if (tid < 32) reinterpret_cast<double *>(smem + L.off_rowacc)[tid] = 0.0;
+    }
+   for (int tile = blockIdx.x;; tile += (int)gridDim.x) {
+    if constexpr (PERSIST) {
+        // the arguments of the three phases are re-read from the kernarg segment in every tile
+#if defined(__HIP_DEVICE_COMPILE__)
+        SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
+        asm volatile("" : "+s"(sp));
+        if (tile >= sp->ntiles) break;
+        KernargPtr ap = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ap));
+        assoc_tile<NB, FAST, KPW, WPB, 1>(*(const SrlAssocArgs *)ap, tile, blockIdx.x == gridDim.x - 1 && tile == (int)blockIdx.x);
+#endif
+    } else {
+        if (assoc_tile<NB, FAST, KPW, WPB, 0>(a, tile, false)) return;
+    }
+    constexpr int P2W_T = (KPB + (64 / (KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4))) - 1) / (64 / (KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4)));
+    // ---- this tile's contribution to the workgroup's row: 28 partial sums + {accepted, candidates visited, NaN flag,
+    // off-fast-path keypoints} carried as doubles (threads 0..31)
+    if (tid < 32) {
+        const LdsLayout L = carve();
+        const double *s_wpart = reinterpret_cast<const double *>(smem + L.off_wpart);     // [P2W][32]
+        const int *s_winfo = reinterpret_cast<const int *>(smem + L.off_winfo);           // [WPB][8]: accepted, sum_pk, 1 + first NaN keypoint, fallback, planes
+        double v = 0.0;
+        if (tid < 28) {
+            v = s_wpart[tid];
+#pragma unroll
+            for (int w = 1; w < P2W_T; ++w) v += s_wpart[w * 32 + tid];
+        } else {
+            int acc = 0, pk = 0, nanf = 0, fb = 0;
+            for (int w = 0; w < WPB; ++w) fb += s_winfo[w * 8 + 3];
+            // nanf: 1 + index inside the tile of its first NaN-planarity keypoint (slots are in keypoint order), 0 = none
+            for (int w = 0; w < P2W_T; ++w) { acc += s_winfo[w * 8 + 0]; pk += s_winfo[w * 8 + 1]; if (nanf == 0) nanf = s_winfo[w * 8 + 2]; }
+            v = tid == 28 ? (double)acc : (tid == 29 ? (double)(unsigned)pk : (tid == 30 ? (double)nanf : (double)fb));
+        }
+        if constexpr (PERSIST) {                                       // tiles in ascending order
+            double *s_rowacc = reinterpret_cast<double *>(smem + L.off_rowacc);
+            const double r = s_rowacc[tid];
+            s_rowacc[tid] = (tid == 30) ? (r == 0.0 ? v : r) : r + v;
+        } else row_v = v;
+    }
+    if constexpr (!PERSIST) break;
+   }   // tiles of this workgroup
+#if defined(__HIP_DEVICE_COMPILE__)
+    KernargPtr bq = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(bq));
+    const __attribute__((address_space(4))) SrlAssocArgs &b = *bq;
+#else
+    const SrlAssocArgs &b = a;
+#endif
+    const LdsLayout L = lds_layout(b.K, NB, KPW, WPB, PERSIST);
+    const int lane = lane_id();
+    const int wave = tid >> 6;
+    const bool finisher = blockIdx.x == gridDim.x - 1;
+    const int *s_winfo = reinterpret_cast<const int *>(smem + L.off_winfo);
+    double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);
+    double *s_rowacc = reinterpret_cast<double *>(smem + L.off_rowacc);
+    (void)lane; (void)wave; (void)finisher; (void)s_pose; (void)s_rowacc;
+
+    // ---------------- fused final reduction: every workgroup publishes its row, the LAST workgroup of the grid finishes.
+    // Row = 28 partial sums + {accepted, candidates visited, NaN flag, off-fast-path keypoints} carried as doubles.
+    // Hand-off across the 8 XCDs (private L2s) in the "data is the flag" form of guide G16 (R2): every double travels as
+    // two 8-byte granules {epoch, 32-bit half}, stored write-through at agent scope -- ONE store instruction per workgroup,
+    // no drain, no counter, no fence; the finisher re-reads the granules it needs (agent-scope loads) until every tag
+    // carries this launch's epoch, then sums the rows in a fixed order.  (Round-2 first version: drained row + two-level
+    // arrival counters = three dependent memory round trips behind the last workgroup, +5.6 us on the 64k launch.)
+    // A stale granule has an older epoch (the epoch is the context's launch sequence number), so nothing is reset
+    // between launches.  The finisher only waits for results every other workgroup produces without it: no co-residency
+    // assumption; its spin is bounded (time-out marker in the mailbox, the host turns it into an error).
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    const unsigned epoch = (unsigned)b.seq + (unsigned)iter;              // persistent solve: one epoch per pass
+    constexpr int KP2 = 64 / (KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4));       // keypoints per phase-2 wave (as in phase 2)
+    constexpr int P2W = (KPB + KP2 - 1) / KP2;
+    if (tid < 64) {
+        // lane l publishes granule l of the row: half l >> 5 of component l & 31
+        double vs;
+        if constexpr (PERSIST) {                                           // written by lanes 0..31 of this very wave
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            vs = s_rowacc[tid & 31];
+        }
+        else vs = __shfl(row_v, tid & 31);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(vs);
+        const unsigned half = (tid < 32) ? (unsigned)bits : (unsigned)(bits >> 32);
+        __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * SRL_ROW_GRANULES + tid), ((unsigned long long)epoch << 32) | half,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (tid < 72 && b.cut_max > 0) {
+        // granules 64..71: which keypoints of this workgroup were accepted (bit i = keypoint i), 32 per granule
+        const int j = tid - 64;
+        unsigned word = 0u;
+        if (KP2 >= 32) {
+            const int w = (32 * j) / KP2;
+            if (w < P2W) word = (unsigned)s_winfo[w * 8 + 5 + (((32 * j) % KP2) >> 5)];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 32 / KP2; ++t) {
+                const int w = (32 * j) / KP2 + t;
+                if (w < P2W) word |= (unsigned)s_winfo[w * 8 + 5] << (t * KP2);
+            }
+        }
+        __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * SRL_ROW_GRANULES + tid), ((unsigned long long)epoch << 32) | word,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if constexpr (!PERSIST) {
+        if (blockIdx.x != gridDim.x - 1) return;
+        finish_rows<KPW, WPB, NB, 0>(iter, epoch);
+        return;
+    }
+    // ---------------- persistent solve: the 17-dim update behind the reduction, then the hand-over of the next pose
+    if constexpr (PERSIST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        using namespace srlw;
+        SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
+        asm volatile("" : "+s"(sp));
+        auto fresh = [epoch](unsigned long long x) { return (unsigned)(x >> 32) == epoch; };
+        if (finisher) {
+            finish_rows_call<NB, KPW>(iter, epoch);
+            __syncthreads();
+        } else {
+            if (wave == 0) {
+                // the other workgroups wait for the verdict and the pose: 44 tagged granules, one per lane, one request per poll
+                const unsigned long long *pg = sp->pose_granules + (lane < 2 * SRL_POSE_DOUBLES ? lane : 0);
+                unsigned long long x = 0ull;
+                unsigned spins = 0;
+                bool timed_out = false;
+                for (;;) {
+                    x = __hip_atomic_load((gu64 *)pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__ballot(!fresh(x)) == 0ull) break;
+                    if (++spins > (1u << 19)) { timed_out = true; break; }   // ~0.5 s: the finishing workgroup died; do not hang the GPU
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                const unsigned hi = __shfl_down((unsigned)x, 1);
+                if (lane < 2 * SRL_POSE_DOUBLES && !(lane & 1)) {
+                    double d = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned)x));
+                    if (timed_out && lane == 2 * (SRL_POSE_DOUBLES - 1)) d = (double)IEKF_TIMEOUT;
+                    s_pose[lane >> 1] = d;
+                }
+            }
+            __syncthreads();
+        }
+        if ((int)s_pose[SRL_POSE_DOUBLES - 1] != IEKF_CONTINUE) return;
+#endif
+    }
+  }   // ESIKF passes
+}
+
+template <int NB, int FAST, int KPW, int WPB>
+__global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_SIMD) srl_assoc_kernel(const SrlAssocArgs a) {
+    assoc_body<NB, FAST, KPW, WPB, 0>(a);
+}
+// The persistent solve: `a` must stay the first argument (its fields are re-read from the kernarg segment at offset 0), the
+// solve arguments sit right behind it.  One 16-wave workgroup per compute unit at most: every workgroup is resident.
+template <int NB, int KPW>
+__global__ void __launch_bounds__(1024, 1) srl_solve_kernel(const SrlAssocArgs a, const SrlSolveArgs sv) {
+    (void)sv;       // read through the kernarg segment pointer
+    assoc_body<NB, 1, KPW, 16, 1>(a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2041,6 +2349,42 @@ hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpw, int w
 }
 // LDS bytes of a configuration (host: does the 16-wave workgroup fit?)
 int srl_assoc_lds_bytes(int K, int nb_voxels, int kpw, int wpb) { return lds_layout(K, nb_voxels, kpw, wpb).total; }
+
+// ---- persistent solve: 16-wave workgroups, FAST paths only
+template <int KPW>
+static hipError_t launch_solve_cfg(const SrlAssocArgs &a, const SrlSolveArgs &sv, int nb_voxels, int grid, hipStream_t s) {
+    const LdsLayout L = lds_layout(a.K, nb_voxels, KPW, 16, 1);
+    auto launch = [&](auto kern) {
+        static thread_local const void *done_fn = nullptr;
+        static thread_local int done_dev = -1;
+        int dev = -1;
+        hipGetDevice(&dev);
+        const void *fn = reinterpret_cast<const void *>(kern);
+        if (fn != done_fn || dev != done_dev) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SRL_LDS_LIMIT);
+            if (e != hipSuccess) return e;
+            done_fn = fn; done_dev = dev;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), L.total, s, a, sv);
+        return hipGetLastError();
+    };
+    if (nb_voxels == 1) return launch(srl_solve_kernel<1, KPW>);
+    return launch(srl_solve_kernel<2, KPW>);
+}
+hipError_t srl_launch_solve(const SrlAssocArgs &a, const SrlSolveArgs &sv, int nb_voxels, int kpw, int grid, hipStream_t s) {
+    if (a.n <= 0 || grid <= 0) return hipErrorInvalidValue;
+    switch (kpw) {
+        case 2: return launch_solve_cfg<2>(a, sv, nb_voxels, grid, s);
+        case 3: return launch_solve_cfg<3>(a, sv, nb_voxels, grid, s);
+        case 4: return launch_solve_cfg<4>(a, sv, nb_voxels, grid, s);
+        case 6: return launch_solve_cfg<6>(a, sv, nb_voxels, grid, s);
+        case 8: return launch_solve_cfg<8>(a, sv, nb_voxels, grid, s);
+        case 12: return launch_solve_cfg<12>(a, sv, nb_voxels, grid, s);
+        case 16: return launch_solve_cfg<16>(a, sv, nb_voxels, grid, s);
+        default: return hipErrorInvalidConfiguration;
+    }
+}
+int srl_solve_lds_bytes(int K, int nb_voxels, int kpw) { return lds_layout(K, nb_voxels, kpw, 16, 1).total; }
 
 hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s) {
     hipLaunchKernelGGL(srl_reduce_kernel, dim3(1), dim3(1024), 0, s, a, mode);

@@ -26,7 +26,7 @@ def _prior(lio, sw):
     synth.eskf_prior(A(lio), sw["q_pred"], sw["t_pred"], sw["vel"])
 
 
-def _both(m, raw, sw, frame_id, opts_p, provider=None, extra_predict=0, laser_cov=0.001, seed=None):
+def _both(m, raw, sw, frame_id, opts_p, provider=None, extra_predict=0, laser_cov=0.001, seed=None, exact_lu=True):
     opts_o = po.opts_from_product(opts_p)
     lio = srl.Lio(-1)
     lio.set_laser_point_cov(laser_cov)
@@ -42,7 +42,7 @@ def _both(m, raw, sw, frame_id, opts_p, provider=None, extra_predict=0, laser_co
     g = lio.update_iekf_provided(opts_p, fresh(), len(raw), st, sw["t_last"], frame_id=frame_id, log_iters=20,
                                  allow=(capi.SRL_ERR_NOT_ENOUGH_RESIDUALS, capi.SRL_ERR_NAN_PLANARITY))
     frame = capi.make_frame(sw["q_pred"], sw["t_pred"], sw["t_last"], frame_id=frame_id)
-    w = capi.iekf_wave_solve(frame, opts_p, laser_cov, es0, P0, fresh(), log_iters=20)
+    w = capi.iekf_wave_solve(frame, opts_p, laser_cov, es0, P0, fresh(), log_iters=20, exact_lu=exact_lu)
     return lio, g, w
 
 
@@ -125,3 +125,27 @@ def test_wave_lu_pivots_like_the_host_on_tied_and_permuted_columns():
     assert g["rc"] == 0 and w["rc"] == 0 and w["iterations"] == g["iters"]
     assert np.array_equal(w["log"], g["log"]) and np.array_equal(w["state"], lio.eskf_get_state())
     assert np.array_equal(w["cov"], lio.eskf_get_cov())
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.mark.parametrize("frame_id,max_res,iters_icp,extra", [(100, INT_MAX, 5, 0), (100, 600, 5, 7), (1, INT_MAX, 3, 0), (5, 300, 5, 3),
+                                                              (100, INT_MAX, 1, 11)])
+def test_schur_form_of_the_second_inverse_agrees_with_the_lu_form(small_scene, frame_id, max_res, iters_icp, extra):
+    """The kernel's default: temp_inv.block<17,6>(0,0) = F (R G + H)^-1 (Schur complement of the H-independent block, a 6 x 6
+    Cholesky behind the reduction) instead of the 17 x 17 partial-pivot LU.  Same matrix, other operation order: the solve
+    must take the same number of passes and land on the same filter within 1e-9 (measured: ~1e-12)."""
+    m, sw = small_scene["map"], small_scene["sweep"]
+    raw = sw["raw"][:700]
+    opts_p = srl.default_opts(max_num_residuals=max_res, num_iters_icp=iters_icp)
+    lio, g, w = _both(m, raw, sw, frame_id, opts_p, extra_predict=extra, seed=frame_id + extra, exact_lu=False)
+    assert g["rc"] == 0 and w["rc"] == 0 and w["iterations"] == g["iters"] and w["verdict"] == capi.IEKF_DONE
+    assert _rel(w["log"][:, 42:59], g["log"][:, 42:59]) < 1e-9            # d_x of every pass
+    assert _rel(w["state"], lio.eskf_get_state()) < 1e-11
+    P_ref = lio.eskf_get_cov()
+    assert _rel(w["cov"], P_ref) < 1e-9
+    d = np.sqrt(np.abs(np.diag(P_ref)))
+    assert np.max(np.abs(w["cov"] - P_ref) / np.outer(d, d)) < 1e-6      # element-wise, scaled by the standard deviations
