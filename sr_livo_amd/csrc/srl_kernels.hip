@@ -1029,7 +1029,7 @@ __device__ __attribute__((noinline)) int dev_iekf_update(const SrlSolveArgs *sv,
 // of the grid sums the rows, one of its waves runs the 17-dim update (srl_iekf_wave.h) and hands the next pose (or the
 // verdict that ends the loop) to the others as tagged granules.  The pose then comes from LDS, not from the kernarg.
 template <int NB, int FAST, int KPW, int WPB, int PERSIST>
-__device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile, const bool do_prior) {
+__device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile, const bool do_prior, const int iter) {
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout L = lds_layout(A.K, NB, KPW, WPB, PERSIST);
@@ -1370,7 +1370,7 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
         typedef __attribute__((address_space(1))) unsigned long long gu64r;
         const bool accd = status == 2;
         const double rec8[8] = {J[0], J[1], J[2], J[3], J[4], J[5], dist, weight};
-        const unsigned long long tag = (unsigned long long)(unsigned)b.seq << 32;
+        const unsigned long long tag = (unsigned long long)((unsigned)b.seq + (unsigned)iter) << 32;   // the epoch of this pass
         gu64r *dst = (gu64r *)(b.rec_granules + ((size_t)blockIdx.x * KPB + kl) * 16);
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
@@ -1488,15 +1488,22 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
 // bind) and leaves the normal equations -- one-shot kernel: in the host mailbox; persistent solve: in its LDS, where its
 // last wave runs the 17-dim update and hands the next pose / the verdict to the other workgroups.
 // ---------------------------------------------------------------------------------------------------------------------
+// karg = the kernarg segment (the kernel's __builtin_amdgcn_kernarg_segment_ptr(): inside a called function the builtin
+// yields a null pointer, so the persistent solve hands it down).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) char *KargBytes;
+#else
+typedef const char *KargBytes;
+#endif
 template <int KPW, int WPB, int NBV, int PERSIST>
-__device__ __forceinline__ void finish_rows(const int iter, const unsigned epoch) {
+__device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, const unsigned epoch) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
     typedef const __attribute__((address_space(4))) SrlSolveArgs *SolveargPtr;
     typedef __attribute__((address_space(1))) unsigned long long gu64;
-    KernargPtr bq = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    KernargPtr bq = (KernargPtr)karg;
     asm volatile("" : "+s"(bq));
     const __attribute__((address_space(4))) SrlAssocArgs &b = *bq;
     const LdsLayout L = lds_layout(b.K, NBV, KPW, WPB, PERSIST);
@@ -1745,7 +1752,7 @@ __device__ __forceinline__ void finish_rows(const int iter, const unsigned epoch
     }
     if constexpr (PERSIST) {
         using namespace srlw;
-        SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
+        SolveargPtr sp = (SolveargPtr)(karg + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
         asm volatile("" : "+s"(sp));
         __syncthreads();                                               // s_out is complete
         if (wave == WPB - 1) {
@@ -1815,7 +1822,14 @@ __device__ __forceinline__ void finish_rows(const int iter, const unsigned epoch
 // the persistent solve calls it as a real function, from the waves of the finishing workgroup only (16 of 4 096: the
 // callee-saved registers it spills cost nothing, and its registers stay out of the association loop's allocation)
 template <int NB, int KPW>
-__device__ __attribute__((noinline)) void finish_rows_call(const int iter, const unsigned epoch) { finish_rows<KPW, 16, NB, 1>(iter, epoch); }
+__device__ __attribute__((noinline)) void finish_rows_call(KargBytes karg, const int iter, const unsigned epoch) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // arguments of a called function arrive in VGPRs: make the (wave-uniform) pointer scalar again
+    const unsigned long long kb = (unsigned long long)karg;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kb), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kb >> 32));
+    finish_rows<KPW, 16, NB, 1>((KargBytes)(((unsigned long long)hi << 32) | lo), __builtin_amdgcn_readfirstlane(iter), (unsigned)__builtin_amdgcn_readfirstlane((int)epoch));
+#endif
+}
 
 template <int NB, int FAST, int KPW, int WPB, int PERSIST>
 __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
@@ -1871,10 +1885,10 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         if (tile >= sp->ntiles) break;
         KernargPtr ap = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ap));
-        assoc_tile<NB, FAST, KPW, WPB, 1>(*(const SrlAssocArgs *)ap, tile, blockIdx.x == gridDim.x - 1 && tile == (int)blockIdx.x);
+        assoc_tile<NB, FAST, KPW, WPB, 1>(*(const SrlAssocArgs *)ap, tile, blockIdx.x == gridDim.x - 1 && tile == (int)blockIdx.x, iter);
 #endif
     } else {
-        if (assoc_tile<NB, FAST, KPW, WPB, 0>(a, tile, false)) return;
+        if (assoc_tile<NB, FAST, KPW, WPB, 0>(a, tile, false, 0)) return;
     }
     constexpr int P2W_T = (KPB + (64 / (KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4))) - 1) / (64 / (KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4)));
     // ---- this tile's contribution to the workgroup's row: 28 partial sums + {accepted, candidates visited, NaN flag,
@@ -1964,7 +1978,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
     }
     if constexpr (!PERSIST) {
         if (blockIdx.x != gridDim.x - 1) return;
-        finish_rows<KPW, WPB, NB, 0>(iter, epoch);
+        finish_rows<KPW, WPB, NB, 0>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), iter, epoch);
         return;
     }
     // ---------------- persistent solve: the 17-dim update behind the reduction, then the hand-over of the next pose
@@ -1975,7 +1989,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         asm volatile("" : "+s"(sp));
         auto fresh = [epoch](unsigned long long x) { return (unsigned)(x >> 32) == epoch; };
         if (finisher) {
-            finish_rows_call<NB, KPW>(iter, epoch);
+            finish_rows_call<NB, KPW>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), iter, epoch);
             __syncthreads();
         } else {
             if (wave == 0) {
