@@ -49,7 +49,29 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB
 CLOCK_HZ = 2.4e9          # max engine clock (same guide)
 N_CU, N_SIMD = 256, 1024
 INT_MAX = 2**31 - 1
-PROFILE = os.path.join(ROOT, "profiles", "r02_headline_rocprofv3_summary.json")
+PROFILE = os.path.join(ROOT, "profiles", "r03_headline_rocprofv3_summary.json")
+KERNEL_SOURCES = ("sr_livo_amd/csrc/srl_kernels.hip", "sr_livo_amd/csrc/srl_iekf_wave.h", "sr_livo_amd/csrc/srl_device.h")
+
+
+def kernel_source_sha():
+    """sha256 over the kernel sources: tools/profile_gpu.sh stamps every profile summary with it, and a summary whose stamp
+    differs from the tree's is stale -- its counters describe another kernel and are not carried into the bench line."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel_path in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel_path), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def load_profile():
+    """(pmc counters of the dominant kernel, stale?) from the committed rocprofv3 summary of this command"""
+    try:
+        prof = json.load(open(PROFILE))
+        ks = [v for n, v in prof["pmc_per_dispatch"].items() if "solve" in n] or [v for n, v in prof["pmc_per_dispatch"].items() if "assoc" in n]
+        return ks[0], prof.get("kernel_source_sha256") != kernel_source_sha()
+    except Exception:
+        return None, True
 
 
 class _EskfAdapter:
@@ -95,10 +117,8 @@ def issue_roofline(assoc_ms):
     cycles) the SIMDs spent issuing VALU work: 1.01 per VALU instruction in this kernel, i.e. one wave64 VALU instruction
     occupies its SIMD for 4 cycles.  floor = busy cycles / (SIMDs x clock): the time the same instruction stream would take
     with every SIMD issuing VALU back to back; frac = floor / measured launch time."""
-    try:
-        prof = json.load(open(PROFILE))
-        k = [v for n, v in prof["pmc_per_dispatch"].items() if "assoc" in n][0]
-    except Exception:
+    k, stale = load_profile()
+    if k is None or stale:
         return None
     valu, salu, lds = k.get("SQ_INSTS_VALU"), k.get("SQ_INSTS_SALU"), k.get("SQ_INSTS_LDS")
     if not valu:
@@ -121,13 +141,11 @@ def issue_roofline(assoc_ms):
 
 
 def traffic_from_profile():
-    try:
-        prof = json.load(open(PROFILE))
-        k = [v for n, v in prof["pmc_per_dispatch"].items() if "assoc" in n][0]
-        # (2 x FETCH_SIZE + WRITE_SIZE) KB: x2 = the gfx950 FETCH_SIZE correction for wide coalesced reads (MI355X_MICROARCH.md)
-        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, os.path.relpath(PROFILE, ROOT) + " (separate --pmc passes of this command)"
-    except Exception:
+    k, stale = load_profile()
+    if k is None or stale or "FETCH_SIZE" not in k:
         return None, None
+    # (2 x FETCH_SIZE + WRITE_SIZE) KB: x2 = the gfx950 FETCH_SIZE correction for wide coalesced reads (MI355X_MICROARCH.md)
+    return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, os.path.relpath(PROFILE, ROOT) + " (separate --pmc passes of this command)"
 
 
 def oracle_solve(po, backend, lio, opts, sweep, prior_state, prior_cov, state0, frame_id, threads):
@@ -182,7 +200,21 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         calls = max(tim.calls, 1)
         assoc_ms = tim.sum_assoc_ms / calls
         bytes_per_launch = tim.sum_algorithmic_bytes / calls
+        passes_per_launch = max(tim.sum_passes, 1) / calls
+        launches_per_solve = lio.last_solve_launches()
         state = solve.state.copy()
+        # A/B: the whole solve in one persistent kernel (opt-in form)
+        lio.set_persistent_solve(True)
+        solve(); solve()
+        torch.cuda.synchronize()
+        t_ab = time.perf_counter()
+        for _ in range(steps):
+            solve()
+        torch.cuda.synchronize()
+        el_ab = time.perf_counter() - t_ab
+        launches_persistent = lio.last_solve_launches()
+        lio.set_persistent_solve(False)
+        solve()
         # the association work alone (final reduction in its own kernel, launch shape chosen for the kernel's own time)
         lio.ctx.set_fused_reduce(0)
         solve()
@@ -197,13 +229,17 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
                                          f" (r={2 if frame_id < 20 else 1})",
                "sweeps_per_s": steps / el, "ms_per_solve": el / steps * 1e3, "esikf_iterations": it, "ms_per_esikf_iter": el / steps * 1e3 / max(it, 1),
                "steps": steps, "ms_per_solve_median": float(np.median(per)) * 1e3, "ms_per_solve_max": float(per.max()) * 1e3,
-               "residuals_used": nr, "assoc_kernel_us": assoc_ms * 1e3, "assoc_launches": tim.calls,
+               "residuals_used": nr, "kernel_launches_per_solve": launches_per_solve,
+               "persistent_solve_ab": {"ms_per_esikf_iter": el_ab / steps * 1e3 / max(it, 1), "launches_per_solve": launches_persistent},
+               "kernel_us": assoc_ms * 1e3, "passes_per_launch": passes_per_launch, "kernel_us_per_pass": assoc_ms * 1e3 / passes_per_launch,
+               "assoc_kernel_us": assoc_ms * 1e3 / passes_per_launch, "assoc_launches": tim.calls,
                "keypoints_per_launch": tim.sum_keypoints / calls, "algorithmic_MB_per_launch": bytes_per_launch / 1e6,
                "hbm_roofline_frac": bytes_per_launch / (assoc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if assoc_ms > 0 else None,
                "association_only_us": ms_u * 1e3,
                "association_only_hbm_roofline_frac": (tu.sum_algorithmic_bytes / max(tu.calls, 1)) / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_u > 0 else None,
-               "note": "assoc_kernel_us = the kernel the timed solves ran (with the fused final reduction where the library fuses); "
-                       "association_only_* = the same pass with the reduction in its own kernel"}
+               "note": "kernel_us = the kernel the timed solves ran: the persistent solve kernel (all passes, reductions, 17-dim updates, "
+                       "hand-overs) where kernel_launches_per_solve = 1, else the one-shot association kernel with the fused final "
+                       "reduction; assoc_kernel_us = kernel_us per pass; association_only_* = one pass with the reduction in its own kernel"}
         if po is not None:
             u, _ = oracle_solve(po, backend, lio, opts, sweep, prior_state, prior_cov, state0, frame_id, threads)
             ent["parity"] = {"state_rel_err_vs_oracle": rel(state, u["state"]), "iterations_oracle": int(u["rc"]),
@@ -350,12 +386,33 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t1
     tim = lio.ctx.timing()
+    launches_timed = lio.last_solve_launches()
     lio.ctx.set_profiling(1)
     for _ in range(max(3, min(10, args.steps))):
         solve()
     tim_full = lio.ctx.timing()
     lio.ctx.set_profiling(0)
     elapsed = max_over_ranks(elapsed)
+    # A/B: the same solves as ONE persistent kernel per solve (srl_solve_iekf: every pass, the reductions, the 17-dim update on
+    # one wave of the finishing workgroup and the pose hand-overs inside one launch) -- opt-in, because on MI355X it is the
+    # slower form; the timed region above runs the default: one launch + host update per ESIKF iteration
+    launches_per_solve = launches_timed
+    persistent_ab = None
+    if world == 1 and not args.no_aux_legs:
+        lio.set_persistent_solve(True)
+        for _ in range(3):
+            solve()
+        torch.cuda.synchronize()
+        t_ab = time.perf_counter()
+        for _ in range(args.steps):
+            r_ab = solve()
+        torch.cuda.synchronize()
+        el_ab = time.perf_counter() - t_ab
+        persistent_ab = {"sweeps_per_s": args.steps / el_ab, "ms_per_esikf_iter": el_ab / args.steps * 1e3 / max(r_ab["iters"], 1),
+                         "launches_per_solve": lio.last_solve_launches(), "iterations": r_ab["iters"],
+                         "what": "srl_lio_set_persistent_solve(1): the whole updateIEKF loop in one kernel launch (srl_solve_iekf)"}
+        lio.set_persistent_solve(False)
+        solve()
     # the association work alone: the same launches with the final reduction in its own kernel (the fused tail -- row
     # publish, arrival counters, final sum by the last workgroup -- is part of the kernel the timed region runs)
     tim_unfused = None
@@ -440,6 +497,7 @@ def main():
 
     calls = max(tim.calls, 1)
     fcalls = max(tim_full.calls, 1)
+    passes = max(tim.sum_passes, 1)
     assoc_ms = tim.sum_assoc_ms / calls
     bytes_per_launch = tim.sum_algorithmic_bytes / calls
     achieved = bytes_per_launch / (assoc_ms * 1e-3) / 1e9 if assoc_ms > 0 else 0.0
@@ -449,8 +507,11 @@ def main():
     traffic, traffic_src = traffic_from_profile() if headline_default else (None, None)
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": f"srl_assoc_kernel<{nb}>", "avg_launch_ms": assoc_ms, "launches": tim.calls,
-            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "kernel": (f"srl_solve_kernel<{nb}> (persistent: all ESIKF passes of a solve, their reductions, the 17-dim updates and the pose "
+                       f"hand-overs in one launch)") if passes > calls else f"srl_assoc_kernel<{nb}>",
+            "avg_launch_ms": assoc_ms, "launches": tim.calls, "passes_per_launch": passes / calls, "avg_pass_ms": tim.sum_assoc_ms / passes,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_pass": tim.sum_algorithmic_bytes / passes,
+            "profile_stale": bool(load_profile()[1]) if headline_default else None,
             "reduce_kernel_avg_ms": tim_full.sum_reduce_ms / fcalls, "device_total_avg_ms": tim_full.sum_total_ms / fcalls,
             "note": "achieved = ALGORITHMIC bytes (24 + 12 (2r+1)^3 + 12 P_k per keypoint, SURVEY 8(d)) / launch time: the rate at which the "
                     "reference's byte stream is consumed.  The working set is L2/MALL resident, so real HBM traffic (`traffic`, "
@@ -490,9 +551,14 @@ def main():
                                f"r={nb}, K=20; inputs resident in HBM",
                    "parallelism": ("point-range shards x%d + RCCL all-reduce of 6x6 normal equations" % world) if sharded
                                   else ("replicas x%d" % world if world > 1 else "single GPU"),
-                   "esikf_iterations_per_solve": iters, "residuals_used": r["num_residuals"]},
+                   "esikf_iterations_per_solve": iters, "residuals_used": r["num_residuals"],
+                   "kernel_launches_per_solve": launches_per_solve,
+                   "value_is": "the HBM-resident rate (sweep uploaded before the timed region); SURVEY 8(d)'s metric includes the H2D of the sweep:",
+                   "pcie_inclusive_sweeps_per_s": {"pipelined_prefetch": rates["pipelined"], "pinned_upload_then_solve": rates["pinned"],
+                                                   "pageable_upload_then_solve": rates["pageable"]}},
         "ms_per_esikf_iter": ms_per_step / max(iters, 1),
         "roofline": roof,
+        "persistent_solve_ab": persistent_ab,
         "host_us_per_iter": {"enqueue": tim_full.sum_host_launch_us / fcalls, "wait_results": tim_full.sum_host_wait_us / fcalls,
                              "build_residuals_call": tim_full.sum_host_total_us / fcalls,
                              "whole_iteration": ms_per_step * 1e3 / max(iters, 1),

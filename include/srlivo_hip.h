@@ -235,6 +235,11 @@ int srl_debug_iekf_wave_solve(const srl_frame *frame, const srl_icp_opts *opts, 
  * both 17 x 17 inverses by partial-pivot LU in the host mirror's operation order (bitwise equal to it up to the device's
  * sin / cos / acos). */
 int srl_debug_set_iekf_exact_lu(srl_ctx *ctx, int exact_lu);
+/* debug time line of srl_solve_iekf's kernel: 16 stamps (100 MHz wall clock) per pass, up to 16 passes -- finishing workgroup:
+ * [0] prior() starts, [1] done, [2] own tiles done and row published, [3] rows summed, [4] update() done, [5] pose / verdict
+ * handed over; workgroup 0: [8] row published, [9] pose seen.  enable = 1 switches the stamps on for the following solves,
+ * out256 (optional) receives those of the last one; enable = 0 switches them off.  tools/persist_probe.py prints them. */
+int srl_debug_solve_stamps(srl_ctx *ctx, int enable, long long *out256);
 
 /* enable/disable the per-keypoint parity taps written by srl_build_residuals (off by default) */
 int srl_set_taps(srl_ctx *ctx, int enable);
@@ -303,6 +308,8 @@ typedef struct srl_timing {
     double  sum_host_launch_us; /* host wall: call entry -> both kernels enqueued */
     double  sum_host_wait_us;   /* host wall: enqueue done -> results on the host (copy + stream sync [+ all-reduce]) */
     double  sum_host_total_us;  /* host wall: whole srl_build_residuals call */
+    int64_t sum_passes;         /* buildPlaneResiduals passes the timed launches ran: 1 per srl_build_residuals launch, the
+                                 * number of ESIKF iterations per srl_solve_iekf launch (light profiling, mode 2) */
 } srl_timing;
 int srl_get_timing(srl_ctx *ctx, srl_timing *t);
 /* ---- debug / parity hooks: never called by the product path ----

@@ -64,7 +64,8 @@ class Timing(C.Structure):
     _fields_ = [("assoc_ms", C.c_float), ("reduce_ms", C.c_float), ("total_ms", C.c_float), ("calls", C.c_int32),
                 ("algorithmic_bytes", C.c_int64), ("sum_assoc_ms", C.c_double), ("sum_reduce_ms", C.c_double),
                 ("sum_total_ms", C.c_double), ("sum_algorithmic_bytes", C.c_int64), ("sum_keypoints", C.c_int64),
-                ("sum_host_launch_us", C.c_double), ("sum_host_wait_us", C.c_double), ("sum_host_total_us", C.c_double)]
+                ("sum_host_launch_us", C.c_double), ("sum_host_wait_us", C.c_double), ("sum_host_total_us", C.c_double),
+                ("sum_passes", C.c_int64)]
 
 
 class ImuState(C.Structure):
@@ -133,6 +134,7 @@ def load_library():
         "srl_debug_iekf_wave_solve": ([C.POINTER(Frame), C.POINTER(IcpOpts), C.c_double, dp, dp, PROVIDER_FN, p, C.c_int,
                                        C.POINTER(IekfResult), p, C.c_int], C.c_int),
         "srl_debug_set_iekf_exact_lu": ([p, C.c_int], C.c_int),
+        "srl_debug_solve_stamps": ([p, C.c_int, p], C.c_int),
         "srl_set_taps": ([p, C.c_int], C.c_int),
         "srl_fetch_neighbors": ([p, p, p, p], C.c_int),
         "srl_fetch_residuals": ([p, p, p, p, p, p, p], C.c_int),
@@ -500,6 +502,11 @@ class Context:
         return dict(rc=rc, verdict=res.verdict, iterations=res.iterations, covariance_updated=res.covariance_updated,
                     observed=res.observed, state=st, cov=P.reshape(17, 17), num_residuals=res.last.num_residuals, neq=res.last,
                     log=None if log is None else log[: min(res.iterations, log_iters)])
+
+    def solve_stamps(self, enable=True, fetch=False):
+        out = np.zeros((16, 16), np.int64) if fetch else None
+        self._chk(self.lib.srl_debug_solve_stamps(self.h, 1 if enable else 0, _ptr(out)), "solve_stamps")
+        return out
 
     def set_iekf_exact_lu(self, on):
         self._chk(self.lib.srl_debug_set_iekf_exact_lu(self.h, 1 if on else 0), "set_iekf_exact_lu")

@@ -176,6 +176,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->h_mail) hipHostFree(ctx->h_mail);
     if (ctx->h_solve) hipHostFree(ctx->h_solve);
     if (ctx->h_solve_log) hipHostFree(ctx->h_solve_log);
+    if (ctx->h_stamps) hipHostFree(ctx->h_stamps);
     if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
     if (ctx->h_ring) { hipHostFree(ctx->h_ring); for (int i = 0; i < srl_ctx::RING_SLOTS; i++) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]); }
     for (auto &b : ctx->pool_free) hipFree(b.p);
@@ -805,7 +806,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         const long long per_kp = 24 + 12 * side * side * side;
         const double pk_share = (ctx->nranks > 1 && ctx->total_n > 0) ? r.d_sum_pk * ((double)ctx->n / (double)ctx->total_n) : r.d_sum_pk;
         ctx->timing.algorithmic_bytes = per_kp * (long long)n_eff + (long long)(12.0 * pk_share);
-        if (prof || prof_light) { ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes; ctx->timing.sum_keypoints += prof_light ? n_eff : 0; }
+        if (prof || prof_light) { ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes; ctx->timing.sum_keypoints += prof_light ? n_eff : 0; ctx->timing.sum_passes += 1; }
     }
     if (ctx->profiling == 3) {
         // host stamps only (no events): argument preparation, the launch call itself, the wait for the result
@@ -930,6 +931,18 @@ int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable) {
     ctx->fuse_reduce = enable != 0;
     return SRL_OK;
 }
+int srl_debug_solve_stamps(srl_ctx *ctx, int enable, long long *out256) {
+    // enable: allocate the stamp buffer; out256 (optional): copy of the stamps the last persistent solve left
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (enable && !ctx->h_stamps) {
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_stamps, 256 * sizeof(long long), hipHostMallocCoherent | hipHostMallocMapped));
+        std::memset(ctx->h_stamps, 0, 256 * sizeof(long long));
+    }
+    if (out256 && ctx->h_stamps) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); std::memcpy(out256, ctx->h_stamps, 256 * sizeof(long long)); }
+    if (!enable && ctx->h_stamps) { hipHostFree(ctx->h_stamps); ctx->h_stamps = nullptr; }
+    return SRL_OK;
+}
 int srl_debug_set_iekf_exact_lu(srl_ctx *ctx, int exact_lu) {
     if (!ctx) return SRL_ERR_BAD_ARG;
     ctx->iekf_exact_lu = exact_lu != 0;
@@ -1037,7 +1050,7 @@ int srl_solve_iekf(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, doub
     const bool single = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
     const bool fast_sel = o->select_mode == 0 || o->select_mode == 4;
     if (!single || ctx->taps || ctx->ablate != 0 || o->max_num_residuals <= 0 || ctx->total_n <= 0 || !fast_sel || !ctx->fuse_reduce ||
-        ctx->force_kpw != 0 || ctx->profiling == 1)
+        ctx->force_kpw != 0 || ctx->profiling == 1 || o->max_number_neighbors != SRL_SOLVE_K)
         return SRL_ERR_RETRY_PER_ITERATION;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // finite max_num_residuals: the sequential loop never looks past the max-th accepted keypoint, so only a prefix that
@@ -1087,6 +1100,8 @@ int srl_solve_iekf(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, doub
     sv.ntiles = ntiles;
     sv.prefix = (cut_possible && n_eff < ctx->n) ? 1 : 0;
     sv.exact_lu = ctx->iekf_exact_lu ? 1 : 0;
+    sv.stamps = ctx->h_stamps;
+    if (ctx->h_stamps) std::memset(ctx->h_stamps, 0, 256 * sizeof(long long));
     // one epoch per pass: rows and pose granules of pass i carry seq + i
     const unsigned long long seq0 = ctx->seq + 1;
     ctx->seq += (unsigned long long)sv.K.max_num_iter + 2;
@@ -1133,7 +1148,10 @@ int srl_solve_iekf(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, doub
         res->last.num_fallback = (int32_t)(r.d_fallback + 0.5);
         const long long side = 2 * nb + 1;
         ctx->timing.algorithmic_bytes = (24 + 12 * side * side * side) * (long long)n_eff + (long long)(12.0 * r.d_sum_pk);
-        if (ctx->profiling == 2) { ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes * std::max(1, res->iterations); ctx->timing.sum_keypoints += (long long)n_eff * std::max(1, res->iterations); }
+        // light profiling: one event pair around the whole launch; bytes, keypoints and passes of all its ESIKF iterations
+        // (a failed pass was associated too)
+        const int passes = res->iterations + (res->verdict == srlw::IEKF_FAIL_RESIDUALS || res->verdict == srlw::IEKF_NAN ? 1 : 0);
+        if (ctx->profiling == 2) { ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes * std::max(1, passes); ctx->timing.sum_keypoints += (long long)n_eff * std::max(1, passes); ctx->timing.sum_passes += std::max(1, passes); }
     }
     ctx->last_K = K;
     ctx->last_nb = nb;

@@ -89,6 +89,7 @@ struct srl_ctx {
     double *h_solve_log = nullptr;     // SRL_SOLVE_LOG_ROWS x 61 doubles
     unsigned long long *d_pose_granules = nullptr;
     bool iekf_exact_lu = false;        // srl_debug_set_iekf_exact_lu
+    long long *h_stamps = nullptr;     // srl_debug_solve_stamps: 16 x 16 wall-clock stamps of the last persistent solve (host-mapped)
     bool solve_lds_opted = false;
     unsigned long long seq = 0;
 

@@ -143,6 +143,7 @@ struct SrlSolveMailbox {       // host-mapped (fine-grained): what the finishing
     unsigned long long seq;    // = launch sequence number once everything above is complete
     unsigned long long pad[7];
 };
+#define SRL_SOLVE_K 20         // max_number_neighbors the persistent solve kernel is built for (both shipped yaml files)
 #define SRL_POSE_DOUBLES 22    // what the finishing workgroup hands to the others after a pass: Rn[9] R[9] t[3] verdict
 struct SrlSolveArgs {
     srlw::IekfConsts K;
@@ -157,6 +158,7 @@ struct SrlSolveArgs {
     int prefix;                // finite max_num_residuals: only a prefix of the shard is associated (too few accepted -> the host repeats)
     int exact_lu;              // 1: both 17 x 17 inverses by partial-pivot LU in the host's order; 0: the Schur-complement form (srl_iekf_wave.h)
     int pad;
+    long long *stamps;         // debug (srl_debug_solve_stamps): 16 wall-clock stamps per pass, host-mapped; null = off
 };
 static_assert(sizeof(SrlAssocArgs) + sizeof(SrlSolveArgs) <= 4096, "both structs travel in the kernarg segment");
 

@@ -1006,6 +1006,21 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, i
 // pair counter of phase 1 evens that out (workgroups 45..48 us).  The kernel itself is not shorter for it -- a CU is busy
 // (instruction issue + LDS) for the same ~47 us either way, tools/block_times.py -- but the reduce kernel sums 256
 // partials instead of 1 024 and a short sweep needs fewer workgroups to fill the chip.
+// karg = the kernarg segment (the kernel's __builtin_amdgcn_kernarg_segment_ptr(): inside a called function the builtin
+// yields a null pointer, so the persistent solve hands it down).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) char *KargBytes;
+#else
+typedef const char *KargBytes;
+#endif
+// debug time line of the persistent solve (tools/persist_probe.py): slot k of pass `iter`, 100 MHz wall clock
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void solve_stamp(const __attribute__((address_space(4))) SrlSolveArgs *sp, int iter, int slot) {
+    long long *st = sp->stamps;
+    if (st != nullptr && iter < 16) __hip_atomic_store(st + iter * 16 + slot, (long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
 // The 17-dim update of the persistent solve as two real functions (not inlined: their registers and their code stay out of
 // the association loop's allocation).  sv = the solve arguments in the kernarg segment, lds_off = byte offset of the
 // finishing workgroup's IekfShared in LDS (the address space is re-established here, so the accesses are ds_ instructions).
@@ -1029,10 +1044,17 @@ __device__ __attribute__((noinline)) int dev_iekf_update(const SrlSolveArgs *sv,
 // of the grid sums the rows, one of its waves runs the 17-dim update (srl_iekf_wave.h) and hands the next pose (or the
 // verdict that ends the loop) to the others as tagged granules.  The pose then comes from LDS, not from the kernarg.
 template <int NB, int FAST, int KPW, int WPB, int PERSIST>
-__device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile, const bool do_prior, const int iter) {
+__device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A, const int tile, const bool do_prior, const int iter) {
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayout L = lds_layout(A.K, NB, KPW, WPB, PERSIST);
+    // Persistent solve: max_number_neighbors is the shipped 20 at compile time (the host routes any other value through the
+    // one-shot kernel): the LDS carve becomes a set of immediates instead of a dozen live SGPRs, and the taps / debug
+    // switches of the one-shot kernel do not exist -- what the selection loop needs on top of the one-shot kernel's budget
+    // (stack pointer, scratch descriptor of a kernel with calls) has to come from somewhere.
+    constexpr int KC = PERSIST ? SRL_SOLVE_K : 0;
+    const int Kn = KC ? KC : A.K;
+    const int abl = PERSIST ? 0 : A.ablate;
+    const LdsLayout L = lds_layout(Kn, NB, KPW, WPB, PERSIST);
     const int NB_ROW = L.nb_row;
     const int tid = threadIdx.x;
     const int lane = lane_id();
@@ -1040,7 +1062,7 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
     // workgroup-level keypoint arrays: any wave may search any keypoint pair of the workgroup (phase 1 hands pairs out
     // dynamically), phase 2 then takes the KPW keypoints of its own quarter
     float *s_nb = reinterpret_cast<float *>(smem + L.off_nb);
-    const int nb_plane = A.K * NB_ROW;
+    const int nb_plane = Kn * NB_ROW;
     double *s_pw = reinterpret_cast<double *>(smem + L.off_pw);
     double *s_pimu = reinterpret_cast<double *>(smem + L.off_pimu);
     float *s_qf = reinterpret_cast<float *>(smem + L.off_qf);
@@ -1055,7 +1077,7 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
     double *s_wpart = reinterpret_cast<double *>(smem + L.off_wpart);     // [4][32]
     int *s_winfo = reinterpret_cast<int *>(smem + L.off_winfo);           // [WPB][8]: accepted, sum_pk, 1 + first NaN keypoint, fallback, planes
 
-    const long long dbg_t0 = (!PERSIST && (A.ablate & 128)) ? (long long)wall_clock64() : 0;   // debug: workgroup start (100 MHz clock)
+    const long long dbg_t0 = (!PERSIST && (abl & 128)) ? (long long)wall_clock64() : 0;   // debug: workgroup start (100 MHz clock)
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
     typedef const __attribute__((address_space(4))) SrlSolveArgs *SolveargPtr;
@@ -1063,6 +1085,20 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
     double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);       // persistent solve: Rn[9] | R[9] | t[3] of the running pass
     srlw::IekfShared *s_iekf = reinterpret_cast<srlw::IekfShared *>(smem + L.off_iekf);
     int n_fallback = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto tile_stamp = [&](int slot) {
+        if constexpr (PERSIST) {
+            if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && tid == 0) {     // workgroup 0: slots 10..13; finishing workgroup: 15, 6, 7, 14
+                SolveargPtr sq = (SolveargPtr)(karg + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
+                const int fs = slot == 10 ? 15 : (slot == 11 ? 6 : (slot == 12 ? 7 : 14));
+                solve_stamp(sq, iter, blockIdx.x == 0 ? slot : fs);
+            }
+        }
+    };
+#else
+    auto tile_stamp = [&](int) {};
+#endif
+    tile_stamp(10);
     const int bbase_kp = tile * KPB;                                      // first keypoint of this tile
     const int wbase_kp = bbase_kp + wave * KPW;                           // first keypoint of this wave's quarter (phases 0 and 2)
 
@@ -1108,15 +1144,20 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
         s_kv[kq * 4 + 0] = 0; s_kv[kq * 4 + 1] = 0; s_kv[kq * 4 + 2] = 0;
     }
     __syncthreads();
+    tile_stamp(11);
 
     // ---------------- persistent solve: the H-independent half of the 17-dim update (optimize.cpp:172-234) on the last
     // wave of the finishing workgroup, before it joins the pair loop below (the other 15 waves start on the pairs)
     if constexpr (PERSIST) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (do_prior && wave == WPB - 1) {
-            SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
+            SolveargPtr sp = (SolveargPtr)(karg + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
             asm volatile("" : "+s"(sp));
+            if (lane == 0) solve_stamp(sp, iter, 0);
+#if !defined(SRL_EXP_NOCALL)
             dev_iekf_prior((const SrlSolveArgs *)sp, (unsigned)(size_t)(IekfLdsPtr)s_iekf);
+#endif
+            if (lane == 0) solve_stamp(sp, iter, 1);
         }
 #endif
     }
@@ -1129,7 +1170,7 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
             sink.col = s_nb + kl;
             sink.row = NB_ROW;
             sink.plane = nb_plane;
-            sink.tap_ids = A.tap_ids ? (A.tap_ids + (size_t)(bbase_kp + kl) * A.K) : nullptr;
+            sink.tap_ids = (!PERSIST && A.tap_ids) ? (A.tap_ids + (size_t)(bbase_kp + kl) * Kn) : nullptr;
             return sink;
         };
         // general path for one keypoint (own hash probes; tie = replay the reference's heap directly)
@@ -1138,10 +1179,10 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
             LdsSink sink = make_sink(kl);
             int total = 0, fb = 0;
             const int nv = probe_voxels<NB>(qx, qy, qz, A.size_voxel, A.thr_cap, A.table, A.table_mask, vox, lane);
-            select_topk(qx, qy, qz, nv, vox, A.slabs, A.K, tie ? 5 : A.select_mode, surv, lane, sink, total, fb);
+            select_topk(qx, qy, qz, nv, vox, A.slabs, Kn, tie ? 5 : A.select_mode, surv, lane, sink, total, fb);
             n_fallback += (NB == 1) ? 1 : fb;      // r = 1: anything off the fast path counts as a fallback
             if (lane == 0) {
-                s_nfound[kl] = total < A.K ? total : A.K;
+                s_nfound[kl] = total < Kn ? total : Kn;
                 s_ncand[kl] = total;
             }
         };
@@ -1158,15 +1199,15 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
             auto take = [&]() { int p = 0; if (lane == 0) p = atomicAdd(s_next, 1); return __builtin_amdgcn_readfirstlane(p); };
             int cur = take();
             ProbeReq preq;
-            if (!(A.ablate & 32)) preq = probe_issue(s_kv, 2 * (cur < npairs ? cur : npairs), role, A.table, A.table_mask, lane);
+            if (!(abl & 32)) preq = probe_issue(s_kv, 2 * (cur < npairs ? cur : npairs), role, A.table, A.table_mask, lane);
             while (cur < npairs) {
                 const int nxt = take();
                 const ProbeReq creq = preq;
-                if (!(A.ablate & 32)) preq = probe_issue(s_kv, 2 * (nxt < npairs ? nxt : npairs), role, A.table, A.table_mask, lane);
-                const int nv_pair = __builtin_amdgcn_readfirstlane((A.ablate & 8) ? 0 : probe_finish(creq, A.thr_cap, A.table, A.table_mask, vox, lane));
+                if (!(abl & 32)) preq = probe_issue(s_kv, 2 * (nxt < npairs ? nxt : npairs), role, A.table, A.table_mask, lane);
+                const int nv_pair = __builtin_amdgcn_readfirstlane((abl & 8) ? 0 : probe_finish(creq, A.thr_cap, A.table, A.table_mask, vox, lane));
                 auto file = [&](int kl, int done, int total) {        // lane 0: result of one keypoint
                     if (done == SEL_DONE) {
-                        s_nfound[kl] = total < A.K ? total : A.K;
+                        s_nfound[kl] = total < Kn ? total : Kn;
                         s_ncand[kl] = total;
                     } else {
                         s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)(kl | (done == SEL_TIE ? 0x8000 : 0));
@@ -1174,13 +1215,13 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
                 };
                 const int r_a = ((nv_pair & 0xFF) + 2) / 3, r_b = ((nv_pair >> 8) + 2) / 3;
                 const int r_max = r_a > r_b ? r_a : r_b;
-                if (2 * cur + 1 < n_here && r_max <= SRL_PAIR_MAX_ROUNDS && !(A.ablate & (4 | 256))) {
+                if (2 * cur + 1 < n_here && r_max <= SRL_PAIR_MAX_ROUNDS && !(abl & (4 | 256))) {
                     // both keypoints exist and their candidate rounds fit in registers together: B's loads fly while A is selected
                     const int kl = 2 * cur;
                     LdsSink sink_a = make_sink(kl), sink_b = make_sink(kl + 1);
                     int total_a = 0, total_b = 0, done;
-                    if (r_max <= 3) done = select_pair_f32_r<3>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, A.K, surv, lane, role, sink_a, sink_b, total_a, total_b, A.ablate);
-                    else done = select_pair_f32_r<4>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, A.K, surv, lane, role, sink_a, sink_b, total_a, total_b, A.ablate);
+                    if (r_max <= 3) done = select_pair_f32_r<3>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, Kn, surv, lane, role, sink_a, sink_b, total_a, total_b, abl);
+                    else done = select_pair_f32_r<4>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, Kn, surv, lane, role, sink_a, sink_b, total_a, total_b, abl);
                     if (lane == 0) { file(kl, done & 0xFF, total_a); file(kl + 1, done >> 8, total_b); }
                 } else {
 #pragma nounroll
@@ -1192,7 +1233,7 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
                         LdsSink sink = make_sink(kl);
                         int total = nv_fast;
                         int done = SEL_DONE;
-                        if (!(A.ablate & 4)) done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv_fast, vox + 32 * h, A.slabs, A.inf_off, A.K, surv, lane, role, sink, total, A.ablate);
+                        if (!(abl & 4)) done = select_topk_f32(qx, qy, qz, s_qf + kl * 8, nv_fast, vox + 32 * h, A.slabs, A.inf_off, Kn, surv, lane, role, sink, total, abl);
                         if (lane == 0) file(kl, done, total);
                     }
                 }
@@ -1209,10 +1250,10 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
                 __builtin_amdgcn_wave_barrier();
                 LdsSink sink = make_sink(kl);
                 int total = 0;
-                const int done = select_topk_f32_loop(qx, qy, qz, s_qf + kl * 8, nv, vox, A.slabs, A.inf_off, A.K, surv, lane, role, sink, total);
+                const int done = select_topk_f32_loop(qx, qy, qz, s_qf + kl * 8, nv, vox, A.slabs, A.inf_off, Kn, surv, lane, role, sink, total);
                 if (lane == 0) {
                     if (done == SEL_DONE) {
-                        s_nfound[kl] = total < A.K ? total : A.K;
+                        s_nfound[kl] = total < Kn ? total : Kn;
                         s_ncand[kl] = total;
                     } else {
                         s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)(kl | (done == SEL_TIE ? 0x8000 : 0));
@@ -1237,12 +1278,13 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
         }
     }
     __syncthreads();
+    tile_stamp(12);
 
-    if (!PERSIST && (A.ablate & 64)) return true;                              // debug: phase 0 + loop skeleton only
+    if (!PERSIST && (abl & 64)) return true;                              // debug: phase 0 + loop skeleton only
     // Phase 2 re-reads its parameters from the kernarg segment through a laundered pointer: kept live across phase 1
     // they cost ~70 SGPRs and pushed the selection loop into SGPR spills (v_readlane / v_writelane).
 #if defined(__HIP_DEVICE_COMPILE__)
-    KernargPtr bp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();     // the struct is the kernel's first argument
+    KernargPtr bp = (KernargPtr)karg;     // the struct is the kernel's first argument
     asm volatile("" : "+s"(bp));
     const __attribute__((address_space(4))) SrlAssocArgs &b = *bp;
 #else
@@ -1278,7 +1320,7 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
     double dist = 0.0, weight = 0.0;
     const int nf = owner_lane ? s_nfound[kl] : 0;
     if (g < b.n) status = 0;
-    const bool fit = (g < b.n) && (nf >= b.min_nb) && !(b.ablate & 1);
+    const bool fit = (g < b.n) && (nf >= b.min_nb) && !(!PERSIST && (b.ablate & 1));
     if (fit) {
 #pragma clang fp contract(fast)      // plane fit / weights / Jacobian are tolerance-bound (1e-9 vs the oracle): products may fuse
         const D3 p_imu = d3(s_pimu[kl * 3 + 0], s_pimu[kl * 3 + 1], s_pimu[kl * 3 + 2]);
@@ -1332,7 +1374,7 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
         const D3 pe = add(matvec(Rm, p_imu), d3(tv[0], tv[1], tv[2]));
         dist = dot3(nv, pe) + off;                                 // optimize.cpp:95
         status = 1;
-        if (b.tap_normal && sl == 0) {
+        if (!PERSIST && b.tap_normal && sl == 0) {
             b.tap_normal[(size_t)g * 3 + 0] = nv.x; b.tap_normal[(size_t)g * 3 + 1] = nv.y; b.tap_normal[(size_t)g * 3 + 2] = nv.z;
             b.tap_a2d[g] = a2D;
             b.tap_offset[g] = off;
@@ -1352,7 +1394,7 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
             J[3] = s0 * weight; J[4] = s1 * weight; J[5] = s2 * weight;
         }
     }
-    if (g < b.n && b.write_rec && sl == 0) {
+    if (!PERSIST && g < b.n && b.write_rec && sl == 0) {
         // per-keypoint record {J[6], distance, weight} (ordered cut-off path + taps; never on the throughput path)
         double2 *r = reinterpret_cast<double2 *>(b.rec + (size_t)g * 8);
         double2 v;
@@ -1454,6 +1496,7 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
         }
     }
     __syncthreads();
+    tile_stamp(13);
 
     if constexpr (!PERSIST) {
     if ((b.ablate & 128) && (tid == 28 || tid == 29 || tid == 30))        // debug: start / end stamps of this workgroup in the spare slots
@@ -1488,13 +1531,6 @@ __device__ __forceinline__ bool assoc_tile(const SrlAssocArgs &A, const int tile
 // bind) and leaves the normal equations -- one-shot kernel: in the host mailbox; persistent solve: in its LDS, where its
 // last wave runs the 17-dim update and hands the next pose / the verdict to the other workgroups.
 // ---------------------------------------------------------------------------------------------------------------------
-// karg = the kernarg segment (the kernel's __builtin_amdgcn_kernarg_segment_ptr(): inside a called function the builtin
-// yields a null pointer, so the persistent solve hands it down).
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef const __attribute__((address_space(4))) char *KargBytes;
-#else
-typedef const char *KargBytes;
-#endif
 template <int KPW, int WPB, int NBV, int PERSIST>
 __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, const unsigned epoch) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1506,7 +1542,7 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
     KernargPtr bq = (KernargPtr)karg;
     asm volatile("" : "+s"(bq));
     const __attribute__((address_space(4))) SrlAssocArgs &b = *bq;
-    const LdsLayout L = lds_layout(b.K, NBV, KPW, WPB, PERSIST);
+    const LdsLayout L = lds_layout(PERSIST ? SRL_SOLVE_K : b.K, NBV, KPW, WPB, PERSIST);
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wave = tid >> 6;
@@ -1757,6 +1793,7 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
         __syncthreads();                                               // s_out is complete
         if (wave == WPB - 1) {
             int verdict;
+            if (lane == 0) solve_stamp(sp, iter, 3);
             const int obs_before = s_iekf->observed;
             const int num_res = (int)(s_out->d_num_res + 0.5);
             if (s_out->pad != 0) verdict = IEKF_TIMEOUT;
@@ -1787,6 +1824,7 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
                     for (int i = 0; i < 3; ++i) s_pose[18 + i] = s_iekf->state[i];
                 }
             }
+            if (lane == 0) solve_stamp(sp, iter, 4);
             if (lane == 0) s_pose[21] = (double)verdict;
             DevWave::barrier();
             if (lane < 2 * SRL_POSE_DOUBLES) {
@@ -1794,6 +1832,7 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
                 const unsigned half = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
                 __hip_atomic_store((gu64 *)(sp->pose_granules + lane), ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (lane == 0) solve_stamp(sp, iter, 5);
             if (verdict != IEKF_CONTINUE) {
                 // the loop is over: filter, posterior covariance, the last normal equations and the summary go to the host
                 SrlSolveMailbox *mb = sp->mailbox;
@@ -1831,6 +1870,22 @@ __device__ __attribute__((noinline)) void finish_rows_call(KargBytes karg, const
 #endif
 }
 
+// The persistent solve runs a tile as a REAL function: its register allocation is the one-shot kernel's (the selection loop
+// sits at 123 of 128 VGPRs and at the SGPR limit; inlined into the pass loop it spills its candidate rounds), and nothing of it
+// stays live across the reduction and the hand-over.  Built with -mllvm -enable-ipra: the function has one caller, the
+// kernel, which keeps nothing in registers across the call, so no callee-saved register is saved or restored.
+template <int NB, int KPW>
+__device__ __attribute__((noinline)) void assoc_tile_call(KargBytes karg, const int tile, const bool do_prior, const int iter) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long kb = (unsigned long long)karg;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kb), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kb >> 32));
+    typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
+    const KargBytes ks = (KargBytes)(((unsigned long long)hi << 32) | lo);
+    assoc_tile<NB, 1, KPW, 16, 1>(ks, *(const SrlAssocArgs *)(KernargPtr)ks, __builtin_amdgcn_readfirstlane(tile),
+                                  __builtin_amdgcn_readfirstlane((int)do_prior) != 0, __builtin_amdgcn_readfirstlane(iter));
+#endif
+}
+
 template <int NB, int FAST, int KPW, int WPB, int PERSIST>
 __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
     constexpr int KPB = WPB * KPW;
@@ -1850,7 +1905,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         if constexpr (PERSIST) {
             KernargPtr q = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(q));
-            return lds_layout(q->K, NB, KPW, WPB, PERSIST);
+            return lds_layout(SRL_SOLVE_K, NB, KPW, WPB, PERSIST);
         }
 #endif
         return lds_layout(a.K, NB, KPW, WPB, PERSIST);
@@ -1883,12 +1938,18 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
         asm volatile("" : "+s"(sp));
         if (tile >= sp->ntiles) break;
-        KernargPtr ap = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ap));
-        assoc_tile<NB, FAST, KPW, WPB, 1>(*(const SrlAssocArgs *)ap, tile, blockIdx.x == gridDim.x - 1 && tile == (int)blockIdx.x, iter);
+#if defined(SRL_TILE_INLINE)
+        {
+            KernargPtr ap = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ap));
+            assoc_tile<NB, FAST, KPW, WPB, 1>((KargBytes)ap, *(const SrlAssocArgs *)ap, tile, blockIdx.x == gridDim.x - 1 && tile == (int)blockIdx.x, iter);
+        }
+#else
+        assoc_tile_call<NB, KPW>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), tile, blockIdx.x == gridDim.x - 1 && tile == (int)blockIdx.x, iter);
+#endif
 #endif
     } else {
-        if (assoc_tile<NB, FAST, KPW, WPB, 0>(a, tile, false, 0)) return;
+        if (assoc_tile<NB, FAST, KPW, WPB, 0>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), a, tile, false, 0)) return;
     }
     constexpr int P2W_T = (KPB + (64 / (KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4))) - 1) / (64 / (KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4)));
     // ---- this tile's contribution to the workgroup's row: 28 partial sums + {accepted, candidates visited, NaN flag,
@@ -1924,7 +1985,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
 #else
     const SrlAssocArgs &b = a;
 #endif
-    const LdsLayout L = lds_layout(b.K, NB, KPW, WPB, PERSIST);
+    const LdsLayout L = lds_layout(PERSIST ? SRL_SOLVE_K : b.K, NB, KPW, WPB, PERSIST);
     const int lane = lane_id();
     const int wave = tid >> 6;
     const bool finisher = blockIdx.x == gridDim.x - 1;
@@ -1989,10 +2050,14 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         asm volatile("" : "+s"(sp));
         auto fresh = [epoch](unsigned long long x) { return (unsigned)(x >> 32) == epoch; };
         if (finisher) {
+            if (tid == 64 * (WPB - 1)) solve_stamp(sp, iter, 2);
+#if !defined(SRL_EXP_NOCALL)
             finish_rows_call<NB, KPW>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), iter, epoch);
+#endif
             __syncthreads();
         } else {
             if (wave == 0) {
+                if (blockIdx.x == 0 && lane == 0) solve_stamp(sp, iter, 8);
                 // the other workgroups wait for the verdict and the pose: 44 tagged granules, one per lane, one request per poll
                 const unsigned long long *pg = sp->pose_granules + (lane < 2 * SRL_POSE_DOUBLES ? lane : 0);
                 unsigned long long x = 0ull;
@@ -2004,6 +2069,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
                     if (++spins > (1u << 19)) { timed_out = true; break; }   // ~0.5 s: the finishing workgroup died; do not hang the GPU
                     __builtin_amdgcn_s_sleep(2);
                 }
+                if (blockIdx.x == 0 && lane == 0) solve_stamp(sp, iter, 9);
                 const unsigned hi = __shfl_down((unsigned)x, 1);
                 if (lane < 2 * SRL_POSE_DOUBLES && !(lane & 1)) {
                     double d = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned)x));

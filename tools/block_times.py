@@ -1,7 +1,6 @@
 """Debug: distribution of workgroup start/end times inside one association launch (SRL_ABLATE=128 build hook)."""
 import os, sys, ctypes as C
 import numpy as np
-os.environ["SRL_ABLATE"] = "128"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sr_livo_amd as srl
 from sr_livo_amd import capi, synth
@@ -12,6 +11,7 @@ sw = synth.make_sweep(seed + 1000, n_kp, L, pattern=pattern)
 ctx = srl.Context(0)
 ctx.map_insert(cands)
 ctx.sweep_upload(sw["raw"])
+ctx.lib.srl_debug_set_ablate(ctx.h, 128)      # workgroup start / end stamps (results stay valid: nothing is switched off)
 opts = srl.default_opts(max_num_residuals=2**31 - 1)
 f = capi.make_frame(sw["q_pred"], sw["t_pred"], sw["t_last"])
 lib = ctx.lib

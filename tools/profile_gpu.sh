@@ -47,6 +47,12 @@ for f in glob.glob('pmc_*/**/*counter_collection.csv', recursive=True):
 out['pmc_per_dispatch'] = {k: {c: agg[k][c] / max(len(disp[k][c]), 1) for c in agg[k]} for k in agg}
 out['pmc_dispatches'] = {k: {c: len(disp[k][c]) for c in agg[k]} for k in agg}
 out['kernel_meta'] = meta
+import hashlib
+h = hashlib.sha256()
+root = os.environ.get('GRAFT_REPO_ROOT', '.')
+for rel in ("sr_livo_amd/csrc/srl_kernels.hip", "sr_livo_amd/csrc/srl_iekf_wave.h", "sr_livo_amd/csrc/srl_device.h"):
+    h.update(open(os.path.join(root, rel), 'rb').read())
+out['kernel_source_sha256'] = h.hexdigest()     # bench.py drops counters whose stamp differs from the tree's (profile_stale)
 json.dump(out, open(os.environ.get('SUM', '.') + '/summary.json', 'w'), indent=1)
 print(json.dumps(out, indent=1)[:7000])
 PY
