@@ -564,6 +564,8 @@ void ref_node_eskf_get(ref_node *n, double s[19], double P[289]) {
     const Eigen::Matrix<double, 17, 17> c = e.getCovariance();
     for (int i = 0; i < 17; i++) for (int j = 0; j < 17; j++) P[17 * i + j] = c(i, j);
 }
+// the node object itself (the drop-in test asks integration/optimize_hip.cpp for the context bound to it)
+const void *ref_node_lio_ptr(ref_node *n) { return &n->lio; }
 // the LiDAR voxel map, in the container's iteration order: keys (V x 3), counts (V), xyz (V x cap x 3 f32); returns V
 int ref_node_map_num_voxels(ref_node *n) { return (int)n->lio.voxel_map.size(); }
 int ref_node_map_export(ref_node *n, int cap, int16_t *keys, int32_t *counts, float *xyz) {

@@ -1039,6 +1039,15 @@ __device__ __attribute__((noinline)) int dev_iekf_update(const SrlSolveArgs *sv,
 }
 #endif
 
+// Phase 2 geometry: lanes per keypoint and keypoints per phase-2 wave for a workgroup of kpb keypoints.  One lane per
+// keypoint from 48 keypoints on; SRL_P2_HALF_MIN (experiment): workgroups of at least that many keypoints use half-filled
+// waves (32 keypoints each) -- twice as many phase-2 waves, two per SIMD, whose dependent FP64 chains interleave.
+#ifndef SRL_P2_HALF_MIN
+#define SRL_P2_HALF_MIN 100000
+#endif
+__host__ __device__ constexpr int p2_lanes_per_keypoint(int kpb) { return kpb >= 48 ? 1 : (kpb >= 32 ? 2 : 4); }
+__host__ __device__ constexpr int p2_keypoints_per_wave(int kpb) { return kpb >= SRL_P2_HALF_MIN ? 32 : 64 / p2_lanes_per_keypoint(kpb); }
+
 // PERSIST = 1: the persistent solve (srl_solve_kernel below) -- the same three phases inside the ESIKF loop of
 // optimize.cpp:147-312: every workgroup walks its tiles of KPB keypoints, publishes ONE row per pass, the last workgroup
 // of the grid sums the rows, one of its waves runs the 17-dim update (srl_iekf_wave.h) and hands the next pose (or the
@@ -1299,14 +1308,14 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     // Which waves work rotates with the workgroup index, so that the phase-2 waves of workgroups sharing a CU sit on
     // different SIMDs.  With one lane per keypoint the neighbour-plane reads are conflict-free and the barycentre / scatter
     // sums run sequentially over the neighbours, the reference's own order (optimize.cpp:320-337).
-    constexpr int LPK = KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4);                         // lanes per keypoint
-    constexpr int KP2 = 64 / LPK;                                                   // keypoints per phase-2 wave
+    constexpr int LPK = p2_lanes_per_keypoint(KPB);                                  // lanes per keypoint
+    constexpr int KP2 = p2_keypoints_per_wave(KPB);                                  // keypoints per phase-2 wave
     constexpr int P2W = (KPB + KP2 - 1) / KP2;
     const int w2 = (wave + WPB - (int)(blockIdx.x % WPB)) % WPB;                    // phase-2 slot of this wave
     const bool p2_wave = w2 < P2W;
     const int klw = lane / LPK, sl = lane % LPK;                                    // keypoint inside this wave, sub-lane
     const int kl = (p2_wave ? w2 : 0) * KP2 + klw;                                  // keypoint inside the workgroup
-    const bool owner_lane = p2_wave && kl < KPB;
+    const bool owner_lane = p2_wave && klw < KP2 && kl < KPB;
     const int g = owner_lane ? bbase_kp + kl : b.n;
     // sum over the LPK lanes of a keypoint (butterfly: all of them end with the same bits)
     auto lpk_sum = [](double v) {
@@ -1430,7 +1439,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         static_assert(P2W * KP2 * 64 <= WPB * (64 * 8 + SRL_WAVE_SCRATCH), "phase-2 rows must fit in the phase-1 per-wave regions");
         double *s_row = reinterpret_cast<double *>(smem + L.off_wave) + w2 * (KP2 * 8);
         const bool accd = status == 2;
-        if (sl == 0) {
+        if (sl == 0 && klw < KP2) {
             const double h = dist * weight;                      // optimize.cpp:169
             double4 v;
             v.x = accd ? J[0] : 0.0; v.y = accd ? J[1] : 0.0; v.z = accd ? J[2] : 0.0; v.w = accd ? J[3] : 0.0;
@@ -1951,7 +1960,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
     } else {
         if (assoc_tile<NB, FAST, KPW, WPB, 0>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), a, tile, false, 0)) return;
     }
-    constexpr int P2W_T = (KPB + (64 / (KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4))) - 1) / (64 / (KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4)));
+    constexpr int P2W_T = (KPB + p2_keypoints_per_wave(KPB) - 1) / p2_keypoints_per_wave(KPB);
     // ---- this tile's contribution to the workgroup's row: 28 partial sums + {accepted, candidates visited, NaN flag,
     // off-fast-path keypoints} carried as doubles (threads 0..31)
     if (tid < 32) {
@@ -2006,7 +2015,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
     // assumption; its spin is bounded (time-out marker in the mailbox, the host turns it into an error).
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     const unsigned epoch = (unsigned)b.seq + (unsigned)iter;              // persistent solve: one epoch per pass
-    constexpr int KP2 = 64 / (KPB >= 48 ? 1 : (KPB >= 32 ? 2 : 4));       // keypoints per phase-2 wave (as in phase 2)
+    constexpr int KP2 = p2_keypoints_per_wave(KPB);                       // keypoints per phase-2 wave (as in phase 2)
     constexpr int P2W = (KPB + KP2 - 1) / KP2;
     if (tid < 64) {
         // lane l publishes granule l of the row: half l >> 5 of component l & 31
