@@ -117,6 +117,11 @@ int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n);
  * untouched until the next call that returns results.  From pageable memory the upload goes through a pinned ring inside
  * the context (CPU copy of a chunk overlapped with the DMA of the previous one) and the buffer is free on return. */
 int srl_pinned_alloc(size_t bytes, void **out);
+/* Blocks until the DMA of the last srl_sweep_upload / srl_sweep_prefetch that read a PAGE-LOCKED caller buffer has finished:
+ * after it the buffer may be refilled.  (A result returned by srl_build_residuals / srl_solve_iekf implies the same for the
+ * sweep it was computed on; a caller that refills its page-locked buffer earlier than that calls this first.  Uploads from
+ * pageable memory never need it: the buffer is consumed on return.)  No-op when nothing is pending. */
+int srl_sweep_wait(srl_ctx *ctx);
 int srl_pinned_free(void *p);
 int srl_host_register(void *p, size_t bytes);
 int srl_host_unregister(void *p);
@@ -284,6 +289,14 @@ typedef int (*srl_allgather_i64_fn)(const int64_t *mine, int64_t *all /* nranks 
 int srl_comm_set_host_callbacks(srl_ctx *ctx, int nranks, int rank, srl_allreduce_fn ar,
                                 srl_allgather_i64_fn ag, void *user);
 
+/* test hook for the ON-DEVICE budget derivation of the sharded ordered cut (optimize.cpp:107 across ordered shards): the
+ * context acts as rank `rank` of `nranks` whose on-stream all-gather of per-rank counts (accepted residuals; keypoints with a
+ * plane when max_num_residuals <= 0) has already delivered `counts`; the all-reduce is the identity, so srl_build_residuals
+ * returns THIS rank's contribution.  Lets one GPU exercise the reduce kernel's rank > 0 branches, which a 1-rank communicator
+ * cannot reach; the same result must come out of the host-side srl_shard_budget path (srl_comm_set_host_callbacks).
+ * counts = NULL switches the hook off.  Upload the sweep after switching (the shard range changes). */
+int srl_debug_set_gather_counts(srl_ctx *ctx, int nranks, int rank, const int64_t *counts);
+
 /* pure helpers of the sharded path (also used internally): the contiguous point range of a rank
  * (SURVEY.md 8(e)), and the residual budget a rank may still spend given the accepted counts of all
  * shards (reproduces the sequential early exit, optimize.cpp:107, across ordered shards).
@@ -322,12 +335,15 @@ int srl_get_timing(srl_ctx *ctx, srl_timing *t);
  *   bounded max-heap of K, writes the read-out order (candidate indices, ascending distance) and returns its size.  No GPU.
  * srl_debug_device_sqrt: out[i] = the device's sqrt(in[i]) (the tie replay relies on it being correctly rounded). */
 int srl_debug_set_ablate(srl_ctx *ctx, int bits);
-/* 0: always run the separate ordered-cut / reduce kernel.  Default 1: when no ordered cut can trigger (max_num_residuals >
- * number of keypoints), nobody reads per-keypoint records and the context is unsharded, the last workgroup of the association
- * kernel sums the block partials and publishes the normal equations itself (one kernel per ESIKF iteration). */
+/* 0: always run the separate ordered-cut / reduce kernel.  Default 1: on an unsharded context without taps the last workgroup
+ * of the association kernel sums the published rows and writes the normal equations itself (one kernel per ESIKF iteration)
+ * -- also WITH the ordered cut of a finite max_num_residuals when the pass runs in workgroups of <= 64 keypoints (the
+ * prefix pass of the shipped 600).  A finisher that gives up waiting for a row (bounded spin) makes srl_build_residuals repeat
+ * the pass once with the separate reduce kernel instead of failing. */
 int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable);
-/* tuning experiments: force the association kernel's launch shape -- keypoints per wave (4 / 8 / 16) and waves per workgroup
- * (4 / 16); 0, 0 = automatic (by sweep size).  Results do not depend on the shape beyond FP64 summation order. */
+/* tuning experiments: force the association kernel's launch shape -- keypoints per wave (16-wave workgroups: 2 / 3 / 4 / 6 / 8 /
+ * 12 / 16; 4-wave workgroups: 4 / 8 / 16) and waves per workgroup (4 / 16); 0, 0 = automatic (by sweep size).  Results do not
+ * depend on the shape beyond FP64 summation order. */
 int srl_debug_set_launch_shape(srl_ctx *ctx, int keypoints_per_wave, int waves_per_workgroup);
 int srl_debug_set_search_select_mode(srl_ctx *ctx, int select_mode);
 int srl_debug_heap_topk(const double *distances, int n, int K, int32_t *out_index);

@@ -122,6 +122,7 @@ def load_library():
         "srl_sweep_shard": ([p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_sweep_prefetch": ([p, p, C.c_int], C.c_int),
         "srl_sweep_swap": ([p], C.c_int),
+        "srl_sweep_wait": ([p], C.c_int),
         "srl_thread_pin_to_gpu_numa": ([p, C.POINTER(C.c_int)], C.c_int),
         "srl_pinned_alloc": ([C.c_size_t, C.POINTER(p)], C.c_int),
         "srl_pinned_free": ([p], C.c_int),
@@ -151,6 +152,7 @@ def load_library():
         "srl_comm_destroy": ([p], C.c_int),
         "srl_comm_suspend": ([p, C.c_int], C.c_int),
         "srl_comm_set_host_callbacks": ([p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, p], C.c_int),
+        "srl_debug_set_gather_counts": ([p, C.c_int, C.c_int, C.POINTER(C.c_int64)], C.c_int),
         "srl_shard_range": ([C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], None),
         "srl_shard_budget": ([C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)], None),
         "srl_get_timing": ([p, C.POINTER(Timing)], C.c_int),
@@ -431,6 +433,9 @@ class Context:
         self._keep_prefetch = r                   # a page-locked source must outlive the copy
         self._chk(self.lib.srl_sweep_prefetch(self.h, _ptr(r), len(r)), "srl_sweep_prefetch")
 
+    def sweep_wait(self):
+        self._chk(self.lib.srl_sweep_wait(self.h), "srl_sweep_wait")
+
     def sweep_swap(self):
         self._chk(self.lib.srl_sweep_swap(self.h), "srl_sweep_swap")
 
@@ -598,6 +603,14 @@ class Context:
 
     def comm_destroy(self):
         self._chk(self.lib.srl_comm_destroy(self.h), "srl_comm_destroy")
+
+    def set_gather_counts(self, nranks=1, rank=0, counts=None):
+        """srl_debug_set_gather_counts (counts=None: off)"""
+        if counts is None:
+            self._chk(self.lib.srl_debug_set_gather_counts(self.h, 1, 0, None), "set_gather_counts")
+            return
+        c = (C.c_int64 * int(nranks))(*[int(x) for x in counts])
+        self._chk(self.lib.srl_debug_set_gather_counts(self.h, int(nranks), int(rank), c), "set_gather_counts")
 
     def comm_set_host_callbacks(self, nranks, rank, allreduce, allgather):
         """allreduce(np.ndarray float64) -> in place sum; allgather(int) -> list of ints."""

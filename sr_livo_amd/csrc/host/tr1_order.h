@@ -89,7 +89,9 @@ private:
         std::size_t recorded = 0;                                     // element counts covered
         std::vector<std::pair<std::size_t, std::size_t>> grow;        // (element count reached by the rehashing insertion, new bucket count)
     };
-    static const Schedule &schedule(int n) {
+    // Returned BY VALUE under the lock: another context's thread asking for a longer schedule replaces the shared one
+    // (and reallocates its vector) while this caller is still walking its copy.
+    static Schedule schedule(int n) {
         static Schedule S;
         static std::mutex mu;
         std::lock_guard<std::mutex> lock(mu);

@@ -184,6 +184,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < srl_ctx::PROF_RING; i++) for (int k = 0; k < 2; k++) if (ctx->ring[i][k]) hipEventDestroy(ctx->ring[i][k]);
     if (ctx->next_ready) hipEventDestroy(ctx->next_ready);
+    if (ctx->upload_ev) hipEventDestroy(ctx->upload_ev);
     if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -284,6 +285,10 @@ namespace {
 int upload_aos(srl_ctx *ctx, const char *src, size_t bytes, double *d_stage, hipStream_t st) {
     if (srl_is_pinned(src)) {
         HIPCHK(ctx, hipMemcpyAsync(d_stage, src, bytes, hipMemcpyHostToDevice, st));
+        // the caller's buffer is being read by the DMA engine: srl_sweep_wait() returns once it is free again
+        if (!ctx->upload_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(ctx->upload_ev, st));
+        ctx->upload_pending = true;
         return SRL_OK;
     }
     int rc2 = srl_ring_init(ctx);
@@ -346,6 +351,16 @@ int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
 // The NEXT sweep, uploaded while the current one is being solved: DMA + SoA transpose run on the context's copy stream
 // into a second sweep buffer; srl_sweep_swap makes it current (the compute stream waits on the upload's event -- the
 // host does not).  With a node that receives sweep k + 1 while it solves sweep k, the H2D hop leaves the critical path.
+int srl_sweep_wait(srl_ctx *ctx) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (ctx->upload_pending) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        HIPCHK(ctx, hipEventSynchronize(ctx->upload_ev));
+        ctx->upload_pending = false;
+    }
+    return SRL_OK;
+}
+
 int srl_sweep_prefetch(srl_ctx *ctx, const double *raw_xyz, int n) {
     if (!ctx || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -507,6 +522,8 @@ int srl_get_timing(srl_ctx *ctx, srl_timing *t) {
 
 // ------------------------------------------------------------------------------------------ hot path
 // one association + reduction pass over the first n_eff keypoints of this rank's shard (n_eff == ctx->n: all of them)
+#define SRL_INTERNAL_FUSED_TIMEOUT 1      // build_residuals_pass only: never leaves srl_build_residuals
+
 // the kernel arguments both forms of the pass share (one-shot kernel per ESIKF iteration / persistent solve)
 static int prepare_assoc_args(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, int n_eff, SrlAssocArgs &a, int &nb_out) {
     // init-mode switches (optimize.cpp:21-23)
@@ -693,6 +710,10 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             // itself -- no D2H copy, no host synchronisation in the loop
             NCCLCHK(ctx, AllGather(ctx->d_count, ctx->d_gather, 1, ncclInt64, ctx->comm, ctx->stream));
             gather_dev = ctx->d_gather;
+        } else if (ctx->dbg_gather) {
+            // srl_debug_set_gather_counts: the counts of the other ranks are already in d_gather -- the reduce kernel derives
+            // budget and mode from them exactly as behind a real all-gather (test hook for rank > 0 on a single GPU)
+            gather_dev = ctx->d_gather;
         } else {
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_count, ctx->d_count, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -751,7 +772,12 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             }
         }
         std::memcpy(ctx->h_out, &ctx->h_mail->out, sizeof(SrlDevOut));
-        if (ctx->h_out->pad != 0) { ctx->err = "fused final reduction timed out waiting for a workgroup's row"; return SRL_ERR_HIP; }
+        if (ctx->h_out->pad != 0) {
+            // the finishing workgroup gave up waiting for a row (bounded spin: another process holding compute units back, a
+            // preempted queue): not an error of the data -- the caller repeats the pass with the reduction in its own kernel
+            ctx->err = "fused final reduction timed out waiting for a workgroup's row";
+            return SRL_INTERNAL_FUSED_TIMEOUT;
+        }
         visited_local = ctx->h_out->last_visited + 1;
     } else {
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));
@@ -1222,9 +1248,22 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         const long long pre = ((4LL * o->max_num_residuals + 2048 + 63) / 64) * 64;
         if (pre < (long long)ctx->n) n_eff = (int)pre;
     }
-    int rc = build_residuals_pass(ctx, f, o, out, n_eff);
+    // a pass whose fused reduction timed out is repeated once with the separate reduce kernel (stream-ordered: it cannot time out)
+    auto pass = [&](int n_pass) -> int {
+        int r = build_residuals_pass(ctx, f, o, out, n_pass);
+        if (r == SRL_INTERNAL_FUSED_TIMEOUT) {
+            const bool fuse = ctx->fuse_reduce;
+            ctx->fuse_reduce = false;
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            r = build_residuals_pass(ctx, f, o, out, n_pass);
+            ctx->fuse_reduce = fuse;
+            if (r == SRL_INTERNAL_FUSED_TIMEOUT) r = SRL_ERR_HIP;
+        }
+        return r;
+    };
+    int rc = pass(n_eff);
     if ((rc == SRL_OK || rc == SRL_ERR_NAN_PLANARITY) && n_eff < ctx->n && out->num_residuals < o->max_num_residuals)
-        rc = build_residuals_pass(ctx, f, o, out, ctx->n);
+        rc = pass(ctx->n);
     return rc;
 }
 
@@ -1298,11 +1337,30 @@ int srl_comm_destroy(srl_ctx *ctx) {
     return SRL_OK;
 }
 
+int srl_debug_set_gather_counts(srl_ctx *ctx, int nranks, int rank, const int64_t *counts) {
+    // counts == NULL: back to an unsharded context.  Otherwise the context behaves as rank `rank` of `nranks` whose
+    // all-gather of per-rank counts has already delivered `counts` (on-device budget derivation), with an identity all-reduce.
+    if (!ctx || (counts && (nranks < 1 || rank < 0 || rank >= nranks))) return SRL_ERR_BAD_ARG;
+    if (ctx->comm) { ctx->err = "srl_debug_set_gather_counts: a communicator is attached"; return SRL_ERR_BAD_ARG; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!counts) { ctx->dbg_gather = false; ctx->nranks = 1; ctx->rank = 0; ctx->cb_ar = nullptr; ctx->cb_ag = nullptr; return SRL_OK; }
+    int rc = ensure(ctx, ctx->d_gather, (size_t)nranks);
+    if (rc) return rc;
+    std::vector<long long> c64(counts, counts + nranks);
+    HIPCHK(ctx, hipMemcpy(ctx->d_gather, c64.data(), (size_t)nranks * sizeof(long long), hipMemcpyHostToDevice));
+    ctx->nranks = nranks; ctx->rank = rank;
+    ctx->cb_ar = [](double *, int, void *) { return 0; };
+    ctx->cb_ag = nullptr;
+    ctx->dbg_gather = true;
+    return SRL_OK;
+}
+
 int srl_comm_set_host_callbacks(srl_ctx *ctx, int nranks, int rank, srl_allreduce_fn ar, srl_allgather_i64_fn ag, void *user) {
     if (!ctx || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && (!ar || !ag))) return SRL_ERR_BAD_ARG;
     if (ctx->comm && srl_rccl()) { srl_rccl()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
     ctx->nranks = nranks; ctx->rank = rank;
     ctx->cb_ar = ar; ctx->cb_ag = ag; ctx->cb_user = user;
+    ctx->dbg_gather = false;
     return SRL_OK;
 }
 

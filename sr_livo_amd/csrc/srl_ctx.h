@@ -54,6 +54,10 @@ struct srl_ctx {
     int corr_cap = 0;
     int corr_n = -1;
 
+    // page-locked sources: event behind the last DMA that read a caller's buffer (srl_sweep_wait)
+    hipEvent_t upload_ev = nullptr;
+    bool upload_pending = false;
+
     // pinned staging ring of srl_sweep_upload (pageable sources): CPU copy of one chunk overlaps the DMA of the previous
     static constexpr int RING_SLOTS = 4;
     static constexpr int RING_SLOT_BYTES = 256 * 1024;
@@ -113,6 +117,7 @@ struct srl_ctx {
     srl_allgather_i64_fn cb_ag = nullptr;
     void *cb_user = nullptr;
     long long *d_gather = nullptr;     // nranks
+    bool dbg_gather = false;           // srl_debug_set_gather_counts: d_gather is preloaded (no all-gather)
 
     // timing
     // scratch pool: device blocks handed out to the map-insert / frame pipeline calls and kept for the next call

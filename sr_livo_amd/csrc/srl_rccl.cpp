@@ -47,7 +47,11 @@ void resolve() {
                 if (h && fill(h)) break;
                 h = nullptr;
             }
-            if (!h) { g_err = std::string("no RCCL found: ") + (dlerror() ? dlerror() : "librccl.so.1 not on the library path"); return; }
+            if (!h) {
+                const char *why = dlerror();            // one call: dlerror() clears the message it returns
+                g_err = std::string("no RCCL found: ") + (why ? why : "librccl.so.1 not on the library path");
+                return;
+            }
             g_tab.preloaded = false;
         }
     }
