@@ -278,6 +278,26 @@ def pin_to_gpu_numa_node(device_index):
     return info
 
 
+class c_stdout_to_stderr:
+    """RCCL prints a version banner through C stdio on communicator creation; the bench contract is ONE JSON line on stdout.
+    Inside this block file descriptor 1 points at stderr, and the C buffers are flushed before it is pointed back."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self.libc = ctypes.CDLL(None)
+        self.libc.fflush(None)
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        self.libc.fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -295,6 +315,9 @@ def main():
     ap.add_argument("--no-numa-pin", action="store_true", help="A/B: do not pin the process to the GPU-local NUMA node")
     ap.add_argument("--no-aux-legs", action="store_true",
                     help="only the timed configuration runs on the GPU (profiling: no association-only / PCIe legs in the trace)")
+    ap.add_argument("--transport", choices=("rccl", "peer"), default="rccl",
+                    help="sharded mode: how the 50-double rows of the ranks are summed.  rccl: ncclAllReduce on the library's own communicator; "
+                         "peer: direct stores into the peers' inboxes over xGMI (srl_peer_attach, HIP IPC handles exchanged over gloo)")
     ap.add_argument("--force-comm", action="store_true",
                     help="attach an RCCL communicator even at world size 1 (exercises the sharded code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -333,10 +356,17 @@ def main():
     lio.add_points_to_map(cands)
     n_map = lio.map_size()
     comm_info = None
-    if sharded or (args.force_comm and dist is not None):
+    if sharded and args.transport == "peer" and world > 1:
+        handles = [None] * world
+        dist.all_gather_object(handles, lio.ctx.peer_export()[0])
+        lio.ctx.peer_attach(world, rank, handles=handles)
+        comm_info = {"transport": "direct peer exchange (srl_peer_attach): rows stored into the peers' inboxes, summed in rank order inside the "
+                                  "association kernel's finishing workgroup; no RCCL call on the data path"}
+    elif sharded or (args.force_comm and dist is not None):
         uid = [srl.Context.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        lio.ctx.comm_init_rank(world, rank, uid[0])
+        with c_stdout_to_stderr():
+            lio.ctx.comm_init_rank(world, rank, uid[0])
         origin, ver, pre = srl.comm_backend_info()
         comm_info = {"rccl": origin, "version": ver, "instance": "already loaded in the process" if pre else "dlopen'ed by libsrlivo_hip.so"}
     prior_state = synth.eskf_prior(_EskfAdapter(lio), sweep["q_pred"], sweep["t_pred"], sweep["vel"]).copy()
@@ -413,6 +443,34 @@ def main():
                          "what": "srl_lio_set_persistent_solve(1): the whole updateIEKF loop in one kernel launch (srl_solve_iekf)"}
         lio.set_persistent_solve(False)
         solve()
+    # the sharded code path with ONE rank (all a 1-GPU box can run of it): 1-rank RCCL communicator, collectives forced --
+    # fused pass into a device-side mailbox, ncclAllReduce of 50 doubles, publish kernel.  What the exchange step costs per
+    # ESIKF iteration when there is nobody to exchange with; not a scaling figure.
+    comm_1rank = None
+    if world == 1 and dist is None and not args.no_aux_legs:
+        try:
+            os.environ["SRL_FORCE_COLLECTIVES"] = "1"
+            with c_stdout_to_stderr():
+                lio.ctx.comm_init_rank(1, 0, srl.Context.comm_unique_id())
+                lio.resident_sweep(sweep["raw"])
+                for _ in range(3):
+                    solve()
+            torch.cuda.synchronize()
+            t_c = time.perf_counter()
+            for _ in range(args.steps):
+                r_c = solve()
+            torch.cuda.synchronize()
+            el_c = time.perf_counter() - t_c
+            comm_1rank = {"ms_per_esikf_iter": el_c / args.steps * 1e3 / max(r_c["iters"], 1), "sweeps_per_s": args.steps / el_c,
+                          "extra_us_per_iter_vs_timed_region": (el_c - elapsed) / args.steps * 1e3 / max(r_c["iters"], 1),
+                          "what": "1-rank RCCL communicator with the collectives forced (fused pass -> device mailbox -> ncclAllReduce of 50 doubles -> publish kernel)"}
+        except Exception as e:  # noqa: BLE001
+            comm_1rank = {"error": repr(e)}
+        finally:
+            os.environ.pop("SRL_FORCE_COLLECTIVES", None)
+            lio.ctx.comm_destroy()
+            lio.resident_sweep(sweep["raw"])
+            solve()
     # the association work alone: the same launches with the final reduction in its own kernel (the fused tail -- row
     # publish, arrival counters, final sum by the last workgroup -- is part of the kernel the timed region runs)
     tim_unfused = None
@@ -549,7 +607,7 @@ def main():
         "config": {"workload": f"{args.workload}: {n_kp}-keypoint {pattern} sweep, {n_map}-pt voxel map "
                                f"({map_pts} target), max_num_residuals={args.max_num_residuals}, "
                                f"r={nb}, K=20; inputs resident in HBM",
-                   "parallelism": ("point-range shards x%d + RCCL all-reduce of 6x6 normal equations" % world) if sharded
+                   "parallelism": ("point-range shards x%d + %s of the 6x6 normal equations" % (world, "direct peer exchange" if args.transport == "peer" else "RCCL all-reduce")) if sharded
                                   else ("replicas x%d" % world if world > 1 else "single GPU"),
                    "esikf_iterations_per_solve": iters, "residuals_used": r["num_residuals"],
                    "kernel_launches_per_solve": launches_per_solve,
@@ -559,6 +617,7 @@ def main():
         "ms_per_esikf_iter": ms_per_step / max(iters, 1),
         "roofline": roof,
         "persistent_solve_ab": persistent_ab,
+        "sharded_path_one_rank": comm_1rank,
         "host_us_per_iter": {"enqueue": tim_full.sum_host_launch_us / fcalls, "wait_results": tim_full.sum_host_wait_us / fcalls,
                              "build_residuals_call": tim_full.sum_host_total_us / fcalls,
                              "whole_iteration": ms_per_step * 1e3 / max(iters, 1),

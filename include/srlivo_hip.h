@@ -289,6 +289,26 @@ typedef int (*srl_allgather_i64_fn)(const int64_t *mine, int64_t *all /* nranks 
 int srl_comm_set_host_callbacks(srl_ctx *ctx, int nranks, int rank, srl_allreduce_fn ar,
                                 srl_allgather_i64_fn ag, void *user);
 
+/* Direct peer exchange: the sum over the point-range shards (optimize.cpp:235,239 see the sum of all residuals) WITHOUT an
+ * RCCL call on the data path -- the alternative of SURVEY.md 5 for one node.  Every rank owns an inbox in fine-grained device
+ * memory; per pass each rank's finishing workgroup stores its 50-double row, as tagged 8-byte granules, into the inbox of every
+ * rank over xGMI and adds the rows it received in rank order (the same bits on every rank).  A sharded pass then is still ONE
+ * kernel; with the ordered cut (max_num_residuals can bind) the per-rank counts travel the same way, followed by the reduce
+ * kernel and a one-wave exchange kernel.
+ *   srl_peer_export : allocates the inbox; ipc_handle (SRL_PEER_HANDLE_BYTES, may be NULL) receives its HIP IPC handle for
+ *                     peers in OTHER processes, *local_ptr (may be NULL) the device pointer for peers in the SAME process.
+ *   srl_peer_attach : ipc_handles = nranks x SRL_PEER_HANDLE_BYTES gathered from all ranks (how they travel is the caller's
+ *                     business: torch.distributed.all_gather_object, MPI, a file) and / or local_ptrs[nranks] for same-process
+ *                     peers (NULL entries fall back to the handle).  Sets the shard layout like srl_comm_init_rank: upload the
+ *                     sweep afterwards.  nranks <= 8.  Mutually exclusive with srl_comm_init_rank / host callbacks.
+ *   srl_peer_detach : back to an unsharded context (unmaps the peers' inboxes).
+ * All ranks must call srl_build_residuals the same number of times with the same options (as with any collective); a rank whose
+ * peers never deliver gets SRL_ERR_COMM after a bounded spin (~1 s), it does not hang the GPU. */
+#define SRL_PEER_HANDLE_BYTES 64
+int srl_peer_export(srl_ctx *ctx, void *ipc_handle, void **local_ptr);
+int srl_peer_attach(srl_ctx *ctx, int nranks, int rank, const void *ipc_handles, void *const *local_ptrs);
+int srl_peer_detach(srl_ctx *ctx);
+
 /* test hook for the ON-DEVICE budget derivation of the sharded ordered cut (optimize.cpp:107 across ordered shards): the
  * context acts as rank `rank` of `nranks` whose on-stream all-gather of per-rank counts (accepted residuals; keypoints with a
  * plane when max_num_residuals <= 0) has already delivered `counts`; the all-reduce is the identity, so srl_build_residuals

@@ -22,6 +22,9 @@ SRL_ERR_RETRY_PER_ITERATION = -10
 SRL_COMM_ID_BYTES = 128
 
 
+SRL_PEER_HANDLE_BYTES = 64
+
+
 class SrlError(RuntimeError):
     def __init__(self, status, what, detail=""):
         self.status = status
@@ -153,6 +156,9 @@ def load_library():
         "srl_comm_suspend": ([p, C.c_int], C.c_int),
         "srl_comm_set_host_callbacks": ([p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, p], C.c_int),
         "srl_debug_set_gather_counts": ([p, C.c_int, C.c_int, C.POINTER(C.c_int64)], C.c_int),
+        "srl_peer_export": ([p, p, C.POINTER(p)], C.c_int),
+        "srl_peer_attach": ([p, C.c_int, C.c_int, p, C.POINTER(p)], C.c_int),
+        "srl_peer_detach": ([p], C.c_int),
         "srl_shard_range": ([C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], None),
         "srl_shard_budget": ([C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)], None),
         "srl_get_timing": ([p, C.POINTER(Timing)], C.c_int),
@@ -611,6 +617,28 @@ class Context:
             return
         c = (C.c_int64 * int(nranks))(*[int(x) for x in counts])
         self._chk(self.lib.srl_debug_set_gather_counts(self.h, int(nranks), int(rank), c), "set_gather_counts")
+
+    def peer_export(self):
+        """srl_peer_export -> (64-byte HIP IPC handle for peers in other processes, device pointer for peers in this process)"""
+        h = (C.c_ubyte * SRL_PEER_HANDLE_BYTES)()
+        ptr = C.c_void_p()
+        self._chk(self.lib.srl_peer_export(self.h, h, C.byref(ptr)), "srl_peer_export")
+        return bytes(h), int(ptr.value)
+
+    def peer_attach(self, nranks, rank, handles=None, local_ptrs=None):
+        """srl_peer_attach: handles = list of nranks 64-byte handles (or None), local_ptrs = list of nranks device pointers (0 / None
+        entries fall back to the handle).  Upload the sweep afterwards."""
+        hb = None
+        if handles is not None:
+            assert len(handles) == nranks and all(len(x) == SRL_PEER_HANDLE_BYTES for x in handles)
+            hb = (C.c_ubyte * (SRL_PEER_HANDLE_BYTES * nranks)).from_buffer_copy(b"".join(handles))
+        lp = None
+        if local_ptrs is not None:
+            lp = (C.c_void_p * nranks)(*[C.c_void_p(int(x) if x else None) for x in local_ptrs])
+        self._chk(self.lib.srl_peer_attach(self.h, int(nranks), int(rank), hb, lp), "srl_peer_attach")
+
+    def peer_detach(self):
+        self._chk(self.lib.srl_peer_detach(self.h), "srl_peer_detach")
 
     def comm_set_host_callbacks(self, nranks, rank, allreduce, allgather):
         """allreduce(np.ndarray float64) -> in place sum; allgather(int) -> list of ints."""

@@ -169,7 +169,9 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
                     ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
-                    ctx->d_tap_offset, ctx->d_gather, ctx->d_pose_granules};
+                    ctx->d_tap_offset, ctx->d_gather, ctx->d_pose_granules, ctx->d_peer, ctx->d_mail};
+    for (int r = 0; r < SRL_MAX_PEERS; r++) if (ctx->peer_mapped[r]) hipIpcCloseMemHandle(ctx->peer_mapped[r]);
+    if (ctx->d_inbox) hipFree(ctx->d_inbox);
     for (void *b : bufs) if (b) hipFree(b);
     if (ctx->h_out) hipHostFree(ctx->h_out);
     if (ctx->h_count) hipHostFree(ctx->h_count);
@@ -618,8 +620,14 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     //   24k keypoints                               30.4 / 47.2                  35.7 / 41.3
     //   64k keypoints  16-wave, 2 kernels           52   / 78                    58   / 72     (1 000 small workgroups fused: +14 us)
     const bool single_rank = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
-    const bool fuse_base = single_rank && !ctx->taps && a.ablate == 0 && o->max_num_residuals > 0 && ctx->fuse_reduce;
-    const bool can_fuse = fuse_base && !cut_possible_here;
+    // A sharded sweep fuses too when no ordered cut can trigger (every rank's finishing workgroup then sums its own shard):
+    // the rank's totals go  - straight into the peers' inboxes (direct peer exchange: still ONE kernel per pass),
+    //                       - into a device-side mailbox the RCCL all-reduce works on,  or
+    //                       - into the host mailbox, for the host all-reduce callback.
+    // With the ordered cut a rank's budget depends on the counts of the ranks before it: count kernel, exchange, reduce kernel.
+    const bool fuse_any = !ctx->taps && a.ablate == 0 && o->max_num_residuals > 0 && ctx->fuse_reduce && !ctx->dbg_gather;
+    const bool fuse_base = single_rank && fuse_any;
+    const bool can_fuse = fuse_any && !cut_possible_here;
     // ... and WITH the ordered cut (the shipped max_num_residuals = 600): the finisher also locates the workgroup that holds the
     // max-th accepted residual and re-accumulates that workgroup's records, which travel as tagged granules like the rows
     // (small workgroups only: one record granule per finisher thread)
@@ -665,10 +673,27 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     can_fuse_cut = can_fuse_cut && wpb == 16 && kpb <= SRL_FUSED_CUT_MAX_KPB && nblocks <= SRL_FUSED_MAX_BLOCKS;
     const bool fused = (can_fuse && wpb == 16 && nblocks <= SRL_FUSED_MAX_BLOCKS) || can_fuse_cut;
     const unsigned long long seq_now = ++ctx->seq;
+    const bool coll = ctx->comm && (ctx->nranks > 1 || ctx->force_coll) && !ctx->peer_on;
+    const bool peer = ctx->peer_on && ctx->nranks > 1;
+    unsigned peer_epoch = 0;
+    int peer_slot = 0;
+    auto next_exchange = [&]() {           // one tag per exchange, the same on every rank (never 0: an untouched inbox holds zeros)
+        ++ctx->peer_seq;
+        peer_epoch = (unsigned)(ctx->peer_seq & 0xFFFFFFFFull);
+        if (peer_epoch == 0) { ++ctx->peer_seq; peer_epoch = 1; }
+        peer_slot = (int)(ctx->peer_seq & 1ull);
+    };
     if (fused) {
         a.granules = ctx->d_granules;
         a.mailbox = ctx->h_mail;
         a.seq = seq_now;
+        if (peer) {
+            next_exchange();
+            a.peer = ctx->d_peer; a.peer_epoch = peer_epoch; a.peer_slot = peer_slot;
+        } else if (coll) {
+            if (!ctx->d_mail) { int rcm = ensure(ctx, ctx->d_mail, 1); if (rcm) return rcm; }
+            a.mailbox = ctx->d_mail;
+        }
     }
     if (can_fuse_cut) {
         const size_t need = (size_t)nblocks * kpb * 16;
@@ -694,7 +719,6 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     // residual budget of this rank (sequential early exit, optimize.cpp:107, across ordered shards)
     int64_t budget = o->max_num_residuals;
     int mode = 0;
-    const bool coll = ctx->comm && (ctx->nranks > 1 || ctx->force_coll);
     const bool multi = ctx->nranks > 1 || coll;
     // the ordered cut can only trigger when max_num_residuals <= number of keypoints: otherwise no exchange of counts.
     // max_num_residuals <= 0: the loop stops at the first keypoint with a plane, wherever (in whichever shard) that is.
@@ -705,7 +729,12 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     } else {
         // per-rank counts (accepted residuals; keypoints with a plane when max_num_residuals <= 0)
         HIPCHK(ctx, srl_launch_count(ctx->d_binfo, nblocks, o->max_num_residuals <= 0 ? 1 : 0, ctx->d_count, ctx->stream));
-        if (ctx->comm) {
+        if (peer) {
+            // the counts travel like the rows: every rank stores its word into every inbox, one wave collects them
+            next_exchange();
+            HIPCHK(ctx, srl_launch_peer_counts(ctx->d_peer, peer_epoch, peer_slot, ctx->d_count, ctx->d_gather, ctx->stream));
+            gather_dev = ctx->d_gather;
+        } else if (coll) {
             // gathered on the stream; the reduce kernel derives its budget and mode from the counts of earlier ranks
             // itself -- no D2H copy, no host synchronisation in the loop
             NCCLCHK(ctx, AllGather(ctx->d_count, ctx->d_gather, 1, ncclInt64, ctx->comm, ctx->stream));
@@ -740,10 +769,17 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     ra.out = ctx->d_out;
     // single rank: the reduce kernel publishes straight into host-mapped memory and the host spins on the
     // sequence word -- no D2H copy, no stream synchronisation on the per-iteration critical path
-    const bool mailbox = (ctx->nranks == 1) && !coll;
-    ra.mailbox = mailbox ? ctx->h_mail : nullptr;
+    // (a fused pass of a sharded sweep without RCCL / peers also ends in the host mailbox: the callback all-reduce follows it)
+    const bool mailbox = ((ctx->nranks == 1) && !coll) || (fused && !coll);
+    ra.mailbox = (mailbox && !fused) ? ctx->h_mail : nullptr;
     ra.seq = seq_now;
-    if (!fused) HIPCHK(ctx, srl_launch_reduce(ra, mode, ctx->stream));
+    if (!fused) {
+        HIPCHK(ctx, srl_launch_reduce(ra, mode, ctx->stream));
+        if (peer) {
+            next_exchange();
+            HIPCHK(ctx, srl_launch_peer_rows(ctx->d_peer, peer_epoch, peer_slot, ctx->d_out, ctx->h_mail, seq_now, gather_dev, ctx->stream));
+        }
+    }
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     const auto t_enq = std::chrono::steady_clock::now();
     // everything is enqueued: the caller's H-independent host work runs now, beside the kernels (srl_build_residuals_overlap)
@@ -754,14 +790,16 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     }
 
     // the one exchange step: sum of the normal equations over the point-range shards
-    const int n_red = 36 + 6 + 1 + 6;   // HtH, Hth, loss, 6 counters carried as doubles (incl. visited keypoints)
+    const int n_red = SRL_REDUCED_DOUBLES;   // HtH, Hth, loss, 6 counters carried as doubles (incl. visited keypoints), fused time-out flag
     long long visited_local = 0;
     if (coll) {
-        // one ncclAllReduce of 49 doubles on the context's stream; last_visited sits behind the reduced range
-        NCCLCHK(ctx, AllReduce(ctx->d_out, ctx->d_out, n_red, ncclDouble, ncclSum, ctx->comm, ctx->stream));
-        HIPCHK(ctx, srl_launch_publish(ctx->d_out, ctx->h_mail, ra.seq, ctx->stream));
+        // one ncclAllReduce of 50 doubles on the context's stream; last_visited sits behind the reduced range
+        SrlDevOut *mine = fused ? &ctx->d_mail->out : ctx->d_out;
+        NCCLCHK(ctx, AllReduce(mine, mine, n_red, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+        HIPCHK(ctx, srl_launch_publish(mine, ctx->h_mail, ra.seq, ctx->stream));
     }
-    if (coll || mailbox) {
+    const bool host_reduce = ctx->nranks > 1 && !coll && !peer;      // the caller's all-reduce callback (CPU / gloo tests, foreign transports)
+    if (coll || mailbox || peer) {
         volatile unsigned long long *seqp = &ctx->h_mail->seq;
         unsigned long long spins = 0;
         while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != ra.seq) {
@@ -772,13 +810,18 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             }
         }
         std::memcpy(ctx->h_out, &ctx->h_mail->out, sizeof(SrlDevOut));
-        if (ctx->h_out->pad != 0) {
+        visited_local = ctx->h_out->last_visited + 1;
+        if (host_reduce) {
+            if (!ctx->cb_ar) { ctx->err = "nranks > 1 without communicator"; return SRL_ERR_COMM; }
+            if (ctx->cb_ar(reinterpret_cast<double *>(ctx->h_out), n_red, ctx->cb_user) != 0) { ctx->err = "allreduce callback failed"; return SRL_ERR_COMM; }
+        }
+        if (ctx->h_out->pad == SRL_PEER_TIMEOUT_MARK) { ctx->err = "direct peer exchange: a rank's row never arrived"; return SRL_ERR_COMM; }
+        if (ctx->h_out->pad != 0 || ctx->h_out->d_timeout > 0.5) {     // (summed over the ranks: all of them repeat the pass together)
             // the finishing workgroup gave up waiting for a row (bounded spin: another process holding compute units back, a
             // preempted queue): not an error of the data -- the caller repeats the pass with the reduction in its own kernel
             ctx->err = "fused final reduction timed out waiting for a workgroup's row";
             return SRL_INTERNAL_FUSED_TIMEOUT;
         }
-        visited_local = ctx->h_out->last_visited + 1;
     } else {
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(SrlDevOut), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -786,6 +829,8 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         if (ctx->nranks > 1) {
             if (!ctx->cb_ar) { ctx->err = "nranks > 1 without communicator"; return SRL_ERR_COMM; }
             if (ctx->cb_ar(reinterpret_cast<double *>(ctx->h_out), n_red, ctx->cb_user) != 0) { ctx->err = "allreduce callback failed"; return SRL_ERR_COMM; }
+            // another rank's fused pass timed out (its flag is part of the sum): this rank repeats the pass with it
+            if (ctx->h_out->d_timeout > 0.5) { ctx->err = "fused final reduction timed out on another rank"; return SRL_INTERNAL_FUSED_TIMEOUT; }
         }
     }
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
@@ -1291,6 +1336,7 @@ int srl_comm_unique_id(void *id) {
 
 int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id) {
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return SRL_ERR_BAD_ARG;
+    if (ctx->peer_on) { ctx->err = "srl_comm_init_rank: direct peer exchange is attached (srl_peer_detach first)"; return SRL_ERR_BAD_ARG; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (ctx->comm && srl_rccl()) { srl_rccl()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
     ncclUniqueId u;
@@ -1337,6 +1383,77 @@ int srl_comm_destroy(srl_ctx *ctx) {
     return SRL_OK;
 }
 
+// ---- direct peer exchange: the sharded sum through stores into the peers' inboxes (no RCCL call on the data path) ----
+int srl_peer_export(srl_ctx *ctx, void *ipc_handle, void **local_ptr) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_inbox) {
+        // fine-grained: a peer's store is visible to this device's polling loads without cache maintenance
+        const size_t bytes = (size_t)SRL_PEER_INBOX_GRANULES * sizeof(unsigned long long);
+        HIPCHK(ctx, hipExtMallocWithFlags((void **)&ctx->d_inbox, bytes, hipDeviceMallocFinegrained));
+        HIPCHK(ctx, hipMemset(ctx->d_inbox, 0, bytes));                      // tag 0 = "nothing here": exchange tags start at 1
+    }
+    if (ipc_handle) {
+        static_assert(sizeof(hipIpcMemHandle_t) <= SRL_PEER_HANDLE_BYTES, "IPC handle does not fit");
+        hipIpcMemHandle_t h;
+        HIPCHK(ctx, hipIpcGetMemHandle(&h, ctx->d_inbox));
+        std::memset(ipc_handle, 0, SRL_PEER_HANDLE_BYTES);
+        std::memcpy(ipc_handle, &h, sizeof h);
+    }
+    if (local_ptr) *local_ptr = ctx->d_inbox;
+    return SRL_OK;
+}
+
+int srl_peer_detach(srl_ctx *ctx) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->stream) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < SRL_MAX_PEERS; r++) if (ctx->peer_mapped[r]) { hipIpcCloseMemHandle(ctx->peer_mapped[r]); ctx->peer_mapped[r] = nullptr; }
+    if (ctx->peer_on) { ctx->peer_on = false; ctx->nranks = 1; ctx->rank = 0; }
+    return SRL_OK;
+}
+
+int srl_peer_attach(srl_ctx *ctx, int nranks, int rank, const void *ipc_handles, void *const *local_ptrs) {
+    if (!ctx || nranks < 1 || nranks > SRL_MAX_PEERS || rank < 0 || rank >= nranks || (nranks > 1 && !ipc_handles && !local_ptrs)) return SRL_ERR_BAD_ARG;
+    if (ctx->comm || ctx->cb_ar) { ctx->err = "srl_peer_attach: another transport is attached (srl_comm_destroy first)"; return SRL_ERR_BAD_ARG; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    { const int rce = srl_peer_export(ctx, nullptr, nullptr); if (rce) return rce; }
+    { const int rcd = srl_peer_detach(ctx); if (rcd) return rcd; }
+    SrlPeerTable t;
+    std::memset(&t, 0, sizeof t);
+    t.nranks = nranks; t.rank = rank;
+    for (int r = 0; r < nranks; r++) {
+        if (r == rank) { t.inbox[r] = ctx->d_inbox; continue; }
+        if (local_ptrs && local_ptrs[r]) {
+            // same process: the peer's allocation itself (another device: peer access is switched on once)
+            hipPointerAttribute_t at;
+            HIPCHK(ctx, hipPointerGetAttributes(&at, local_ptrs[r]));
+            if (at.device != ctx->device) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(at.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { ctx->err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe); return SRL_ERR_HIP; }
+                (void)hipGetLastError();
+            }
+            t.inbox[r] = (unsigned long long *)local_ptrs[r];
+        } else {
+            if (!ipc_handles) { ctx->err = "srl_peer_attach: no handle for a peer"; return SRL_ERR_BAD_ARG; }
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, (const char *)ipc_handles + (size_t)r * SRL_PEER_HANDLE_BYTES, sizeof h);
+            void *p = nullptr;
+            HIPCHK(ctx, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+            ctx->peer_mapped[r] = p;
+            t.inbox[r] = (unsigned long long *)p;
+        }
+    }
+    if (!ctx->d_peer) { int rcp = ensure(ctx, ctx->d_peer, 1); if (rcp) return rcp; }
+    HIPCHK(ctx, hipMemcpy(ctx->d_peer, &t, sizeof t, hipMemcpyHostToDevice));
+    { int rcg = ensure(ctx, ctx->d_gather, (size_t)nranks); if (rcg) return rcg; }
+    ctx->nranks = nranks; ctx->rank = rank;
+    ctx->peer_on = nranks > 1;
+    ctx->peer_seq = 0;                       // every rank starts counting from the same attach
+    ctx->dbg_gather = false;
+    return SRL_OK;
+}
+
 int srl_debug_set_gather_counts(srl_ctx *ctx, int nranks, int rank, const int64_t *counts) {
     // counts == NULL: back to an unsharded context.  Otherwise the context behaves as rank `rank` of `nranks` whose
     // all-gather of per-rank counts has already delivered `counts` (on-device budget derivation), with an identity all-reduce.
@@ -1357,6 +1474,7 @@ int srl_debug_set_gather_counts(srl_ctx *ctx, int nranks, int rank, const int64_
 
 int srl_comm_set_host_callbacks(srl_ctx *ctx, int nranks, int rank, srl_allreduce_fn ar, srl_allgather_i64_fn ag, void *user) {
     if (!ctx || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && (!ar || !ag))) return SRL_ERR_BAD_ARG;
+    if (ctx->peer_on) { ctx->err = "srl_comm_set_host_callbacks: direct peer exchange is attached (srl_peer_detach first)"; return SRL_ERR_BAD_ARG; }
     if (ctx->comm && srl_rccl()) { srl_rccl()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
     ctx->nranks = nranks; ctx->rank = rank;
     ctx->cb_ar = ar; ctx->cb_ag = ag; ctx->cb_user = user;

@@ -117,6 +117,13 @@ struct srl_ctx {
     srl_allgather_i64_fn cb_ag = nullptr;
     void *cb_user = nullptr;
     long long *d_gather = nullptr;     // nranks
+    // direct peer exchange (srl_peer_export / srl_peer_attach): the sharded sum without an RCCL call on the data path
+    unsigned long long *d_inbox = nullptr;     // fine-grained device memory the peers store into (SRL_PEER_INBOX_GRANULES)
+    SrlPeerTable *d_peer = nullptr;            // the table the kernels read (device copy)
+    void *peer_mapped[SRL_MAX_PEERS] = {};     // HIP IPC mappings of the other ranks' inboxes (closed at detach)
+    bool peer_on = false;
+    unsigned long long peer_seq = 0;           // exchange counter: advances in lock-step on every rank
+    SrlMailbox *d_mail = nullptr;              // device-side mailbox: where a FUSED pass leaves its rank's result for the RCCL all-reduce
     bool dbg_gather = false;           // srl_debug_set_gather_counts: d_gather is preloaded (no all-gather)
 
     // timing

@@ -73,6 +73,7 @@ struct SrlDevOut {             // result of the reduce kernel (device, then copi
     double d_nan;
     double d_fallback;
     double d_visited;          // keypoints visited by the sequential loop in this shard (summed by the all-reduce)
+    double d_timeout;          // fused finisher: 1 when a workgroup's row never arrived (summed too: every rank repeats the pass together)
     long long last_visited;    // local index of last visited keypoint (n-1 if no cut)
     long long pad;
 };
@@ -81,6 +82,24 @@ struct SrlMailbox {            // host-mapped (fine-grained) memory the reduce k
     SrlDevOut out;
     unsigned long long seq;    // = launch sequence number once `out` is complete
     unsigned long long pad[7];
+};
+
+#define SRL_REDUCED_DOUBLES 50 // leading doubles of SrlDevOut that are summed over the shards (HtH .. d_timeout)
+
+// ---- direct peer exchange of the sharded sum (srl_peer_attach): no RCCL call on the data path ---------------------------
+// Every rank owns an INBOX in fine-grained device memory that its peers can store into (same process: the raw pointer; other
+// processes: a HIP IPC mapping).  An exchange = every rank stores its row, as tagged 8-byte granules {epoch, 32-bit half}
+// ("the data is the flag", like the rows of the fused reduction), into the inbox of EVERY rank including itself, then polls
+// its own inbox for the rows of all ranks and adds them in rank order -- the same bits on every rank, one xGMI store hop.
+// Slots alternate with the exchange counter: a rank can only be one exchange ahead of a peer (it needs the peer's row of
+// exchange e + 1, which the peer sends after finishing e), so two slots never collide.
+#define SRL_MAX_PEERS 8
+#define SRL_PEER_ROW 64        // doubles per row (>= SRL_REDUCED_DOUBLES; a row = 2 x 64 granules: low halves, then high halves)
+#define SRL_PEER_INBOX_GRANULES (2 * SRL_MAX_PEERS * 2 * SRL_PEER_ROW)   // [slot][source rank][half][lane]
+#define SRL_PEER_TIMEOUT_MARK 0x9EE9ll   // SrlDevOut::pad when a PEER's row never arrived (0x7117: a workgroup's row of the own launch)
+struct SrlPeerTable {          // device memory, written once at srl_peer_attach
+    unsigned long long *inbox[SRL_MAX_PEERS];   // inbox of rank r as mapped into this process
+    int nranks, rank;
 };
 
 struct SrlAssocArgs {
@@ -116,8 +135,11 @@ struct SrlAssocArgs {
     unsigned long long *granules;   // nblocks x SRL_ROW_GRANULES tagged 8-byte granules {epoch, 32-bit payload}: the published rows (null = not fused)
     unsigned long long *rec_granules;   // fused ORDERED CUT: per keypoint 16 tagged granules = the record {J[6], distance, weight} (else null)
     long long cut_max;              // fused ordered cut: max_num_residuals (> 0), the sequential loop's budget (optimize.cpp:107); 0 = no cut possible
-    SrlMailbox *mailbox;        // host-mapped result mailbox
+    SrlMailbox *mailbox;        // host-mapped result mailbox (fused + RCCL: a device-side mailbox the all-reduce then works on)
     unsigned long long seq;     // launch sequence number published with the result
+    const SrlPeerTable *peer;   // fused + direct peer exchange: the finishing workgroup exchanges its totals itself (else null)
+    unsigned peer_epoch;        // tag of this exchange (exchange counter, never 0)
+    int peer_slot;              // exchange counter & 1
     // outputs
     double *rec;            // n x 8
     unsigned char *status;  // n
@@ -213,6 +235,12 @@ static inline int srl_keypoints_per_wave_one_round(int n, int num_cu) {
 hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s);
 hipError_t srl_launch_count(const SrlBlockInfo *binfo, int nblocks, int count_planes, long long *out_total, hipStream_t s);
 hipError_t srl_launch_publish(const SrlDevOut *src, SrlMailbox *mb, unsigned long long seq, hipStream_t s);
+// direct peer exchange as its own one-wave kernel (the pass was not fused, or the ordered cut needs the per-rank counts first):
+// rows: the leading SRL_REDUCED_DOUBLES of *src summed over the ranks into the host mailbox (+ this rank's last_visited);
+// counts: *count of every rank into gather_out[rank] (device memory the reduce kernel reads)
+hipError_t srl_launch_peer_rows(const SrlPeerTable *peer, unsigned epoch, int slot, const SrlDevOut *src, SrlMailbox *mb, unsigned long long seq,
+                                const long long *gather_check, hipStream_t s);
+hipError_t srl_launch_peer_counts(const SrlPeerTable *peer, unsigned epoch, int slot, const long long *count, long long *gather_out, hipStream_t s);
 hipError_t srl_launch_search(const SrlSearchArgs &a, int nb_voxels, hipStream_t s);
 struct SrlXform { double R[9], t[3], R_il[9], t_il[3]; };
 hipError_t srl_launch_transform(const double *raw_aos, int n, const SrlXform &X, double *out_aos, hipStream_t s);

@@ -1536,6 +1536,49 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Direct peer exchange of one row (SrlPeerTable, srl_device.h), run by ONE wave: lane t < nwords stores the 64-bit word
+// `mine` of its rank's row, as two tagged granules, into the inbox of every rank (its own included), then collects word t
+// of every rank's row from its own inbox -- rank 0 first -- and hands it to take(rank, word).  System-scope stores and
+// loads on fine-grained memory: a peer's store over xGMI is visible to the polling load without any cache maintenance.
+// Returns false (wave-uniform) when some row did not arrive within the bounded spin (a peer died or never launched).
+// ---------------------------------------------------------------------------------------------------------------------
+template <class Take>
+__device__ __forceinline__ bool peer_exchange(const SrlPeerTable *pt, unsigned epoch, int slot, int lane, int nwords,
+                                              unsigned long long mine, Take take) {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    const int G = pt->nranks, me = pt->rank;
+    const bool act = lane < nwords;
+    const unsigned long long tag = (unsigned long long)epoch << 32;
+    const size_t slot_off = (size_t)slot * SRL_MAX_PEERS * (2 * SRL_PEER_ROW);
+    if (act) {
+        const unsigned long long lo = tag | (unsigned)mine, hi = tag | (unsigned)(mine >> 32);
+        for (int r = 0; r < G; ++r) {
+            unsigned long long *dst = pt->inbox[r] + slot_off + (size_t)me * (2 * SRL_PEER_ROW);
+            __hip_atomic_store((gu64 *)(dst + lane), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store((gu64 *)(dst + SRL_PEER_ROW + lane), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    bool ok = true;
+    const unsigned long long *own = pt->inbox[me] + slot_off;
+    for (int r = 0; r < G; ++r) {
+        if (act) {
+            const unsigned long long *src = own + (size_t)r * (2 * SRL_PEER_ROW);
+            unsigned long long x0, x1;
+            unsigned spins = 0;
+            for (;;) {
+                x0 = __hip_atomic_load((gu64 *)(src + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                x1 = __hip_atomic_load((gu64 *)(src + SRL_PEER_ROW + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch) break;
+                if (++spins > (1u << 20)) { ok = false; x0 = x1 = 0ull; break; }     // ~1 s
+                __builtin_amdgcn_s_sleep(8);
+            }
+            take(r, (x1 << 32) | (unsigned long long)(unsigned)x0);
+        }
+    }
+    return __ballot(!ok) == 0ull;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The finishing workgroup: sums the published rows (with the ordered cut of optimize.cpp:107 when max_num_residuals can
 // bind) and leaves the normal equations -- one-shot kernel: in the host mailbox; persistent solve: in its LDS, where its
 // last wave runs the 17-dim update and hands the next pose / the verdict to the other workgroups.
@@ -1714,6 +1757,7 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
                 put_f(&out->d_nan, (long long)s_i[4] <= last_visited ? 1.0 : 0.0);   // NaN planarity only counts for visited keypoints
                 put_f(&out->d_fallback, s_part[31]);
                 put_f(&out->d_visited, (double)(last_visited + 1));
+                put_f(&out->d_timeout, s_i[0] ? 1.0 : 0.0);
                 put_i(&out->last_visited, last_visited);
                 put_i(&out->pad, s_i[0] ? 0x7117ll : 0ll);      // time-out marker
             }
@@ -1768,7 +1812,38 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
         }
         __syncthreads();
         SrlDevOut *out = PERSIST ? s_out : &b.mailbox->out;
-        if (tid < 21) {
+        bool peer_done = false;
+        if constexpr (!PERSIST) {
+            if (b.peer) {
+                // sharded sweep with direct peer exchange: wave 0 lays this rank's totals out as SrlDevOut's leading doubles,
+                // exchanges them with the other ranks' finishing workgroups and publishes the sum -- still one kernel per pass
+                peer_done = true;
+                if (tid < 64) {
+                    double v = 0.0;
+                    if (tid < 36) {
+                        const int i0 = tid / 6, i1 = tid % 6;
+                        const int ia = i0 < i1 ? i0 : i1, ib = i0 < i1 ? i1 : i0;
+                        v = s_part[ia * 6 - (ia * (ia - 1)) / 2 + (ib - ia)];
+                    } else if (tid < 42) v = s_part[21 + (tid - 36)];
+                    else if (tid == 42) v = s_part[27];
+                    else if (tid == 43 || tid == 44) v = s_part[28];
+                    else if (tid == 45) v = s_part[29];
+                    else if (tid == 46) v = s_part[30] > 0.0 ? 1.0 : 0.0;
+                    else if (tid == 47) v = s_part[31];
+                    else if (tid == 48) v = (double)b.n;
+                    else if (tid == 49) v = *s_bad ? 1.0 : 0.0;
+                    double sum = 0.0;
+                    const bool ok = peer_exchange(b.peer, b.peer_epoch, b.peer_slot, lane, SRL_REDUCED_DOUBLES, (unsigned long long)__double_as_longlong(v),
+                                                  [&](int, unsigned long long w) { sum += __longlong_as_double((long long)w); });
+                    double *od = reinterpret_cast<double *>(out);
+                    if (tid < SRL_REDUCED_DOUBLES) put_f(od + tid, sum);
+                    else if (tid == SRL_REDUCED_DOUBLES) put_i(&out->last_visited, (long long)b.n - 1);
+                    else if (tid == SRL_REDUCED_DOUBLES + 1) put_i(&out->pad, ok ? 0ll : SRL_PEER_TIMEOUT_MARK);
+                }
+            }
+        }
+        if (peer_done) {
+        } else if (tid < 21) {
             int ia = 0, c = tid, rowlen = 6;
             while (c >= rowlen) { c -= rowlen; ia++; rowlen--; }
             const int ib = ia + c;
@@ -1785,6 +1860,7 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
             put_f(&out->d_nan, s_part[30] > 0.0 ? 1.0 : 0.0);              // every keypoint is visited
             put_f(&out->d_fallback, s_part[31]);
             put_f(&out->d_visited, (double)b.n);
+            put_f(&out->d_timeout, *s_bad ? 1.0 : 0.0);
             put_i(&out->last_visited, (long long)b.n - 1);
             put_i(&out->pad, *s_bad ? 0x7117ll : 0ll);          // time-out marker
         }
@@ -2310,6 +2386,7 @@ __global__ void __launch_bounds__(1024) srl_reduce_kernel(const SrlReduceArgs a,
         put_f(&out->d_nan, (s_nan_min <= last_visited) ? 1.0 : 0.0);
         put_f(&out->d_fallback, (double)s_tot[3]);
         put_f(&out->d_visited, (double)(last_visited + 1));
+        put_f(&out->d_timeout, 0.0);
         put_i(&out->last_visited, (long long)last_visited);
         put_i(&out->pad, 0);
     }
@@ -2494,6 +2571,44 @@ __global__ void __launch_bounds__(64) srl_publish_kernel(const SrlDevOut *src, S
 hipError_t srl_launch_publish(const SrlDevOut *src, SrlMailbox *mb, unsigned long long seq, hipStream_t s) {
     static_assert(sizeof(SrlDevOut) / 8 <= 64, "one wave publishes the result");
     hipLaunchKernelGGL(srl_publish_kernel, dim3(1), dim3(64), 0, s, src, mb, seq);
+    return hipGetLastError();
+}
+
+// Direct peer exchange behind an un-fused pass: the reduce kernel left this rank's result in device memory; one wave
+// exchanges its leading doubles with the peers and publishes the sum (rank order) into the host mailbox.
+__global__ void __launch_bounds__(64) srl_peer_rows_kernel(const SrlPeerTable *pt, unsigned epoch, int slot, const SrlDevOut *src, SrlMailbox *mb,
+                                                            unsigned long long seq, const long long *gather_check) {
+    const int tid = threadIdx.x;
+    const unsigned long long *sw = reinterpret_cast<const unsigned long long *>(src);
+    double sum = 0.0;
+    bool ok = peer_exchange(pt, epoch, slot, tid, SRL_REDUCED_DOUBLES, tid < SRL_REDUCED_DOUBLES ? sw[tid] : 0ull,
+                            [&](int, unsigned long long w) { sum += __longlong_as_double((long long)w); });
+    if (gather_check)                      // the counts of the ordered cut came through a peer exchange too: a missing one poisons the pass
+        for (int r = 0; r < pt->nranks; ++r) ok = ok && gather_check[r] != (long long)0x8000000000000000ull;
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(&mb->out);
+    if (tid < SRL_REDUCED_DOUBLES) __hip_atomic_store(d + tid, (unsigned long long)__double_as_longlong(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (tid == SRL_REDUCED_DOUBLES) __hip_atomic_store(&mb->out.last_visited, src->last_visited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (tid == SRL_REDUCED_DOUBLES + 1) __hip_atomic_store(&mb->out.pad, ok ? 0ll : SRL_PEER_TIMEOUT_MARK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... and of the per-rank counts the ordered cut across shards starts from (one word per rank; a missing one = INT64_MIN)
+__global__ void __launch_bounds__(64) srl_peer_counts_kernel(const SrlPeerTable *pt, unsigned epoch, int slot, const long long *count, long long *gather_out) {
+    const int tid = threadIdx.x;
+    if (tid == 0) for (int r = 0; r < pt->nranks; ++r) gather_out[r] = (long long)0x8000000000000000ull;
+    __builtin_amdgcn_wave_barrier();
+    peer_exchange(pt, epoch, slot, tid, 1, tid == 0 ? (unsigned long long)*count : 0ull,
+                  [&](int r, unsigned long long w) { gather_out[r] = (long long)w; });
+}
+hipError_t srl_launch_peer_rows(const SrlPeerTable *peer, unsigned epoch, int slot, const SrlDevOut *src, SrlMailbox *mb, unsigned long long seq,
+                                const long long *gather_check, hipStream_t s) {
+    static_assert(SRL_REDUCED_DOUBLES + 2 <= 64 && SRL_REDUCED_DOUBLES <= SRL_PEER_ROW, "one wave exchanges the row");
+    static_assert(offsetof(SrlDevOut, last_visited) == SRL_REDUCED_DOUBLES * 8, "the reduced range ends where last_visited starts");
+    hipLaunchKernelGGL(srl_peer_rows_kernel, dim3(1), dim3(64), 0, s, peer, epoch, slot, src, mb, seq, gather_check);
+    return hipGetLastError();
+}
+hipError_t srl_launch_peer_counts(const SrlPeerTable *peer, unsigned epoch, int slot, const long long *count, long long *gather_out, hipStream_t s) {
+    hipLaunchKernelGGL(srl_peer_counts_kernel, dim3(1), dim3(64), 0, s, peer, epoch, slot, count, gather_out);
     return hipGetLastError();
 }
 

@@ -904,6 +904,36 @@ def test_rccl_single_rank_communicator(golden, monkeypatch):
         ctx.close()
 
 
+def test_rccl_single_rank_fused_pass(golden, monkeypatch):
+    """Sharded sweep, no ordered cut possible: every rank's pass stays FUSED (its finishing workgroup leaves the rank's result in
+    a device-side mailbox), then one ncclAllReduce of 50 doubles and the publish kernel -- no reduce kernel.  1-rank
+    communicator: the result must equal the communicator-free fused pass bit for bit, pass after pass."""
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        ctx.sweep_upload(golden["raw"])
+        f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+        opts = srl.default_opts(max_num_residuals=INT_MAX)
+        base, _ = ctx.build_residuals(f, opts)
+        monkeypatch.setenv("SRL_FORCE_COLLECTIVES", "1")
+        ctx.comm_init_rank(1, 0, srl.Context.comm_unique_id())
+        monkeypatch.delenv("SRL_FORCE_COLLECTIVES")
+        ctx.sweep_upload(golden["raw"])
+        for fused in (1, 0, 1):
+            ctx.set_fused_reduce(fused)
+            for _ in range(3):
+                g, _ = ctx.build_residuals(f, opts)
+                if fused:
+                    assert np.array_equal(np.array(g.HtH), np.array(base.HtH)) and np.array_equal(np.array(g.Hth), np.array(base.Hth))
+                    assert g.loss_sum == base.loss_sum
+                else:       # the reduce kernel adds the workgroup partials in another order
+                    assert rel(np.array(g.HtH), np.array(base.HtH)) < 1e-12 and rel(np.array(g.Hth), np.array(base.Hth)) < 1e-12
+                assert g.num_residuals == base.num_residuals and g.last_visited == base.last_visited
+                assert g.sum_candidates == base.sum_candidates
+    finally:
+        ctx.close()
+
+
 def test_profiling_modes_report_consistent_kernel_times(golden):
     """srl_set_profiling: mode 1 (four events + sync per call) and mode 2 (one lazily read event pair per association
     launch) must count the same launches, the same algorithmic bytes, and kernel times of the same size."""

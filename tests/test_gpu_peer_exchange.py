@@ -1,0 +1,241 @@
+"""Direct peer exchange of the sharded sum (srl_peer_export / srl_peer_attach, include/srlivo_hip.h): every rank's finishing
+workgroup stores its row into every rank's inbox and adds the rows it received in rank order -- no RCCL call, still one
+kernel per pass.  What the sum must reproduce is the reference's single loop over ALL keypoints (optimize.cpp:68-110, the
+sums of :235,239), ordered cut included (optimize.cpp:107 across ordered point-range shards).
+
+A 1-GPU box offers two stand-ins for G GPUs: G contexts of one process (threads; the peers' inboxes are plain device pointers)
+and G processes on the same device (the inboxes travel as HIP IPC handles -- the very path G GPUs of a node take).  The
+in-process form stops at G = 2: a process owns 4 hardware queues by default (GPU_MAX_HW_QUEUES), each context uses two
+streams, and a spinning exchange kernel that shares a hardware queue with the kernel it waits for can only time out.
+Processes have their own queues, as ranks on G GPUs do: G = 2, 4, 8 run that way."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import sr_livo_amd as srl
+from sr_livo_amd import capi
+
+pytestmark = pytest.mark.gpu
+INT_MAX = 2**31 - 1
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def _single(golden, raw, max_res, passes=1):
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        ctx.sweep_upload(raw)
+        f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+        for _ in range(passes):
+            neq, _rc = ctx.build_residuals(f, srl.default_opts(max_num_residuals=max_res))
+        return neq
+    finally:
+        ctx.close()
+
+
+def _peer_threads(golden, raw, G, max_res, passes=3, fused=True, skip_rank=None):
+    """G contexts on device 0, one thread each; returns the per-rank results of the LAST pass (or the exception per rank)."""
+    ctxs = [srl.Context(0) for _ in range(G)]
+    ptrs = [c.peer_export()[1] for c in ctxs]
+    out, errors = [None] * G, [None] * G
+    start = threading.Barrier(G)
+
+    def worker(rank):
+        ctx = ctxs[rank]
+        try:
+            ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+            ctx.peer_attach(G, rank, local_ptrs=ptrs)
+            ctx.set_fused_reduce(1 if fused else 0)
+            ctx.sweep_upload(raw)
+            f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+            start.wait()
+            if rank == skip_rank:
+                return
+            for _ in range(passes):
+                neq, _rc = ctx.build_residuals(f, srl.default_opts(max_num_residuals=max_res))
+            out[rank] = (neq, ctx.sweep_shard())
+        except Exception as e:  # noqa: BLE001
+            errors[rank] = e
+            try:
+                start.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for c in ctxs:
+        c.close()
+    return out, errors
+
+
+@pytest.mark.parametrize("G", [2])
+@pytest.mark.parametrize("max_res", [INT_MAX, 600, 37, -1])
+@pytest.mark.parametrize("fused", [True, False])
+def test_peer_exchange_reproduces_the_single_context_pass(golden, G, max_res, fused):
+    ref = _single(golden, golden["raw"], max_res)
+    out, errors = _peer_threads(golden, golden["raw"], G, max_res, fused=fused)
+    assert not any(errors), errors
+    n_total = len(golden["raw"])
+    for r in range(G):
+        neq, (b, n, tot) = out[r]
+        assert tot == n_total and b == n_total * r // G and n == n_total * (r + 1) // G - b        # contiguous point ranges
+        assert neq.num_residuals == ref.num_residuals and neq.success == ref.success and neq.last_visited == ref.last_visited
+        assert neq.nan_error == ref.nan_error
+        if max_res == INT_MAX:
+            assert neq.sum_candidates == ref.sum_candidates
+        assert rel(np.array(neq.HtH), np.array(ref.HtH)) < 1e-12 and rel(np.array(neq.Hth), np.array(ref.Hth)) < 1e-12
+        assert abs(neq.loss_sum - ref.loss_sum) <= 1e-12 * abs(ref.loss_sum)
+        # rows are added in rank order on every rank: the SAME bits everywhere (the filters of all ranks stay identical)
+        assert np.array_equal(np.array(neq.HtH), np.array(out[0][0].HtH)) and np.array_equal(np.array(neq.Hth), np.array(out[0][0].Hth))
+        assert neq.loss_sum == out[0][0].loss_sum
+
+
+def test_peer_exchange_many_passes_and_a_headline_sized_sweep():
+    """64k keypoints over 2 logical ranks (32k each: the FUSED pass, exchange inside the association kernel), 40 passes back to
+    back: slot parity and tags survive a long run (a rank may be one exchange ahead of a peer, never two)."""
+    from sr_livo_amd import synth
+    n_kp, map_pts, pattern, seed = synth.CONFIGS["HEADLINE"]
+    cands, L = synth.map_candidates(seed, map_pts)
+    sw = synth.make_sweep(seed + 1000, n_kp, L, pattern=pattern)
+    ref_ctx = srl.Context(0)
+    ref_ctx.map_insert(cands)
+    keys, counts, xyz = ref_ctx.map_download()
+    ref_ctx.close()
+    g = dict(map_keys=keys, map_counts=counts, map_xyz=xyz, q_pred=sw["q_pred"], t_pred=sw["t_pred"], t_last=sw["t_last"])
+    ref = _single(g, sw["raw"], INT_MAX)
+    out, errors = _peer_threads(g, sw["raw"], 2, INT_MAX, passes=40)
+    assert not any(errors), errors
+    for r in range(2):
+        neq = out[r][0]
+        assert neq.num_residuals == ref.num_residuals and neq.sum_candidates == ref.sum_candidates
+        assert rel(np.array(neq.HtH), np.array(ref.HtH)) < 1e-12
+        assert np.array_equal(np.array(neq.HtH), np.array(out[0][0].HtH))
+
+
+def test_a_missing_peer_is_an_error_not_a_hang(golden):
+    """Rank 1 of 2 never calls: rank 0's exchange gives up after its bounded spin and srl_build_residuals returns SRL_ERR_COMM."""
+    out, errors = _peer_threads(golden, golden["raw"], 2, INT_MAX, passes=1, skip_rank=1)
+    assert out[0] is None and isinstance(errors[0], srl.SrlError) and errors[0].status == capi.SRL_ERR_COMM, (out, errors)
+    assert "peer" in str(errors[0])
+
+
+def test_peer_attach_refuses_a_second_transport(golden):
+    ctx = srl.Context(0)
+    other = srl.Context(0)
+    try:
+        ptrs = [ctx.peer_export()[1], other.peer_export()[1]]
+        ctx.comm_set_host_callbacks(2, 0, lambda a: None, lambda m: [m, 0])
+        with pytest.raises(srl.SrlError):
+            ctx.peer_attach(2, 0, local_ptrs=ptrs)
+        ctx.comm_set_host_callbacks(1, 0, lambda a: None, lambda m: [m])
+        ctx.comm_destroy()
+        ctx.peer_attach(2, 0, local_ptrs=ptrs)
+        with pytest.raises(srl.SrlError):
+            ctx.comm_set_host_callbacks(2, 0, lambda a: None, lambda m: [m, 0])
+        ctx.peer_detach()
+        with pytest.raises(srl.SrlError):
+            ctx.peer_attach(9, 0, local_ptrs=(ptrs * 5)[:9])          # one node: at most 8 ranks
+    finally:
+        ctx.close()
+        other.close()
+
+
+_IPC_SCRIPT = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import sr_livo_amd as srl
+from sr_livo_amd import capi
+rank, G, d, max_res, scene, fused = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), sys.argv[6], int(sys.argv[7])
+ctx = srl.Context(0)
+if scene == "golden":
+    g = np.load(os.path.join(sys.argv[1], "tests", "golden", "golden_small.npz"))
+    ctx.map_upload(g["map_keys"], g["map_counts"], g["map_xyz"])
+else:
+    from sr_livo_amd import synth
+    n_kp, map_pts, pattern, seed = synth.CONFIGS[scene]
+    cands, L = synth.map_candidates(seed, map_pts)
+    g = synth.make_sweep(seed + 1000, n_kp, L, pattern=pattern)
+    ctx.map_insert(cands)
+ctx.set_fused_reduce(fused)
+handle, _ptr = ctx.peer_export()
+open(os.path.join(d, f"h{rank}.tmp"), "wb").write(handle); os.replace(os.path.join(d, f"h{rank}.tmp"), os.path.join(d, f"h{rank}.bin"))
+handles = []
+for r in range(G):
+    p = os.path.join(d, f"h{r}.bin"); t0 = time.time()
+    while not os.path.exists(p):
+        if time.time() - t0 > 120: raise SystemExit(3)
+        time.sleep(0.02)
+    handles.append(open(p, "rb").read())
+ctx.peer_attach(G, rank, handles=handles)
+ctx.sweep_upload(g["raw"])
+f = capi.make_frame(g["q_pred"], g["t_pred"], g["t_last"])
+for _ in range(5):
+    neq, rc = ctx.build_residuals(f, srl.default_opts(max_num_residuals=max_res))
+np.savez(os.path.join(d, f"out{rank}.npz"), HtH=np.array(neq.HtH), Hth=np.array(neq.Hth), loss=neq.loss_sum, n=neq.num_residuals, last=neq.last_visited,
+         pk=neq.sum_candidates)
+# nobody unmaps an inbox a peer may still be storing into
+open(os.path.join(d, f"done{rank}"), "w").close()
+t0 = time.time()
+while not all(os.path.exists(os.path.join(d, f"done{r}")) for r in range(G)) and time.time() - t0 < 60:
+    time.sleep(0.02)
+ctx.close()
+print("OK", rank, flush=True)
+"""
+
+
+def _peer_processes(tmp_path, G, max_res, scene, fused):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", _IPC_SCRIPT, root, str(r), str(G), str(tmp_path), str(max_res), scene, str(int(fused))],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(G)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        outs.append((p.returncode, o.decode(errors="replace")[-2000:]))
+    assert all(rc == 0 for rc, _ in outs), outs
+    return [np.load(tmp_path / f"out{r}.npz") for r in range(G)]
+
+
+@pytest.mark.parametrize("G,max_res,fused", [(2, INT_MAX, 1), (2, 600, 1), (4, INT_MAX, 1), (4, 600, 0), (4, -1, 1), (8, INT_MAX, 0), (8, 37, 1)])
+def test_peer_exchange_between_processes_through_hip_ipc(golden, tmp_path, G, max_res, fused):
+    """G PROCESSES on the one device: the inboxes travel as HIP IPC handles (what G GPUs of one node do)."""
+    res = _peer_processes(tmp_path, G, max_res, "golden", fused)
+    ref = _single(golden, golden["raw"], max_res)
+    for r in range(G):
+        assert int(res[r]["n"]) == ref.num_residuals and int(res[r]["last"]) == ref.last_visited
+        assert rel(res[r]["HtH"], np.array(ref.HtH)) < 1e-12 and rel(res[r]["Hth"], np.array(ref.Hth)) < 1e-12
+        assert np.array_equal(res[r]["HtH"], res[0]["HtH"]) and float(res[r]["loss"]) == float(res[0]["loss"])
+
+
+def test_peer_exchange_four_processes_headline_sweep_fused(tmp_path):
+    """64k keypoints over 4 processes (16k each): every rank runs the FUSED pass -- the exchange happens inside the association
+    kernel's finishing workgroup, one kernel per pass and rank."""
+    from sr_livo_amd import synth
+    n_kp, map_pts, pattern, seed = synth.CONFIGS["HEADLINE"]
+    cands, L = synth.map_candidates(seed, map_pts)
+    sw = synth.make_sweep(seed + 1000, n_kp, L, pattern=pattern)
+    ctx = srl.Context(0)
+    try:
+        ctx.map_insert(cands)
+        ctx.sweep_upload(sw["raw"])
+        ref, _ = ctx.build_residuals(capi.make_frame(sw["q_pred"], sw["t_pred"], sw["t_last"]), srl.default_opts(max_num_residuals=INT_MAX))
+    finally:
+        ctx.close()
+    res = _peer_processes(tmp_path, 4, INT_MAX, "HEADLINE", 1)
+    for r in range(4):
+        assert int(res[r]["n"]) == ref.num_residuals and int(res[r]["pk"]) == ref.sum_candidates
+        assert rel(res[r]["HtH"], np.array(ref.HtH)) < 1e-12 and rel(res[r]["Hth"], np.array(ref.Hth)) < 1e-12
+        assert np.array_equal(res[r]["HtH"], res[0]["HtH"])
