@@ -10,8 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PLAIN = os.path.join(_HERE, "liboracle.so")
-LIB_TSL = os.path.join(_HERE, "_ref", "liboracle_tsl.so")
+# ORC_LIB_PLAIN / ORC_LIB_TSL: another build of the same sources (tests/test_sanitizers.py loads the ASan + UBSan build this way)
+LIB_PLAIN = os.environ.get("ORC_LIB_PLAIN") or os.path.join(_HERE, "liboracle.so")
+LIB_TSL = os.environ.get("ORC_LIB_TSL") or os.path.join(_HERE, "_ref", "liboracle_tsl.so")
 
 
 class OrcOpts(C.Structure):
