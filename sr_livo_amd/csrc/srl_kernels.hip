@@ -1040,13 +1040,10 @@ __device__ __attribute__((noinline)) int dev_iekf_update(const SrlSolveArgs *sv,
 #endif
 
 // Phase 2 geometry: lanes per keypoint and keypoints per phase-2 wave for a workgroup of kpb keypoints.  One lane per
-// keypoint from 48 keypoints on; SRL_P2_HALF_MIN (experiment): workgroups of at least that many keypoints use half-filled
-// waves (32 keypoints each) -- twice as many phase-2 waves, two per SIMD, whose dependent FP64 chains interleave.
-#ifndef SRL_P2_HALF_MIN
-#define SRL_P2_HALF_MIN 100000
-#endif
+// keypoint from 48 keypoints on.  (Half-filled phase-2 waves -- 32 keypoints each, twice as many waves so that two dependent
+// FP64 chains interleave per SIMD -- were measured in round 3: no gain)
 __host__ __device__ constexpr int p2_lanes_per_keypoint(int kpb) { return kpb >= 48 ? 1 : (kpb >= 32 ? 2 : 4); }
-__host__ __device__ constexpr int p2_keypoints_per_wave(int kpb) { return kpb >= SRL_P2_HALF_MIN ? 32 : 64 / p2_lanes_per_keypoint(kpb); }
+__host__ __device__ constexpr int p2_keypoints_per_wave(int kpb) { return 64 / p2_lanes_per_keypoint(kpb); }
 
 // PERSIST = 1: the persistent solve (srl_solve_kernel below) -- the same three phases inside the ESIKF loop of
 // optimize.cpp:147-312: every workgroup walks its tiles of KPB keypoints, publishes ONE row per pass, the last workgroup
@@ -1163,9 +1160,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
             SolveargPtr sp = (SolveargPtr)(karg + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
             asm volatile("" : "+s"(sp));
             if (lane == 0) solve_stamp(sp, iter, 0);
-#if !defined(SRL_EXP_NOCALL)
             dev_iekf_prior((const SrlSolveArgs *)sp, (unsigned)(size_t)(IekfLdsPtr)s_iekf);
-#endif
             if (lane == 0) solve_stamp(sp, iter, 1);
         }
 #endif
@@ -2023,15 +2018,8 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
         asm volatile("" : "+s"(sp));
         if (tile >= sp->ntiles) break;
-#if defined(SRL_TILE_INLINE)
-        {
-            KernargPtr ap = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(ap));
-            assoc_tile<NB, FAST, KPW, WPB, 1>((KargBytes)ap, *(const SrlAssocArgs *)ap, tile, blockIdx.x == gridDim.x - 1 && tile == (int)blockIdx.x, iter);
-        }
-#else
+        // (the tile is a CALL here: inlined into the pass loop it spilled the selection loop -- phase 1 47.7 us against 37.3 us)
         assoc_tile_call<NB, KPW>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), tile, blockIdx.x == gridDim.x - 1 && tile == (int)blockIdx.x, iter);
-#endif
 #endif
     } else {
         if (assoc_tile<NB, FAST, KPW, WPB, 0>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), a, tile, false, 0)) return;
@@ -2136,9 +2124,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         auto fresh = [epoch](unsigned long long x) { return (unsigned)(x >> 32) == epoch; };
         if (finisher) {
             if (tid == 64 * (WPB - 1)) solve_stamp(sp, iter, 2);
-#if !defined(SRL_EXP_NOCALL)
             finish_rows_call<NB, KPW>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), iter, epoch);
-#endif
             __syncthreads();
         } else {
             if (wave == 0) {
