@@ -49,7 +49,6 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB
 CLOCK_HZ = 2.4e9          # max engine clock (same guide)
 N_CU, N_SIMD = 256, 1024
 INT_MAX = 2**31 - 1
-PROFILE = os.path.join(ROOT, "profiles", "r03_headline_rocprofv3_summary.json")
 KERNEL_SOURCES = ("sr_livo_amd/csrc/srl_kernels.hip", "sr_livo_amd/csrc/srl_iekf_wave.h", "sr_livo_amd/csrc/srl_device.h")
 
 
@@ -64,10 +63,14 @@ def kernel_source_sha():
     return h.hexdigest()
 
 
-def load_profile():
-    """(pmc counters of the dominant kernel, stale?) from the committed rocprofv3 summary of this command"""
+def profile_path(tag="headline"):
+    return os.path.join(ROOT, "profiles", f"r03_{tag}_rocprofv3_summary.json")
+
+
+def load_profile(tag="headline"):
+    """(pmc counters of the dominant kernel, stale?) from the committed rocprofv3 summary of this command (tag: which configuration)"""
     try:
-        prof = json.load(open(PROFILE))
+        prof = json.load(open(profile_path(tag)))
         ks = [v for n, v in prof["pmc_per_dispatch"].items() if "solve" in n] or [v for n, v in prof["pmc_per_dispatch"].items() if "assoc" in n]
         return ks[0], prof.get("kernel_source_sha256") != kernel_source_sha()
     except Exception:
@@ -110,14 +113,14 @@ def compulsory_bytes(keys, counts, world_pts, nb):
     return 24 * len(world_pts) + 12 * len(probed) + 12 * p_unique, int(len(probed)), p_unique
 
 
-def issue_roofline(assoc_ms):
+def issue_roofline(assoc_ms, tag="headline"):
     """Instruction-issue roofline of the association kernel from the committed PMC pass of this command (bench.py cannot
     count its own instructions).  The working set is cache resident and the kernel is bound by VALU issue, so this -- not
     the HBM figure -- says how close the kernel runs to the machine.  SQ_ACTIVE_INST_VALU counts the quad-cycles (4 shader
     cycles) the SIMDs spent issuing VALU work: 1.01 per VALU instruction in this kernel, i.e. one wave64 VALU instruction
     occupies its SIMD for 4 cycles.  floor = busy cycles / (SIMDs x clock): the time the same instruction stream would take
     with every SIMD issuing VALU back to back; frac = floor / measured launch time."""
-    k, stale = load_profile()
+    k, stale = load_profile(tag)
     if k is None or stale:
         return None
     valu, salu, lds = k.get("SQ_INSTS_VALU"), k.get("SQ_INSTS_SALU"), k.get("SQ_INSTS_LDS")
@@ -136,16 +139,36 @@ def issue_roofline(assoc_ms):
             "achieved_us": assoc_ms * 1e3, "frac": floor_us / (assoc_ms * 1e3) if assoc_ms > 0 else None,
             "valu_busy_share_of_wave_lifetime_x_waves_per_simd": busy_quads / max(k.get("SQ_WAVE_CYCLES") or 1.0, 1.0) * (waves / N_SIMD),
             "wait_inst_any_share": (k.get("SQ_WAIT_INST_ANY") or 0.0) / max(k.get("SQ_WAVE_CYCLES") or 1.0, 1.0),
-            "lds_bank_conflict_cycles": k.get("SQ_LDS_BANK_CONFLICT"), "source": os.path.relpath(PROFILE, ROOT),
+            "lds_bank_conflict_cycles": k.get("SQ_LDS_BANK_CONFLICT"), "source": os.path.relpath(profile_path(tag), ROOT),
             "model": "floor = SQ_ACTIVE_INST_VALU quad-cycles x 4 / (1024 SIMDs x 2.4 GHz); measured time = the live HIP-event average"}
 
 
-def traffic_from_profile():
-    k, stale = load_profile()
+def traffic_from_profile(tag="headline"):
+    k, stale = load_profile(tag)
     if k is None or stale or "FETCH_SIZE" not in k:
         return None, None
     # (2 x FETCH_SIZE + WRITE_SIZE) KB: x2 = the gfx950 FETCH_SIZE correction for wide coalesced reads (MI355X_MICROARCH.md)
-    return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, os.path.relpath(PROFILE, ROOT) + " (separate --pmc passes of this command)"
+    return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, os.path.relpath(profile_path(tag), ROOT) + " (separate --pmc passes of this command)"
+
+
+PROFILE_TAG = {"C1": "c1", "C2": "c2", "C3": "c3", "C4": "c4", "HEADLINE@600": "headline600", "INIT(frame_id=5)": "init"}
+
+
+def profile_entry(name, assoc_ms):
+    """what the committed rocprofv3 passes of this configuration say (profiles/r03_<tag>_*): HBM traffic per launch, hit rate,
+    instruction mix and the issue floor -- dropped when the kernel sources changed since (profile_stale)"""
+    tag = PROFILE_TAG.get(name)
+    if tag is None or not os.path.exists(profile_path(tag)):
+        return None
+    k, stale = load_profile(tag)
+    ent = {"source": os.path.relpath(profile_path(tag), ROOT), "profile_stale": bool(stale)}
+    if k is None or stale:
+        return ent
+    traffic, _ = traffic_from_profile(tag)
+    hit, miss = k.get("TCC_HIT_sum"), k.get("TCC_MISS_sum")
+    ent.update({"traffic_bytes_per_launch": traffic, "l2_hit_rate": (hit / (hit + miss)) if hit and miss is not None and (hit + miss) > 0 else None,
+                "hbm_measured_GBs": (traffic / (assoc_ms * 1e-3) / 1e9) if traffic and assoc_ms > 0 else None, "issue": issue_roofline(assoc_ms, tag)})
+    return ent
 
 
 def oracle_solve(po, backend, lio, opts, sweep, prior_state, prior_cov, state0, frame_id, threads):
@@ -240,6 +263,7 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
                "note": "kernel_us = the kernel the timed solves ran: the persistent solve kernel (all passes, reductions, 17-dim updates, "
                        "hand-overs) where kernel_launches_per_solve = 1, else the one-shot association kernel with the fused final "
                        "reduction; assoc_kernel_us = kernel_us per pass; association_only_* = one pass with the reduction in its own kernel"}
+        ent["profile"] = profile_entry(name, assoc_ms / passes_per_launch)
         if po is not None:
             u, _ = oracle_solve(po, backend, lio, opts, sweep, prior_state, prior_cov, state0, frame_id, threads)
             ent["parity"] = {"state_rel_err_vs_oracle": rel(state, u["state"]), "iterations_oracle": int(u["rc"]),
@@ -315,6 +339,8 @@ def main():
     ap.add_argument("--no-numa-pin", action="store_true", help="A/B: do not pin the process to the GPU-local NUMA node")
     ap.add_argument("--no-aux-legs", action="store_true",
                     help="only the timed configuration runs on the GPU (profiling: no association-only / PCIe legs in the trace)")
+    ap.add_argument("--persistent-solve", action="store_true",
+                    help="A/B, profiling: the timed region runs the opt-in one-launch-per-solve kernel (srl_solve_iekf) instead of one launch per ESIKF iteration")
     ap.add_argument("--transport", choices=("rccl", "peer"), default="rccl",
                     help="sharded mode: how the 50-double rows of the ranks are summed.  rccl: ncclAllReduce on the library's own communicator; "
                          "peer: direct stores into the peers' inboxes over xGMI (srl_peer_attach, HIP IPC handles exchanged over gloo)")
@@ -384,6 +410,8 @@ def main():
     # one step = eskf_set_state + eskf_set_cov (reset the prior) + update_iekf on the resident sweep, through a closure
     # that converts its arguments once (the per-call numpy/ctypes marshalling of the generic wrappers costs ~10 us)
     _solve = lio.bound_solver(opts, prior_state, prior_cov, state0, sweep["t_last"], args.frame_id, n_kp)
+    if args.persistent_solve:
+        lio.set_persistent_solve(True)
 
     def solve():
         rc, it, nr = _solve()
@@ -428,7 +456,7 @@ def main():
     # slower form; the timed region above runs the default: one launch + host update per ESIKF iteration
     launches_per_solve = launches_timed
     persistent_ab = None
-    if world == 1 and not args.no_aux_legs:
+    if world == 1 and not args.no_aux_legs and not args.persistent_solve:
         lio.set_persistent_solve(True)
         for _ in range(3):
             solve()
@@ -447,7 +475,7 @@ def main():
     # fused pass into a device-side mailbox, ncclAllReduce of 50 doubles, publish kernel.  What the exchange step costs per
     # ESIKF iteration when there is nobody to exchange with; not a scaling figure.
     comm_1rank = None
-    if world == 1 and dist is None and not args.no_aux_legs:
+    if world == 1 and dist is None and not args.no_aux_legs and not args.persistent_solve:
         try:
             os.environ["SRL_FORCE_COLLECTIVES"] = "1"
             with c_stdout_to_stderr():
