@@ -75,11 +75,20 @@ __global__ void k_create(const int *new_segs_sorted, int n_new, const unsigned l
     }
 }
 
-// sequential replay of one voxel's segment (lioOptimization.cpp:409-445), one thread per voxel.  A 32-lane group per voxel
-// (stored points in lanes, 32 incoming points fetched at once and handed round by shuffles, inner loop = compare + ballot)
-// was measured on the 1M-point build (67k voxels, tools/map_build_probe.py under rocprofv3): 321 us against 161 us for this
-// version -- 32x the waves for a <= 20-wide compare costs more issue slots than the serial inner loop it removes.
-__global__ void k_replay(const int *seg_start, const int *seg_len, const unsigned *sorted_idx, int S, const double *xyz,
+// sequential replay of one voxel's segment (lioOptimization.cpp:409-445), one thread per voxel.  The kernel is latency bound,
+// not work bound: a 1 M-point batch touches 67 k voxels = ONE wave per SIMD, and every point costs its thread two dependent
+// memory round trips (sorted index -> coordinates, ~2 us together from HBM) before 20 compares.  So the incoming points are
+// fetched SRL_REPLAY_BATCH at a time -- all indices, then all coordinates in flight together -- and the voxel's stored points
+// are kept in registers, so that the 20-wide compare is arithmetic only (read from the slab it cost ~20 dependent L1 round
+// trips per point: that, not the work, was the kernel).  Same decisions in the same order, the same FP64 operations.
+// Measured on the 1 M-point / 10 M-point builds (67 k / 500 k voxels; tools/map_build_probe.py under rocprofv3): round 2's
+// form (one load per iteration, compares against the slab) 161 us / 3.03 ms; batched loads alone 146 us / 2.08 ms; batched
+// loads + stored points in registers 88 us / 0.70 ms (this kernel).  Rejected: a 32-lane group per voxel 321 us (32x the
+// waves for a <= 20-wide compare); a hybrid -- this kernel for segments <= 48 points plus one WAVE per longer segment (chunks
+// of 64 points resolved in order with ballots) -- 157 + 131 us and 2.5 + 1.2 ms: the long segments were never the tail (a
+// dense voxel fills to 20 and stops), the per-point latency of the many short ones was.
+#define SRL_REPLAY_BATCH 8
+__global__ void __launch_bounds__(128) k_replay(const int *seg_start, const int *seg_len, const unsigned *sorted_idx, int S, const double *xyz,
                          const int *seg_slot, const unsigned char *is_new, SrlMapSlot *table, unsigned char *slabs,
                          double voxel_size, double min_distance_points, int min_num_points, int *added_total) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -93,28 +102,51 @@ __global__ void k_replay(const int *seg_start, const int *seg_len, const unsigne
     const int j0 = seg_start[s], j1 = j0 + seg_len[s];
     int added = 0;
     const double min_d2 = min_distance_points * min_distance_points;
-    for (int j = j0; j < j1; ++j) {
-        if (count == SRL_CAP) break;            // IsFull(): every later point of the batch is dropped too
-        const unsigned i = sorted_idx[j];
-        const float fx = (float)xyz[(size_t)i * 3], fy = (float)xyz[(size_t)i * 3 + 1], fz = (float)xyz[(size_t)i * 3 + 2];
-        bool add;
-        if (fresh && count == 0) {
-            add = true;                         // new voxel: first point is stored unconditionally (:437-443)
-        } else {
-            double sq_dist_min = 10 * voxel_size * voxel_size;
-            for (int k = 0; k < count; ++k) {
-                const double dx = (double)sl->xyz[k][0] - (double)fx;
-                const double dy = (double)sl->xyz[k][1] - (double)fy;
-                const double dz = (double)sl->xyz[k][2] - (double)fz;
-                const double sq = (dx * dx + dy * dy) + dz * dz;
-                if (sq < sq_dist_min) sq_dist_min = sq;
-            }
-            add = (sq_dist_min > min_d2) && (min_num_points <= 0 || count >= min_num_points);
+    // the voxel's stored points live in REGISTERS for the whole replay (statically indexed: every loop over them is unrolled
+    // and predicated on k < count); the slab is written through as points are added
+    float sx[SRL_CAP], sy[SRL_CAP], sz[SRL_CAP];
+#pragma unroll
+    for (int k = 0; k < SRL_CAP; ++k) {
+        const bool h = k < count;
+        sx[k] = h ? sl->xyz[k][0] : 0.0f; sy[k] = h ? sl->xyz[k][1] : 0.0f; sz[k] = h ? sl->xyz[k][2] : 0.0f;
+    }
+    for (int jb = j0; jb < j1 && count < SRL_CAP; jb += SRL_REPLAY_BATCH) {
+        unsigned idx[SRL_REPLAY_BATCH];
+        float px[SRL_REPLAY_BATCH], py[SRL_REPLAY_BATCH], pz[SRL_REPLAY_BATCH];
+#pragma unroll
+        for (int b = 0; b < SRL_REPLAY_BATCH; ++b) idx[b] = sorted_idx[jb + b < j1 ? jb + b : j1 - 1];
+#pragma unroll
+        for (int b = 0; b < SRL_REPLAY_BATCH; ++b) {
+            px[b] = (float)xyz[(size_t)idx[b] * 3]; py[b] = (float)xyz[(size_t)idx[b] * 3 + 1]; pz[b] = (float)xyz[(size_t)idx[b] * 3 + 2];
         }
-        if (add) {
-            sl->xyz[count][0] = fx; sl->xyz[count][1] = fy; sl->xyz[count][2] = fz;
-            ++count;
-            ++added;
+#pragma unroll
+        for (int b = 0; b < SRL_REPLAY_BATCH; ++b) {
+            if (jb + b >= j1 || count == SRL_CAP) break;            // IsFull(): every later point of the batch is dropped too
+            const float fx = px[b], fy = py[b], fz = pz[b];
+            bool add;
+            if (fresh && count == 0) {
+                add = true;                         // new voxel: first point is stored unconditionally (:437-443)
+            } else {
+                double sq_dist_min = 10 * voxel_size * voxel_size;
+#pragma unroll
+                for (int k = 0; k < SRL_CAP; ++k) {
+                    if (k < count) {
+                        const double dx = (double)sx[k] - (double)fx;
+                        const double dy = (double)sy[k] - (double)fy;
+                        const double dz = (double)sz[k] - (double)fz;
+                        const double sq = (dx * dx + dy * dy) + dz * dz;
+                        if (sq < sq_dist_min) sq_dist_min = sq;
+                    }
+                }
+                add = (sq_dist_min > min_d2) && (min_num_points <= 0 || count >= min_num_points);
+            }
+            if (add) {
+                sl->xyz[count][0] = fx; sl->xyz[count][1] = fy; sl->xyz[count][2] = fz;
+#pragma unroll
+                for (int k = 0; k < SRL_CAP; ++k) if (k == count) { sx[k] = fx; sy[k] = fy; sz[k] = fz; }
+                ++count;
+                ++added;
+            }
         }
     }
     sl->count = (unsigned)count;

@@ -991,6 +991,49 @@ def test_prefix_pass_for_finite_max_num_residuals(oracle_lib, scene100k):
         ctx.close()
 
 
+def test_bulk_map_insert_long_and_odd_segments(oracle_lib, oracle_backend):
+    """Bulk batches (> 250 k points) must reproduce the sequential addPointsToMap (lioOptimization.cpp:409-445) bit for bit
+    whatever the segments look like: dense voxels that fill to 20 early, thin slivers that never fill (thousands of points,
+    nearly all closer than min_distance to the few stored ones), segment lengths around the replay kernel's batch size and its
+    multiples (7 / 8 / 9 / 16 / 17, 48 ... 129), duplicated points, negative coordinates, a second bulk batch onto the partly
+    filled map, and min_num_points > 0 on existing voxels."""
+    rng = np.random.default_rng(4242)
+    parts = []
+    # dense room surfaces (the usual case)
+    pts, _ = synth.map_candidates(4243, 150_000)
+    parts.append(pts)
+    # slivers: 3000 points inside a 0.12 m ball per voxel -> one stored point, everything else rejected, never full
+    for c in range(40):
+        centre = np.array([100.5 + c, 0.5, 0.5])
+        parts.append(centre + rng.uniform(-0.06, 0.06, size=(3000, 3)))
+    # exact segment lengths around the thresholds, on a coarse lattice so that most points are accepted
+    for n_seg, x0 in ((48, 200), (49, 201), (64, 202), (65, 203), (128, 204), (129, 205), (7, 206), (8, 207), (9, 208), (16, 209), (17, 210), (1, 211)):
+        parts.append(np.array([x0, 0, 0]) + rng.uniform(0.02, 0.98, size=(n_seg, 3)))
+    # duplicated points and a voxel on negative coordinates
+    dup = np.array([-300.25, -7.5, 3.25]) + np.zeros((500, 3))
+    parts.append(dup)
+    parts.append(np.array([-300.0, -8.0, 3.0]) + rng.uniform(0.0, 0.99, size=(5000, 3)))
+    allp = np.concatenate(parts)
+    allp = allp[rng.permutation(len(allp))]
+    assert len(allp) > 250_000
+    m = oracle_lib.Map(oracle_backend)
+    ctx = srl.Context(0)
+    try:
+        half = len(allp) // 2
+        for a, b, mnp in ((0, half, 0), (half, len(allp), 0), (0, 120_000, 3), (half, half + 130_000, 25)):
+            batch = allp[a:b] + (0.07 if mnp else 0.0)                  # the min_num_points batches: shifted copies onto existing voxels
+            added_o = m.add_points(batch, min_num_points=mnp)
+            added_g = ctx.map_insert(batch, min_num_points=mnp)
+            assert added_g == added_o, (a, b, mnp)
+            assert ctx.map_size() == (m.size(), m.num_voxels())
+        ko, co, xo = m.export()
+        kg, cg, xg = ctx.map_download()
+        assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
+        assert (co == 20).sum() > 100 and (co < 5).sum() > 40
+    finally:
+        ctx.close()
+
+
 def test_volumetric_map_all_27_voxels_occupied(oracle_lib, oracle_backend):
     """A map that fills space (not surfaces): every one of the 27 probed voxels is occupied and full, so the fast path
     runs its 9-round instance, the survivor set is large, and min-distance pruning shapes the slabs.  Ids, status and
