@@ -348,7 +348,9 @@ int srl_get_timing(srl_ctx *ctx, srl_timing *t);
 /* ---- debug / parity hooks: never called by the product path ----
  * srl_debug_set_ablate: bit mask that switches parts of the association kernel off (profiling tools only; results are
  *   wrong while it is set).  Replaces the SRL_ABLATE environment variable of round 1 -- the library reads no environment
- *   variable on the per-iteration path.
+ *   variable on the per-iteration path.  The switches live in ONE extra instantiation of the kernel (r = 1 fast path, 16 x 16
+ *   keypoints per workgroup); while the mask is non-zero every pass is launched in that shape, whatever the sweep size.  The
+ *   production instantiations carry no trace of them.
  * srl_debug_set_search_select_mode: selection path used by srl_search_neighbors (0 default, 1 extraction, 5 heap replay).
  * srl_debug_heap_topk: the device kernels' restatement of libstdc++'s push_heap / pop_heap (csrc/srl_heap.h, the
  *   std::priority_queue of optimize.cpp:355-363,394-404,411-422) run on the host: offers distances[0..n) in order to a

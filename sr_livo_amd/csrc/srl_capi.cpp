@@ -651,6 +651,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         wpb = ((ctx->force_wpb == 16 || only16) && srl_assoc_lds_bytes(K, nb, kpw, 16) <= SRL_LDS_LIMIT) ? 16 : 4;
         if (only16 && wpb != 16) kpw = 4;
     }
+    if (ctx->ablate != 0 && srl_assoc_lds_bytes(K, nb, 16, 16) <= SRL_LDS_LIMIT) { kpw = 16; wpb = 16; }   // the one shape that carries the debug switches
     const int kpb = kpw * wpb;
     const int nblocks = (n_eff + kpb - 1) / kpb;
     ctx->last_nblocks = nblocks;

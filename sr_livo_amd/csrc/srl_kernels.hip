@@ -1049,7 +1049,10 @@ __host__ __device__ constexpr int p2_keypoints_per_wave(int kpb) { return 64 / p
 // optimize.cpp:147-312: every workgroup walks its tiles of KPB keypoints, publishes ONE row per pass, the last workgroup
 // of the grid sums the rows, one of its waves runs the 17-dim update (srl_iekf_wave.h) and hands the next pose (or the
 // verdict that ends the loop) to the others as tagged granules.  The pose then comes from LDS, not from the kernarg.
-template <int NB, int FAST, int KPW, int WPB, int PERSIST>
+// DBG = 1: the instantiation the profiling tools run (srl_debug_set_ablate: parts of the kernel switched off at run time, workgroup
+// time stamps).  The production instantiations carry none of those tests: read in the pair loop they cost ~10 lane reads of
+// spilled flags per keypoint pair (headline launch 49.4 -> 48.4 us together with the probe reordering below).
+template <int NB, int FAST, int KPW, int WPB, int PERSIST, int DBG = 0>
 __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A, const int tile, const bool do_prior, const int iter) {
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1059,7 +1062,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     // (stack pointer, scratch descriptor of a kernel with calls) has to come from somewhere.
     constexpr int KC = PERSIST ? SRL_SOLVE_K : 0;
     const int Kn = KC ? KC : A.K;
-    const int abl = PERSIST ? 0 : A.ablate;
+    const int abl = (DBG && !PERSIST) ? A.ablate : 0;
     const LdsLayout L = lds_layout(Kn, NB, KPW, WPB, PERSIST);
     const int NB_ROW = L.nb_row;
     const int tid = threadIdx.x;
@@ -1083,7 +1086,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     double *s_wpart = reinterpret_cast<double *>(smem + L.off_wpart);     // [4][32]
     int *s_winfo = reinterpret_cast<int *>(smem + L.off_winfo);           // [WPB][8]: accepted, sum_pk, 1 + first NaN keypoint, fallback, planes
 
-    const long long dbg_t0 = (!PERSIST && (abl & 128)) ? (long long)wall_clock64() : 0;   // debug: workgroup start (100 MHz clock)
+    const long long dbg_t0 = (DBG && !PERSIST && (abl & 128)) ? (long long)wall_clock64() : 0;   // debug: workgroup start (100 MHz clock)
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
     typedef const __attribute__((address_space(4))) SrlSolveArgs *SolveargPtr;
@@ -1206,9 +1209,10 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
             if (!(abl & 32)) preq = probe_issue(s_kv, 2 * (cur < npairs ? cur : npairs), role, A.table, A.table_mask, lane);
             while (cur < npairs) {
                 const int nxt = take();
-                const ProbeReq creq = preq;
+                // this pair's probes are consumed BEFORE the next pair's are issued: one probe state live at a time (no copy
+                // of the 11-register request per pair); the next pair's table loads still have the whole selection to land
+                const int nv_pair = __builtin_amdgcn_readfirstlane((abl & 8) ? 0 : probe_finish(preq, A.thr_cap, A.table, A.table_mask, vox, lane));
                 if (!(abl & 32)) preq = probe_issue(s_kv, 2 * (nxt < npairs ? nxt : npairs), role, A.table, A.table_mask, lane);
-                const int nv_pair = __builtin_amdgcn_readfirstlane((abl & 8) ? 0 : probe_finish(creq, A.thr_cap, A.table, A.table_mask, vox, lane));
                 auto file = [&](int kl, int done, int total) {        // lane 0: result of one keypoint
                     if (done == SEL_DONE) {
                         s_nfound[kl] = total < Kn ? total : Kn;
@@ -1324,7 +1328,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     double dist = 0.0, weight = 0.0;
     const int nf = owner_lane ? s_nfound[kl] : 0;
     if (g < b.n) status = 0;
-    const bool fit = (g < b.n) && (nf >= b.min_nb) && !(!PERSIST && (b.ablate & 1));
+    const bool fit = (g < b.n) && (nf >= b.min_nb) && !(DBG && !PERSIST && (b.ablate & 1));
     if (fit) {
 #pragma clang fp contract(fast)      // plane fit / weights / Jacobian are tolerance-bound (1e-9 vs the oracle): products may fuse
         const D3 p_imu = d3(s_pimu[kl * 3 + 0], s_pimu[kl * 3 + 1], s_pimu[kl * 3 + 2]);
@@ -1503,7 +1507,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     tile_stamp(13);
 
     if constexpr (!PERSIST) {
-    if ((b.ablate & 128) && (tid == 28 || tid == 29 || tid == 30))        // debug: start / end stamps of this workgroup in the spare slots
+    if (DBG && (b.ablate & 128) && (tid == 28 || tid == 29 || tid == 30))        // debug: start / end stamps of this workgroup in the spare slots
         b.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] =
             (tid == 28) ? (double)dbg_t0 : ((tid == 29) ? (double)(long long)wall_clock64() : (double)__builtin_amdgcn_s_getreg(6164) /* XCC_ID */);
     // ---- block partial = wave partials added in wave order (deterministic)
@@ -1966,7 +1970,7 @@ __device__ __attribute__((noinline)) void assoc_tile_call(KargBytes karg, const 
 #endif
 }
 
-template <int NB, int FAST, int KPW, int WPB, int PERSIST>
+template <int NB, int FAST, int KPW, int WPB, int PERSIST, int DBG = 0>
 __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2022,7 +2026,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         assoc_tile_call<NB, KPW>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), tile, blockIdx.x == gridDim.x - 1 && tile == (int)blockIdx.x, iter);
 #endif
     } else {
-        if (assoc_tile<NB, FAST, KPW, WPB, 0>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), a, tile, false, 0)) return;
+        if (assoc_tile<NB, FAST, KPW, WPB, 0, DBG>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), a, tile, false, 0)) return;
     }
     constexpr int P2W_T = (KPB + p2_keypoints_per_wave(KPB) - 1) / p2_keypoints_per_wave(KPB);
     // ---- this tile's contribution to the workgroup's row: 28 partial sums + {accepted, candidates visited, NaN flag,
@@ -2156,9 +2160,9 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
   }   // ESIKF passes
 }
 
-template <int NB, int FAST, int KPW, int WPB>
+template <int NB, int FAST, int KPW, int WPB, int DBG = 0>
 __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_SIMD) srl_assoc_kernel(const SrlAssocArgs a) {
-    assoc_body<NB, FAST, KPW, WPB, 0>(a);
+    assoc_body<NB, FAST, KPW, WPB, 0, DBG>(a);
 }
 // The persistent solve: `a` must stay the first argument (its fields are re-read from the kernarg segment at offset 0), the
 // solve arguments sit right behind it.  One 16-wave workgroup per compute unit at most: every workgroup is resident.
@@ -2479,6 +2483,9 @@ static hipError_t launch_assoc_cfg(const SrlAssocArgs &a, int nb_voxels, hipStre
     };
     // select_mode 0 / 4: fast paths; 1, 2, 5: general path only
     const bool fast = a.select_mode == 0 || a.select_mode == 4;
+    // the debug switches exist in ONE instantiation (r = 1 fast path, 16 x 16 keypoints per workgroup: the host forces that shape
+    // while srl_debug_set_ablate is non-zero); everywhere else a non-zero a.ablate is ignored
+    if constexpr (KPW == 16 && WPB == 16) { if (a.ablate != 0 && nb_voxels == 1 && fast) return launch(srl_assoc_kernel<1, 1, 16, 16, 1>); }
     if (nb_voxels == 1) return fast ? launch(srl_assoc_kernel<1, 1, KPW, WPB>) : launch(srl_assoc_kernel<1, 0, KPW, WPB>);
     return fast ? launch(srl_assoc_kernel<2, 1, KPW, WPB>) : launch(srl_assoc_kernel<2, 0, KPW, WPB>);
 }

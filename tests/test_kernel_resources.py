@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_association_kernel_has_no_spills(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     src = os.path.join(ROOT, "sr_livo_amd", "csrc", "srl_kernels.hip")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fPIC",
            "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "k.o")]
     out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
     blocks = re.split(r"remark: Function Name: ", out)

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "sr_livo_amd", "csrc", "srl_kernels.hip")
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 with tempfile.TemporaryDirectory() as d:
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fPIC",
            "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.path.join(d, "k.o")]
     out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
 for b in re.split(r"remark: Function Name: ", out)[1:]:
