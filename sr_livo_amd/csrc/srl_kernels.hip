@@ -536,10 +536,11 @@ __device__ __forceinline__ void cand_compact(const float (&px)[R], const float (
                                              const unsigned long long (&svm)[R], const LaneRole &role, SurvRec *recs) {
     const int code0 = (role.c0 << 5) | role.slot;
     int base = 0;
+    (void)d2f; (void)thr;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         if (svm[j] != 0ull) {                  // wave-uniform: most rounds (far voxels) have no survivor at all
-            if (d2f[j] <= thr) {
+            if (__builtin_amdgcn_inverse_ballot_w64(svm[j])) {   // this lane's bit of the ballot: the mask goes straight into exec, no second compare
                 SurvRec r; r.x = px[j]; r.y = py[j]; r.z = pz[j]; r.code = code0 + ((3 * j) << 5);
                 recs[base + lanes_below(svm[j])] = r;
             }
@@ -653,14 +654,32 @@ __device__ __forceinline__ int select_pair_f32_r(const double *qa, const double 
     float da[R], db[R];
     const unsigned va = __float_as_uint(cand_d2f<R>(ax, ay, az, qfa, da));
     const unsigned vb = __float_as_uint(cand_d2f<R>(bx, by, bz, qfb, db));
-    unsigned lo_a = 0, lo_b = 0;
+    // Bisection on the bit pattern of the per-lane minima.  Every pattern in [2^-15, 2) m^2 starts 0111 in bits 30..27, so with
+    // the minima clamped into that band nine steps (bits 26..18) do what thirteen did -- the same lo whenever the K-th smallest
+    // minimum lies inside the band (a minimum below it only ever makes the bound looser, never wrong).  If the K-th smallest
+    // is not below 2 m^2 (lo ends on the band's last pattern: sparse voxels, fewer than K candidates) the full search runs.
+    constexpr unsigned BAND_LO = 0x38000000u, BAND_HI = 0x40000000u, BAND_LAST = 0x3FFC0000u;
+    const unsigned ca_v = va < BAND_LO ? BAND_LO : (va > BAND_HI ? BAND_HI : va);
+    const unsigned cb_v = vb < BAND_LO ? BAND_LO : (vb > BAND_HI ? BAND_HI : vb);
+    unsigned lo_a = BAND_LO, lo_b = BAND_LO;
 #pragma unroll
-    for (int bit = 30; bit >= 18; --bit) {
+    for (int bit = 26; bit >= 18; --bit) {
         const unsigned ta = lo_a | (1u << bit), tb = lo_b | (1u << bit);
-        const int cnt_a = __popcll(__ballot(va < ta));
-        const int cnt_b = __popcll(__ballot(vb < tb));
+        const int cnt_a = __popcll(__ballot(ca_v < ta));
+        const int cnt_b = __popcll(__ballot(cb_v < tb));
         lo_a = (cnt_a < K) ? ta : lo_a;
         lo_b = (cnt_b < K) ? tb : lo_b;
+    }
+    if (lo_a == BAND_LAST || lo_b == BAND_LAST) {            // rare: the original 13 steps, rolled
+        lo_a = 0; lo_b = 0;
+#pragma nounroll
+        for (int bit = 30; bit >= 18; --bit) {
+            const unsigned ta = lo_a | (1u << bit), tb = lo_b | (1u << bit);
+            const int cnt_a = __popcll(__ballot(va < ta));
+            const int cnt_b = __popcll(__ballot(vb < tb));
+            lo_a = (cnt_a < K) ? ta : lo_a;
+            lo_b = (cnt_b < K) ? tb : lo_b;
+        }
     }
     const float thr_a = thr_from_bisection(lo_a, qfa), thr_b = thr_from_bisection(lo_b, qfb);
     unsigned long long sa[R], sb[R];
@@ -1221,7 +1240,8 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
                         s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)(kl | (done == SEL_TIE ? 0x8000 : 0));
                     }
                 };
-                const int r_a = ((nv_pair & 0xFF) + 2) / 3, r_b = ((nv_pair >> 8) + 2) / 3;
+                // ceil(nv / 3) for nv <= 27 as a multiply-shift (the signed / 3 went through s_mul_hi)
+                const int r_a = (int)((((unsigned)nv_pair & 0xFFu) + 2u) * 0x5556u >> 16), r_b = (int)(((((unsigned)nv_pair >> 8) & 0xFFu) + 2u) * 0x5556u >> 16);
                 const int r_max = r_a > r_b ? r_a : r_b;
                 if (2 * cur + 1 < n_here && r_max <= SRL_PAIR_MAX_ROUNDS && !(abl & (4 | 256))) {
                     // both keypoints exist and their candidate rounds fit in registers together: B's loads fly while A is selected
