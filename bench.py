@@ -365,7 +365,8 @@ def main():
         dist = dist_mod
         # control plane only (barrier, 128-byte id broadcast, one max-reduce): gloo over loopback.  No torch NCCL process
         # group is created -- the only communicator on the GPUs is the library's own, on the process's one RCCL instance.
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+        with c_stdout_to_stderr():          # gloo announces its connections on stdout
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
 
     n_kp, map_pts, pattern, seed = synth.CONFIGS[args.workload]
     sharded = ((world > 1 or (args.force_comm and "RANK" in os.environ)) and args.mode == "sharded")
@@ -770,9 +771,10 @@ def main():
                 cfgs.append({"name": name, "error": repr(e)})
         out["configs"] = cfgs
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        with c_stdout_to_stderr():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
