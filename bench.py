@@ -351,6 +351,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SRL_BENCH_ALL_ON_DEVICE0") == "1":
+        # test hook (1-GPU boxes): every rank on device 0 -- lets `--transport peer` run its N > 1 path end to end (the inboxes travel
+        # as HIP IPC handles exactly as between GPUs); RCCL refuses two ranks on one device.  Never a performance figure.
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")

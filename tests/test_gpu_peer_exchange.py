@@ -239,3 +239,22 @@ def test_peer_exchange_four_processes_headline_sweep_fused(tmp_path):
         assert int(res[r]["n"]) == ref.num_residuals and int(res[r]["pk"]) == ref.sum_candidates
         assert rel(res[r]["HtH"], np.array(ref.HtH)) < 1e-12 and rel(res[r]["Hth"], np.array(ref.Hth)) < 1e-12
         assert np.array_equal(res[r]["HtH"], res[0]["HtH"])
+
+
+def test_bench_two_ranks_with_the_peer_transport_on_one_device(tmp_path):
+    """bench.py's N > 1 path end to end (gloo control plane, IPC handles gathered with all_gather_object, sharded solve, barriers,
+    max over ranks, the replicas leg): two ranks on the one device through the SRL_BENCH_ALL_ON_DEVICE0 test hook.  Checks the
+    contract of the line, not its speed (two processes share a GPU)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SRL_BENCH_ALL_ON_DEVICE0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29531",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--transport", "peer"]
+    p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().split("\n") if l.strip()]
+    assert len(lines) == 1, lines                                          # ONE JSON line on stdout (rank 0 only, no library chatter)
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "strong" and d["unit"] == "sweeps/s"
+    assert d["config"]["residuals_used"] == 65536 and "direct peer exchange" in d["config"]["parallelism"]
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
