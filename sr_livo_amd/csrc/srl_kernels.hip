@@ -338,26 +338,30 @@ __device__ __forceinline__ ProbeReq probe_issue(const int *kv, int kl, const Lan
 // Compacts the occupied voxels of both keypoints into their lists (list h at vox + 32 h, visit order kept,
 // zero-filled up to 27 entries so the candidate rounds need no bounds branch).  Returns nv_A | nv_B << 8.
 __device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, const SrlMapSlot *table, unsigned mask,
-                                            VoxEnt *vox, int lane) {
-    bool found = false;
-    unsigned slab = 0, cnt = 0;
+                                            VoxEnt *vox, int lane, int *ncand_pair) {
     const bool prober = (lane & 31) < 27;
-    if (prober) {
-        if (r.s0.key == r.key) { slab = r.s0.slab; cnt = r.s0.count; found = true; }
-        else if (r.s0.key != SRL_EMPTY_KEY) {
-            if (r.s1.key == r.key) { slab = r.s1.slab; cnt = r.s1.count; found = true; }
-            else if (r.s1.key != SRL_EMPTY_KEY) {
-                unsigned h = (r.h + 2) & mask;                 // rare: continue the linear probe
-                for (unsigned probe = 2; probe <= mask; ++probe) {
-                    const SrlMapSlot sl = table[h];
-                    if (sl.key == r.key) { slab = sl.slab; cnt = sl.count; found = true; break; }
-                    if (sl.key == SRL_EMPTY_KEY) break;
-                    h = (h + 1) & mask;
-                }
+    // the 2-slot window by selects (non-probing lanes carry EMPTY keys and match nothing) ...
+    const bool m0 = prober && r.s0.key == r.key;
+    const bool m1 = prober && !m0 && r.s0.key != SRL_EMPTY_KEY && r.s1.key == r.key;
+    bool found = m0 || m1;
+    unsigned slab = m0 ? r.s0.slab : r.s1.slab, cnt = m0 ? r.s0.count : r.s1.count;
+    // ... and ONE uniform branch for the rare case (< 1 % of the probes at load <= 0.25) that both slots hold other keys
+    const bool more = prober && !found && r.s0.key != SRL_EMPTY_KEY && r.s1.key != SRL_EMPTY_KEY;
+    if (__ballot(more) != 0ull) {
+        if (more) {
+            unsigned h = (r.h + 2) & mask;
+            for (unsigned probe = 2; probe <= mask; ++probe) {
+                const SrlMapSlot sl = table[h];
+                if (sl.key == r.key) { slab = sl.slab; cnt = sl.count; found = true; break; }
+                if (sl.key == SRL_EMPTY_KEY) break;
+                h = (h + 1) & mask;
             }
         }
-        found = found && (int)cnt >= thr_cap && cnt > 0;        // NumPoints() < threshold -> skipped (optimize.cpp:389)
     }
+    found = found && (int)cnt >= thr_cap && cnt > 0;            // NumPoints() < threshold -> skipped (optimize.cpp:389)
+    // P_k of the two keypoints (the candidates the reference's loop visits, optimize.cpp:391-404) = the resident points of the
+    // voxels found: added up here, once per voxel, instead of by ballots over every candidate round
+    if (found) atomicAdd(ncand_pair + (lane >> 5), (int)cnt);
     const unsigned long long m = __ballot(found);
     const unsigned m_lo = (unsigned)m, m_hi = (unsigned)(m >> 32);
     const int nv_a = __popc(m_lo), nv_b = __popc(m_hi);
@@ -539,8 +543,8 @@ __device__ __forceinline__ void cand_compact(const float (&px)[R], const float (
     (void)d2f; (void)thr;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        if (svm[j] != 0ull) {                  // wave-uniform: most rounds (far voxels) have no survivor at all
-            if (__builtin_amdgcn_inverse_ballot_w64(svm[j])) {   // this lane's bit of the ballot: the mask goes straight into exec, no second compare
+        {
+            if (__builtin_amdgcn_inverse_ballot_w64(svm[j])) {   // (a round without survivors runs the store with an empty exec mask)   // this lane's bit of the ballot: the mask goes straight into exec, no second compare
                 SurvRec r; r.x = px[j]; r.y = py[j]; r.z = pz[j]; r.code = code0 + ((3 * j) << 5);
                 recs[base + lanes_below(svm[j])] = r;
             }
@@ -1230,7 +1234,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
                 const int nxt = take();
                 // this pair's probes are consumed BEFORE the next pair's are issued: one probe state live at a time (no copy
                 // of the 11-register request per pair); the next pair's table loads still have the whole selection to land
-                const int nv_pair = __builtin_amdgcn_readfirstlane((abl & 8) ? 0 : probe_finish(preq, A.thr_cap, A.table, A.table_mask, vox, lane));
+                const int nv_pair = __builtin_amdgcn_readfirstlane((abl & 8) ? 0 : probe_finish(preq, A.thr_cap, A.table, A.table_mask, vox, lane, s_ncand + 2 * cur));
                 if (!(abl & 32)) preq = probe_issue(s_kv, 2 * (nxt < npairs ? nxt : npairs), role, A.table, A.table_mask, lane);
                 auto file = [&](int kl, int done, int total) {        // lane 0: result of one keypoint
                     if (done == SEL_DONE) {
@@ -1250,7 +1254,15 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
                     int total_a = 0, total_b = 0, done;
                     if (r_max <= 3) done = select_pair_f32_r<3>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, Kn, surv, lane, role, sink_a, sink_b, total_a, total_b, abl);
                     else done = select_pair_f32_r<4>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, Kn, surv, lane, role, sink_a, sink_b, total_a, total_b, abl);
-                    if (lane == 0) { file(kl, done & 0xFF, total_a); file(kl + 1, done >> 8, total_b); }
+                    // (candidate totals: accumulated by probe_finish; neighbour counts: derived from them in phase 2 -- a pair that
+                    // finished on the fast path files nothing)
+                    (void)total_a; (void)total_b;
+                    if (done != (SEL_DONE | (SEL_DONE << 8))) {
+                        if (lane == 0) {
+                            if ((done & 0xFF) != SEL_DONE) s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)(kl | ((done & 0xFF) == SEL_TIE ? 0x8000 : 0));
+                            if ((done >> 8) != SEL_DONE) s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)((kl + 1) | ((done >> 8) == SEL_TIE ? 0x8000 : 0));
+                        }
+                    }
                 } else {
 #pragma nounroll
                     for (int h = 0; h < 2; ++h) {
@@ -1346,7 +1358,9 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     bool nan_bad = false;
     double J[6] = {0, 0, 0, 0, 0, 0};
     double dist = 0.0, weight = 0.0;
-    const int nf = owner_lane ? s_nfound[kl] : 0;
+    // neighbours found = min(candidates visited, K): every path leaves the candidate count in s_ncand
+    const int nc2 = owner_lane ? s_ncand[kl] : 0;
+    const int nf = nc2 < Kn ? nc2 : Kn;
     if (g < b.n) status = 0;
     const bool fit = (g < b.n) && (nf >= b.min_nb) && !(DBG && !PERSIST && (b.ablate & 1));
     if (fit) {
