@@ -1,13 +1,18 @@
-"""The committed bench line (profiles/r02_bench.json, an un-edited output of `python bench.py` on an MI355X box) carries every
-field the driver's contract names, with consistent values.  CPU only: it guards the shape of the line, not the numbers."""
+"""The committed bench lines (profiles/r02_bench.json, profiles/r03_bench.json: un-edited outputs of `python bench.py` on an MI355X
+box) carry every field the driver's contract names, with consistent values; the round-3 line and the committed profile summaries
+belong to the kernel sources in the tree (SHA stamp).  CPU only: it guards the shape of the lines, not the numbers."""
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+import pytest
+
+
+@pytest.mark.parametrize("name", ["r02_bench.json", "r03_bench.json"])
+def test_committed_bench_line_has_the_contract_fields(name):
+    d = json.load(open(os.path.join(ROOT, "profiles", name)))
     b = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
@@ -30,3 +35,22 @@ def test_committed_bench_line_has_the_contract_fields():
     assert names[:4] == ["C1", "C2", "C3", "C4"] and all(x["parity"]["ok"] for x in d["configs"])
     assert d["parity"]["iterations_gpu"] == d["parity"]["iterations_oracle"]
     assert isinstance(b.get("metric", ""), str)
+
+
+def test_round3_line_and_profiles_belong_to_the_kernel_sources_in_the_tree():
+    """bench.py drops `traffic` / `issue` and says profile_stale when the stamp of a profile summary differs from the sources: the
+    committed line must have been taken with fresh profiles, and the committed summaries must still match the tree."""
+    import glob
+    import hashlib
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    r = d["roofline"]
+    assert r["profile_stale"] is False and r["traffic"] and r["issue"] and "pcie_inclusive_sweeps_per_s" in d["config"] and "value_is" in d["config"]
+    assert all(c.get("profile") and c["profile"]["profile_stale"] is False for c in d["configs"])
+    assert d["persistent_solve_ab"]["launches_per_solve"] == 1 and d["config"]["kernel_launches_per_solve"] >= 2
+    h = hashlib.sha256()
+    for rel in ("sr_livo_amd/csrc/srl_kernels.hip", "sr_livo_amd/csrc/srl_iekf_wave.h", "sr_livo_amd/csrc/srl_device.h"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    files = glob.glob(os.path.join(ROOT, "profiles", "r03_*_rocprofv3_summary.json"))
+    assert len(files) >= 9
+    for f in files:
+        assert json.load(open(f))["kernel_source_sha256"] == h.hexdigest(), os.path.basename(f)
