@@ -58,3 +58,20 @@ def test_round3_line_and_profiles_belong_to_the_kernel_sources_in_the_tree():
         # a later round edits the kernel before it re-profiles: bench.py then reports profile_stale itself -- say so here, do not fail
         import warnings
         warnings.warn("profiles/r03_* were collected on other kernel sources than the tree's: bench.py will report profile_stale")
+
+
+def test_bench_drops_profile_counters_when_the_kernel_sources_changed(monkeypatch):
+    """bench.py's own staleness logic: with another source SHA the committed PMC figures must not appear in the line."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    k, stale = bench.load_profile("headline")
+    assert k and "FETCH_SIZE" in k and "SQ_INSTS_VALU" in k
+    fresh = bench.profile_entry("C2", 0.03)
+    assert fresh["source"].endswith("r03_c2_rocprofv3_summary.json") and ("traffic_bytes_per_launch" in fresh) == (not fresh["profile_stale"])
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "0" * 64)
+    assert bench.load_profile("headline")[1] is True
+    assert bench.traffic_from_profile("headline") == (None, None) and bench.issue_roofline(0.05, "headline") is None
+    e = bench.profile_entry("C4", 0.18)
+    assert e["profile_stale"] is True and "traffic_bytes_per_launch" not in e and "issue" not in e
