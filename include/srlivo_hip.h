@@ -295,8 +295,10 @@ int srl_comm_set_host_callbacks(srl_ctx *ctx, int nranks, int rank, srl_allreduc
  * rank over xGMI and adds the rows it received in rank order (the same bits on every rank).  A sharded pass then is still ONE
  * kernel; with the ordered cut (max_num_residuals can bind) the per-rank counts travel the same way, followed by the reduce
  * kernel and a one-wave exchange kernel.
- *   srl_peer_export : allocates the inbox; ipc_handle (SRL_PEER_HANDLE_BYTES, may be NULL) receives its HIP IPC handle for
- *                     peers in OTHER processes, *local_ptr (may be NULL) the device pointer for peers in the SAME process.
+ *   srl_peer_export : creates the inbox on first use and RESETS it (a new session: call it before every attachment, on every
+ *                     rank, before the handles are exchanged -- never while peers are attached); ipc_handle
+ *                     (SRL_PEER_HANDLE_BYTES, may be NULL) receives its HIP IPC handle for peers in OTHER processes,
+ *                     *local_ptr (may be NULL) the device pointer for peers in the SAME process.
  *   srl_peer_attach : ipc_handles = nranks x SRL_PEER_HANDLE_BYTES gathered from all ranks (how they travel is the caller's
  *                     business: torch.distributed.all_gather_object, MPI, a file) and / or local_ptrs[nranks] for same-process
  *                     peers (NULL entries fall back to the handle).  Sets the shard layout like srl_comm_init_rank: upload the

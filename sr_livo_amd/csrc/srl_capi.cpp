@@ -1388,12 +1388,15 @@ int srl_comm_destroy(srl_ctx *ctx) {
 int srl_peer_export(srl_ctx *ctx, void *ipc_handle, void **local_ptr) {
     if (!ctx) return SRL_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!ctx->d_inbox) {
-        // fine-grained: a peer's store is visible to this device's polling loads without cache maintenance
-        const size_t bytes = (size_t)SRL_PEER_INBOX_GRANULES * sizeof(unsigned long long);
+    if (ctx->peer_on) { ctx->err = "srl_peer_export: peers are attached (srl_peer_detach first)"; return SRL_ERR_BAD_ARG; }
+    const size_t bytes = (size_t)SRL_PEER_INBOX_GRANULES * sizeof(unsigned long long);
+    if (!ctx->d_inbox)       // fine-grained: a peer's store is visible to this device's polling loads without cache maintenance
         HIPCHK(ctx, hipExtMallocWithFlags((void **)&ctx->d_inbox, bytes, hipDeviceMallocFinegrained));
-        HIPCHK(ctx, hipMemset(ctx->d_inbox, 0, bytes));                      // tag 0 = "nothing here": exchange tags start at 1
-    }
+    // Every export starts a new session: tag 0 = "nothing here", exchange tags start at 1 again at srl_peer_attach.  The reset
+    // happens HERE -- before the handle leaves this rank, hence before any peer can store into the inbox -- never at attach
+    // time, when a faster peer may already have delivered the first row of the session.
+    if (ctx->stream) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemset(ctx->d_inbox, 0, bytes));
     if (ipc_handle) {
         static_assert(sizeof(hipIpcMemHandle_t) <= SRL_PEER_HANDLE_BYTES, "IPC handle does not fit");
         hipIpcMemHandle_t h;
@@ -1418,7 +1421,7 @@ int srl_peer_attach(srl_ctx *ctx, int nranks, int rank, const void *ipc_handles,
     if (!ctx || nranks < 1 || nranks > SRL_MAX_PEERS || rank < 0 || rank >= nranks || (nranks > 1 && !ipc_handles && !local_ptrs)) return SRL_ERR_BAD_ARG;
     if (ctx->comm || ctx->cb_ar) { ctx->err = "srl_peer_attach: another transport is attached (srl_comm_destroy first)"; return SRL_ERR_BAD_ARG; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    { const int rce = srl_peer_export(ctx, nullptr, nullptr); if (rce) return rce; }
+    if (!ctx->d_inbox) { ctx->err = "srl_peer_attach: srl_peer_export first (it creates and resets this rank's inbox)"; return SRL_ERR_BAD_ARG; }
     { const int rcd = srl_peer_detach(ctx); if (rcd) return rcd; }
     SrlPeerTable t;
     std::memset(&t, 0, sizeof t);

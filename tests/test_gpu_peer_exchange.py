@@ -120,6 +120,47 @@ def test_peer_exchange_many_passes_and_a_headline_sized_sweep():
         assert np.array_equal(np.array(neq.HtH), np.array(out[0][0].HtH))
 
 
+def test_a_second_session_does_not_see_the_rows_of_the_first(golden):
+    """Detach, export again (the export resets the inbox), attach again with the ranks SWAPPED and another sweep: exchange tags
+    start at 1 again, so a stale row of the first session would be taken for a fresh one if the reset were missing."""
+    ctxs = [srl.Context(0) for _ in range(2)]
+    f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    try:
+        for c in ctxs:
+            c.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        results = []
+        for session, (raw, order) in enumerate(((golden["raw"], (0, 1)), (golden["raw"][: len(golden["raw"]) // 2], (1, 0)))):
+            ptrs = [c.peer_export()[1] for c in ctxs]                      # every rank exports (= resets) before anybody attaches
+            out = [None, None]
+
+            def worker(i):
+                rank = order[i]
+                c = ctxs[i]
+                c.peer_attach(2, rank, local_ptrs=[ptrs[order.index(0)], ptrs[order.index(1)]])
+                c.sweep_upload(raw)
+                for _ in range(3 + session):
+                    out[i] = c.build_residuals(f, opts)[0]
+
+            ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            ref = _single(golden, raw, INT_MAX)
+            for i in range(2):
+                assert out[i] is not None and out[i].num_residuals == ref.num_residuals
+                assert rel(np.array(out[i].HtH), np.array(ref.HtH)) < 1e-12
+            assert np.array_equal(np.array(out[0].HtH), np.array(out[1].HtH))
+            results.append(np.array(out[0].HtH))
+            with pytest.raises(srl.SrlError):
+                ctxs[0].peer_export()                                      # not while peers are attached
+            for c in ctxs:
+                c.peer_detach()
+        assert not np.array_equal(results[0], results[1])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_a_missing_peer_is_an_error_not_a_hang(golden):
     """Rank 1 of 2 never calls: rank 0's exchange gives up after its bounded spin and srl_build_residuals returns SRL_ERR_COMM."""
     out, errors = _peer_threads(golden, golden["raw"], 2, INT_MAX, passes=1, skip_rank=1)
