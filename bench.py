@@ -322,6 +322,116 @@ class c_stdout_to_stderr:
         return False
 
 
+LINE_LIMIT_BYTES = 8000     # the driver keeps an 8 KB tail of stdout: the ONE line it parses must fit with room to spare
+DETAIL_PATH = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+
+
+def _num(x, sig=6):
+    """floats to `sig` significant digits (the line is read by a parser and by people: 17 digits help neither); NaN / inf -> None
+    (strict JSON has neither)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, np.integer):
+        return int(x)
+    if isinstance(x, dict):
+        return {k: _num(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out):
+    """The ONE stdout line of the bench contract, from the full result dictionary: contract keys, config.workload, a compact roofline
+    and cpu_baseline, parity, the PCIe-inclusive rates and one short tuple per BASELINE configuration.  Everything else (per-config
+    profile blocks, A/B legs, notes) goes to gpurun_out/bench_detail.json (`detail`).  Strict JSON, < LINE_LIMIT_BYTES."""
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data")}
+    cfg = out.get("config", {})
+    line["config"] = _pick(cfg, ("workload", "parallelism", "esikf_iterations_per_solve", "residuals_used", "kernel_launches_per_solve", "launch_mode"))
+    line["ms_per_esikf_iter"] = out.get("ms_per_esikf_iter")
+    r = out.get("roofline") or {}
+    roof = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    roof.update(_pick(r, ("kernel", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch", "compulsory_bytes_per_launch",
+                          "hbm_measured_GBs", "traffic_source", "profile_stale", "launch_duration_includes")))
+    if isinstance(r.get("issue"), dict):
+        roof["issue"] = _pick(r["issue"], ("bound", "frac", "floor_us", "valu_floor_us", "salu_floor_us", "lds_floor_us"))
+    for k in ("association_only", "unarmed"):
+        if isinstance(r.get(k), dict):
+            roof[k] = _pick(r[k], ("avg_launch_ms", "frac", "launches"))
+    line["roofline"] = roof
+    for k in ("cpu_baseline", "cpu_baseline_port", "cpu_baseline_all_cores"):
+        c = out.get(k)
+        if isinstance(c, dict):
+            e = _pick(c, ("value", "unit", "cores", "kind", "ms_per_solve"))
+            if k == "cpu_baseline" and "sample" in c:
+                e["sample"] = str(c["sample"])[:160]
+            line[k] = e
+    if isinstance(out.get("parity"), dict):
+        line["parity"] = out["parity"]
+    pc = cfg.get("pcie_inclusive_sweeps_per_s") or {}
+    line["pcie_inclusive_sweeps_per_s"] = {"pipelined_prefetch": pc.get("pipelined_prefetch"), "pinned": pc.get("pinned_upload_then_solve"),
+                                           "pageable": pc.get("pageable_upload_then_solve")}
+    for k in ("launch_ab", "pipeline", "comm", "aux_independent_sweeps_per_s", "multi_gpu_note", "fallback"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    cfgs = []
+    for c in out.get("configs") or []:
+        if "error" in c:
+            cfgs.append({"name": c.get("name"), "error": str(c["error"])[:120]})
+            continue
+        cfgs.append({"name": c["name"], "us_per_iter": c["ms_per_esikf_iter"] * 1e3, "kernel_us": c.get("kernel_us", c.get("assoc_kernel_us")), "frac": c.get("hbm_roofline_frac"),
+                     "sweeps_per_s": c["sweeps_per_s"], "iters": c["esikf_iterations"],
+                     "parity_ok": (c.get("parity") or {}).get("ok")})
+    if cfgs:
+        line["configs"] = cfgs
+    line["detail"] = os.path.relpath(DETAIL_PATH, ROOT)
+    line = _num(line)
+    # value and ms_per_step keep their full precision: the driver cross-checks one against the other
+    line["value"], line["ms_per_step"] = out.get("value"), out.get("ms_per_step")
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) > LINE_LIMIT_BYTES:      # never print a line the driver cannot parse: shed the optional blocks, largest first
+        for k in ("pipeline", "launch_ab", "configs", "cpu_baseline_all_cores", "cpu_baseline_port", "comm"):
+            line.pop(k, None)
+            text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT_BYTES:
+                break
+    return text
+
+
+def write_detail(out):
+    try:
+        os.makedirs(os.path.dirname(DETAIL_PATH), exist_ok=True)
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(_num(out, 9), f, indent=1)
+    except OSError as e:
+        print(f"bench.py: could not write {DETAIL_PATH}: {e}", file=sys.stderr)
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher around it: re-run this command line as N ranks under torch.distributed.run
+    (one process per GPU, rendezvous over loopback) and pass rank 0's line through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,9 +465,10 @@ def main():
         # test hook (1-GPU boxes): every rank on device 0 -- lets `--transport peer` run its N > 1 path end to end (the inboxes travel
         # as HIP IPC handles exactly as between GPUs); RCCL refuses two ranks on one device.  Never a performance figure.
         local_rank = 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))           # `python bench.py --gpus N`: this process becomes the launcher of N ranks
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -775,7 +886,8 @@ def main():
                 cfgs.append({"name": name, "error": repr(e)})
         out["configs"] = cfgs
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        write_detail(out)
+        print(compact_line(out), flush=True)
     if dist is not None:
         with c_stdout_to_stderr():
             dist.destroy_process_group()

@@ -289,12 +289,16 @@ def test_bench_two_ranks_with_the_peer_transport_on_one_device(tmp_path):
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SRL_BENCH_ALL_ON_DEVICE0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29531",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--transport", "peer"]
+    # launched the way the driver does it: `python bench.py --gpus 2`, no torch.distributed.run around it -- bench.py becomes the
+    # launcher of its own ranks (WORLD_SIZE must not leak in from the test environment)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--transport", "peer"]
     p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in p.stdout.decode().split("\n") if l.strip()]
     assert len(lines) == 1, lines                                          # ONE JSON line on stdout (rank 0 only, no library chatter)
+    assert len(lines[0]) < 8000                                            # the driver keeps an 8 KB tail of stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "strong" and d["unit"] == "sweeps/s"
     assert d["config"]["residuals_used"] == 65536 and "direct peer exchange" in d["config"]["parallelism"]
