@@ -238,6 +238,17 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         launches_persistent = lio.last_solve_launches()
         lio.set_persistent_solve(False)
         solve()
+        # A/B: one launch per ESIKF iteration (armed launches off: round 3's form)
+        lio.ctx.set_armed_launch(False)
+        solve(); solve()
+        torch.cuda.synchronize()
+        t_un = time.perf_counter()
+        for _ in range(steps):
+            solve()
+        torch.cuda.synchronize()
+        el_un = time.perf_counter() - t_un
+        lio.ctx.set_armed_launch(True)
+        solve()
         # the association work alone (final reduction in its own kernel, launch shape chosen for the kernel's own time)
         lio.ctx.set_fused_reduce(0)
         solve()
@@ -254,6 +265,7 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
                "steps": steps, "ms_per_solve_median": float(np.median(per)) * 1e3, "ms_per_solve_max": float(per.max()) * 1e3,
                "residuals_used": nr, "kernel_launches_per_solve": launches_per_solve,
                "persistent_solve_ab": {"ms_per_esikf_iter": el_ab / steps * 1e3 / max(it, 1), "launches_per_solve": launches_persistent},
+               "launch_per_iteration_ab": {"ms_per_esikf_iter": el_un / steps * 1e3 / max(it, 1), "what": "armed launches off (srl_set_armed_launch(0))"},
                "kernel_us": assoc_ms * 1e3, "passes_per_launch": passes_per_launch, "kernel_us_per_pass": assoc_ms * 1e3 / passes_per_launch,
                "assoc_kernel_us": assoc_ms * 1e3 / passes_per_launch, "assoc_launches": tim.calls,
                "keypoints_per_launch": tim.sum_keypoints / calls, "algorithmic_MB_per_launch": bytes_per_launch / 1e6,
@@ -451,6 +463,8 @@ def main():
                     help="only the timed configuration runs on the GPU (profiling: no association-only / PCIe legs in the trace)")
     ap.add_argument("--persistent-solve", action="store_true",
                     help="A/B, profiling: the timed region runs the opt-in one-launch-per-solve kernel (srl_solve_iekf) instead of one launch per ESIKF iteration")
+    ap.add_argument("--no-armed", action="store_true",
+                    help="A/B, profiling: armed launches off -- every ESIKF iteration pays its launch call, dispatch and ramp (round 3's form)")
     ap.add_argument("--transport", choices=("rccl", "peer"), default="rccl",
                     help="sharded mode: how the 50-double rows of the ranks are summed.  rccl: ncclAllReduce on the library's own communicator; "
                          "peer: direct stores into the peers' inboxes over xGMI (srl_peer_attach, HIP IPC handles exchanged over gloo)")
@@ -528,6 +542,8 @@ def main():
     _solve = lio.bound_solver(opts, prior_state, prior_cov, state0, sweep["t_last"], args.frame_id, n_kp)
     if args.persistent_solve:
         lio.set_persistent_solve(True)
+    if args.no_armed:
+        lio.ctx.set_armed_launch(False)
 
     def solve():
         rc, it, nr = _solve()
@@ -571,6 +587,28 @@ def main():
     # one wave of the finishing workgroup and the pose hand-overs inside one launch) -- opt-in, because on MI355X it is the
     # slower form; the timed region above runs the default: one launch + host update per ESIKF iteration
     launches_per_solve = launches_timed
+    # A/B: the same solves with one launch call per ESIKF iteration on the critical path (armed launches off: round 3's form), with the
+    # kernel's HIP-event duration in that form (an armed launch's event pair also brackets its wait for the host's pose)
+    launch_ab, tim_unarmed = None, None
+    arm_stats = lio.ctx.arm_stats()
+    if world == 1 and not args.no_aux_legs and not args.persistent_solve and not args.no_armed:
+        lio.ctx.set_armed_launch(False)
+        for _ in range(3):
+            solve()
+        lio.ctx.set_profiling(2)
+        torch.cuda.synchronize()
+        t_un = time.perf_counter()
+        for _ in range(args.steps):
+            r_un = solve()
+        torch.cuda.synchronize()
+        el_un = time.perf_counter() - t_un
+        tim_unarmed = lio.ctx.timing()
+        lio.ctx.set_profiling(0)
+        lio.ctx.set_armed_launch(True)
+        launch_ab = {"armed_us_per_iter": elapsed / args.steps * 1e6 / max(r["iters"], 1),
+                     "launch_per_iteration_us_per_iter": el_un / args.steps * 1e6 / max(r_un["iters"], 1),
+                     "state_bitwise_equal": bool(np.array_equal(r_un["state"], r["state"]))}
+        solve()
     persistent_ab = None
     if world == 1 and not args.no_aux_legs and not args.persistent_solve:
         lio.set_persistent_solve(True)
@@ -718,6 +756,14 @@ def main():
             "note": "achieved = ALGORITHMIC bytes (24 + 12 (2r+1)^3 + 12 P_k per keypoint, SURVEY 8(d)) / launch time: the rate at which the "
                     "reference's byte stream is consumed.  The working set is L2/MALL resident, so real HBM traffic (`traffic`, "
                     "`hbm_measured_GBs`) is far below it and the kernel is bound by instruction issue: see `issue`."}
+    armed_used = (lio.ctx.arm_stats()["fired"] > 0) and not args.no_armed
+    if armed_used:
+        roof["launch_duration_includes"] = "the armed launch's wait for the host's pose (its event pair opens when the pass before it ends)"
+    if tim_unarmed is not None and tim_unarmed.calls > 0:
+        ms_n = tim_unarmed.sum_assoc_ms / tim_unarmed.calls
+        roof["unarmed"] = {"avg_launch_ms": ms_n, "launches": tim_unarmed.calls,
+                           "frac": (tim_unarmed.sum_algorithmic_bytes / tim_unarmed.calls) / (ms_n * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_n > 0 else None,
+                           "what": "the same kernel launched per iteration (armed launches off): duration without any wait inside"}
     if tim_unfused is not None and tim_unfused.calls > 0:
         ms_u = tim_unfused.sum_assoc_ms / tim_unfused.calls
         roof["association_only"] = {"avg_launch_ms": ms_u, "launches": tim_unfused.calls,
@@ -755,12 +801,15 @@ def main():
                                   else ("replicas x%d" % world if world > 1 else "single GPU"),
                    "esikf_iterations_per_solve": iters, "residuals_used": r["num_residuals"],
                    "kernel_launches_per_solve": launches_per_solve,
+                   "launch_mode": "one launch per ESIKF iteration" if args.no_armed else "armed launches: the kernel of pass k+1 is enqueued while pass k runs and receives its pose through the pose box",
                    "value_is": "the HBM-resident rate (sweep uploaded before the timed region); SURVEY 8(d)'s metric includes the H2D of the sweep:",
                    "pcie_inclusive_sweeps_per_s": {"pipelined_prefetch": rates["pipelined"], "pinned_upload_then_solve": rates["pinned"],
                                                    "pageable_upload_then_solve": rates["pageable"]}},
         "ms_per_esikf_iter": ms_per_step / max(iters, 1),
         "roofline": roof,
         "persistent_solve_ab": persistent_ab,
+        "launch_ab": launch_ab,
+        "arm_stats_timed_region": arm_stats,
         "sharded_path_one_rank": comm_1rank,
         "host_us_per_iter": {"enqueue": tim_full.sum_host_launch_us / fcalls, "wait_results": tim_full.sum_host_wait_us / fcalls,
                              "build_residuals_call": tim_full.sum_host_total_us / fcalls,

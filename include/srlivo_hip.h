@@ -195,6 +195,22 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts
 typedef void (*srl_overlap_fn)(void *user);
 int srl_build_residuals_overlap(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts *opts, srl_normal_eq *out,
                                 srl_overlap_fn fn, void *user);
+/* ARMED LAUNCHES.  The loop of updateIEKF (src/optimize.cpp:147-312) alternates kernel and host: buildPlaneResiduals' normal
+ * equations (:153,:235,:239) -> 17-dim update (:172-261) -> next pose -> buildPlaneResiduals.  With armed launches on (the
+ * default) every srl_build_residuals call on an unsharded context, besides running its own pass, enqueues the kernel of the NEXT
+ * pass while the current one is in flight -- same sweep, map and options; the pose, which does not exist yet, arrives later
+ * through a small host-written "pose box" the waiting workgroups poll.  The next call, if its arguments are those of the armed
+ * launch (the pose may differ: that is the point), only writes the pose: the launch call, the dispatch and the ramp of the kernel
+ * are off the per-iteration critical path.  Any other call on the context, or a pass with other arguments, cancels the armed
+ * launch first (one 384-byte write; the waiting kernel exits), so nothing observable changes: same kernels, same arithmetic,
+ * same results.  An armed launch that is neither fired nor cancelled leaves by itself (kernel-side bound: 20 ms), and a call
+ * arriving more than 1 ms after arming cancels instead of firing.
+ *   srl_set_armed_launch(ctx, 0 | 1)   turn the mechanism off / on (default on)
+ *   srl_disarm(ctx)                    cancel an armed launch now (optional: e.g. before the thread goes idle)
+ *   srl_get_arm_stats                  counters {armed, fired, cancelled, expired} since context creation */
+int srl_set_armed_launch(srl_ctx *ctx, int mode);
+int srl_disarm(srl_ctx *ctx);
+int srl_get_arm_stats(srl_ctx *ctx, uint64_t out[4]);
 
 /* ------------------------------------------------------------------ one launch per solve
  * replaces: the whole loop of lioOptimization::updateIEKF (optimize.cpp:133-314) on the sweep resident in HBM -- every
@@ -365,6 +381,14 @@ int srl_debug_set_ablate(srl_ctx *ctx, int bits);
  * prefix pass of the shipped 600).  A finisher that gives up waiting for a row (bounded spin) makes srl_build_residuals repeat
  * the pass once with the separate reduce kernel instead of failing. */
 int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable);
+/* Where the pose box of the armed launches lives.  kind 0 (default): page-locked host memory -- workgroup 0 of the waiting kernel polls
+ * it across PCIe and republishes the pose into device memory for the other workgroups.  kind 1: fine-grained DEVICE memory the host
+ * writes through the PCIe BAR (every workgroup polls it locally); SRL_ERR_UNSUPPORTED when device memory is not CPU-visible on this
+ * system.
+ * srl_debug_set_arm_linger: the age (us) beyond which a call cancels an armed launch instead of firing it (default 1000), and the
+ * kernel-side bound (us, default 20000) after which a waiting launch leaves by itself -- tests drive both paths with it. */
+int srl_debug_set_pose_box(srl_ctx *ctx, int kind);
+int srl_debug_set_arm_linger(srl_ctx *ctx, double host_linger_us, double kernel_linger_us);
 /* tuning experiments: force the association kernel's launch shape -- keypoints per wave (16-wave workgroups: 2 / 3 / 4 / 6 / 8 /
  * 12 / 16; 4-wave workgroups: 4 / 8 / 16) and waves per workgroup (4 / 16); 0, 0 = automatic (by sweep size).  Results do not
  * depend on the shape beyond FP64 summation order. */

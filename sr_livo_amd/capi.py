@@ -165,6 +165,11 @@ def load_library():
         "srl_debug_block_times": ([p, p, C.c_int, C.POINTER(C.c_int)], C.c_int),
         "srl_debug_set_ablate": ([p, C.c_int], C.c_int),
         "srl_debug_set_fused_reduce": ([p, C.c_int], C.c_int),
+        "srl_debug_set_pose_box": ([p, C.c_int], C.c_int),
+        "srl_debug_set_arm_linger": ([p, C.c_double, C.c_double], C.c_int),
+        "srl_set_armed_launch": ([p, C.c_int], C.c_int),
+        "srl_disarm": ([p], C.c_int),
+        "srl_get_arm_stats": ([p, C.POINTER(C.c_uint64)], C.c_int),
         "srl_debug_set_launch_shape": ([p, C.c_int, C.c_int], C.c_int),
         "srl_debug_set_search_select_mode": ([p, C.c_int], C.c_int),
         "srl_debug_heap_topk": ([p, C.c_int, C.c_int, p], C.c_int),
@@ -530,6 +535,25 @@ class Context:
 
     def set_search_select_mode(self, mode):
         self._chk(self.lib.srl_debug_set_search_select_mode(self.h, int(mode)), "srl_debug_set_search_select_mode")
+
+    def set_armed_launch(self, on):
+        """armed launches (the next pass's kernel enqueued while the current one runs): on by default"""
+        self._chk(self.lib.srl_set_armed_launch(self.h, 1 if on else 0), "srl_set_armed_launch")
+
+    def disarm(self):
+        self._chk(self.lib.srl_disarm(self.h), "srl_disarm")
+
+    def arm_stats(self):
+        out = (C.c_uint64 * 4)()
+        self._chk(self.lib.srl_get_arm_stats(self.h, out), "srl_get_arm_stats")
+        return dict(zip(("armed", "fired", "cancelled", "expired"), (int(v) for v in out)))
+
+    def set_pose_box(self, kind):
+        """0: pinned host memory + device relay; 1: fine-grained device memory written through the BAR (raises if not CPU-visible)"""
+        self._chk(self.lib.srl_debug_set_pose_box(self.h, int(kind)), "srl_debug_set_pose_box")
+
+    def set_arm_linger(self, host_linger_us=1000.0, kernel_linger_us=20000.0):
+        self._chk(self.lib.srl_debug_set_arm_linger(self.h, float(host_linger_us), float(kernel_linger_us)), "srl_debug_set_arm_linger")
 
     def device_sqrt(self, x):
         x = _f64(x).ravel()

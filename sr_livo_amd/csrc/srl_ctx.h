@@ -97,6 +97,24 @@ struct srl_ctx {
     bool solve_lds_opted = false;
     unsigned long long seq = 0;
 
+    // ARMED launches (srl_capi.cpp: arm_next / pose_box_write / srl_ctx_disarm): the kernel of the NEXT pass is enqueued while the
+    // current one runs and waits, resident, for its pose
+    int arm_mode = 1;                           // srl_set_armed_launch: 0 off, 1 on
+    int pose_box_kind = 0;                      // 0: pinned host memory, workgroup 0 relays into device memory; 1: fine-grained device memory the host writes through the PCIe BAR
+    unsigned long long *h_pose_box = nullptr;   // where the HOST writes the pose granules (kind 1: the CPU-visible device pointer)
+    unsigned long long *pose_box_pinned = nullptr;   // kind 0 allocation (hipHostMalloc)
+    unsigned long long *pose_box_dev = nullptr;      // kind 1 allocation (hipExtMallocWithFlags, fine-grained)
+    unsigned long long *d_pose_relay = nullptr;
+    bool armed = false;
+    SrlAssocArgs armed_sig;                     // the armed launch's arguments with the pose zeroed: a pass must equal them to fire it
+    int armed_nb = 0, armed_kpw = 0;
+    int armed_ring = -1;                        // light profiling: ring slot of the armed launch's event pair (-1: none)
+    long long armed_at_ns = 0;                  // steady clock at arm time
+    double arm_host_linger_us = 1000.0;         // an armed launch older than this is cancelled, never fired (the kernel's own bound is far longer)
+    unsigned arm_linger_ticks = 2000000u;       // 20 ms of the 100 MHz clock: the kernel-side safety net
+    unsigned long long arm_stats[4] = {0, 0, 0, 0};   // armed, fired, cancelled, expired
+    bool ring_void[512] = {};                   // light profiling: event pairs of cancelled armed launches (not counted)
+
     // taps
     bool taps = false;
     int tap_cap = 0, tap_K = 0;
@@ -134,7 +152,7 @@ struct srl_ctx {
 
     int last_nblocks = 0;
     int profiling = 0;                 // 0 off, 1 full (4 events + sync per call), 2 light (assoc kernel only, read lazily)
-    static constexpr int PROF_RING = 512;
+    static constexpr int PROF_RING = 512;       // (= sizeof ring_void)
     hipEvent_t ring[PROF_RING][2] = {};
     unsigned ring_head = 0, ring_tail = 0;   // [tail, head) recorded and not yet read
 
@@ -165,6 +183,11 @@ struct srl_ctx {
             return SRL_ERR_COMM;                                                               \
         }                                                                                      \
     } while (0)
+
+// cancel an armed launch, if any (every entry point that touches the stream or waits for it calls this first: an armed launch
+// that nobody fires would hold the stream until its bound)
+extern "C" int srl_ctx_disarm(srl_ctx *ctx);
+#define SRL_DISARM(ctx) do { if ((ctx)->armed) { int rcd__ = srl_ctx_disarm(ctx); if (rcd__) return rcd__; } } while (0)
 
 inline int ensure_host_scratch(srl_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->h_scratch_bytes) return SRL_OK;

@@ -84,6 +84,15 @@ struct SrlMailbox {            // host-mapped (fine-grained) memory the reduce k
     unsigned long long pad[7];
 };
 
+// ---- armed launches: the pose box
+#define SRL_POSE_BOX_CTRL 42       // granule index of the control word {epoch, code}; granules 2d, 2d + 1 = halves of pose double d (Rn R t)
+#define SRL_POSE_BOX_USED 43       // granules a launch waits for
+#define SRL_POSE_BOX_GRANULES 64   // allocated (the host writes whole 64-byte lines: 48 granules)
+#define SRL_ARM_GO 1u
+#define SRL_ARM_CANCEL 2u
+#define SRL_ARM_EXPIRED 3u
+#define SRL_ARM_EXPIRED_MARK 0xA53Dll   // SrlDevOut::pad: an armed launch gave up waiting before it was fired
+
 #define SRL_REDUCED_DOUBLES 50 // leading doubles of SrlDevOut that are summed over the shards (HtH .. d_timeout)
 
 // ---- direct peer exchange of the sharded sum (srl_peer_attach): no RCCL call on the data path ---------------------------
@@ -137,6 +146,11 @@ struct SrlAssocArgs {
     long long cut_max;              // fused ordered cut: max_num_residuals (> 0), the sequential loop's budget (optimize.cpp:107); 0 = no cut possible
     SrlMailbox *mailbox;        // host-mapped result mailbox (fused + RCCL: a device-side mailbox the all-reduce then works on)
     unsigned long long seq;     // launch sequence number published with the result
+    // ARMED launch (enqueued before its pose exists; null = the pose is Rn / R / t above): see assoc_body's prologue
+    const unsigned long long *pose_box;   // tagged granules the host writes: 2 x 21 pose halves + the control granule
+    unsigned long long *pose_relay;       // device memory workgroup 0 republishes the box into for the others (null: everybody polls the box)
+    unsigned pose_epoch;                  // tag of THIS launch's pose (low 32 bits of its sequence number, never 0)
+    unsigned arm_linger_ticks;            // 100 MHz ticks an armed launch waits at most (safety net)
     const SrlPeerTable *peer;   // fused + direct peer exchange: the finishing workgroup exchanges its totals itself (else null)
     unsigned peer_epoch;        // tag of this exchange (exchange counter, never 0)
     int peer_slot;              // exchange counter & 1

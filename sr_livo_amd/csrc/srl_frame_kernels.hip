@@ -257,6 +257,7 @@ int srl_frame_undistort(srl_ctx *ctx, const double *raw_xyz, const double *relat
                         const double R_il[9], const double t_il[3], double *imu_point_out, double *raw_out) {
     if (!ctx || n < 0 || (n > 0 && (!raw_xyz || !relative_time_ms)) || !imu_states || n_states < 1 || !R_il || !t_il)
         return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
     if (motion_compensation != SRL_MC_IMU && motion_compensation != SRL_MC_CONSTANT_VELOCITY && motion_compensation != SRL_MC_NONE)
         return SRL_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -332,6 +333,7 @@ int srl_frame_undistort(srl_ctx *ctx, const double *raw_xyz, const double *relat
 
 int srl_frame_take(srl_ctx *ctx, const int32_t *index, int m) {
     if (!ctx || m < 0 || (m > 0 && !index)) return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
     if (ctx->corr_n < 0) { ctx->err = "no undistorted sweep (srl_frame_undistort first)"; return SRL_ERR_NO_SWEEP; }
     for (int k = 0; k < m; k++)
         if (index[k] < 0 || index[k] >= ctx->corr_n) { ctx->err = "frame index out of range"; return SRL_ERR_BAD_ARG; }
@@ -352,6 +354,7 @@ int srl_frame_take(srl_ctx *ctx, const int32_t *index, int m) {
 
 int srl_frame_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     if (!ctx || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc0 = ensure_frame(ctx, n);
     if (rc0) return rc0;
@@ -372,6 +375,7 @@ int srl_frame_size(srl_ctx *ctx, int *n) {
 int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3], const double R_il[9], const double t_il[3],
                                double sample_voxel_size, int32_t *keypoint_index, int *num_keypoints) {
     if (!ctx || !q || !t || !R_il || !t_il || !(sample_voxel_size > 0.0)) return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
     if (ctx->frame_n < 0 || !ctx->d_frame_raw) { ctx->err = "no frame uploaded"; return SRL_ERR_NO_SWEEP; }
     if (ctx->nranks > 1) { ctx->err = "frame pipeline is single-rank (shard with srl_sweep_upload instead)"; return SRL_ERR_UNSUPPORTED; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -489,6 +493,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
 int srl_frame_commit(srl_ctx *ctx, const double q[4], const double t[3], const double R_il[9], const double t_il[3],
                      double voxel_size, int cap, double min_distance_points, int min_num_points, double *world_out, int *num_added) {
     if (!ctx || !q || !t || !R_il || !t_il) return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
     if (cap != SRL_VOXEL_CAP) { ctx->err = "max_num_points_in_voxel must be 20"; return SRL_ERR_UNSUPPORTED; }
     if (ctx->frame_n < 0 || !ctx->d_frame_raw) { ctx->err = "no frame uploaded"; return SRL_ERR_NO_SWEEP; }
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -1010,7 +1010,10 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, i
     L.off_wpart = o;   o += wpb * 32 * 8;
     L.off_winfo = o;   o += wpb * 8 * 4;
     L.off_pose = L.off_out = L.off_iekf = L.off_rowacc = o;
-    if (persist) {
+    if (persist == 2) {
+        // armed launch: the pose of this pass arrives through the pose box (Rn[9] R[9] t[3]) + the control word
+        L.off_pose = o;   o += up16((SRL_POSE_DOUBLES + 2) * 8);
+    } else if (persist) {
         // the pose of the running pass (+ verdict), the finishing workgroup's normal equations and its filter / matrices
         L.off_pose = o;   o += up16(SRL_POSE_DOUBLES * 8);
         L.off_out = o;    o += up16((int)sizeof(SrlDevOut));
@@ -1075,7 +1078,7 @@ __host__ __device__ constexpr int p2_keypoints_per_wave(int kpb) { return 64 / p
 // DBG = 1: the instantiation the profiling tools run (srl_debug_set_ablate: parts of the kernel switched off at run time, workgroup
 // time stamps).  The production instantiations carry none of those tests: read in the pair loop they cost ~10 lane reads of
 // spilled flags per keypoint pair (headline launch 49.4 -> 48.4 us together with the probe reordering below).
-template <int NB, int FAST, int KPW, int WPB, int PERSIST, int DBG = 0>
+template <int NB, int FAST, int KPW, int WPB, int PERSIST, int DBG = 0, int ARMED = 0>
 __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A, const int tile, const bool do_prior, const int iter) {
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1086,7 +1089,8 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     constexpr int KC = PERSIST ? SRL_SOLVE_K : 0;
     const int Kn = KC ? KC : A.K;
     const int abl = (DBG && !PERSIST) ? A.ablate : 0;
-    const LdsLayout L = lds_layout(Kn, NB, KPW, WPB, PERSIST);
+    constexpr bool POSE_LDS = PERSIST || ARMED;                           // the pose of this pass sits in LDS, not in the kernarg
+    const LdsLayout L = lds_layout(Kn, NB, KPW, WPB, PERSIST ? 1 : (ARMED ? 2 : 0));
     const int NB_ROW = L.nb_row;
     const int tid = threadIdx.x;
     const int lane = lane_id();
@@ -1143,7 +1147,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         if (g < A.n) {
             const D3 raw = d3(A.raw_x[g], A.raw_y[g], A.raw_z[g]);
             p_imu = add(matvec(A.R_il, raw), d3(A.t_il[0], A.t_il[1], A.t_il[2]));
-            if constexpr (PERSIST) p_w = add(matvec(s_pose, p_imu), d3(s_pose[18], s_pose[19], s_pose[20]));
+            if constexpr (POSE_LDS) p_w = add(matvec(s_pose, p_imu), d3(s_pose[18], s_pose[19], s_pose[20]));
             else p_w = add(matvec(A.Rn, p_imu), d3(A.t[0], A.t[1], A.t[2]));
         }
         s_pw[kq * 3 + 0] = p_w.x; s_pw[kq * 3 + 1] = p_w.y; s_pw[kq * 3 + 2] = p_w.z;
@@ -1410,9 +1414,9 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         // the residual uses the un-normalised rotation (optimize.cpp:95,101); persistent solve: the pose block of this pass
         double Rm[9], tv[3];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Rm[i] = PERSIST ? s_pose[9 + i] : b.R[i];
+        for (int i = 0; i < 9; ++i) Rm[i] = POSE_LDS ? s_pose[9 + i] : b.R[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) tv[i] = PERSIST ? s_pose[18 + i] : b.t[i];
+        for (int i = 0; i < 3; ++i) tv[i] = POSE_LDS ? s_pose[18 + i] : b.t[i];
         const D3 pe = add(matvec(Rm, p_imu), d3(tv[0], tv[1], tv[2]));
         dist = dot3(nv, pe) + off;                                 // optimize.cpp:95
         status = 1;
@@ -2004,7 +2008,7 @@ __device__ __attribute__((noinline)) void assoc_tile_call(KargBytes karg, const 
 #endif
 }
 
-template <int NB, int FAST, int KPW, int WPB, int PERSIST, int DBG = 0>
+template <int NB, int FAST, int KPW, int WPB, int PERSIST, int DBG = 0, int ARMED = 0>
 __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2026,8 +2030,68 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
             return lds_layout(SRL_SOLVE_K, NB, KPW, WPB, PERSIST);
         }
 #endif
-        return lds_layout(a.K, NB, KPW, WPB, PERSIST);
+        return lds_layout(a.K, NB, KPW, WPB, ARMED ? 2 : 0);
     };
+    if constexpr (ARMED && !PERSIST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // ---- ARMED launch (srl_capi.cpp: arm_next): this kernel was enqueued while the pass before it was still running, before
+        // its pose existed; its workgroups are resident and waiting when the host has finished the 17-dim update, so the launch call,
+        // the dispatch and the ramp of this pass are off the per-iteration critical path.  The pose (Rn[9] R[9] t[3], the only
+        // arguments that differ from the pass before) arrives through the POSE BOX: 8-byte granules {epoch, 32-bit half} the host
+        // writes ("the data is the flag": no ordering between the stores is needed) + one control granule {epoch, GO | CANCEL}.
+        // Wave 0 of every workgroup polls: the box itself, or -- when a relay is given (box in host memory: 256 pollers across PCIe
+        // would be 256 round trips per poll) -- workgroup 0 polls the box and republishes into device memory for the others.
+        // A tag NEWER than this launch's epoch means the host has moved on: cancelled.  The wait is bounded (arm_linger_ticks of
+        // the 100 MHz clock; the host never fires a launch that old, so the bound is a safety net, not a protocol step).
+        typedef __attribute__((address_space(1))) unsigned long long gu64a;
+        const LdsLayout L = carve();
+        double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);
+        int *s_ctrl = reinterpret_cast<int *>(s_pose + SRL_POSE_DOUBLES);
+        if (tid < 64) {
+            const int lane = tid;
+            const unsigned epoch = a.pose_epoch;
+            const bool relayed = a.pose_relay != nullptr;
+            const bool leader = !relayed || blockIdx.x == 0;
+            const bool act = lane < SRL_POSE_BOX_USED;
+            const unsigned long long *src = (leader ? a.pose_box : (const unsigned long long *)a.pose_relay) + (act ? lane : 0);
+            const long long t0 = (long long)wall_clock64();
+            const long long limit = leader ? (long long)a.arm_linger_ticks : 2 * (long long)a.arm_linger_ticks + 100000;
+            unsigned long long x = 0ull;
+            unsigned code = 0u;
+            for (;;) {
+                x = leader ? __hip_atomic_load((gu64a *)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                           : __hip_atomic_load((gu64a *)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned tag = (unsigned)(x >> 32);
+                if (__ballot(act && tag != epoch) == 0ull) { code = (unsigned)__shfl((unsigned)x, SRL_POSE_BOX_CTRL); break; }
+                if (__ballot(act && (int)(tag - epoch) > 0) != 0ull) { code = SRL_ARM_CANCEL; break; }
+                if ((long long)wall_clock64() - t0 > limit) { code = SRL_ARM_EXPIRED; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (relayed && leader && act) {
+                // the verdict of the poll for the other workgroups: the pose as it arrived, or a control granule that ends them
+                unsigned long long y = x;
+                if (code != SRL_ARM_GO) y = ((unsigned long long)epoch << 32) | (lane == SRL_POSE_BOX_CTRL ? code : 0u);
+                __hip_atomic_store((gu64a *)(a.pose_relay + lane), y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const unsigned hi = (unsigned)__shfl_down((unsigned)x, 1);
+            if (lane < 2 * (SRL_POSE_DOUBLES - 1) && !(lane & 1)) s_pose[lane >> 1] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned)x));
+            if (lane == 0) *s_ctrl = (int)code;
+        }
+        __syncthreads();
+        {
+            const int code = *s_ctrl;
+            if (code != (int)SRL_ARM_GO) {
+                if (code == (int)SRL_ARM_EXPIRED && blockIdx.x == gridDim.x - 1 && tid == 0) {
+                    // nobody is listening any more: a host that fires this launch after all learns it from the mailbox and relaunches
+                    __hip_atomic_store(&a.mailbox->out.pad, (long long)SRL_ARM_EXPIRED_MARK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&a.mailbox->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                return;
+            }
+        }
+#endif
+    }
     if constexpr (PERSIST) {
 #if defined(__HIP_DEVICE_COMPILE__)
         // ---- persistent solve: pose block of the first pass, the finishing workgroup's filter
@@ -2060,7 +2124,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         assoc_tile_call<NB, KPW>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), tile, blockIdx.x == gridDim.x - 1 && tile == (int)blockIdx.x, iter);
 #endif
     } else {
-        if (assoc_tile<NB, FAST, KPW, WPB, 0, DBG>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), a, tile, false, 0)) return;
+        if (assoc_tile<NB, FAST, KPW, WPB, 0, DBG, ARMED>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), a, tile, false, 0)) return;
     }
     constexpr int P2W_T = (KPB + p2_keypoints_per_wave(KPB) - 1) / p2_keypoints_per_wave(KPB);
     // ---- this tile's contribution to the workgroup's row: 28 partial sums + {accepted, candidates visited, NaN flag,
@@ -2096,7 +2160,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
 #else
     const SrlAssocArgs &b = a;
 #endif
-    const LdsLayout L = lds_layout(PERSIST ? SRL_SOLVE_K : b.K, NB, KPW, WPB, PERSIST);
+    const LdsLayout L = lds_layout(PERSIST ? SRL_SOLVE_K : b.K, NB, KPW, WPB, PERSIST ? 1 : (ARMED ? 2 : 0));
     const int lane = lane_id();
     const int wave = tid >> 6;
     const bool finisher = blockIdx.x == gridDim.x - 1;
@@ -2197,6 +2261,12 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
 template <int NB, int FAST, int KPW, int WPB, int DBG = 0>
 __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_SIMD) srl_assoc_kernel(const SrlAssocArgs a) {
     assoc_body<NB, FAST, KPW, WPB, 0, DBG>(a);
+}
+// the same pass as an ARMED launch (16-wave workgroups, fast paths): enqueued before its pose exists, the pose arrives through
+// the pose box (assoc_body's prologue); everything behind the prologue is the one-shot kernel
+template <int NB, int KPW>
+__global__ void __launch_bounds__(1024, 1) srl_assoc_armed_kernel(const SrlAssocArgs a) {
+    assoc_body<NB, 1, KPW, 16, 0, 0, 1>(a);
 }
 // The persistent solve: `a` must stay the first argument (its fields are re-read from the kernarg segment at offset 0), the
 // solve arguments sit right behind it.  One 16-wave workgroup per compute unit at most: every workgroup is resident.
@@ -2497,7 +2567,8 @@ hipError_t srl_launch_sqrt(double *io, int n, hipStream_t s) {
 template <int KPW, int WPB>
 static hipError_t launch_assoc_cfg(const SrlAssocArgs &a, int nb_voxels, hipStream_t s) {
     const int nblocks = (a.n + WPB * KPW - 1) / (WPB * KPW);
-    const LdsLayout L = lds_layout(a.K, nb_voxels, KPW, WPB);
+    const bool armed = a.pose_box != nullptr;
+    const LdsLayout L = lds_layout(a.K, nb_voxels, KPW, WPB, armed ? 2 : 0);
     const dim3 blk(64 * WPB);
     auto launch = [&](auto kern) {
         if (L.total > 64 * 1024) {      // more dynamic LDS than the default limit: opt in (once per kernel, device and size)
@@ -2517,6 +2588,10 @@ static hipError_t launch_assoc_cfg(const SrlAssocArgs &a, int nb_voxels, hipStre
     };
     // select_mode 0 / 4: fast paths; 1, 2, 5: general path only
     const bool fast = a.select_mode == 0 || a.select_mode == 4;
+    if (armed) {
+        if constexpr (WPB == 16) { if (fast && a.ablate == 0) return nb_voxels == 1 ? launch(srl_assoc_armed_kernel<1, KPW>) : launch(srl_assoc_armed_kernel<2, KPW>); }
+        return hipErrorInvalidConfiguration;      // the host arms only what has an armed instantiation
+    }
     // the debug switches exist in ONE instantiation (r = 1 fast path, 16 x 16 keypoints per workgroup: the host forces that shape
     // while srl_debug_set_ablate is non-zero); everywhere else a non-zero a.ablate is ignored
     if constexpr (KPW == 16 && WPB == 16) { if (a.ablate != 0 && nb_voxels == 1 && fast) return launch(srl_assoc_kernel<1, 1, 16, 16, 1>); }
