@@ -203,8 +203,9 @@ int srl_build_residuals_overlap(srl_ctx *ctx, const srl_frame *frame, const srl_
  * launch (the pose may differ: that is the point), only writes the pose: the launch call, the dispatch and the ramp of the kernel
  * are off the per-iteration critical path.  Any other call on the context, or a pass with other arguments, cancels the armed
  * launch first (one 384-byte write; the waiting kernel exits), so nothing observable changes: same kernels, same arithmetic,
- * same results.  An armed launch that is neither fired nor cancelled leaves by itself (kernel-side bound: 20 ms), and a call
- * arriving more than 1 ms after arming cancels instead of firing.
+ * same results.  An armed launch that is neither fired nor cancelled leaves by itself after 300 us (so a device-wide
+ * synchronisation issued from outside this library waits that long at most), and a call arriving more than 150 us after arming
+ * cancels instead of firing.
  *   srl_set_armed_launch(ctx, 0 | 1)   turn the mechanism off / on (default on)
  *   srl_disarm(ctx)                    cancel an armed launch now (optional: e.g. before the thread goes idle)
  *   srl_get_arm_stats                  counters {armed, fired, cancelled, expired} since context creation */
@@ -385,10 +386,15 @@ int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable);
  * it across PCIe and republishes the pose into device memory for the other workgroups.  kind 1: fine-grained DEVICE memory the host
  * writes through the PCIe BAR (every workgroup polls it locally); SRL_ERR_UNSUPPORTED when device memory is not CPU-visible on this
  * system.
- * srl_debug_set_arm_linger: the age (us) beyond which a call cancels an armed launch instead of firing it (default 1000), and the
- * kernel-side bound (us, default 20000) after which a waiting launch leaves by itself -- tests drive both paths with it. */
+ * srl_debug_set_arm_linger: the age (us) beyond which a call cancels an armed launch instead of firing it (default 150), and the
+ * kernel-side bound (us, default 300) after which a waiting launch leaves by itself -- tests drive both paths with it. */
 int srl_debug_set_pose_box(srl_ctx *ctx, int kind);
 int srl_debug_set_arm_linger(srl_ctx *ctx, double host_linger_us, double kernel_linger_us);
+/* Time line of the armed passes (tools/arm_timeline.py): enable allocates a host-mapped stamp buffer the armed kernels file into;
+ * gpu_out[64 * 16] (optional): per pass (row = sequence number & 63) the 100 MHz device clock at {entry, pose received, tile start,
+ * phase 0 / 1 / 2 done, row published, finisher done} of workgroup 0 (slots 0..7) and of the finishing workgroup (8..15);
+ * host_out[64 * 4] (optional): steady-clock ns at {call entry, pose written or launch returned, result seen} and a fired flag. */
+int srl_debug_pass_stamps(srl_ctx *ctx, int enable, long long *gpu_out, long long *host_out);
 /* tuning experiments: force the association kernel's launch shape -- keypoints per wave (16-wave workgroups: 2 / 3 / 4 / 6 / 8 /
  * 12 / 16; 4-wave workgroups: 4 / 8 / 16) and waves per workgroup (4 / 16); 0, 0 = automatic (by sweep size).  Results do not
  * depend on the shape beyond FP64 summation order. */

@@ -167,6 +167,7 @@ def load_library():
         "srl_debug_set_fused_reduce": ([p, C.c_int], C.c_int),
         "srl_debug_set_pose_box": ([p, C.c_int], C.c_int),
         "srl_debug_set_arm_linger": ([p, C.c_double, C.c_double], C.c_int),
+        "srl_debug_pass_stamps": ([p, C.c_int, p, p], C.c_int),
         "srl_set_armed_launch": ([p, C.c_int], C.c_int),
         "srl_disarm": ([p], C.c_int),
         "srl_get_arm_stats": ([p, C.POINTER(C.c_uint64)], C.c_int),
@@ -552,7 +553,13 @@ class Context:
         """0: pinned host memory + device relay; 1: fine-grained device memory written through the BAR (raises if not CPU-visible)"""
         self._chk(self.lib.srl_debug_set_pose_box(self.h, int(kind)), "srl_debug_set_pose_box")
 
-    def set_arm_linger(self, host_linger_us=1000.0, kernel_linger_us=20000.0):
+    def pass_stamps(self, enable=True, read=True):
+        """(gpu[64, 16] device-clock ticks of 10 ns, host[64, 4] steady-clock ns) of the last 64 passes; see srl_debug_pass_stamps"""
+        g = np.zeros((64, 32), dtype=np.int64); h = np.zeros((64, 4), dtype=np.int64)
+        self._chk(self.lib.srl_debug_pass_stamps(self.h, 1 if enable else 0, _ptr(g) if read else None, _ptr(h) if read else None), "srl_debug_pass_stamps")
+        return g, h
+
+    def set_arm_linger(self, host_linger_us=150.0, kernel_linger_us=300.0):
         self._chk(self.lib.srl_debug_set_arm_linger(self.h, float(host_linger_us), float(kernel_linger_us)), "srl_debug_set_arm_linger")
 
     def device_sqrt(self, x):

@@ -656,6 +656,21 @@ int srl_debug_set_arm_linger(srl_ctx *ctx, double host_linger_us, double kernel_
     return SRL_OK;
 }
 
+int srl_debug_pass_stamps(srl_ctx *ctx, int enable, long long *gpu_out, long long *host_out) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (enable && !ctx->h_arm_stamps) {
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_arm_stamps, 64 * 32 * sizeof(long long), hipHostMallocCoherent | hipHostMallocMapped));
+        std::memset(ctx->h_arm_stamps, 0, 64 * 32 * sizeof(long long));
+    }
+    if (gpu_out && ctx->h_arm_stamps) std::memcpy(gpu_out, ctx->h_arm_stamps, 64 * 32 * sizeof(long long));
+    if (host_out) std::memcpy(host_out, ctx->arm_host_stamps, sizeof ctx->arm_host_stamps);
+    if (!enable && ctx->h_arm_stamps) { hipHostFree(ctx->h_arm_stamps); ctx->h_arm_stamps = nullptr; }
+    return SRL_OK;
+}
+
 int srl_get_arm_stats(srl_ctx *ctx, uint64_t out[4]) {
     if (!ctx || !out) return SRL_ERR_BAD_ARG;
     for (int i = 0; i < 4; i++) out[i] = ctx->arm_stats[i];
@@ -719,6 +734,7 @@ static int prepare_assoc_args(srl_ctx *ctx, const srl_frame *f, const srl_icp_op
     a.thr_cap = thr;
     a.select_mode = o->select_mode;
     a.ablate = ctx->ablate;                                     // 0 unless srl_debug_set_ablate was called (profiling tools only)
+    a.stamps = ctx->h_arm_stamps;                               // null unless srl_debug_pass_stamps is on
     a.rec = ctx->d_rec;
     a.status = ctx->d_status;
     a.partials = ctx->d_partials;
@@ -884,6 +900,12 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         if (prof_light) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_head++; }
     }
     const auto t_launched = std::chrono::steady_clock::now();
+    if (ctx->h_arm_stamps) {
+        long long *hs = ctx->arm_host_stamps[seq_now & 63ull];
+        hs[0] = std::chrono::duration_cast<std::chrono::nanoseconds>(t_entry.time_since_epoch()).count();
+        hs[1] = std::chrono::duration_cast<std::chrono::nanoseconds>(t_launched.time_since_epoch()).count();
+        hs[3] = fired ? 1 : 0;
+    }
     if (arm_ok) {
         // ... and arm the next pass now, while this one runs: same arguments, the sequence number this context hands out next
         int rcp = ensure_pose_box(ctx);
@@ -1034,6 +1056,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     }
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     const auto t_res = std::chrono::steady_clock::now();
+    if (ctx->h_arm_stamps) ctx->arm_host_stamps[seq_now & 63ull][2] = std::chrono::duration_cast<std::chrono::nanoseconds>(t_res.time_since_epoch()).count();
 
     // total visited keypoints over all shards (part of the reduced range) -> global index of the last visited one
     const long long visited_total = (long long)(ctx->h_out->d_visited + 0.5);

@@ -110,10 +110,13 @@ struct srl_ctx {
     int armed_nb = 0, armed_kpw = 0;
     int armed_ring = -1;                        // light profiling: ring slot of the armed launch's event pair (-1: none)
     long long armed_at_ns = 0;                  // steady clock at arm time
-    double arm_host_linger_us = 1000.0;         // an armed launch older than this is cancelled, never fired (the kernel's own bound is far longer)
-    unsigned arm_linger_ticks = 2000000u;       // 20 ms of the 100 MHz clock: the kernel-side safety net
+    double arm_host_linger_us = 150.0;          // an armed launch older than this is cancelled, never fired (the kernel's own bound is longer)
+    unsigned arm_linger_ticks = 30000u;         // 300 us of the 100 MHz clock: after that a waiting launch leaves by itself (a device-wide
+                                                // synchronisation from outside this library waits that long at most)
     unsigned long long arm_stats[4] = {0, 0, 0, 0};   // armed, fired, cancelled, expired
-    bool ring_void[512] = {};                   // light profiling: event pairs of cancelled armed launches (not counted)
+    bool ring_void[512] = {};
+    long long *h_arm_stamps = nullptr;          // srl_debug_pass_stamps: 64 rows x 16 slots the armed kernels file (host-mapped)
+    long long arm_host_stamps[64][4] = {};      // per pass (row seq & 63), steady-clock ns: call entry, pose written / launch returned, result seen, fired?                   // light profiling: event pairs of cancelled armed launches (not counted)
 
     // taps
     bool taps = false;

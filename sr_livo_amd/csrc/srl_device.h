@@ -151,6 +151,7 @@ struct SrlAssocArgs {
     unsigned long long *pose_relay;       // device memory workgroup 0 republishes the box into for the others (null: everybody polls the box)
     unsigned pose_epoch;                  // tag of THIS launch's pose (low 32 bits of its sequence number, never 0)
     unsigned arm_linger_ticks;            // 100 MHz ticks an armed launch waits at most (safety net)
+    long long *stamps;                    // debug time line of armed passes (host-mapped, 64 rows x 16 slots; null = off)
     const SrlPeerTable *peer;   // fused + direct peer exchange: the finishing workgroup exchanges its totals itself (else null)
     unsigned peer_epoch;        // tag of this exchange (exchange counter, never 0)
     int peer_slot;              // exchange counter & 1

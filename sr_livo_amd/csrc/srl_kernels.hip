@@ -1047,6 +1047,25 @@ __device__ __forceinline__ void solve_stamp(const __attribute__((address_space(4
 }
 #endif
 
+// debug time line of an ARMED pass (srl_debug_pass_stamps, tools/arm_timeline.py): workgroup 0 files slots 0..7, the finishing
+// workgroup slots 8..15 of row (seq & 63); the pointer is re-read from the kernarg segment at every site (nothing stays live)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void arm_stamp(KargBytes karg, int slot) {
+    typedef const __attribute__((address_space(4))) SrlAssocArgs *KP;
+    KP q = (KP)karg;
+    asm volatile("" : "+s"(q));
+    long long *st = q->stamps;
+    if (st != nullptr && threadIdx.x == 0) {
+        const bool first = blockIdx.x == 0, last = blockIdx.x == gridDim.x - 1;
+        if (slot >= 16) { if (last) __hip_atomic_store(st + ((q->seq & 63ull) * 32 + slot), (long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+        if (first) __hip_atomic_store(st + ((q->seq & 63ull) * 32 + slot), (long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (last) __hip_atomic_store(st + ((q->seq & 63ull) * 32 + 8 + slot), (long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+#else
+__device__ inline void arm_stamp(KargBytes, int) {}
+#endif
+
 // The 17-dim update of the persistent solve as two real functions (not inlined: their registers and their code stay out of
 // the association loop's allocation).  sv = the solve arguments in the kernarg segment, lds_off = byte offset of the
 // finishing workgroup's IekfShared in LDS (the address space is re-established here, so the accesses are ds_ instructions).
@@ -1129,6 +1148,8 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
                 const int fs = slot == 10 ? 15 : (slot == 11 ? 6 : (slot == 12 ? 7 : 14));
                 solve_stamp(sq, iter, blockIdx.x == 0 ? slot : fs);
             }
+        } else if constexpr (ARMED) {
+            arm_stamp(karg, slot - 8);                                   // 10..13 -> slots 2..5: phase 0 / 1 / 2 done
         }
     };
 #else
@@ -1840,14 +1861,17 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
             for (int k = 0; k < INF; ++k) s0 += __longlong_as_double((long long)(((unsigned long long)hi[k] << 32) | lo[k]));
         }
         if (timed_out) atomicOr(s_bad, 1);
+        if constexpr (!PERSIST) arm_stamp(karg, 16);
         s_part[part * 32 + comp] = s0;
         __syncthreads();
+        if constexpr (!PERSIST) arm_stamp(karg, 17);
         if (tid < 32) {
             double sum = s_part[tid];
             for (int p = 1; p < NPART; ++p) sum += s_part[p * 32 + tid];
             s_part[tid] = sum;                                             // row 0 = the totals
         }
         __syncthreads();
+        if constexpr (!PERSIST) arm_stamp(karg, 18);
         SrlDevOut *out = PERSIST ? s_out : &b.mailbox->out;
         bool peer_done = false;
         if constexpr (!PERSIST) {
@@ -1903,7 +1927,9 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
         }
         if constexpr (!PERSIST) {
         if (tid < 64) {
+            arm_stamp(karg, 19);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every mailbox writer sits in wave 0
+            arm_stamp(karg, 20);
             if (tid == 0) __hip_atomic_store(&b.mailbox->seq, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         }
@@ -2047,6 +2073,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         const LdsLayout L = carve();
         double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);
         int *s_ctrl = reinterpret_cast<int *>(s_pose + SRL_POSE_DOUBLES);
+        arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 0);
         if (tid < 64) {
             const int lane = tid;
             const unsigned epoch = a.pose_epoch;
@@ -2078,6 +2105,7 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
             if (lane == 0) *s_ctrl = (int)code;
         }
         __syncthreads();
+        arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 1);
         {
             const int code = *s_ctrl;
             if (code != (int)SRL_ARM_GO) {
@@ -2213,8 +2241,10 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (!PERSIST) {
+        if constexpr (ARMED) arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 6);
         if (blockIdx.x != gridDim.x - 1) return;
         finish_rows<KPW, WPB, NB, 0>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), iter, epoch);
+        if constexpr (ARMED) arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 7);
         return;
     }
     // ---------------- persistent solve: the 17-dim update behind the reduction, then the hand-over of the next pose
