@@ -49,7 +49,8 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB
 CLOCK_HZ = 2.4e9          # max engine clock (same guide)
 N_CU, N_SIMD = 256, 1024
 INT_MAX = 2**31 - 1
-KERNEL_SOURCES = ("sr_livo_amd/csrc/srl_kernels.hip", "sr_livo_amd/csrc/srl_iekf_wave.h", "sr_livo_amd/csrc/srl_device.h")
+PROFILE_ROUND = "r04"    # the committed rocprofv3 summaries the line may quote: profiles/<round>_<config>_rocprofv3_summary.json
+KERNEL_SOURCES = ("sr_livo_amd/csrc/srl_kernels.hip", "sr_livo_amd/csrc/srl_device.h")
 
 
 def kernel_source_sha():
@@ -64,14 +65,14 @@ def kernel_source_sha():
 
 
 def profile_path(tag="headline"):
-    return os.path.join(ROOT, "profiles", f"r03_{tag}_rocprofv3_summary.json")
+    return os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{tag}_rocprofv3_summary.json")
 
 
 def load_profile(tag="headline"):
     """(pmc counters of the dominant kernel, stale?) from the committed rocprofv3 summary of this command (tag: which configuration)"""
     try:
         prof = json.load(open(profile_path(tag)))
-        ks = [v for n, v in prof["pmc_per_dispatch"].items() if "solve" in n] or [v for n, v in prof["pmc_per_dispatch"].items() if "assoc" in n]
+        ks = [v for n, v in prof["pmc_per_dispatch"].items() if "assoc" in n]
         return ks[0], prof.get("kernel_source_sha256") != kernel_source_sha()
     except Exception:
         return None, True
@@ -226,18 +227,6 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         passes_per_launch = max(tim.sum_passes, 1) / calls
         launches_per_solve = lio.last_solve_launches()
         state = solve.state.copy()
-        # A/B: the whole solve in one persistent kernel (opt-in form)
-        lio.set_persistent_solve(True)
-        solve(); solve()
-        torch.cuda.synchronize()
-        t_ab = time.perf_counter()
-        for _ in range(steps):
-            solve()
-        torch.cuda.synchronize()
-        el_ab = time.perf_counter() - t_ab
-        launches_persistent = lio.last_solve_launches()
-        lio.set_persistent_solve(False)
-        solve()
         # A/B: one launch per ESIKF iteration (armed launches off: round 3's form)
         lio.ctx.set_armed_launch(False)
         solve(); solve()
@@ -264,7 +253,6 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
                "sweeps_per_s": steps / el, "ms_per_solve": el / steps * 1e3, "esikf_iterations": it, "ms_per_esikf_iter": el / steps * 1e3 / max(it, 1),
                "steps": steps, "ms_per_solve_median": float(np.median(per)) * 1e3, "ms_per_solve_max": float(per.max()) * 1e3,
                "residuals_used": nr, "kernel_launches_per_solve": launches_per_solve,
-               "persistent_solve_ab": {"ms_per_esikf_iter": el_ab / steps * 1e3 / max(it, 1), "launches_per_solve": launches_persistent},
                "launch_per_iteration_ab": {"ms_per_esikf_iter": el_un / steps * 1e3 / max(it, 1), "what": "armed launches off (srl_set_armed_launch(0))"},
                "kernel_us": assoc_ms * 1e3, "passes_per_launch": passes_per_launch, "kernel_us_per_pass": assoc_ms * 1e3 / passes_per_launch,
                "assoc_kernel_us": assoc_ms * 1e3 / passes_per_launch, "assoc_launches": tim.calls,
@@ -272,9 +260,9 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
                "hbm_roofline_frac": bytes_per_launch / (assoc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if assoc_ms > 0 else None,
                "association_only_us": ms_u * 1e3,
                "association_only_hbm_roofline_frac": (tu.sum_algorithmic_bytes / max(tu.calls, 1)) / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_u > 0 else None,
-               "note": "kernel_us = the kernel the timed solves ran: the persistent solve kernel (all passes, reductions, 17-dim updates, "
-                       "hand-overs) where kernel_launches_per_solve = 1, else the one-shot association kernel with the fused final "
-                       "reduction; assoc_kernel_us = kernel_us per pass; association_only_* = one pass with the reduction in its own kernel"}
+               "note": "kernel_us = HIP-event duration of the association kernel with the fused final reduction (an armed launch's event pair opens "
+                       "when the pass before it ends: its wait for the host's pose is inside); association_only_* = one pass with the "
+                       "reduction in its own kernel, launched per iteration"}
         ent["profile"] = profile_entry(name, assoc_ms / passes_per_launch)
         if po is not None:
             u, _ = oracle_solve(po, backend, lio, opts, sweep, prior_state, prior_cov, state0, frame_id, threads)
@@ -461,8 +449,6 @@ def main():
     ap.add_argument("--no-numa-pin", action="store_true", help="A/B: do not pin the process to the GPU-local NUMA node")
     ap.add_argument("--no-aux-legs", action="store_true",
                     help="only the timed configuration runs on the GPU (profiling: no association-only / PCIe legs in the trace)")
-    ap.add_argument("--persistent-solve", action="store_true",
-                    help="A/B, profiling: the timed region runs the opt-in one-launch-per-solve kernel (srl_solve_iekf) instead of one launch per ESIKF iteration")
     ap.add_argument("--no-armed", action="store_true",
                     help="A/B, profiling: armed launches off -- every ESIKF iteration pays its launch call, dispatch and ramp (round 3's form)")
     ap.add_argument("--transport", choices=("rccl", "peer"), default="rccl",
@@ -540,8 +526,6 @@ def main():
     # one step = eskf_set_state + eskf_set_cov (reset the prior) + update_iekf on the resident sweep, through a closure
     # that converts its arguments once (the per-call numpy/ctypes marshalling of the generic wrappers costs ~10 us)
     _solve = lio.bound_solver(opts, prior_state, prior_cov, state0, sweep["t_last"], args.frame_id, n_kp)
-    if args.persistent_solve:
-        lio.set_persistent_solve(True)
     if args.no_armed:
         lio.ctx.set_armed_launch(False)
 
@@ -584,15 +568,12 @@ def main():
     tim_full = lio.ctx.timing()
     lio.ctx.set_profiling(0)
     elapsed = max_over_ranks(elapsed)
-    # A/B: the same solves as ONE persistent kernel per solve (srl_solve_iekf: every pass, the reductions, the 17-dim update on
-    # one wave of the finishing workgroup and the pose hand-overs inside one launch) -- opt-in, because on MI355X it is the
-    # slower form; the timed region above runs the default: one launch + host update per ESIKF iteration
     launches_per_solve = launches_timed
     # A/B: the same solves with one launch call per ESIKF iteration on the critical path (armed launches off: round 3's form), with the
     # kernel's HIP-event duration in that form (an armed launch's event pair also brackets its wait for the host's pose)
     launch_ab, tim_unarmed = None, None
     arm_stats = lio.ctx.arm_stats()
-    if world == 1 and not args.no_aux_legs and not args.persistent_solve and not args.no_armed:
+    if world == 1 and not args.no_aux_legs and not args.no_armed:
         lio.ctx.set_armed_launch(False)
         for _ in range(3):
             solve()
@@ -610,27 +591,11 @@ def main():
                      "launch_per_iteration_us_per_iter": el_un / args.steps * 1e6 / max(r_un["iters"], 1),
                      "state_bitwise_equal": bool(np.array_equal(r_un["state"], r["state"]))}
         solve()
-    persistent_ab = None
-    if world == 1 and not args.no_aux_legs and not args.persistent_solve:
-        lio.set_persistent_solve(True)
-        for _ in range(3):
-            solve()
-        torch.cuda.synchronize()
-        t_ab = time.perf_counter()
-        for _ in range(args.steps):
-            r_ab = solve()
-        torch.cuda.synchronize()
-        el_ab = time.perf_counter() - t_ab
-        persistent_ab = {"sweeps_per_s": args.steps / el_ab, "ms_per_esikf_iter": el_ab / args.steps * 1e3 / max(r_ab["iters"], 1),
-                         "launches_per_solve": lio.last_solve_launches(), "iterations": r_ab["iters"],
-                         "what": "srl_lio_set_persistent_solve(1): the whole updateIEKF loop in one kernel launch (srl_solve_iekf)"}
-        lio.set_persistent_solve(False)
-        solve()
     # the sharded code path with ONE rank (all a 1-GPU box can run of it): 1-rank RCCL communicator, collectives forced --
     # fused pass into a device-side mailbox, ncclAllReduce of 50 doubles, publish kernel.  What the exchange step costs per
     # ESIKF iteration when there is nobody to exchange with; not a scaling figure.
     comm_1rank = None
-    if world == 1 and dist is None and not args.no_aux_legs and not args.persistent_solve:
+    if world == 1 and dist is None and not args.no_aux_legs:
         try:
             os.environ["SRL_FORCE_COLLECTIVES"] = "1"
             with c_stdout_to_stderr():
@@ -748,8 +713,7 @@ def main():
     traffic, traffic_src = traffic_from_profile() if headline_default else (None, None)
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": (f"srl_solve_kernel<{nb}> (persistent: all ESIKF passes of a solve, their reductions, the 17-dim updates and the pose "
-                       f"hand-overs in one launch)") if passes > calls else f"srl_assoc_kernel<{nb}>",
+            "kernel": f"srl_assoc_armed_kernel<{nb}>" if (not args.no_armed and world == 1) else f"srl_assoc_kernel<{nb}>",
             "avg_launch_ms": assoc_ms, "launches": tim.calls, "passes_per_launch": passes / calls, "avg_pass_ms": tim.sum_assoc_ms / passes,
             "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_pass": tim.sum_algorithmic_bytes / passes,
             "profile_stale": bool(load_profile()[1]) if headline_default else None,
@@ -808,7 +772,6 @@ def main():
                                                    "pageable_upload_then_solve": rates["pageable"]}},
         "ms_per_esikf_iter": ms_per_step / max(iters, 1),
         "roofline": roof,
-        "persistent_solve_ab": persistent_ab,
         "launch_ab": launch_ab,
         "arm_stats_timed_region": arm_stats,
         "sharded_path_one_rank": comm_1rank,

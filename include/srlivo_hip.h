@@ -37,8 +37,7 @@ typedef enum srl_status {
     SRL_ERR_NO_SWEEP = -6,
     SRL_ERR_COMM = -7,          /* RCCL failure */
     SRL_ERR_NAN_PLANARITY = -8, /* optimize.cpp:348-350: a2D is NaN -> the reference throws std::runtime_error("error") */
-    SRL_ERR_NOT_ENOUGH_RESIDUALS = -9, /* optimize.cpp:110-123: summary.success = false */
-    SRL_ERR_RETRY_PER_ITERATION = -10  /* srl_solve_iekf: run this solve through srl_build_residuals (nothing was changed) */
+    SRL_ERR_NOT_ENOUGH_RESIDUALS = -9  /* optimize.cpp:110-123: summary.success = false */
 } srl_status;
 
 typedef struct srl_ctx srl_ctx;
@@ -118,7 +117,7 @@ int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n);
  * the context (CPU copy of a chunk overlapped with the DMA of the previous one) and the buffer is free on return. */
 int srl_pinned_alloc(size_t bytes, void **out);
 /* Blocks until the DMA of the last srl_sweep_upload / srl_sweep_prefetch that read a PAGE-LOCKED caller buffer has finished:
- * after it the buffer may be refilled.  (A result returned by srl_build_residuals / srl_solve_iekf implies the same for the
+ * after it the buffer may be refilled.  (A result returned by srl_build_residuals implies the same for the
  * sweep it was computed on; a caller that refills its page-locked buffer earlier than that calls this first.  Uploads from
  * pageable memory never need it: the buffer is consumed on return.)  No-op when nothing is pending. */
 int srl_sweep_wait(srl_ctx *ctx);
@@ -212,56 +211,6 @@ int srl_build_residuals_overlap(srl_ctx *ctx, const srl_frame *frame, const srl_
 int srl_set_armed_launch(srl_ctx *ctx, int mode);
 int srl_disarm(srl_ctx *ctx);
 int srl_get_arm_stats(srl_ctx *ctx, uint64_t out[4]);
-
-/* ------------------------------------------------------------------ one launch per solve
- * replaces: the whole loop of lioOptimization::updateIEKF (optimize.cpp:133-314) on the sweep resident in HBM -- every
- * buildPlaneResiduals pass (optimize.cpp:153), the 17-dim update (optimize.cpp:172-261), the step guard (:248-251), the
- * convergence rule (:263-270) and the posterior covariance (:272-310) -- in ONE persistent kernel: the workgroups stay
- * resident across the ESIKF iterations, the finishing workgroup sums the normal equations, one of its waves runs the
- * 17-dim algebra in FP64 with the host mirror's operation order (csrc/srl_iekf_wave.h) and publishes the next pose to the
- * other workgroups.  No kernel launch, no PCIe round trip and no host arithmetic between iterations.
- *   frame      pose prior of the sweep (p_frame->p_state), t_last, extrinsics, frame_id -- as for srl_build_residuals
- *   state      eskfEstimator's p(3) q(wxyz) v(3) ba(3) bg(3) g(3) at entry (= the "predict" values of optimize.cpp:138-143);
- *              on return the filter state after the last observe() (optimize.cpp:253), also p_frame->p_state (:255-261)
- *   covariance eskfEstimator's 17 x 17 covariance, row-major; replaced by the posterior when res->covariance_updated
- *   log        optional, per pass HtH(36) Hth(6) d_x(17) num_residuals loss = 61 doubles (host memory, max_log_iters rows)
- * Returns SRL_OK with res->verdict in {SRL_IEKF_DONE, SRL_IEKF_DONE_NO_COV, SRL_IEKF_FAIL_RESIDUALS} (the last one is
- * optimizeSummary.success = false, optimize.cpp:110-123: state as left by the passes before it), SRL_ERR_NAN_PLANARITY
- * (optimize.cpp:348-350), or SRL_ERR_RETRY_PER_ITERATION: this configuration or this solve has to go through
- * srl_build_residuals (sharded context, taps, max_num_residuals <= 0, a keypoint prefix that turned out too short for a
- * finite max_num_residuals, a workgroup that did not report in time); state and covariance are untouched then and
- * lioOptimization::updateIEKF of the host mirror does exactly that. */
-typedef enum srl_iekf_verdict {
-    SRL_IEKF_CONTINUE = 0, SRL_IEKF_DONE = 1, SRL_IEKF_DONE_NO_COV = 2, SRL_IEKF_FAIL_RESIDUALS = 3, SRL_IEKF_NAN = 4,
-    SRL_IEKF_TIMEOUT = 5, SRL_IEKF_PREFIX_SHORT = 6, SRL_IEKF_SINGULAR = 7
-} srl_iekf_verdict;
-typedef struct srl_iekf_result {
-    int32_t verdict;              /* srl_iekf_verdict */
-    int32_t iterations;           /* passes that delivered normal equations (optimizeSummary.success) */
-    int32_t covariance_updated;   /* optimize.cpp:272-310 ran */
-    int32_t observed;             /* observe() calls (optimize.cpp:253): > 0 means the frame's pose is now the filter's (:255-261) */
-    srl_normal_eq last;           /* normal equations of the last pass */
-} srl_iekf_result;
-int srl_solve_iekf(srl_ctx *ctx, const srl_frame *frame, const srl_icp_opts *opts, double laser_point_cov,
-                   double state[19], double covariance[289], srl_iekf_result *res, double *log, int max_log_iters);
-/* debug / parity hook: the one-wave algebra of that kernel (csrc/srl_iekf_wave.h: the same source, instantiated for an
- * emulated wave of 64 lanes) run on the HOST around normal equations delivered by `fn` -- lets the CPU tests compare the
- * kernel's arithmetic with the host mirror's updateIEKF bit for bit.  No GPU.  Same state / covariance / log conventions. */
-typedef int (*srl_neq_fn)(const srl_frame *frame, const srl_icp_opts *opts, srl_normal_eq *out, void *user);
-int srl_debug_iekf_wave_solve(const srl_frame *frame, const srl_icp_opts *opts, double laser_point_cov, double state[19],
-                              double covariance[289], srl_neq_fn fn, void *user, int exact_lu, srl_iekf_result *res,
-                              double *log, int max_log_iters);
-/* Which form of the second inverse (optimize.cpp:237) srl_solve_iekf's kernel uses: 0 (default) the Schur-complement form
- * -- the H-independent 11 x 11 block is eliminated while the sweep is associated, a symmetric positive definite 6 x 6
- * system is left behind the reduction (csrc/srl_iekf_wave.h, ~1e-10 relative to the LU form) --, 1 the reference form:
- * both 17 x 17 inverses by partial-pivot LU in the host mirror's operation order (bitwise equal to it up to the device's
- * sin / cos / acos). */
-int srl_debug_set_iekf_exact_lu(srl_ctx *ctx, int exact_lu);
-/* debug time line of srl_solve_iekf's kernel: 16 stamps (100 MHz wall clock) per pass, up to 16 passes -- finishing workgroup:
- * [0] prior() starts, [1] done, [2] own tiles done and row published, [3] rows summed, [4] update() done, [5] pose / verdict
- * handed over; workgroup 0: [8] row published, [9] pose seen.  enable = 1 switches the stamps on for the following solves,
- * out256 (optional) receives those of the last one; enable = 0 switches them off.  tools/persist_probe.py prints them. */
-int srl_debug_solve_stamps(srl_ctx *ctx, int enable, long long *out256);
 
 /* enable/disable the per-keypoint parity taps written by srl_build_residuals (off by default) */
 int srl_set_taps(srl_ctx *ctx, int enable);
@@ -360,8 +309,7 @@ typedef struct srl_timing {
     double  sum_host_launch_us; /* host wall: call entry -> both kernels enqueued */
     double  sum_host_wait_us;   /* host wall: enqueue done -> results on the host (copy + stream sync [+ all-reduce]) */
     double  sum_host_total_us;  /* host wall: whole srl_build_residuals call */
-    int64_t sum_passes;         /* buildPlaneResiduals passes the timed launches ran: 1 per srl_build_residuals launch, the
-                                 * number of ESIKF iterations per srl_solve_iekf launch (light profiling, mode 2) */
+    int64_t sum_passes;         /* buildPlaneResiduals passes the timed launches ran (1 per launch) */
 } srl_timing;
 int srl_get_timing(srl_ctx *ctx, srl_timing *t);
 /* ---- debug / parity hooks: never called by the product path ----

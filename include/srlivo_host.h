@@ -26,10 +26,8 @@ const char *srl_lio_last_error(srl_lio *lio);
 /* members of class lioOptimization the path reads (lioOptimization.h:221,227-228) */
 int srl_lio_set_extrinsics(srl_lio *lio, const double R_il[9], const double t_il[3]);
 int srl_lio_set_laser_point_cov(srl_lio *lio, double cov);
-/* updateIEKF as one persistent kernel (1: srl_solve_iekf where the configuration allows) or as one srl_build_residuals call
- * per ESIKF iteration with the 17-dim algebra on the host (0, the default: measured faster on MI355X).
- * srl_lio_last_solve_launches: kernel launches the last solve cost. */
-int srl_lio_set_persistent_solve(srl_lio *lio, int enable);
+/* srl_lio_last_solve_launches: kernel launches the last solve enqueued for its passes (one per ESIKF iteration; with armed launches
+ * all but the first are enqueued ahead of time, include/srlivo_hip.h). */
 int srl_lio_last_solve_launches(srl_lio *lio, int *launches);
 
 /* eskfEstimator accessors (eskfEstimator.h:74-108).  state = p(3) q(wxyz,4) v(3) ba(3) bg(3) g(3) */

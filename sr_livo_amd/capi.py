@@ -18,7 +18,6 @@ SRL_ERR_NO_DEVICE = -1
 SRL_ERR_COMM = -7
 SRL_ERR_NAN_PLANARITY = -8
 SRL_ERR_NOT_ENOUGH_RESIDUALS = -9
-SRL_ERR_RETRY_PER_ITERATION = -10
 SRL_COMM_ID_BYTES = 128
 
 
@@ -54,13 +53,6 @@ class NormalEq(C.Structure):
                 ("num_residuals", C.c_int32), ("success", C.c_int32), ("sum_candidates", C.c_int64),
                 ("last_visited", C.c_int64), ("nan_error", C.c_int32), ("num_fallback", C.c_int32)]
 
-
-class IekfResult(C.Structure):
-    _fields_ = [("verdict", C.c_int32), ("iterations", C.c_int32), ("covariance_updated", C.c_int32), ("observed", C.c_int32),
-                ("last", NormalEq)]
-
-
-IEKF_CONTINUE, IEKF_DONE, IEKF_DONE_NO_COV, IEKF_FAIL_RESIDUALS, IEKF_NAN, IEKF_TIMEOUT, IEKF_PREFIX_SHORT, IEKF_SINGULAR = range(8)
 
 
 class Timing(C.Structure):
@@ -134,11 +126,6 @@ def load_library():
         "srl_comm_backend_info": ([C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_build_residuals": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq)], C.c_int),
         "srl_build_residuals_overlap": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.POINTER(NormalEq), p, p], C.c_int),
-        "srl_solve_iekf": ([p, C.POINTER(Frame), C.POINTER(IcpOpts), C.c_double, dp, dp, C.POINTER(IekfResult), p, C.c_int], C.c_int),
-        "srl_debug_iekf_wave_solve": ([C.POINTER(Frame), C.POINTER(IcpOpts), C.c_double, dp, dp, PROVIDER_FN, p, C.c_int,
-                                       C.POINTER(IekfResult), p, C.c_int], C.c_int),
-        "srl_debug_set_iekf_exact_lu": ([p, C.c_int], C.c_int),
-        "srl_debug_solve_stamps": ([p, C.c_int, p], C.c_int),
         "srl_set_taps": ([p, C.c_int], C.c_int),
         "srl_fetch_neighbors": ([p, p, p, p], C.c_int),
         "srl_fetch_residuals": ([p, p, p, p, p, p, p], C.c_int),
@@ -183,7 +170,6 @@ def load_library():
         "srl_lio_last_error": ([p], C.c_char_p),
         "srl_lio_set_extrinsics": ([p, dp, dp], C.c_int),
         "srl_lio_set_laser_point_cov": ([p, C.c_double], C.c_int),
-        "srl_lio_set_persistent_solve": ([p, C.c_int], C.c_int),
         "srl_lio_last_solve_launches": ([p, C.POINTER(C.c_int)], C.c_int),
         "srl_lio_eskf_get_state": ([p, dp], C.c_int),
         "srl_lio_eskf_set_state": ([p, dp], C.c_int),
@@ -280,23 +266,6 @@ def heap_topk(distances, K):
     return out[:n].copy()
 
 
-def iekf_wave_solve(frame, opts, laser_point_cov, state19, cov, provider, log_iters=0, exact_lu=True):
-    """srl_debug_iekf_wave_solve: the persistent kernel's one-wave ESIKF algebra (csrc/srl_iekf_wave.h) run on the host
-    around normal equations from provider(frame, opts, out) -> status.  Returns dict(rc, verdict, iterations, state, cov, log)."""
-    def _p(fp, op, outp, _user):
-        return int(provider(fp.contents, op.contents, outp.contents))
-    cb = PROVIDER_FN(_p)
-    st = _f64(state19).copy()
-    P = _f64(cov).ravel().copy()
-    res = IekfResult()
-    log = np.zeros((max(log_iters, 1), 61)) if log_iters else None
-    rc = load_library().srl_debug_iekf_wave_solve(C.byref(frame), C.byref(opts), float(laser_point_cov), _dptr(st), _dptr(P), cb, None,
-                                                  1 if exact_lu else 0, C.byref(res), _ptr(log) if log is not None else None, int(log_iters))
-    return dict(rc=rc, verdict=res.verdict, iterations=res.iterations, covariance_updated=res.covariance_updated, state=st,
-                cov=P.reshape(17, 17), num_residuals=res.last.num_residuals,
-                log=None if log is None else log[: min(res.iterations, log_iters)])
-
-
 class PinnedArray:
     """A float64 numpy array in page-locked host memory (srl_pinned_alloc): srl_sweep_upload DMAs straight out of it."""
 
@@ -321,7 +290,6 @@ class PinnedArray:
             self.close()
         except Exception:
             pass
-
 
 def comm_backend_info():
     """(path of the RCCL shared object in use, ncclGetVersion, found-already-loaded-in-the-process) or raises."""
@@ -507,26 +475,6 @@ class Context:
         nf = np.empty(len(q), dtype=np.int32)
         self._chk(self.lib.srl_search_neighbors(self.h, _ptr(q), len(q), nb, size, K, thr, _ptr(ids), _ptr(xyz), _ptr(nf)), "srl_search_neighbors")
         return ids, xyz, nf
-
-    def solve_iekf(self, frame, opts, laser_point_cov, state19, cov, log_iters=0, allow=(SRL_ERR_NAN_PLANARITY, SRL_ERR_RETRY_PER_ITERATION)):
-        """srl_solve_iekf: the whole updateIEKF loop in one persistent kernel on the resident sweep."""
-        st = _f64(state19).copy()
-        P = _f64(cov).ravel().copy()
-        res = IekfResult()
-        log = np.zeros((max(log_iters, 1), 61)) if log_iters else None
-        rc = self._chk(self.lib.srl_solve_iekf(self.h, C.byref(frame), C.byref(opts), float(laser_point_cov), _dptr(st), _dptr(P),
-                                               C.byref(res), _ptr(log) if log is not None else None, int(log_iters)), "solve_iekf", ok=allow)
-        return dict(rc=rc, verdict=res.verdict, iterations=res.iterations, covariance_updated=res.covariance_updated,
-                    observed=res.observed, state=st, cov=P.reshape(17, 17), num_residuals=res.last.num_residuals, neq=res.last,
-                    log=None if log is None else log[: min(res.iterations, log_iters)])
-
-    def solve_stamps(self, enable=True, fetch=False):
-        out = np.zeros((16, 16), np.int64) if fetch else None
-        self._chk(self.lib.srl_debug_solve_stamps(self.h, 1 if enable else 0, _ptr(out)), "solve_stamps")
-        return out
-
-    def set_iekf_exact_lu(self, on):
-        self._chk(self.lib.srl_debug_set_iekf_exact_lu(self.h, 1 if on else 0), "set_iekf_exact_lu")
 
     def set_launch_shape(self, kpw, wpb):
         self._chk(self.lib.srl_debug_set_launch_shape(self.h, int(kpw), int(wpb)), "srl_debug_set_launch_shape")
@@ -719,9 +667,6 @@ class Lio:
 
     def set_extrinsics(self, R_il, t_il):
         self._chk(self.lib.srl_lio_set_extrinsics(self.h, _dptr(_f64(R_il).ravel()), _dptr(_f64(t_il))), "set_extrinsics")
-
-    def set_persistent_solve(self, on):
-        self._chk(self.lib.srl_lio_set_persistent_solve(self.h, 1 if on else 0), "set_persistent_solve")
 
     def last_solve_launches(self):
         n = C.c_int()

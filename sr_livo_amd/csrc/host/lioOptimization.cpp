@@ -222,78 +222,6 @@ optimizeSummary lioOptimization::solveIEKF(const icpOptions &cur_icp_options, cl
     last_num_iterations = 0;
     last_solve_launches = 0;
 
-    // One launch per solve: the loop below, as it stands in the reference (optimize.cpp:147-312), runs inside the persistent
-    // kernel (srl_solve_iekf: every pass, the 17-dim update, step guard, convergence rule, posterior covariance).  What the
-    // kernel does not cover -- shards, taps, max_num_residuals <= 0, a keypoint prefix that proves too short, a workgroup
-    // that does not report in time -- comes back as SRL_ERR_RETRY_PER_ITERATION with nothing changed, and the loop below
-    // does the solve with one srl_build_residuals call per pass.
-    if (!provider && persistent_solve) {
-        srl_ctx *ctx = voxel_map.ctx;
-        srl_frame f;
-        fillFrame(p_frame, f);
-        const srl_icp_opts abi = cur_icp_options.toAbi();
-        double st[19], P[289];
-        for (int a = 0; a < 3; a++) { st[a] = p_predict[a]; st[7 + a] = v_predict[a]; st[10 + a] = ba_predict[a]; st[13 + a] = bg_predict[a]; st[16 + a] = g_predict[a]; }
-        st[3] = q_predict.w; st[4] = q_predict.x; st[5] = q_predict.y; st[6] = q_predict.z;
-        const Mat17 P0 = eskf_pro->getCovariance();
-        for (int a = 0; a < 289; a++) P[a] = P0.a[a];
-        srl_iekf_result res;
-        std::vector<double> log;
-        if (record_iterations) log.assign((size_t)32 * 61, 0.0);
-        const int rc = srl_solve_iekf(ctx, &f, &abi, laser_point_cov, st, P, &res, record_iterations ? log.data() : nullptr, 32);
-        if (rc == SRL_ERR_NAN_PLANARITY) throw std::runtime_error("error");      // optimize.cpp:348-350
-        if (rc != SRL_ERR_RETRY_PER_ITERATION) {
-            check(ctx, rc, "srl_solve_iekf");
-            last_solve_launches = 1;
-            last_num_iterations = res.iterations;
-            summary.num_residuals_used = res.last.num_residuals;
-            if (record_iterations)
-                for (int it = 0; it < res.iterations && it < 32; it++) {
-                    iterationLog L;
-                    std::memset(&L.neq, 0, sizeof L.neq);
-                    const double *row = log.data() + (size_t)it * 61;
-                    for (int a = 0; a < 36; a++) L.neq.HtH[a] = row[a];
-                    for (int a = 0; a < 6; a++) L.neq.Hth[a] = row[36 + a];
-                    for (int a = 0; a < 17; a++) L.d_x[a] = row[42 + a];
-                    L.neq.num_residuals = (int32_t)row[59];
-                    L.neq.loss_sum = row[60];
-                    L.neq.success = 1;
-                    iteration_log.push_back(L);
-                }
-            // the filter: eskf_pro->observe() ran on the device (optimize.cpp:253)
-            eskf_pro->setTranslation(srl::vec3(st[0], st[1], st[2]));
-            eskf_pro->setRotation(Quat(st[3], st[4], st[5], st[6]));
-            eskf_pro->setVelocity(srl::vec3(st[7], st[8], st[9]));
-            eskf_pro->setBa(srl::vec3(st[10], st[11], st[12]));
-            eskf_pro->setBg(srl::vec3(st[13], st[14], st[15]));
-            eskf_pro->setGravity(srl::vec3(st[16], st[17], st[18]));
-            if (res.observed > 0) {                                              // optimize.cpp:255-261
-                p_frame->p_state->translation = eskf_pro->getTranslation();
-                p_frame->p_state->rotation = eskf_pro->getRotation();
-                p_frame->p_state->velocity = eskf_pro->getVelocity();
-                p_frame->p_state->ba = eskf_pro->getBa();
-                p_frame->p_state->bg = eskf_pro->getBg();
-                G = eskf_pro->getGravity();
-                G_norm = G.norm();
-            }
-            if (res.covariance_updated) {                                        // optimize.cpp:307
-                Mat17 Pn;
-                for (int a = 0; a < 289; a++) Pn.a[a] = P[a];
-                eskf_pro->setCovariance(Pn);
-            }
-            if (res.verdict == SRL_IEKF_FAIL_RESIDUALS) {                        // optimize.cpp:110-123,155-156
-                std::stringstream ss_out;
-                ss_out << "[Optimization] Error : not enough keypoints selected in ct-icp !" << std::endl;
-                ss_out << "[Optimization] number_of_residuals : " << res.last.num_residuals << std::endl;
-                summary.success = false;
-                summary.error_log = ss_out.str();
-                return summary;
-            }
-            summary.success = true;
-            return summary;
-        }
-    }
-
     // covariance projection helpers (optimize.cpp:220-232): rows then columns of the so3 / S2 blocks
     auto left3 = [](Mat17 &dst, const Mat3 &J, const Mat17 &src) {
         for (int j = 0; j < 17; j++) { const Vec3 c = J * src.block<3, 1>(3, j); dst.setBlock<3, 1>(3, j, c); }

@@ -210,13 +210,7 @@ public:
     bool record_iterations = false;
     std::vector<iterationLog> iteration_log;
     int last_num_iterations = 0;
-    // true: updateIEKF as ONE persistent kernel (srl_solve_iekf) where the configuration allows.  Default false: one
-    // srl_build_residuals call per ESIKF iteration with the 17-dim algebra on the host, H-independent half beside the kernel --
-    // measured faster on MI355X (headline: 58 us against 68 us per iteration; DESIGN.md section 4.6 has the time line: the
-    // kernel boundary and the host hop it saves cost ~10 us, the single-wave update, the cross-workgroup hand-overs and the
-    // tile call it adds ~20 us).
-    bool persistent_solve = false;
-    int last_solve_launches = 0;       // kernel launches the last solve cost: 1, or one per pass
+    int last_solve_launches = 0;       // passes (= association kernel launches) of the last solve
 
 private:
     int normalEquations(const icpOptions &o, cloudFrame *p_frame, srl_normal_eq &neq, void (*while_running)(void *) = nullptr, void *user = nullptr);

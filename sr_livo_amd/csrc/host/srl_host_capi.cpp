@@ -129,7 +129,6 @@ int srl_lio_set_extrinsics(srl_lio *h, const double R_il[9], const double t_il[3
     return SRL_OK;
 }
 int srl_lio_set_laser_point_cov(srl_lio *h, double cov) { if (!h) return SRL_ERR_BAD_ARG; h->lio->laser_point_cov = cov; return SRL_OK; }
-int srl_lio_set_persistent_solve(srl_lio *h, int enable) { if (!h) return SRL_ERR_BAD_ARG; h->lio->persistent_solve = enable != 0; return SRL_OK; }
 int srl_lio_last_solve_launches(srl_lio *h, int *launches) { if (!h || !launches) return SRL_ERR_BAD_ARG; *launches = h->lio->last_solve_launches; return SRL_OK; }
 
 int srl_lio_eskf_get_state(srl_lio *h, double s[19]) {

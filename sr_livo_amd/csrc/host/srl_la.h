@@ -9,8 +9,8 @@
 #include <cmath>
 #include <cstring>
 
-// The same fixed-size algebra also runs inside the persistent ESIKF kernel (csrc/srl_iekf_wave.h): in a HIP translation
-// unit every function below is __host__ __device__, elsewhere the marker is empty.
+// In a HIP translation unit every function below is __host__ __device__ (the kernels use the quaternion / 3 x 3 forms), elsewhere
+// the marker is empty.
 #if defined(__HIP__)
 #include <hip/hip_runtime.h>
 #define SRL_HD __host__ __device__

@@ -6,7 +6,6 @@
 #include "srl_device.h"
 #include "srl_hash.h"
 #include "srl_heap.h"
-#include "srl_iekf_wave.h"
 
 #include <hip/hip_runtime.h>
 #include <sched.h>
@@ -104,7 +103,6 @@ const char *srl_status_str(int s) {
         case SRL_ERR_COMM: return "RCCL error";
         case SRL_ERR_NAN_PLANARITY: return "NaN planarity (optimize.cpp:348-350 throws)";
         case SRL_ERR_NOT_ENOUGH_RESIDUALS: return "not enough residuals (optimize.cpp:110)";
-        case SRL_ERR_RETRY_PER_ITERATION: return "solve not run by the persistent kernel: go through srl_build_residuals";
         default: return "unknown status";
     }
 }
@@ -150,13 +148,6 @@ int srl_ctx_create(int device, srl_ctx **out) {
         return SRL_ERR_HIP;
     }
     std::memset(ctx->h_mail, 0, sizeof(SrlMailbox));
-    if (hipHostMalloc((void **)&ctx->h_solve, sizeof(SrlSolveMailbox), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->h_solve_log, (size_t)SRL_SOLVE_LOG_ROWS * 61 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_pose_granules, 64 * 8) != hipSuccess || hipMemset(ctx->d_pose_granules, 0, 64 * 8) != hipSuccess) {
-        delete ctx;
-        return SRL_ERR_HIP;
-    }
-    std::memset(ctx->h_solve, 0, sizeof(SrlSolveMailbox));
     for (int i = 0; i < 4; i++) hipEventCreate(&ctx->ev[i]);
     *out = ctx;
     return SRL_OK;
@@ -175,16 +166,14 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
                     ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
-                    ctx->d_tap_offset, ctx->d_gather, ctx->d_pose_granules, ctx->d_peer, ctx->d_mail};
+                    ctx->d_tap_offset, ctx->d_gather, ctx->d_peer, ctx->d_mail};
     for (int r = 0; r < SRL_MAX_PEERS; r++) if (ctx->peer_mapped[r]) hipIpcCloseMemHandle(ctx->peer_mapped[r]);
     if (ctx->d_inbox) hipFree(ctx->d_inbox);
     for (void *b : bufs) if (b) hipFree(b);
     if (ctx->h_out) hipHostFree(ctx->h_out);
     if (ctx->h_count) hipHostFree(ctx->h_count);
     if (ctx->h_mail) hipHostFree(ctx->h_mail);
-    if (ctx->h_solve) hipHostFree(ctx->h_solve);
-    if (ctx->h_solve_log) hipHostFree(ctx->h_solve_log);
-    if (ctx->h_stamps) hipHostFree(ctx->h_stamps);
+    if (ctx->h_arm_stamps) hipHostFree(ctx->h_arm_stamps);
     if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
     if (ctx->h_ring) { hipHostFree(ctx->h_ring); for (int i = 0; i < srl_ctx::RING_SLOTS; i++) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]); }
     for (auto &b : ctx->pool_free) hipFree(b.p);
@@ -496,7 +485,10 @@ int drain_ring(srl_ctx *ctx, bool all) {
         const unsigned slot = ctx->ring_tail % srl_ctx::PROF_RING;
         if (ctx->ring_void[slot]) { ctx->ring_void[slot] = false; ctx->ring_tail++; continue; }   // a cancelled armed launch
         float ms = 0.f;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, e[0], e[1]));
+        // an armed launch has no start event of its own: it is enqueued behind the launch of the pass before it and the stream turns
+        // to it the moment that one completes -- its start IS the end event of its predecessor in the ring
+        hipEvent_t start = ctx->ring_prev[slot] >= 0 ? ctx->ring[ctx->ring_prev[slot]][1] : e[0];
+        HIPCHK(ctx, hipEventElapsedTime(&ms, start, e[1]));
         ctx->timing.assoc_ms = ms;
         ctx->timing.sum_assoc_ms += ms;
         ctx->timing.calls += 1;
@@ -517,6 +509,7 @@ int srl_set_profiling(srl_ctx *ctx, int enable) {
         for (int i = 0; i < srl_ctx::PROF_RING; i++)
             for (int k = 0; k < 2; k++) if (!ctx->ring[i][k]) HIPCHK(ctx, hipEventCreate(&ctx->ring[i][k]));
         ctx->ring_head = ctx->ring_tail = 0;
+        std::memset(ctx->ring_void, 0, sizeof ctx->ring_void);
     }
     return SRL_OK;
 }
@@ -682,7 +675,7 @@ int srl_get_arm_stats(srl_ctx *ctx, uint64_t out[4]) {
 #define SRL_INTERNAL_FUSED_TIMEOUT 1      // build_residuals_pass only: never leaves srl_build_residuals
 #define SRL_INTERNAL_ARM_EXPIRED 2        // the armed launch this pass fired had given up waiting: the pass is repeated with a normal launch
 
-// the kernel arguments both forms of the pass share (one-shot kernel per ESIKF iteration / persistent solve)
+// the kernel arguments of one pass
 static int prepare_assoc_args(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, int n_eff, SrlAssocArgs &a, int &nb_out) {
     // init-mode switches (optimize.cpp:21-23)
     const bool init_mode = f->frame_id < o->init_num_frames;
@@ -841,9 +834,11 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         if (peer_epoch == 0) { ++ctx->peer_seq; peer_epoch = 1; }
         peer_slot = (int)(ctx->peer_seq & 1ull);
     };
+    const bool tagged_mail = fused && !(ctx->comm && (ctx->nranks > 1 || ctx->force_coll) && !ctx->peer_on);   // fused and not the RCCL form: the finisher reports to the host
     if (fused) {
         a.granules = ctx->d_granules;
         a.mailbox = ctx->h_mail;
+        a.mail_tagged = tagged_mail ? 1 : 0;
         a.seq = seq_now;
         if (peer) {
             next_exchange();
@@ -897,7 +892,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         if (prof_light) HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
         HIPCHK(ctx, srl_launch_assoc(a, nb, kpw, wpb, ctx->stream));
         if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-        if (prof_light) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_head++; }
+        if (prof_light) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_prev[ctx->ring_head % srl_ctx::PROF_RING] = -1; ctx->ring_head++; }
     }
     const auto t_launched = std::chrono::steady_clock::now();
     if (ctx->h_arm_stamps) {
@@ -917,14 +912,24 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         nx.pose_epoch = (unsigned)nx.seq;
         nx.arm_linger_ticks = ctx->arm_linger_ticks;
         hipEvent_t *nev = nullptr;
+        bool own_start = true;
         if (prof_light) {
-            if (ctx->ring_head - ctx->ring_tail >= (unsigned)srl_ctx::PROF_RING - 1) { int rc = drain_ring(ctx, true); if (rc) return rc; }
+            if (ctx->ring_head - ctx->ring_tail >= (unsigned)srl_ctx::PROF_RING - 2) { int rc = drain_ring(ctx, true); if (rc) return rc; }
             nev = ctx->ring[ctx->ring_head % srl_ctx::PROF_RING];
-            HIPCHK(ctx, hipEventRecord(nev[0], ctx->stream));
+            // the launch of THIS pass is the ring entry before: its end event is the armed launch's start (an event record between
+            // the two kernels would sit on the path the armed launch is there to shorten: measured +5 us per iteration)
+            own_start = ctx->ring_head == 0 || ctx->ring_void[(ctx->ring_head - 1) % srl_ctx::PROF_RING];
+            if (own_start) HIPCHK(ctx, hipEventRecord(nev[0], ctx->stream));
         }
         HIPCHK(ctx, srl_launch_assoc(nx, nb, kpw, wpb, ctx->stream));
         ctx->armed_ring = -1;
-        if (prof_light) { HIPCHK(ctx, hipEventRecord(nev[1], ctx->stream)); ctx->armed_ring = (int)(ctx->ring_head % srl_ctx::PROF_RING); ctx->ring_void[ctx->armed_ring] = false; ctx->ring_head++; }
+        if (prof_light) {
+            HIPCHK(ctx, hipEventRecord(nev[1], ctx->stream));
+            ctx->armed_ring = (int)(ctx->ring_head % srl_ctx::PROF_RING);
+            ctx->ring_void[ctx->armed_ring] = false;
+            ctx->ring_prev[ctx->armed_ring] = own_start ? -1 : (int)((ctx->ring_head - 1) % srl_ctx::PROF_RING);
+            ctx->ring_head++;
+        }
         ctx->armed_sig = signature(nx);
         ctx->armed_nb = nb; ctx->armed_kpw = kpw;
         ctx->armed_at_ns = steady_ns();
@@ -1016,16 +1021,32 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     }
     const bool host_reduce = ctx->nranks > 1 && !coll && !peer;      // the caller's all-reduce callback (CPU / gloo tests, foreign transports)
     if (coll || mailbox || peer) {
-        volatile unsigned long long *seqp = &ctx->h_mail->seq;
+        constexpr int NW = (int)(sizeof(SrlDevOut) / 8);
+        const unsigned tag32 = (unsigned)ra.seq;
+        unsigned long long *gran = ctx->h_mail->g;
+        // arrived: the plain form's sequence word; the tagged form: every granule carries this pass's tag (the last one is looked at
+        // first: while it is stale nothing else is read)
+        auto arrived = [&]() -> bool {
+            if (!tagged_mail) return __atomic_load_n(&ctx->h_mail->seq, __ATOMIC_ACQUIRE) == ra.seq;
+            if ((unsigned)(__atomic_load_n(&gran[2 * NW - 1], __ATOMIC_RELAXED) >> 32) != tag32) return false;
+            for (int i = 0; i < 2 * NW - 1; i++) if ((unsigned)(__atomic_load_n(&gran[i], __ATOMIC_RELAXED) >> 32) != tag32) return false;
+            return true;
+        };
         unsigned long long spins = 0;
-        while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != ra.seq) {
+        while (!arrived()) {
             if ((++spins & 0xFFFFF) == 0) {           // every ~1M polls: make sure the stream has not faulted
                 const hipError_t qe = hipStreamQuery(ctx->stream);
                 if (qe != hipSuccess && qe != hipErrorNotReady) { ctx->err = std::string("reduce kernel: ") + hipGetErrorString(qe); return SRL_ERR_HIP; }
-                if (qe == hipSuccess && __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != ra.seq) { ctx->err = "reduce kernel finished without publishing"; return SRL_ERR_HIP; }
+                if (qe == hipSuccess && !arrived()) { ctx->err = "reduce kernel finished without publishing"; return SRL_ERR_HIP; }
             }
         }
-        std::memcpy(ctx->h_out, &ctx->h_mail->out, sizeof(SrlDevOut));
+        if (tagged_mail) {
+            unsigned long long *w = reinterpret_cast<unsigned long long *>(ctx->h_out);
+            for (int i = 0; i < NW; i++)
+                w[i] = (__atomic_load_n(&gran[2 * i], __ATOMIC_RELAXED) & 0xFFFFFFFFull) | (__atomic_load_n(&gran[2 * i + 1], __ATOMIC_RELAXED) << 32);
+        } else {
+            std::memcpy(ctx->h_out, &ctx->h_mail->out, sizeof(SrlDevOut));
+        }
         visited_local = ctx->h_out->last_visited + 1;
         if (host_reduce) {
             if (!ctx->cb_ar) { ctx->err = "nranks > 1 without communicator"; return SRL_ERR_COMM; }
@@ -1056,6 +1077,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     }
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     const auto t_res = std::chrono::steady_clock::now();
+    if (ctx->armed) ctx->armed_at_ns = steady_ns();      // the armed launch starts waiting about now (when this pass ends): its age counts from here
     if (ctx->h_arm_stamps) ctx->arm_host_stamps[seq_now & 63ull][2] = std::chrono::duration_cast<std::chrono::nanoseconds>(t_res.time_since_epoch()).count();
 
     // total visited keypoints over all shards (part of the reduced range) -> global index of the last visited one
@@ -1231,23 +1253,6 @@ int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable) {
     ctx->fuse_reduce = enable != 0;
     return SRL_OK;
 }
-int srl_debug_solve_stamps(srl_ctx *ctx, int enable, long long *out256) {
-    // enable: allocate the stamp buffer; out256 (optional): copy of the stamps the last persistent solve left
-    if (!ctx) return SRL_ERR_BAD_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (enable && !ctx->h_stamps) {
-        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_stamps, 256 * sizeof(long long), hipHostMallocCoherent | hipHostMallocMapped));
-        std::memset(ctx->h_stamps, 0, 256 * sizeof(long long));
-    }
-    if (out256 && ctx->h_stamps) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); std::memcpy(out256, ctx->h_stamps, 256 * sizeof(long long)); }
-    if (!enable && ctx->h_stamps) { hipHostFree(ctx->h_stamps); ctx->h_stamps = nullptr; }
-    return SRL_OK;
-}
-int srl_debug_set_iekf_exact_lu(srl_ctx *ctx, int exact_lu) {
-    if (!ctx) return SRL_ERR_BAD_ARG;
-    ctx->iekf_exact_lu = exact_lu != 0;
-    return SRL_OK;
-}
 int srl_debug_set_search_select_mode(srl_ctx *ctx, int select_mode) {
     if (!ctx || select_mode < 0 || select_mode > 5) return SRL_ERR_BAD_ARG;
     ctx->search_select_mode = select_mode;
@@ -1276,198 +1281,6 @@ int srl_debug_device_sqrt(srl_ctx *ctx, const double *in, int n, double *out) {
     HIPCHK(ctx, srl_launch_sqrt(b.as<double>(), n, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(out, b.as<double>(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return SRL_OK;
-}
-
-// ---- the persistent kernel's one-wave ESIKF algebra on the host (emulated wave of 64 lanes; csrc/srl_iekf_wave.h) ----
-static void iekf_consts_from(const srl_frame *f, const srl_icp_opts *o, double laser_point_cov, const double state[19], srlw::IekfConsts &K) {
-    std::memcpy(K.pred, state, sizeof K.pred);
-    K.laser_point_cov = laser_point_cov;
-    K.thr_translation = o->threshold_translation_norm;
-    K.thr_orientation = o->threshold_orientation_norm;
-    K.frame_id = f->frame_id;
-    K.max_num_iter = f->frame_id < o->init_num_frames ? std::max(15, o->num_iters_icp) : o->num_iters_icp;   // optimize.cpp:135-136
-}
-static void iekf_log_row(double *log, int row, const srl_normal_eq &neq, const double *d_x) {
-    double *L = log + (size_t)row * 61;
-    std::memcpy(L, neq.HtH, 36 * sizeof(double));
-    std::memcpy(L + 36, neq.Hth, 6 * sizeof(double));
-    std::memcpy(L + 42, d_x, 17 * sizeof(double));
-    L[59] = (double)neq.num_residuals;
-    L[60] = neq.loss_sum;
-}
-int srl_debug_iekf_wave_solve(const srl_frame *frame, const srl_icp_opts *o, double laser_point_cov, double state[19],
-                              double covariance[289], srl_neq_fn fn, void *user, int exact_lu, srl_iekf_result *res, double *log,
-                              int max_log_iters) {
-    if (!frame || !o || !state || !covariance || !fn || !res) return SRL_ERR_BAD_ARG;
-    using namespace srlw;
-    IekfConsts K;
-    iekf_consts_from(frame, o, laser_point_cov, state, K);
-    static thread_local IekfShared sh;
-    std::memcpy(sh.state, state, sizeof sh.state);
-    sh.singular = 0;
-    sh.observed = 0;
-    srl_frame f = *frame;
-    std::memset(res, 0, sizeof *res);
-    double cov_out[289];
-    int verdict = IEKF_CONTINUE;
-    for (int iter = 0; iter <= K.max_num_iter && verdict == IEKF_CONTINUE; iter++) {
-        if (exact_lu) iekf_prior<HostWave, false>(K, covariance, sh);
-        else iekf_prior<HostWave, true>(K, covariance, sh);
-        srl_normal_eq neq;
-        std::memset(&neq, 0, sizeof neq);
-        const int rc = fn(&f, o, &neq, user);
-        res->last = neq;
-        if (rc == SRL_ERR_NAN_PLANARITY) { verdict = IEKF_NAN; break; }
-        if (rc != SRL_OK) return rc;
-        if (!neq.success) { verdict = IEKF_FAIL_RESIDUALS; break; }
-        res->iterations++;
-        std::memcpy(sh.HtH, neq.HtH, sizeof sh.HtH);
-        std::memcpy(sh.Hth, neq.Hth, sizeof sh.Hth);
-        verdict = exact_lu ? iekf_update<HostWave, false>(K, iter, sh, cov_out) : iekf_update<HostWave, true>(K, iter, sh, cov_out);
-        if (log && iter < max_log_iters) iekf_log_row(log, iter, neq, sh.d_x);
-        if (sh.singular) { verdict = IEKF_SINGULAR; break; }
-        // the pose of the next pass is the filter's (optimize.cpp:255-256)
-        f.q[0] = sh.state[3]; f.q[1] = sh.state[4]; f.q[2] = sh.state[5]; f.q[3] = sh.state[6];
-        f.t[0] = sh.state[0]; f.t[1] = sh.state[1]; f.t[2] = sh.state[2];
-    }
-    res->verdict = verdict;
-    res->observed = sh.observed;
-    if (verdict == IEKF_SINGULAR) return SRL_ERR_RETRY_PER_ITERATION;
-    std::memcpy(state, sh.state, sizeof sh.state);
-    if (verdict == IEKF_DONE) { std::memcpy(covariance, cov_out, sizeof cov_out); res->covariance_updated = 1; }
-    return verdict == IEKF_NAN ? SRL_ERR_NAN_PLANARITY : SRL_OK;
-}
-
-// ---- one launch per solve: the whole loop of updateIEKF (optimize.cpp:133-314) in the persistent kernel
-int srl_solve_iekf(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, double laser_point_cov, double state[19],
-                   double covariance[289], srl_iekf_result *res, double *log, int max_log_iters) {
-    if (!ctx || !f || !o || !state || !covariance || !res) return SRL_ERR_BAD_ARG;
-    SRL_DISARM(ctx);
-    if (!ctx->d_table) return SRL_ERR_NO_MAP;
-    if (!ctx->sweep_loaded) return SRL_ERR_NO_SWEEP;
-    std::memset(res, 0, sizeof *res);
-    // what the persistent kernel does not cover goes through srl_build_residuals (the caller's loop): shards, taps, debug
-    // ablations, max_num_residuals <= 0 (the stop-at-the-first-plane quirk), empty sweeps, the general selection paths
-    const bool single = ctx->nranks == 1 && !(ctx->comm && ctx->force_coll);
-    const bool fast_sel = o->select_mode == 0 || o->select_mode == 4;
-    if (!single || ctx->taps || ctx->ablate != 0 || o->max_num_residuals <= 0 || ctx->total_n <= 0 || !fast_sel || !ctx->fuse_reduce ||
-        ctx->force_kpw != 0 || ctx->profiling == 1 || o->max_number_neighbors != SRL_SOLVE_K)
-        return SRL_ERR_RETRY_PER_ITERATION;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    // finite max_num_residuals: the sequential loop never looks past the max-th accepted keypoint, so only a prefix that
-    // almost surely contains it is associated (as srl_build_residuals does); if a pass finds it too short the kernel stops
-    // with IEKF_PREFIX_SHORT and the caller repeats the solve per iteration
-    const bool cut_possible = (long long)o->max_num_residuals <= (long long)ctx->total_n;
-    int n_eff = ctx->n;
-    if (cut_possible) {
-        const long long pre = ((4LL * o->max_num_residuals + 2048 + 63) / 64) * 64;
-        if (pre < (long long)ctx->n) n_eff = (int)pre;
-    }
-    SrlAssocArgs a;
-    int nb = 1;
-    { const int rca = prepare_assoc_args(ctx, f, o, n_eff, a, nb); if (rca) return rca; }
-    const int K = o->max_number_neighbors;
-    const int kpw = srl_keypoints_per_wave_one_round(n_eff, ctx->num_cu);
-    if (srl_solve_lds_bytes(K, nb, kpw) > SRL_LDS_LIMIT) return SRL_ERR_RETRY_PER_ITERATION;
-    const int kpb = 16 * kpw;
-    const int ntiles = (n_eff + kpb - 1) / kpb;
-    if (cut_possible && (kpb > SRL_FUSED_CUT_MAX_KPB || ntiles > ctx->num_cu)) return SRL_ERR_RETRY_PER_ITERATION;   // the fused ordered cut needs one small tile per workgroup
-    const int grid = std::min(ntiles, ctx->num_cu);          // every workgroup resident: one 16-wave workgroup per compute unit at most
-    a.write_rec = 0;
-    a.granules = ctx->d_granules;
-    a.mailbox = ctx->h_mail;                                  // unused by the persistent kernel (its result goes to h_solve)
-    if (cut_possible) {
-        const size_t need = (size_t)ntiles * kpb * 16;
-        if (need > ctx->rec_granule_cap) {
-            int rcg;
-            if ((rcg = ensure(ctx, ctx->d_rec_granules, need))) return rcg;
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_rec_granules, 0, need * sizeof(unsigned long long), ctx->stream));
-            ctx->rec_granule_cap = need;
-        }
-        a.rec_granules = ctx->d_rec_granules;
-        a.cut_max = o->max_num_residuals;
-    }
-    SrlSolveArgs sv;
-    std::memset(&sv, 0, sizeof sv);
-    iekf_consts_from(f, o, laser_point_cov, state, sv.K);
-    std::memcpy(sv.state0, state, sizeof sv.state0);
-    std::memcpy(sv.cov0, covariance, sizeof sv.cov0);
-    sv.pose_granules = ctx->d_pose_granules;
-    sv.mailbox = ctx->h_solve;
-    const int log_rows = log ? std::min(max_log_iters, SRL_SOLVE_LOG_ROWS) : 0;
-    sv.log = log_rows > 0 ? ctx->h_solve_log : nullptr;
-    sv.max_log = log_rows;
-    sv.min_residuals = o->min_number_neighbors;
-    sv.ntiles = ntiles;
-    sv.prefix = (cut_possible && n_eff < ctx->n) ? 1 : 0;
-    sv.exact_lu = ctx->iekf_exact_lu ? 1 : 0;
-    sv.stamps = ctx->h_stamps;
-    if (ctx->h_stamps) std::memset(ctx->h_stamps, 0, 256 * sizeof(long long));
-    // one epoch per pass: rows and pose granules of pass i carry seq + i
-    const unsigned long long seq0 = ctx->seq + 1;
-    ctx->seq += (unsigned long long)sv.K.max_num_iter + 2;
-    a.seq = seq0;
-    ctx->last_nblocks = grid;
-    hipEvent_t *ring_ev = nullptr;
-    if (ctx->profiling == 2) {
-        if (ctx->ring_head - ctx->ring_tail >= (unsigned)srl_ctx::PROF_RING) { int rc = drain_ring(ctx, true); if (rc) return rc; }
-        ring_ev = ctx->ring[ctx->ring_head % srl_ctx::PROF_RING];
-        HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
-    }
-    HIPCHK(ctx, srl_launch_solve(a, sv, nb, kpw, grid, ctx->stream));
-    if (ring_ev) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_head++; }
-    {
-        volatile unsigned long long *seqp = &ctx->h_solve->seq;
-        unsigned long long spins = 0;
-        while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq0) {
-            if ((++spins & 0xFFFFF) == 0) {
-                const hipError_t qe = hipStreamQuery(ctx->stream);
-                if (qe != hipSuccess && qe != hipErrorNotReady) { ctx->err = std::string("solve kernel: ") + hipGetErrorString(qe); return SRL_ERR_HIP; }
-                if (qe == hipSuccess && __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq0) {
-                    // every workgroup left without a verdict from the finishing one (its bounded waits ran out)
-                    ctx->err = "solve kernel finished without publishing";
-                    return SRL_ERR_RETRY_PER_ITERATION;
-                }
-            }
-        }
-    }
-    const SrlSolveMailbox &mb = *ctx->h_solve;
-    res->verdict = (int32_t)mb.verdict;
-    res->iterations = (int32_t)mb.iterations;
-    res->covariance_updated = (int32_t)mb.covariance_updated;
-    res->observed = (int32_t)mb.observed;
-    {
-        const SrlDevOut &r = mb.last;
-        std::memcpy(res->last.HtH, r.HtH, sizeof res->last.HtH);
-        std::memcpy(res->last.Hth, r.Hth, sizeof res->last.Hth);
-        res->last.loss_sum = r.loss;
-        res->last.num_residuals = (int32_t)(r.d_num_res + 0.5);
-        res->last.success = res->last.num_residuals >= o->min_number_neighbors ? 1 : 0;
-        res->last.sum_candidates = (int64_t)(r.d_sum_pk + 0.5);
-        res->last.last_visited = (int64_t)(r.d_visited + 0.5) - 1;
-        res->last.nan_error = r.d_nan > 0.5 ? 1 : 0;
-        res->last.num_fallback = (int32_t)(r.d_fallback + 0.5);
-        const long long side = 2 * nb + 1;
-        ctx->timing.algorithmic_bytes = (24 + 12 * side * side * side) * (long long)n_eff + (long long)(12.0 * r.d_sum_pk);
-        // light profiling: one event pair around the whole launch; bytes, keypoints and passes of all its ESIKF iterations
-        // (a failed pass was associated too)
-        const int passes = res->iterations + (res->verdict == srlw::IEKF_FAIL_RESIDUALS || res->verdict == srlw::IEKF_NAN ? 1 : 0);
-        if (ctx->profiling == 2) { ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes * std::max(1, passes); ctx->timing.sum_keypoints += (long long)n_eff * std::max(1, passes); ctx->timing.sum_passes += std::max(1, passes); }
-    }
-    ctx->last_K = K;
-    ctx->last_nb = nb;
-    ctx->taps_valid = false;
-    switch (res->verdict) {
-        case srlw::IEKF_DONE: case srlw::IEKF_DONE_NO_COV: case srlw::IEKF_FAIL_RESIDUALS: break;
-        case srlw::IEKF_NAN: ctx->err = "NaN planarity"; return SRL_ERR_NAN_PLANARITY;
-        case srlw::IEKF_PREFIX_SHORT: ctx->err = "solve kernel: the keypoint prefix held fewer accepted residuals than max_num_residuals"; return SRL_ERR_RETRY_PER_ITERATION;
-        case srlw::IEKF_TIMEOUT: ctx->err = "solve kernel: a workgroup's row did not arrive in time"; return SRL_ERR_RETRY_PER_ITERATION;
-        default: ctx->err = "solve kernel: singular normal equations"; return SRL_ERR_RETRY_PER_ITERATION;
-    }
-    std::memcpy(state, mb.state, sizeof(double) * 19);
-    if (res->covariance_updated) std::memcpy(covariance, mb.cov, sizeof(double) * 289);
-    if (log_rows > 0) std::memcpy(log, ctx->h_solve_log, (size_t)std::min(log_rows, res->iterations) * 61 * sizeof(double));
     return SRL_OK;
 }
 

@@ -88,13 +88,6 @@ struct srl_ctx {
     int force_kpw = 0, force_wpb = 0;  // srl_debug_set_launch_shape (0 = automatic)
     bool fuse_reduce = true;           // srl_debug_set_fused_reduce(0): always run the separate reduce kernel (A/B, tests)
     SrlMailbox *h_mail = nullptr;      // host-mapped fine-grained mailbox the reduce kernel publishes into
-    // persistent solve (srl_solve_iekf): result mailbox and per-pass log in host-mapped memory, the pose hand-over granules
-    SrlSolveMailbox *h_solve = nullptr;
-    double *h_solve_log = nullptr;     // SRL_SOLVE_LOG_ROWS x 61 doubles
-    unsigned long long *d_pose_granules = nullptr;
-    bool iekf_exact_lu = false;        // srl_debug_set_iekf_exact_lu
-    long long *h_stamps = nullptr;     // srl_debug_solve_stamps: 16 x 16 wall-clock stamps of the last persistent solve (host-mapped)
-    bool solve_lds_opted = false;
     unsigned long long seq = 0;
 
     // ARMED launches (srl_capi.cpp: arm_next / pose_box_write / srl_ctx_disarm): the kernel of the NEXT pass is enqueued while the
@@ -115,6 +108,7 @@ struct srl_ctx {
                                                 // synchronisation from outside this library waits that long at most)
     unsigned long long arm_stats[4] = {0, 0, 0, 0};   // armed, fired, cancelled, expired
     bool ring_void[512] = {};
+    int ring_prev[512] = {};                    // light profiling: ring slot whose END event is this launch's start (armed launches), -1 = own start event
     long long *h_arm_stamps = nullptr;          // srl_debug_pass_stamps: 64 rows x 16 slots the armed kernels file (host-mapped)
     long long arm_host_stamps[64][4] = {};      // per pass (row seq & 63), steady-clock ns: call entry, pose written / launch returned, result seen, fired?                   // light profiling: event pairs of cancelled armed launches (not counted)
 
@@ -163,8 +157,6 @@ struct srl_ctx {
     srl_timing timing = {};
     int last_nb = 1;
 };
-
-#define SRL_SOLVE_LOG_ROWS 32
 
 #define HIPCHK(ctx, call)                                                                      \
     do {                                                                                       \

@@ -14,9 +14,9 @@
 //   * partials  : per workgroup 32 doubles (21 upper-tri HtH, 6 Hth, loss) + counts.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
-#include "srl_iekf_wave.h"
 
 #define SRL_CAP 20
 #define SRL_SLAB_BYTES 256
@@ -79,10 +79,15 @@ struct SrlDevOut {             // result of the reduce kernel (device, then copi
 };
 
 struct SrlMailbox {            // host-mapped (fine-grained) memory the reduce kernel publishes into (single rank)
-    SrlDevOut out;
-    unsigned long long seq;    // = launch sequence number once `out` is complete
-    unsigned long long pad[7];
+    SrlDevOut out;             // plain form: the record ...
+    unsigned long long seq;    // ... = launch sequence number once `out` is complete
+    unsigned long long pad[11];   // (g starts on a 64-byte line)
+    // tagged form (the fused finisher of a single-context pass): word w of the record as granules g[2w], g[2w + 1] = {low 32 bits of the
+    // sequence number, 32-bit half} -- "the data is the flag": no drain and no second PCIe write behind the data
+    unsigned long long g[2 * (sizeof(SrlDevOut) / 8)];
 };
+static_assert(sizeof(SrlDevOut) == 52 * 8 && offsetof(SrlDevOut, pad) == 51 * 8, "SrlDevOut is 52 words, the marker word last");
+static_assert(offsetof(SrlMailbox, g) % 64 == 0, "the tagged record starts on a cache line");
 
 // ---- armed launches: the pose box
 #define SRL_POSE_BOX_CTRL 42       // granule index of the control word {epoch, code}; granules 2d, 2d + 1 = halves of pose double d (Rn R t)
@@ -145,6 +150,8 @@ struct SrlAssocArgs {
     unsigned long long *rec_granules;   // fused ORDERED CUT: per keypoint 16 tagged granules = the record {J[6], distance, weight} (else null)
     long long cut_max;              // fused ordered cut: max_num_residuals (> 0), the sequential loop's budget (optimize.cpp:107); 0 = no cut possible
     SrlMailbox *mailbox;        // host-mapped result mailbox (fused + RCCL: a device-side mailbox the all-reduce then works on)
+    int mail_tagged;            // 1: the finisher reports in the mailbox's tagged form (host mailbox), 0: plain form + sequence word
+    int pad_mail;
     unsigned long long seq;     // launch sequence number published with the result
     // ARMED launch (enqueued before its pose exists; null = the pose is Rn / R / t above): see assoc_body's prologue
     const unsigned long long *pose_box;   // tagged granules the host writes: 2 x 21 pose halves + the control granule
@@ -168,36 +175,8 @@ struct SrlAssocArgs {
     double *tap_offset;     // n
 };
 
-// ---- persistent solve (one launch per updateIEKF, optimize.cpp:133-314): second kernel argument, behind SrlAssocArgs ----
-struct SrlSolveMailbox {       // host-mapped (fine-grained): what the finishing workgroup leaves when the loop ends
-    double state[19];          // the filter after the last observe(): p q(wxyz) v ba bg g
-    double cov[289];           // posterior covariance (valid when covariance_updated)
-    SrlDevOut last;            // normal equations of the last pass
-    long long verdict;         // srlw::IEKF_*
-    long long iterations;      // passes that delivered normal equations
-    long long covariance_updated;
-    long long observed;        // observe() calls (optimize.cpp:253)
-    unsigned long long seq;    // = launch sequence number once everything above is complete
-    unsigned long long pad[7];
-};
-#define SRL_SOLVE_K 20         // max_number_neighbors the persistent solve kernel is built for (both shipped yaml files)
-#define SRL_POSE_DOUBLES 22    // what the finishing workgroup hands to the others after a pass: Rn[9] R[9] t[3] verdict
-struct SrlSolveArgs {
-    srlw::IekfConsts K;
-    double state0[19];         // eskfEstimator state at entry
-    double cov0[289];          // its covariance, row-major
-    unsigned long long *pose_granules;   // 2 * SRL_POSE_DOUBLES tagged granules {epoch, 32-bit half}
-    SrlSolveMailbox *mailbox;
-    double *log;               // host-mapped: 61 doubles per pass (HtH Hth d_x num_residuals loss), or null
-    int max_log;
-    int min_residuals;         // min_number_neighbors: fewer accepted residuals fail the solve (optimize.cpp:110)
-    int ntiles;                // tiles of KPW x 16 keypoints; workgroup b takes tiles b, b + gridDim, ...
-    int prefix;                // finite max_num_residuals: only a prefix of the shard is associated (too few accepted -> the host repeats)
-    int exact_lu;              // 1: both 17 x 17 inverses by partial-pivot LU in the host's order; 0: the Schur-complement form (srl_iekf_wave.h)
-    int pad;
-    long long *stamps;         // debug (srl_debug_solve_stamps): 16 wall-clock stamps per pass, host-mapped; null = off
-};
-static_assert(sizeof(SrlAssocArgs) + sizeof(SrlSolveArgs) <= 4096, "both structs travel in the kernarg segment");
+#define SRL_POSE_DOUBLES 22    // armed launches: the LDS pose block Rn[9] R[9] t[3] (+ one spare), the control word behind it
+static_assert(sizeof(SrlAssocArgs) <= 4096, "the struct travels in the kernarg segment");
 
 struct SrlReduceArgs {
     const double *rec;
@@ -234,9 +213,6 @@ struct SrlSearchArgs {
 // launchers (srl_kernels.hip)
 hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpw, int wpb, hipStream_t s);
 int srl_assoc_lds_bytes(int K, int nb_voxels, int kpw, int wpb);
-// persistent solve: 16-wave workgroups, `grid` of them (<= compute units: every workgroup must be resident)
-hipError_t srl_launch_solve(const SrlAssocArgs &a, const SrlSolveArgs &sv, int nb_voxels, int kpw, int grid, hipStream_t s);
-int srl_solve_lds_bytes(int K, int nb_voxels, int kpw);
 // keypoints per wave for a pass over n keypoints: the largest of 4 / 8 / 16 that still yields >= ~4096 waves
 static inline int srl_keypoints_per_wave(int n) { return n <= 16384 ? 4 : (n <= 32768 ? 8 : 16); }
 // ... and for 16-wave workgroups that fuse the final reduction: the smallest instantiated count that still puts the sweep on

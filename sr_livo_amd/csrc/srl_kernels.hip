@@ -983,9 +983,9 @@ struct LdsLayout {
     int off_nb, off_pw, off_pimu, off_qf, off_kv, off_nfound, off_ncand, off_next, off_defer;
     int off_wave, wave_bytes, off_vox, off_scratch;     // per-wave: off_wave + w * wave_bytes + {off_vox, off_scratch}
     int off_wpart, off_winfo, total;
-    int off_pose, off_out, off_iekf, off_rowacc;      // persistent solve only
+    int off_pose;                  // armed launches only: the pose of this pass + the control word
 };
-__host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, int wpb, int persist = 0) {
+__host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, int wpb, int armed = 0) {
     const int kpb = wpb * kpw;
     LdsLayout L;
     // stride = 17 (mod 32): the K winner lanes of one keypoint and the (keypoint, sub-lane) readers of phase 2 spread over the banks
@@ -1009,17 +1009,8 @@ __host__ __device__ inline LdsLayout lds_layout(int K, int nb_voxels, int kpw, i
     o += wpb * w;
     L.off_wpart = o;   o += wpb * 32 * 8;
     L.off_winfo = o;   o += wpb * 8 * 4;
-    L.off_pose = L.off_out = L.off_iekf = L.off_rowacc = o;
-    if (persist == 2) {
-        // armed launch: the pose of this pass arrives through the pose box (Rn[9] R[9] t[3]) + the control word
-        L.off_pose = o;   o += up16((SRL_POSE_DOUBLES + 2) * 8);
-    } else if (persist) {
-        // the pose of the running pass (+ verdict), the finishing workgroup's normal equations and its filter / matrices
-        L.off_pose = o;   o += up16(SRL_POSE_DOUBLES * 8);
-        L.off_out = o;    o += up16((int)sizeof(SrlDevOut));
-        L.off_iekf = o;   o += up16((int)sizeof(srlw::IekfShared));
-        L.off_rowacc = o; o += 32 * 8;                      // this workgroup's row, summed over its tiles
-    }
+    L.off_pose = o;
+    if (armed) o += up16((SRL_POSE_DOUBLES + 2) * 8);          // Rn[9] R[9] t[3] as they arrive through the pose box, + the control word
     L.total = o;
     return L;
 }
@@ -1039,12 +1030,18 @@ typedef const __attribute__((address_space(4))) char *KargBytes;
 #else
 typedef const char *KargBytes;
 #endif
-// debug time line of the persistent solve (tools/persist_probe.py): slot k of pass `iter`, 100 MHz wall clock
+// one 64-bit word as two tagged granules {tag, low half} {tag, high half} in ONE 16-byte system-scope store: the lanes of a wave
+// write consecutive 16-byte chunks, i.e. whole 64-byte lines (52 lanes = 13 lines) -- as 8-byte stores at stride 16 the same bytes
+// crossed PCIe as 104 partial-line writes and reached the host 10-16 us later (measured, tools/arm_timeline.py)
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ void solve_stamp(const __attribute__((address_space(4))) SrlSolveArgs *sp, int iter, int slot) {
-    long long *st = sp->stamps;
-    if (st != nullptr && iter < 16) __hip_atomic_store(st + iter * 16 + slot, (long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+__device__ __forceinline__ void store_granule_pair(unsigned long long *dst, unsigned tag, unsigned long long w) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u v;
+    v.x = (unsigned)w; v.y = tag; v.z = (unsigned)(w >> 32); v.w = tag;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
 }
+#else
+__device__ inline void store_granule_pair(unsigned long long *, unsigned, unsigned long long) {}
 #endif
 
 // debug time line of an ARMED pass (srl_debug_pass_stamps, tools/arm_timeline.py): workgroup 0 files slots 0..7, the finishing
@@ -1066,50 +1063,24 @@ __device__ __forceinline__ void arm_stamp(KargBytes karg, int slot) {
 __device__ inline void arm_stamp(KargBytes, int) {}
 #endif
 
-// The 17-dim update of the persistent solve as two real functions (not inlined: their registers and their code stay out of
-// the association loop's allocation).  sv = the solve arguments in the kernarg segment, lds_off = byte offset of the
-// finishing workgroup's IekfShared in LDS (the address space is re-established here, so the accesses are ds_ instructions).
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __attribute__((address_space(3))) srlw::IekfShared *IekfLdsPtr;
-__device__ __attribute__((noinline)) void dev_iekf_prior(const SrlSolveArgs *sv, unsigned lds_off) {
-    srlw::IekfShared &sh = *(srlw::IekfShared *)(IekfLdsPtr)(size_t)lds_off;
-    const srlw::IekfConsts K = sv->K;
-    if (sv->exact_lu) srlw::iekf_prior<srlw::DevWave, false>(K, sv->cov0, sh);
-    else srlw::iekf_prior<srlw::DevWave, true>(K, sv->cov0, sh);
-}
-__device__ __attribute__((noinline)) int dev_iekf_update(const SrlSolveArgs *sv, int iter, unsigned lds_off) {
-    srlw::IekfShared &sh = *(srlw::IekfShared *)(IekfLdsPtr)(size_t)lds_off;
-    const srlw::IekfConsts K = sv->K;
-    return sv->exact_lu ? srlw::iekf_update<srlw::DevWave, false>(K, iter, sh, sh.temp) : srlw::iekf_update<srlw::DevWave, true>(K, iter, sh, sh.temp);
-}
-#endif
-
 // Phase 2 geometry: lanes per keypoint and keypoints per phase-2 wave for a workgroup of kpb keypoints.  One lane per
 // keypoint from 48 keypoints on.  (Half-filled phase-2 waves -- 32 keypoints each, twice as many waves so that two dependent
 // FP64 chains interleave per SIMD -- were measured in round 3: no gain)
 __host__ __device__ constexpr int p2_lanes_per_keypoint(int kpb) { return kpb >= 48 ? 1 : (kpb >= 32 ? 2 : 4); }
 __host__ __device__ constexpr int p2_keypoints_per_wave(int kpb) { return 64 / p2_lanes_per_keypoint(kpb); }
 
-// PERSIST = 1: the persistent solve (srl_solve_kernel below) -- the same three phases inside the ESIKF loop of
-// optimize.cpp:147-312: every workgroup walks its tiles of KPB keypoints, publishes ONE row per pass, the last workgroup
-// of the grid sums the rows, one of its waves runs the 17-dim update (srl_iekf_wave.h) and hands the next pose (or the
-// verdict that ends the loop) to the others as tagged granules.  The pose then comes from LDS, not from the kernarg.
+// ARMED = 1: the pass as an armed launch (assoc_body's prologue): the pose sits in LDS, not in the kernarg segment.
 // DBG = 1: the instantiation the profiling tools run (srl_debug_set_ablate: parts of the kernel switched off at run time, workgroup
 // time stamps).  The production instantiations carry none of those tests: read in the pair loop they cost ~10 lane reads of
 // spilled flags per keypoint pair (headline launch 49.4 -> 48.4 us together with the probe reordering below).
-template <int NB, int FAST, int KPW, int WPB, int PERSIST, int DBG = 0, int ARMED = 0>
-__device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A, const int tile, const bool do_prior, const int iter) {
+template <int NB, int FAST, int KPW, int WPB, int DBG = 0, int ARMED = 0>
+__device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A, const int tile) {
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // Persistent solve: max_number_neighbors is the shipped 20 at compile time (the host routes any other value through the
-    // one-shot kernel): the LDS carve becomes a set of immediates instead of a dozen live SGPRs, and the taps / debug
-    // switches of the one-shot kernel do not exist -- what the selection loop needs on top of the one-shot kernel's budget
-    // (stack pointer, scratch descriptor of a kernel with calls) has to come from somewhere.
-    constexpr int KC = PERSIST ? SRL_SOLVE_K : 0;
-    const int Kn = KC ? KC : A.K;
-    const int abl = (DBG && !PERSIST) ? A.ablate : 0;
-    constexpr bool POSE_LDS = PERSIST || ARMED;                           // the pose of this pass sits in LDS, not in the kernarg
-    const LdsLayout L = lds_layout(Kn, NB, KPW, WPB, PERSIST ? 1 : (ARMED ? 2 : 0));
+    const int Kn = A.K;
+    const int abl = DBG ? A.ablate : 0;
+    constexpr bool POSE_LDS = ARMED != 0;                                 // the pose of this pass sits in LDS, not in the kernarg
+    const LdsLayout L = lds_layout(Kn, NB, KPW, WPB, ARMED);
     const int NB_ROW = L.nb_row;
     const int tid = threadIdx.x;
     const int lane = lane_id();
@@ -1132,23 +1103,15 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     double *s_wpart = reinterpret_cast<double *>(smem + L.off_wpart);     // [4][32]
     int *s_winfo = reinterpret_cast<int *>(smem + L.off_winfo);           // [WPB][8]: accepted, sum_pk, 1 + first NaN keypoint, fallback, planes
 
-    const long long dbg_t0 = (DBG && !PERSIST && (abl & 128)) ? (long long)wall_clock64() : 0;   // debug: workgroup start (100 MHz clock)
+    const long long dbg_t0 = (DBG && (abl & 128)) ? (long long)wall_clock64() : 0;   // debug: workgroup start (100 MHz clock)
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
-    typedef const __attribute__((address_space(4))) SrlSolveArgs *SolveargPtr;
 #endif
-    double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);       // persistent solve: Rn[9] | R[9] | t[3] of the running pass
-    srlw::IekfShared *s_iekf = reinterpret_cast<srlw::IekfShared *>(smem + L.off_iekf);
+    double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);       // armed launch: Rn[9] | R[9] | t[3] of this pass
     int n_fallback = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     auto tile_stamp = [&](int slot) {
-        if constexpr (PERSIST) {
-            if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && tid == 0) {     // workgroup 0: slots 10..13; finishing workgroup: 15, 6, 7, 14
-                SolveargPtr sq = (SolveargPtr)(karg + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
-                const int fs = slot == 10 ? 15 : (slot == 11 ? 6 : (slot == 12 ? 7 : 14));
-                solve_stamp(sq, iter, blockIdx.x == 0 ? slot : fs);
-            }
-        } else if constexpr (ARMED) {
+        if constexpr (ARMED) {
             arm_stamp(karg, slot - 8);                                   // 10..13 -> slots 2..5: phase 0 / 1 / 2 done
         }
     };
@@ -1203,19 +1166,6 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     __syncthreads();
     tile_stamp(11);
 
-    // ---------------- persistent solve: the H-independent half of the 17-dim update (optimize.cpp:172-234) on the last
-    // wave of the finishing workgroup, before it joins the pair loop below (the other 15 waves start on the pairs)
-    if constexpr (PERSIST) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (do_prior && wave == WPB - 1) {
-            SolveargPtr sp = (SolveargPtr)(karg + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
-            asm volatile("" : "+s"(sp));
-            if (lane == 0) solve_stamp(sp, iter, 0);
-            dev_iekf_prior((const SrlSolveArgs *)sp, (unsigned)(size_t)(IekfLdsPtr)s_iekf);
-            if (lane == 0) solve_stamp(sp, iter, 1);
-        }
-#endif
-    }
     // ---------------- phase 1: searchNeighbors, the whole wave on one keypoint at a time
     {
         const int left = A.n - bbase_kp;
@@ -1225,7 +1175,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
             sink.col = s_nb + kl;
             sink.row = NB_ROW;
             sink.plane = nb_plane;
-            sink.tap_ids = (!PERSIST && A.tap_ids) ? (A.tap_ids + (size_t)(bbase_kp + kl) * Kn) : nullptr;
+            sink.tap_ids = A.tap_ids ? (A.tap_ids + (size_t)(bbase_kp + kl) * Kn) : nullptr;
             return sink;
         };
         // general path for one keypoint (own hash probes; tie = replay the reference's heap directly)
@@ -1345,7 +1295,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     __syncthreads();
     tile_stamp(12);
 
-    if (!PERSIST && (abl & 64)) return true;                              // debug: phase 0 + loop skeleton only
+    if (abl & 64) return true;                              // debug: phase 0 + loop skeleton only
     // Phase 2 re-reads its parameters from the kernarg segment through a laundered pointer: kept live across phase 1
     // they cost ~70 SGPRs and pushed the selection loop into SGPR spills (v_readlane / v_writelane).
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1387,7 +1337,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     const int nc2 = owner_lane ? s_ncand[kl] : 0;
     const int nf = nc2 < Kn ? nc2 : Kn;
     if (g < b.n) status = 0;
-    const bool fit = (g < b.n) && (nf >= b.min_nb) && !(DBG && !PERSIST && (b.ablate & 1));
+    const bool fit = (g < b.n) && (nf >= b.min_nb) && !(DBG && (b.ablate & 1));
     if (fit) {
 #pragma clang fp contract(fast)      // plane fit / weights / Jacobian are tolerance-bound (1e-9 vs the oracle): products may fuse
         const D3 p_imu = d3(s_pimu[kl * 3 + 0], s_pimu[kl * 3 + 1], s_pimu[kl * 3 + 2]);
@@ -1432,7 +1382,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         weight = b.lambda_w * w_plan + b.lambda_n * exp(-sqrt(dot3(dq, dq)) * rcp_nr(b.nbr_scale));   // optimize.cpp:87-88
         const D3 nv = normalized3_fast(nrm);                       // optimize.cpp:93
         const double off = -dot3(nv, nn0);                         // optimize.cpp:94
-        // the residual uses the un-normalised rotation (optimize.cpp:95,101); persistent solve: the pose block of this pass
+        // the residual uses the un-normalised rotation (optimize.cpp:95,101); armed launch: the pose block in LDS
         double Rm[9], tv[3];
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rm[i] = POSE_LDS ? s_pose[9 + i] : b.R[i];
@@ -1441,7 +1391,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         const D3 pe = add(matvec(Rm, p_imu), d3(tv[0], tv[1], tv[2]));
         dist = dot3(nv, pe) + off;                                 // optimize.cpp:95
         status = 1;
-        if (!PERSIST && b.tap_normal && sl == 0) {
+        if (b.tap_normal && sl == 0) {
             b.tap_normal[(size_t)g * 3 + 0] = nv.x; b.tap_normal[(size_t)g * 3 + 1] = nv.y; b.tap_normal[(size_t)g * 3 + 2] = nv.z;
             b.tap_a2d[g] = a2D;
             b.tap_offset[g] = off;
@@ -1461,7 +1411,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
             J[3] = s0 * weight; J[4] = s1 * weight; J[5] = s2 * weight;
         }
     }
-    if (!PERSIST && g < b.n && b.write_rec && sl == 0) {
+    if (g < b.n && b.write_rec && sl == 0) {
         // per-keypoint record {J[6], distance, weight} (ordered cut-off path + taps; never on the throughput path)
         double2 *r = reinterpret_cast<double2 *>(b.rec + (size_t)g * 8);
         double2 v;
@@ -1479,7 +1429,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         typedef __attribute__((address_space(1))) unsigned long long gu64r;
         const bool accd = status == 2;
         const double rec8[8] = {J[0], J[1], J[2], J[3], J[4], J[5], dist, weight};
-        const unsigned long long tag = (unsigned long long)((unsigned)b.seq + (unsigned)iter) << 32;   // the epoch of this pass
+        const unsigned long long tag = (unsigned long long)(unsigned)b.seq << 32;   // the epoch of this pass
         gu64r *dst = (gu64r *)(b.rec_granules + ((size_t)blockIdx.x * KPB + kl) * 16);
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
@@ -1565,7 +1515,6 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     __syncthreads();
     tile_stamp(13);
 
-    if constexpr (!PERSIST) {
     if (DBG && (b.ablate & 128) && (tid == 28 || tid == 29 || tid == 30))        // debug: start / end stamps of this workgroup in the spare slots
         b.partials[(size_t)blockIdx.x * SRL_PART_STRIDE + tid] =
             (tid == 28) ? (double)dbg_t0 : ((tid == 29) ? (double)(long long)wall_clock64() : (double)__builtin_amdgcn_s_getreg(6164) /* XCC_ID */);
@@ -1588,9 +1537,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         }
         b.binfo[blockIdx.x] = bi;
     }
-    if (b.granules == nullptr) return true;
-    }
-    return false;
+    return b.granules == nullptr;       // true: not fused -- the reduce kernel takes it from here
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1638,31 +1585,43 @@ __device__ __forceinline__ bool peer_exchange(const SrlPeerTable *pt, unsigned e
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The finishing workgroup: sums the published rows (with the ordered cut of optimize.cpp:107 when max_num_residuals can
-// bind) and leaves the normal equations -- one-shot kernel: in the host mailbox; persistent solve: in its LDS, where its
-// last wave runs the 17-dim update and hands the next pose / the verdict to the other workgroups.
+// bind) and sends the normal equations to the host mailbox.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KPW, int WPB, int NBV, int PERSIST>
-__device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, const unsigned epoch) {
+template <int KPW, int WPB>
+__device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
-    typedef const __attribute__((address_space(4))) SrlSolveArgs *SolveargPtr;
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     KernargPtr bq = (KernargPtr)karg;
     asm volatile("" : "+s"(bq));
     const __attribute__((address_space(4))) SrlAssocArgs &b = *bq;
-    const LdsLayout L = lds_layout(PERSIST ? SRL_SOLVE_K : b.K, NBV, KPW, WPB, PERSIST);
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wave = tid >> 6;
-    double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);
-    SrlDevOut *s_out = reinterpret_cast<SrlDevOut *>(smem + L.off_out);
-    srlw::IekfShared *s_iekf = reinterpret_cast<srlw::IekfShared *>(smem + L.off_iekf);
-    // where the finishing workgroup leaves the normal equations: the host mailbox (system-scope stores), or -- persistent
-    // solve -- its own LDS, for the wave that runs the 17-dim update
-    auto put_f = [](double *p, double x) { if constexpr (PERSIST) *p = x; else __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-    auto put_i = [](long long *p, long long x) { if constexpr (PERSIST) *p = x; else __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    (void)lane; (void)wave;
+    // The normal equations are assembled in LDS (every writer sits in wave 0) and leave in ONE step: mail_out() below.
+    auto put_f = [](double *p, double x) { *p = x; };
+    auto put_i = [](long long *p, long long x) { *p = x; };
+    // mail_out: wave 0 sends the 52 words of the staged SrlDevOut.  Tagged form (the host mailbox of a single-context pass): word w
+    // travels as two granules {sequence number, 32-bit half} -- the host checks the tags, so no store has to wait for another (the
+    // plain form pays a drain + a second PCIe write for the sequence word: ~1.2 us).  Plain form: a device-side mailbox the RCCL
+    // all-reduce works on, read as doubles.
+    auto mail_out = [&](const SrlDevOut *staged) {
+        constexpr int NW = (int)(sizeof(SrlDevOut) / 8);
+        if (tid < 64) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned long long w = tid < NW ? reinterpret_cast<const unsigned long long *>(staged)[tid] : 0ull;
+            if (b.mail_tagged) {
+                if (tid < NW) store_granule_pair(&b.mailbox->g[2 * tid], (unsigned)b.seq, w);
+            } else {
+                if (tid < NW) __hip_atomic_store(reinterpret_cast<unsigned long long *>(&b.mailbox->out) + tid, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (tid == 0) __hip_atomic_store(&b.mailbox->seq, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
     if (b.cut_max > 0) {
         // ---- finisher WITH the ordered cut (optimize.cpp:107: the sequential loop stops at the max-th accepted residual).
         // (a) every thread t < #workgroups reads the counters of row t; a prefix over the accepted counts finds the workgroup c that
@@ -1796,7 +1755,7 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
                 s_part[tid] = sum;
             }
             __syncthreads();
-            SrlDevOut *out = PERSIST ? s_out : &b.mailbox->out;
+            SrlDevOut *out = reinterpret_cast<SrlDevOut *>(smem + NPART * 32 * 8 + SRL_FUSED_CUT_MAX_KPB * 64 + WPB * 8 + 64);
             if (tid < 21) {
                 int ia = 0, cc = tid, rowlen = 6;
                 while (cc >= rowlen) { cc -= rowlen; ia++; rowlen--; }
@@ -1819,14 +1778,9 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
                 put_i(&out->last_visited, last_visited);
                 put_i(&out->pad, s_i[0] ? 0x7117ll : 0ll);      // time-out marker
             }
-            if constexpr (!PERSIST) {
-            if (tid < 64) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (tid == 0) __hip_atomic_store(&b.mailbox->seq, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            }
+            mail_out(out);
         }
-        if constexpr (!PERSIST) return;
+        return;
     } else {
         // deterministic: part p sums rows p, p + NPART, ... ascending; parts are then added in order
         constexpr int NT = 64 * WPB, NPART = NT / 32, INF = 8;
@@ -1861,20 +1815,20 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
             for (int k = 0; k < INF; ++k) s0 += __longlong_as_double((long long)(((unsigned long long)hi[k] << 32) | lo[k]));
         }
         if (timed_out) atomicOr(s_bad, 1);
-        if constexpr (!PERSIST) arm_stamp(karg, 16);
+        arm_stamp(karg, 16);
         s_part[part * 32 + comp] = s0;
         __syncthreads();
-        if constexpr (!PERSIST) arm_stamp(karg, 17);
+        arm_stamp(karg, 17);
         if (tid < 32) {
             double sum = s_part[tid];
             for (int p = 1; p < NPART; ++p) sum += s_part[p * 32 + tid];
             s_part[tid] = sum;                                             // row 0 = the totals
         }
         __syncthreads();
-        if constexpr (!PERSIST) arm_stamp(karg, 18);
-        SrlDevOut *out = PERSIST ? s_out : &b.mailbox->out;
+        arm_stamp(karg, 18);
+        SrlDevOut *out = reinterpret_cast<SrlDevOut *>(smem + NPART * 32 * 8 + 64);
         bool peer_done = false;
-        if constexpr (!PERSIST) {
+        {
             if (b.peer) {
                 // sharded sweep with direct peer exchange: wave 0 lays this rank's totals out as SrlDevOut's leading doubles,
                 // exchanges them with the other ranks' finishing workgroups and publishes the sum -- still one kernel per pass
@@ -1925,116 +1879,14 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const int iter, cons
             put_i(&out->last_visited, (long long)b.n - 1);
             put_i(&out->pad, *s_bad ? 0x7117ll : 0ll);          // time-out marker
         }
-        if constexpr (!PERSIST) {
-        if (tid < 64) {
-            arm_stamp(karg, 19);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every mailbox writer sits in wave 0
-            arm_stamp(karg, 20);
-            if (tid == 0) __hip_atomic_store(&b.mailbox->seq, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        }
-    }
-    if constexpr (PERSIST) {
-        using namespace srlw;
-        SolveargPtr sp = (SolveargPtr)(karg + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
-        asm volatile("" : "+s"(sp));
-        __syncthreads();                                               // s_out is complete
-        if (wave == WPB - 1) {
-            int verdict;
-            if (lane == 0) solve_stamp(sp, iter, 3);
-            const int obs_before = s_iekf->observed;
-            const int num_res = (int)(s_out->d_num_res + 0.5);
-            if (s_out->pad != 0) verdict = IEKF_TIMEOUT;
-            else if (s_out->d_nan > 0.5) verdict = IEKF_NAN;                                     // optimize.cpp:348-350
-            else if (sp->prefix && (long long)num_res < b.cut_max) verdict = IEKF_PREFIX_SHORT;  // nothing can be concluded from the prefix
-            else if (num_res < sp->min_residuals) verdict = IEKF_FAIL_RESIDUALS;                 // optimize.cpp:110-123
-            else {
-                s_iekf->passes = s_iekf->passes + 1;
-                if (lane < 36) s_iekf->HtH[lane] = s_out->HtH[lane];
-                if (lane < 6) s_iekf->Hth[lane] = s_out->Hth[lane];
-                DevWave::barrier();
-                verdict = dev_iekf_update((const SrlSolveArgs *)sp, iter, (unsigned)(size_t)(IekfLdsPtr)s_iekf);
-                if (s_iekf->singular) verdict = IEKF_SINGULAR;
-                if (sp->log != nullptr && iter < sp->max_log && lane < 61) {
-                    // per-pass log row: HtH(36) Hth(6) d_x(17) num_residuals loss
-                    const double x = lane < 36 ? s_out->HtH[lane] : (lane < 42 ? s_out->Hth[lane - 36] : (lane < 59 ? s_iekf->d_x[lane - 42] : (lane == 59 ? (double)num_res : s_out->loss)));
-                    __hip_atomic_store(sp->log + (size_t)iter * 61 + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
-            // the pose of the next pass is the filter's once observe() has run (optimize.cpp:253-256; a guarded pass leaves
-            // p_frame->p_state alone): Rn = R(q.normalized()), R = R(q) as the host computes them for the one-shot kernel
-            if (verdict == IEKF_CONTINUE && s_iekf->observed != obs_before) {
-                const srl::Quat q(s_iekf->state[3], s_iekf->state[4], s_iekf->state[5], s_iekf->state[6]);
-                const srl::Mat3 Rn = q.normalized().toRotationMatrix();
-                const srl::Mat3 R = q.toRotationMatrix();
-                if (lane == 0) {
-                    for (int i = 0; i < 9; ++i) { s_pose[i] = Rn.a[i]; s_pose[9 + i] = R.a[i]; }
-                    for (int i = 0; i < 3; ++i) s_pose[18 + i] = s_iekf->state[i];
-                }
-            }
-            if (lane == 0) solve_stamp(sp, iter, 4);
-            if (lane == 0) s_pose[21] = (double)verdict;
-            DevWave::barrier();
-            if (lane < 2 * SRL_POSE_DOUBLES) {
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(s_pose[lane >> 1]);
-                const unsigned half = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
-                __hip_atomic_store((gu64 *)(sp->pose_granules + lane), ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (lane == 0) solve_stamp(sp, iter, 5);
-            if (verdict != IEKF_CONTINUE) {
-                // the loop is over: filter, posterior covariance, the last normal equations and the summary go to the host
-                SrlSolveMailbox *mb = sp->mailbox;
-                if (lane < 19) __hip_atomic_store(&mb->state[lane], s_iekf->state[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (verdict == IEKF_DONE)
-                    for (int i = lane; i < 289; i += 64) __hip_atomic_store(&mb->cov[i], s_iekf->temp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                {
-                    constexpr int NW = (int)(sizeof(SrlDevOut) / 8);
-                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(s_out);
-                    unsigned long long *dst = reinterpret_cast<unsigned long long *>(&mb->last);
-                    if (lane < NW) __hip_atomic_store(dst + lane, src[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-                if (lane == 0) {
-                    __hip_atomic_store(&mb->verdict, (long long)verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(&mb->iterations, (long long)s_iekf->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(&mb->covariance_updated, verdict == IEKF_DONE ? 1ll : 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(&mb->observed, (long long)s_iekf->observed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(&mb->seq, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+        arm_stamp(karg, 19);
+        mail_out(out);                                                     // every writer of the staged record sits in wave 0
+        arm_stamp(karg, 20);
     }
 #endif
 }
-// the persistent solve calls it as a real function, from the waves of the finishing workgroup only (16 of 4 096: the
-// callee-saved registers it spills cost nothing, and its registers stay out of the association loop's allocation)
-template <int NB, int KPW>
-__device__ __attribute__((noinline)) void finish_rows_call(KargBytes karg, const int iter, const unsigned epoch) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // arguments of a called function arrive in VGPRs: make the (wave-uniform) pointer scalar again
-    const unsigned long long kb = (unsigned long long)karg;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kb), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kb >> 32));
-    finish_rows<KPW, 16, NB, 1>((KargBytes)(((unsigned long long)hi << 32) | lo), __builtin_amdgcn_readfirstlane(iter), (unsigned)__builtin_amdgcn_readfirstlane((int)epoch));
-#endif
-}
 
-// The persistent solve runs a tile as a REAL function: its register allocation is the one-shot kernel's (the selection loop
-// sits at 123 of 128 VGPRs and at the SGPR limit; inlined into the pass loop it spills its candidate rounds), and nothing of it
-// stays live across the reduction and the hand-over.  Built with -mllvm -enable-ipra: the function has one caller, the
-// kernel, which keeps nothing in registers across the call, so no callee-saved register is saved or restored.
-template <int NB, int KPW>
-__device__ __attribute__((noinline)) void assoc_tile_call(KargBytes karg, const int tile, const bool do_prior, const int iter) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned long long kb = (unsigned long long)karg;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kb), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kb >> 32));
-    typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
-    const KargBytes ks = (KargBytes)(((unsigned long long)hi << 32) | lo);
-    assoc_tile<NB, 1, KPW, 16, 1>(ks, *(const SrlAssocArgs *)(KernargPtr)ks, __builtin_amdgcn_readfirstlane(tile),
-                                  __builtin_amdgcn_readfirstlane((int)do_prior) != 0, __builtin_amdgcn_readfirstlane(iter));
-#endif
-}
-
-template <int NB, int FAST, int KPW, int WPB, int PERSIST, int DBG = 0, int ARMED = 0>
+template <int NB, int FAST, int KPW, int WPB, int DBG = 0, int ARMED = 0>
 __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2042,23 +1894,11 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
     if (a.ablate & 16) return;                                            // debug: launch/drain floor
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
-    typedef const __attribute__((address_space(4))) SrlSolveArgs *SolveargPtr;
 #endif
-    // The LDS carve.  Persistent solve: re-derived from a freshly read max_number_neighbors wherever it is needed -- kept in
-    // registers across the tiles its dozen offsets, like everything else that outlives a tile, come out of the selection
-    // loop's budget (the one-shot kernel runs at 123 of 128 VGPRs and 102 of 102 SGPRs; two SGPR spill registers more and
-    // the loop spills its candidate rounds).
-    auto carve = [&]() -> LdsLayout {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (PERSIST) {
-            KernargPtr q = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(q));
-            return lds_layout(SRL_SOLVE_K, NB, KPW, WPB, PERSIST);
-        }
-#endif
-        return lds_layout(a.K, NB, KPW, WPB, ARMED ? 2 : 0);
-    };
-    if constexpr (ARMED && !PERSIST) {
+    // the LDS carve is re-derived from max_number_neighbors wherever it is needed: kept in registers its dozen offsets come out of
+    // the selection loop's budget (the kernel runs at 121 of 128 VGPRs and at the SGPR limit)
+    auto carve = [&]() -> LdsLayout { return lds_layout(a.K, NB, KPW, WPB, ARMED); };
+    if constexpr (ARMED) {
 #if defined(__HIP_DEVICE_COMPILE__)
         // ---- ARMED launch (srl_capi.cpp: arm_next): this kernel was enqueued while the pass before it was still running, before
         // its pose existed; its workgroups are resident and waiting when the host has finished the 17-dim update, so the launch call,
@@ -2109,53 +1949,22 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         {
             const int code = *s_ctrl;
             if (code != (int)SRL_ARM_GO) {
-                if (code == (int)SRL_ARM_EXPIRED && blockIdx.x == gridDim.x - 1 && tid == 0) {
+                if (code == (int)SRL_ARM_EXPIRED && blockIdx.x == gridDim.x - 1 && tid < 64) {
                     // nobody is listening any more: a host that fires this launch after all learns it from the mailbox and relaunches
-                    __hip_atomic_store(&a.mailbox->out.pad, (long long)SRL_ARM_EXPIRED_MARK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(&a.mailbox->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // (an armed launch always reports into the tagged host mailbox: zeros + the marker in SrlDevOut::pad, the last word)
+                    constexpr int NW = (int)(sizeof(SrlDevOut) / 8);
+                    const unsigned long long w = tid == NW - 1 ? (unsigned long long)SRL_ARM_EXPIRED_MARK : 0ull;
+                    if (tid < NW) store_granule_pair(&a.mailbox->g[2 * tid], (unsigned)a.seq, w);
                 }
                 return;
             }
         }
 #endif
     }
-    if constexpr (PERSIST) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        // ---- persistent solve: pose block of the first pass, the finishing workgroup's filter
-        const LdsLayout L = carve();
-        double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);       // Rn[9] | R[9] | t[3] | verdict of the pass before
-        srlw::IekfShared *s_iekf = reinterpret_cast<srlw::IekfShared *>(smem + L.off_iekf);
-        SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
-        const bool fin = blockIdx.x == gridDim.x - 1;
-        if (tid < 9) { s_pose[tid] = a.Rn[tid]; s_pose[9 + tid] = a.R[tid]; }
-        if (tid < 3) s_pose[18 + tid] = a.t[tid];
-        if (fin && tid < 19) s_iekf->state[tid] = sp->state0[tid];
-        if (fin && tid == 19) { s_iekf->singular = 0; s_iekf->observed = 0; s_iekf->passes = 0; }
-#endif
-        __syncthreads();
-    }
-  for (int iter = 0;; ++iter) {                                           // ESIKF passes (PERSIST == 0: one trip, every path returns)
-    double row_v = 0.0;                                                   // one-shot kernel, tid < 32: component tid of this workgroup's row
-    if constexpr (PERSIST) {                                              // persistent solve: the row lives in LDS across the tiles
-        const LdsLayout L = carve();
-        if (tid < 32) reinterpret_cast<double *>(smem + L.off_rowacc)[tid] = 0.0;
-    }
-   for (int tile = blockIdx.x;; tile += (int)gridDim.x) {
-    if constexpr (PERSIST) {
-        // the arguments of the three phases are re-read from the kernarg segment in every tile
-#if defined(__HIP_DEVICE_COMPILE__)
-        SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
-        asm volatile("" : "+s"(sp));
-        if (tile >= sp->ntiles) break;
-        // (the tile is a CALL here: inlined into the pass loop it spilled the selection loop -- phase 1 47.7 us against 37.3 us)
-        assoc_tile_call<NB, KPW>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), tile, blockIdx.x == gridDim.x - 1 && tile == (int)blockIdx.x, iter);
-#endif
-    } else {
-        if (assoc_tile<NB, FAST, KPW, WPB, 0, DBG, ARMED>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), a, tile, false, 0)) return;
-    }
+    if (assoc_tile<NB, FAST, KPW, WPB, DBG, ARMED>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), a, (int)blockIdx.x)) return;
+    double row_v = 0.0;                                                   // tid < 32: component tid of this workgroup's row
     constexpr int P2W_T = (KPB + p2_keypoints_per_wave(KPB) - 1) / p2_keypoints_per_wave(KPB);
-    // ---- this tile's contribution to the workgroup's row: 28 partial sums + {accepted, candidates visited, NaN flag,
+    // ---- the workgroup's row: 28 partial sums + {accepted, candidates visited, NaN flag,
     // off-fast-path keypoints} carried as doubles (threads 0..31)
     if (tid < 32) {
         const LdsLayout L = carve();
@@ -2173,14 +1982,8 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
             for (int w = 0; w < P2W_T; ++w) { acc += s_winfo[w * 8 + 0]; pk += s_winfo[w * 8 + 1]; if (nanf == 0) nanf = s_winfo[w * 8 + 2]; }
             v = tid == 28 ? (double)acc : (tid == 29 ? (double)(unsigned)pk : (tid == 30 ? (double)nanf : (double)fb));
         }
-        if constexpr (PERSIST) {                                       // tiles in ascending order
-            double *s_rowacc = reinterpret_cast<double *>(smem + L.off_rowacc);
-            const double r = s_rowacc[tid];
-            s_rowacc[tid] = (tid == 30) ? (r == 0.0 ? v : r) : r + v;
-        } else row_v = v;
+        row_v = v;
     }
-    if constexpr (!PERSIST) break;
-   }   // tiles of this workgroup
 #if defined(__HIP_DEVICE_COMPILE__)
     KernargPtr bq = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(bq));
@@ -2188,14 +1991,8 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
 #else
     const SrlAssocArgs &b = a;
 #endif
-    const LdsLayout L = lds_layout(PERSIST ? SRL_SOLVE_K : b.K, NB, KPW, WPB, PERSIST ? 1 : (ARMED ? 2 : 0));
-    const int lane = lane_id();
-    const int wave = tid >> 6;
-    const bool finisher = blockIdx.x == gridDim.x - 1;
+    const LdsLayout L = lds_layout(b.K, NB, KPW, WPB, ARMED);
     const int *s_winfo = reinterpret_cast<const int *>(smem + L.off_winfo);
-    double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);
-    double *s_rowacc = reinterpret_cast<double *>(smem + L.off_rowacc);
-    (void)lane; (void)wave; (void)finisher; (void)s_pose; (void)s_rowacc;
 
     // ---------------- fused final reduction: every workgroup publishes its row, the LAST workgroup of the grid finishes.
     // Row = 28 partial sums + {accepted, candidates visited, NaN flag, off-fast-path keypoints} carried as doubles.
@@ -2208,17 +2005,12 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
     // between launches.  The finisher only waits for results every other workgroup produces without it: no co-residency
     // assumption; its spin is bounded (time-out marker in the mailbox, the host turns it into an error).
     typedef __attribute__((address_space(1))) unsigned long long gu64;
-    const unsigned epoch = (unsigned)b.seq + (unsigned)iter;              // persistent solve: one epoch per pass
+    const unsigned epoch = (unsigned)b.seq;
     constexpr int KP2 = p2_keypoints_per_wave(KPB);                       // keypoints per phase-2 wave (as in phase 2)
     constexpr int P2W = (KPB + KP2 - 1) / KP2;
     if (tid < 64) {
         // lane l publishes granule l of the row: half l >> 5 of component l & 31
-        double vs;
-        if constexpr (PERSIST) {                                           // written by lanes 0..31 of this very wave
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            vs = s_rowacc[tid & 31];
-        }
-        else vs = __shfl(row_v, tid & 31);
+        const double vs = __shfl(row_v, tid & 31);
         const unsigned long long bits = (unsigned long long)__double_as_longlong(vs);
         const unsigned half = (tid < 32) ? (unsigned)bits : (unsigned)(bits >> 32);
         __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * SRL_ROW_GRANULES + tid), ((unsigned long long)epoch << 32) | half,
@@ -2240,72 +2032,22 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * SRL_ROW_GRANULES + tid), ((unsigned long long)epoch << 32) | word,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if constexpr (!PERSIST) {
-        if constexpr (ARMED) arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 6);
-        if (blockIdx.x != gridDim.x - 1) return;
-        finish_rows<KPW, WPB, NB, 0>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), iter, epoch);
-        if constexpr (ARMED) arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 7);
-        return;
-    }
-    // ---------------- persistent solve: the 17-dim update behind the reduction, then the hand-over of the next pose
-    if constexpr (PERSIST) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        using namespace srlw;
-        SolveargPtr sp = (SolveargPtr)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(SrlAssocArgs) + 7) & ~size_t(7)));
-        asm volatile("" : "+s"(sp));
-        auto fresh = [epoch](unsigned long long x) { return (unsigned)(x >> 32) == epoch; };
-        if (finisher) {
-            if (tid == 64 * (WPB - 1)) solve_stamp(sp, iter, 2);
-            finish_rows_call<NB, KPW>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), iter, epoch);
-            __syncthreads();
-        } else {
-            if (wave == 0) {
-                if (blockIdx.x == 0 && lane == 0) solve_stamp(sp, iter, 8);
-                // the other workgroups wait for the verdict and the pose: 44 tagged granules, one per lane, one request per poll
-                const unsigned long long *pg = sp->pose_granules + (lane < 2 * SRL_POSE_DOUBLES ? lane : 0);
-                unsigned long long x = 0ull;
-                unsigned spins = 0;
-                bool timed_out = false;
-                for (;;) {
-                    x = __hip_atomic_load((gu64 *)pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__ballot(!fresh(x)) == 0ull) break;
-                    if (++spins > (1u << 19)) { timed_out = true; break; }   // ~0.5 s: the finishing workgroup died; do not hang the GPU
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (blockIdx.x == 0 && lane == 0) solve_stamp(sp, iter, 9);
-                const unsigned hi = __shfl_down((unsigned)x, 1);
-                if (lane < 2 * SRL_POSE_DOUBLES && !(lane & 1)) {
-                    double d = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned)x));
-                    if (timed_out && lane == 2 * (SRL_POSE_DOUBLES - 1)) d = (double)IEKF_TIMEOUT;
-                    s_pose[lane >> 1] = d;
-                }
-            }
-            __syncthreads();
-        }
-        if ((int)s_pose[SRL_POSE_DOUBLES - 1] != IEKF_CONTINUE) return;
-#endif
-    }
-  }   // ESIKF passes
+    if constexpr (ARMED) arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 6);
+    if (blockIdx.x != gridDim.x - 1) return;
+    finish_rows<KPW, WPB>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), epoch);
+    if constexpr (ARMED) arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 7);
 }
 
 template <int NB, int FAST, int KPW, int WPB, int DBG = 0>
 __global__ void __launch_bounds__(64 * WPB, WPB == 16 ? 1 : SRL_ASSOC_WAVES_PER_SIMD) srl_assoc_kernel(const SrlAssocArgs a) {
-    assoc_body<NB, FAST, KPW, WPB, 0, DBG>(a);
+    assoc_body<NB, FAST, KPW, WPB, DBG>(a);
 }
 // the same pass as an ARMED launch (16-wave workgroups, fast paths): enqueued before its pose exists, the pose arrives through
 // the pose box (assoc_body's prologue); everything behind the prologue is the one-shot kernel
 template <int NB, int KPW>
 __global__ void __launch_bounds__(1024, 1) srl_assoc_armed_kernel(const SrlAssocArgs a) {
-    assoc_body<NB, 1, KPW, 16, 0, 0, 1>(a);
+    assoc_body<NB, 1, KPW, 16, 0, 1>(a);
 }
-// The persistent solve: `a` must stay the first argument (its fields are re-read from the kernarg segment at offset 0), the
-// solve arguments sit right behind it.  One 16-wave workgroup per compute unit at most: every workgroup is resident.
-template <int NB, int KPW>
-__global__ void __launch_bounds__(1024, 1) srl_solve_kernel(const SrlAssocArgs a, const SrlSolveArgs sv) {
-    (void)sv;       // read through the kernarg segment pointer
-    assoc_body<NB, 1, KPW, 16, 1>(a);
-}
-
 // ---------------------------------------------------------------------------------------------
 // ordered cut-off + final reduction (single workgroup)
 // mode: 0 = budget max_res >= 1; 1 = max_num_residuals <= 0: the loop stops at the first keypoint that reaches the
@@ -2598,7 +2340,7 @@ template <int KPW, int WPB>
 static hipError_t launch_assoc_cfg(const SrlAssocArgs &a, int nb_voxels, hipStream_t s) {
     const int nblocks = (a.n + WPB * KPW - 1) / (WPB * KPW);
     const bool armed = a.pose_box != nullptr;
-    const LdsLayout L = lds_layout(a.K, nb_voxels, KPW, WPB, armed ? 2 : 0);
+    const LdsLayout L = lds_layout(a.K, nb_voxels, KPW, WPB, armed ? 1 : 0);
     const dim3 blk(64 * WPB);
     auto launch = [&](auto kern) {
         if (L.total > 64 * 1024) {      // more dynamic LDS than the default limit: opt in (once per kernel, device and size)
@@ -2647,42 +2389,6 @@ hipError_t srl_launch_assoc(const SrlAssocArgs &a, int nb_voxels, int kpw, int w
 }
 // LDS bytes of a configuration (host: does the 16-wave workgroup fit?)
 int srl_assoc_lds_bytes(int K, int nb_voxels, int kpw, int wpb) { return lds_layout(K, nb_voxels, kpw, wpb).total; }
-
-// ---- persistent solve: 16-wave workgroups, FAST paths only
-template <int KPW>
-static hipError_t launch_solve_cfg(const SrlAssocArgs &a, const SrlSolveArgs &sv, int nb_voxels, int grid, hipStream_t s) {
-    const LdsLayout L = lds_layout(a.K, nb_voxels, KPW, 16, 1);
-    auto launch = [&](auto kern) {
-        static thread_local const void *done_fn = nullptr;
-        static thread_local int done_dev = -1;
-        int dev = -1;
-        hipGetDevice(&dev);
-        const void *fn = reinterpret_cast<const void *>(kern);
-        if (fn != done_fn || dev != done_dev) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SRL_LDS_LIMIT);
-            if (e != hipSuccess) return e;
-            done_fn = fn; done_dev = dev;
-        }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), L.total, s, a, sv);
-        return hipGetLastError();
-    };
-    if (nb_voxels == 1) return launch(srl_solve_kernel<1, KPW>);
-    return launch(srl_solve_kernel<2, KPW>);
-}
-hipError_t srl_launch_solve(const SrlAssocArgs &a, const SrlSolveArgs &sv, int nb_voxels, int kpw, int grid, hipStream_t s) {
-    if (a.n <= 0 || grid <= 0) return hipErrorInvalidValue;
-    switch (kpw) {
-        case 2: return launch_solve_cfg<2>(a, sv, nb_voxels, grid, s);
-        case 3: return launch_solve_cfg<3>(a, sv, nb_voxels, grid, s);
-        case 4: return launch_solve_cfg<4>(a, sv, nb_voxels, grid, s);
-        case 6: return launch_solve_cfg<6>(a, sv, nb_voxels, grid, s);
-        case 8: return launch_solve_cfg<8>(a, sv, nb_voxels, grid, s);
-        case 12: return launch_solve_cfg<12>(a, sv, nb_voxels, grid, s);
-        case 16: return launch_solve_cfg<16>(a, sv, nb_voxels, grid, s);
-        default: return hipErrorInvalidConfiguration;
-    }
-}
-int srl_solve_lds_bytes(int K, int nb_voxels, int kpw) { return lds_layout(K, nb_voxels, kpw, 16, 1).total; }
 
 hipError_t srl_launch_reduce(const SrlReduceArgs &a, int mode, hipStream_t s) {
     hipLaunchKernelGGL(srl_reduce_kernel, dim3(1), dim3(1024), 0, s, a, mode);

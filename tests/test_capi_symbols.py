@@ -21,7 +21,6 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.NormalEq) == 36 * 8 + 6 * 8 + 8 + 4 + 4 + 8 + 8 + 4 + 4
     assert C.sizeof(capi.Frame) == (4 + 3 + 3 + 9 + 3) * 8 + 8
     assert C.sizeof(capi.Timing) == 4 * 4 + 8 + 3 * 8 + 2 * 8 + 3 * 8 + 8           # + sum_passes (round 3)
-    assert C.sizeof(capi.IekfResult) == 4 * 4 + C.sizeof(capi.NormalEq)
 
 
 def test_default_options_are_the_effective_yaml_values():

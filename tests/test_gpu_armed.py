@@ -75,7 +75,7 @@ def test_armed_launches_change_no_bit(scene, max_res, frame_id, box):
         s1 = lio.ctx.arm_stats()
         assert ref[0][0] == 0 and ref[0][1] >= 2
         for g in got:
-            assert g[:3] == ref[0][:3]
+            assert g[:3] == ref[0][:3], (g[:3], ref[0][:3], lio.ctx.arm_stats())
             for a, b in zip(g[3:], ref[0][3:]):
                 assert np.array_equal(a, b)
         iters = ref[0][1]

@@ -3,7 +3,7 @@ checking of its own; this is the product's).  Two instrumented builds, each driv
 subprocess with the sanitizer runtime preloaded (the interpreter itself is not instrumented):
   * oracle/srl_oracle.cpp (g++ -fsanitize=address,undefined) under tests/test_oracle.py, test_heap_replay.py, test_eigen_solver.py;
   * every host translation unit of libsrlivo_hip.so -- the C-ABI (srl_capi.cpp), the RCCL table, the host mirror
-    (csrc/host/*.cpp) -- under tests/test_host_logic.py, test_iekf_wave.py, test_tr1_order.py.  Device code is not instrumented.
+    (csrc/host/*.cpp) -- under tests/test_host_logic.py, test_tr1_order.py.  Device code is not instrumented.
 Any report (heap / stack overflow, use after free, signed overflow, misaligned or null access, out-of-range shift or cast ...)
 aborts the subprocess: -fno-sanitize-recover, halt_on_error."""
 import glob
@@ -55,5 +55,5 @@ def test_host_side_of_the_product_under_asan_and_ubsan(tmp_path):
     b = subprocess.run(["make", "-C", csrc, "san", f"SAN_OUT={out_dir}"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert b.returncode == 0 and os.path.exists(os.path.join(out_dir, "libsrlivo_hip.so")), b.stdout.decode(errors="replace")[-3000:]
     env = {"LD_PRELOAD": rts[0], "SRL_LIB_PATH": os.path.join(out_dir, "libsrlivo_hip.so")}
-    out = _run_pytest(env, ["tests/test_host_logic.py", "tests/test_iekf_wave.py", "tests/test_tr1_order.py", "tests/test_capi_symbols.py"])
+    out = _run_pytest(env, ["tests/test_host_logic.py", "tests/test_tr1_order.py", "tests/test_capi_symbols.py"])
     assert " passed" in out

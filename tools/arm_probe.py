@@ -1,7 +1,6 @@
 """A/B of the launch forms of the per-iteration loop: one launch per ESIKF iteration (armed launches off), armed
 launches with the pose box in pinned host memory (workgroup 0 relays), armed launches with the pose box in fine-grained device
-memory written through the PCIe BAR, and the opt-in persistent solve kernel -- on the four configurations the round-3 review
-names (headline, C2, C3, headline @ max_num_residuals = 600) + C1.  Same box, same minute; solved states must be bit-identical
+memory written through the PCIe BAR -- on the four configurations the round-3 review names (headline, C2, C3, headline @ max_num_residuals = 600) + C1.  Same box, same minute; solved states must be bit-identical
 between the launch forms (same kernels, same arithmetic).
 
     python tools/arm_probe.py [--solves 300] [--configs HEADLINE,C2,C3,HEADLINE@600]
@@ -25,7 +24,7 @@ from bench import _EskfAdapter  # noqa: E402
 INT_MAX = 2**31 - 1
 
 
-def run(name, workload, max_res, frame_id, solves, want_persistent):
+def run(name, workload, max_res, frame_id, solves):
     n_kp, map_pts, pattern, seed = synth.CONFIGS[workload]
     cands, L = synth.map_candidates(seed, map_pts)
     sweep = synth.make_sweep(seed + 1000, n_kp, L, pattern=pattern)
@@ -60,30 +59,27 @@ def run(name, workload, max_res, frame_id, solves, want_persistent):
                 per[k] = time.perf_counter() - tk
             el = time.perf_counter() - t
             s1 = lio.ctx.arm_stats()
-            # kernel time by events in a second pass
+            # kernel time by events in a second pass (timed too: what the event pairs cost the loop)
             lio.ctx.set_profiling(2)
-            for _ in range(20):
+            solve(); solve()
+            t = time.perf_counter()
+            for _ in range(40):
                 solve()
+            el_ev = time.perf_counter() - t
             tim = lio.ctx.timing()
             lio.ctx.set_profiling(0)
             out[label] = {"us_per_iter": el / solves / max(it, 1) * 1e6, "us_per_iter_median": float(np.median(per)) / max(it, 1) * 1e6,
                           "sweeps_per_s": solves / el, "iters": it, "residuals": nr, "event_kernel_us": tim.sum_assoc_ms / max(tim.calls, 1) * 1e3,
+                          "us_per_iter_with_events": el_ev / 40 / max(it, 1) * 1e6,
                           "arm": {k: s1[k] - s0[k] for k in s1}}
             return solve.state.copy()
 
-        lio.set_persistent_solve(False)
         ref = leg("per_iteration", lambda: lio.ctx.set_armed_launch(False))
         a0 = leg("armed_hostbox", lambda: (lio.ctx.set_armed_launch(True), lio.ctx.set_pose_box(0)))
         a1 = leg("armed_barbox", lambda: (lio.ctx.set_armed_launch(True), lio.ctx.set_pose_box(1)))
         lio.ctx.set_pose_box(0)
         out["armed_hostbox_bitwise_equal"] = bool(a0 is not None and np.array_equal(ref, a0))
         out["armed_barbox_bitwise_equal"] = None if a1 is None else bool(np.array_equal(ref, a1))
-        if want_persistent:
-            lio.ctx.set_armed_launch(False)
-            lio.set_persistent_solve(True)
-            ps = leg("persistent_solve", lambda: None)
-            lio.set_persistent_solve(False)
-            out["persistent_state_rel_diff"] = None if ps is None else float(np.max(np.abs(ps - ref)) / np.max(np.abs(ref)))
     finally:
         lio.close()
     return out
@@ -93,7 +89,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--solves", type=int, default=300)
     ap.add_argument("--configs", default="HEADLINE,C2,C3,HEADLINE@600,C1")
-    ap.add_argument("--no-persistent", action="store_true")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "arm_probe.json"))
     args = ap.parse_args()
     plan = {"HEADLINE": ("HEADLINE", INT_MAX, 100), "C1": ("C1", INT_MAX, 100), "C2": ("C2", INT_MAX, 100), "C3": ("C3", INT_MAX, 100),
@@ -101,15 +96,15 @@ def main():
     res = []
     for name in args.configs.split(","):
         wl, mr, fid = plan[name]
-        r = run(name, wl, mr, fid, args.solves if name not in ("C4", "INIT") else max(10, args.solves // 10), not args.no_persistent)
+        r = run(name, wl, mr, fid, args.solves if name not in ("C4", "INIT") else max(10, args.solves // 10))
         res.append(r)
         print(json.dumps(r), flush=True)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(res, open(args.out, "w"), indent=1)
-    print("%-14s %14s %14s %14s %14s" % ("config", "per-iteration", "armed(host)", "armed(BAR)", "persistent"))
+    print("%-14s %14s %14s %14s" % ("config", "per-iteration", "armed(host)", "armed(BAR)"))
     for r in res:
         g = lambda k: ("%.1f" % r[k]["us_per_iter"]) if isinstance(r.get(k), dict) and "us_per_iter" in r[k] else "-"   # noqa: E731
-        print("%-14s %14s %14s %14s %14s   us per ESIKF iteration" % (r["name"], g("per_iteration"), g("armed_hostbox"), g("armed_barbox"), g("persistent_solve")))
+        print("%-14s %14s %14s %14s   us per ESIKF iteration" % (r["name"], g("per_iteration"), g("armed_hostbox"), g("armed_barbox")))
 
 
 if __name__ == "__main__":

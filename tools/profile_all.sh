@@ -1,11 +1,10 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): the un-profiled bench line + rocprofv3 (kernel trace + separate PMC passes) of every
 # configuration quoted in DESIGN.md section 5.  Summaries land in gpurun_out/prof_<tag>/ and gpurun_out/bench_final.json.
-R=${1:-r03}
+R=${1:-r04}
 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
 tools/profile_gpu.sh ${R}_headline 10 "" > /dev/null 2>&1
 tools/profile_gpu.sh ${R}_headline_unfused 10 "--no-fused-reduce" > /dev/null 2>&1
-tools/profile_gpu.sh ${R}_headline_persistent 10 "--persistent-solve" > /dev/null 2>&1
 tools/profile_gpu.sh ${R}_c1 10 "--workload C1" > /dev/null 2>&1
 tools/profile_gpu.sh ${R}_c2 10 "--workload C2" > /dev/null 2>&1
 tools/profile_gpu.sh ${R}_c3 10 "--workload C3" > /dev/null 2>&1
