@@ -330,17 +330,19 @@ int srl_debug_set_ablate(srl_ctx *ctx, int bits);
  * prefix pass of the shipped 600).  A finisher that gives up waiting for a row (bounded spin) makes srl_build_residuals repeat
  * the pass once with the separate reduce kernel instead of failing. */
 int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable);
-/* Where the pose box of the armed launches lives.  kind 0 (default): page-locked host memory -- workgroup 0 of the waiting kernel polls
- * it across PCIe and republishes the pose into device memory for the other workgroups.  kind 1: fine-grained DEVICE memory the host
- * writes through the PCIe BAR (every workgroup polls it locally); SRL_ERR_UNSUPPORTED when device memory is not CPU-visible on this
- * system.
+/* Where the pose box of the armed launches lives.  kind 1: fine-grained DEVICE memory the host writes through the PCIe BAR (every
+ * workgroup polls it locally; SRL_ERR_UNSUPPORTED when device memory is not CPU-visible on this system).  kind 0: page-locked host
+ * memory -- workgroup 0 of the waiting kernel polls it across PCIe and republishes the pose into device memory for the other
+ * workgroups (~0.7 us per pass slower).  kind -1 (the default): 1 where possible, else 0.
  * srl_debug_set_arm_linger: the age (us) beyond which a call cancels an armed launch instead of firing it (default 150), and the
  * kernel-side bound (us, default 300) after which a waiting launch leaves by itself -- tests drive both paths with it. */
 int srl_debug_set_pose_box(srl_ctx *ctx, int kind);
 int srl_debug_set_arm_linger(srl_ctx *ctx, double host_linger_us, double kernel_linger_us);
-/* Time line of the armed passes (tools/arm_timeline.py): enable allocates a host-mapped stamp buffer the armed kernels file into;
- * gpu_out[64 * 16] (optional): per pass (row = sequence number & 63) the 100 MHz device clock at {entry, pose received, tile start,
- * phase 0 / 1 / 2 done, row published, finisher done} of workgroup 0 (slots 0..7) and of the finishing workgroup (8..15);
+/* Time line of the armed passes (tools/arm_timeline.py): enable allocates a host-mapped stamp buffer the armed kernels file into
+ * (kernels built with -DSRL_ARM_STAMPS only: the product build has no stamp sites and leaves the buffer at zero);
+ * gpu_out[64 * 32] (optional): per pass (row = sequence number & 63) the 100 MHz device clock at {entry, pose received, tile start,
+ * phase 0 / 1 / 2 done, row published, finisher done} of workgroup 0 (slots 0..7) and of the finishing workgroup (8..15), slots
+ * 16..24 inside the finisher and phase 2 (-DSRL_STAMP_DETAIL);
  * host_out[64 * 4] (optional): steady-clock ns at {call entry, pose written or launch returned, result seen} and a fired flag. */
 int srl_debug_pass_stamps(srl_ctx *ctx, int enable, long long *gpu_out, long long *host_out);
 /* tuning experiments: force the association kernel's launch shape -- keypoints per wave (16-wave workgroups: 2 / 3 / 4 / 6 / 8 /

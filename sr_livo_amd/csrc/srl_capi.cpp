@@ -568,21 +568,24 @@ int ensure_pose_box(srl_ctx *ctx) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_pose_relay, SRL_POSE_BOX_GRANULES * 8));
         HIPCHK(ctx, hipMemset(ctx->d_pose_relay, 0, SRL_POSE_BOX_GRANULES * 8));
     }
-    if (ctx->pose_box_kind == 1) {
+    // kind -1 (default): device memory when the CPU can write it (large BAR: every workgroup polls locally, ~0.7 us less per pass
+    // than a box in host memory that workgroup 0 polls across PCIe and relays), else pinned host memory
+    if (ctx->pose_box_kind != 0) {
         if (!ctx->pose_box_dev) {
             HIPCHK(ctx, hipExtMallocWithFlags((void **)&ctx->pose_box_dev, 4096, hipDeviceMallocFinegrained));
             HIPCHK(ctx, hipMemset(ctx->pose_box_dev, 0, 4096));
             HIPCHK(ctx, hipDeviceSynchronize());
-            if (!host_can_write(ctx->pose_box_dev)) { ctx->err = "pose box: device memory is not CPU-visible on this system (no large BAR)"; return SRL_ERR_UNSUPPORTED; }
+            ctx->pose_box_dev_visible = host_can_write(ctx->pose_box_dev);
         }
-        ctx->h_pose_box = ctx->pose_box_dev;
-    } else {
-        if (!ctx->pose_box_pinned) {
-            HIPCHK(ctx, hipHostMalloc((void **)&ctx->pose_box_pinned, 4096, hipHostMallocCoherent | hipHostMallocMapped));
-            std::memset(ctx->pose_box_pinned, 0, 4096);
-        }
-        ctx->h_pose_box = ctx->pose_box_pinned;
+        if (ctx->pose_box_dev_visible) { ctx->pose_box_kind = 1; ctx->h_pose_box = ctx->pose_box_dev; return SRL_OK; }
+        if (ctx->pose_box_kind == 1) { ctx->err = "pose box: device memory is not CPU-visible on this system (no large BAR)"; return SRL_ERR_UNSUPPORTED; }
+        ctx->pose_box_kind = 0;
     }
+    if (!ctx->pose_box_pinned) {
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->pose_box_pinned, 4096, hipHostMallocCoherent | hipHostMallocMapped));
+        std::memset(ctx->pose_box_pinned, 0, 4096);
+    }
+    ctx->h_pose_box = ctx->pose_box_pinned;
     return SRL_OK;
 }
 
@@ -629,7 +632,7 @@ int srl_set_armed_launch(srl_ctx *ctx, int mode) {
 }
 
 int srl_debug_set_pose_box(srl_ctx *ctx, int kind) {
-    if (!ctx || kind < 0 || kind > 1) return SRL_ERR_BAD_ARG;
+    if (!ctx || kind < -1 || kind > 1) return SRL_ERR_BAD_ARG;
     SRL_DISARM(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -908,7 +911,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         SrlAssocArgs nx = a;
         nx.seq = ctx->seq + 1;
         nx.pose_box = ctx->h_pose_box;                    // (host-mapped pinned memory and CPU-visible device memory: one address for both sides)
-        nx.pose_relay = ctx->pose_box_kind == 0 ? ctx->d_pose_relay : nullptr;
+        nx.pose_relay = ctx->pose_box_kind == 1 ? nullptr : ctx->d_pose_relay;
         nx.pose_epoch = (unsigned)nx.seq;
         nx.arm_linger_ticks = ctx->arm_linger_ticks;
         hipEvent_t *nev = nullptr;

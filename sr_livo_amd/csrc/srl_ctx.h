@@ -93,7 +93,8 @@ struct srl_ctx {
     // ARMED launches (srl_capi.cpp: arm_next / pose_box_write / srl_ctx_disarm): the kernel of the NEXT pass is enqueued while the
     // current one runs and waits, resident, for its pose
     int arm_mode = 1;                           // srl_set_armed_launch: 0 off, 1 on
-    int pose_box_kind = 0;                      // 0: pinned host memory, workgroup 0 relays into device memory; 1: fine-grained device memory the host writes through the PCIe BAR
+    int pose_box_kind = -1;                     // -1: not chosen yet (1 where possible); 0: pinned host memory, workgroup 0 relays into device memory; 1: fine-grained device memory the host writes through the PCIe BAR
+    bool pose_box_dev_visible = false;
     unsigned long long *h_pose_box = nullptr;   // where the HOST writes the pose granules (kind 1: the CPU-visible device pointer)
     unsigned long long *pose_box_pinned = nullptr;   // kind 0 allocation (hipHostMalloc)
     unsigned long long *pose_box_dev = nullptr;      // kind 1 allocation (hipExtMallocWithFlags, fine-grained)

@@ -25,6 +25,7 @@
 #include "srl_heap.h"
 
 #include <math.h>
+#include <type_traits>
 
 namespace {
 
@@ -1044,10 +1045,37 @@ __device__ __forceinline__ void store_granule_pair(unsigned long long *dst, unsi
 __device__ inline void store_granule_pair(unsigned long long *, unsigned, unsigned long long) {}
 #endif
 
+// The published rows of the fused final reduction: component c of a row = the 16 bytes {low half, epoch, high half, epoch} at granules
+// 2c, 2c + 1 -- ONE write-through (sc1) 16-byte store per lane, whole lines per workgroup, and ONE 16-byte sc1 load per component on
+// the finisher's side (half the load instructions of two 8-byte granules; 8-byte accesses run at 0.54-0.70x the 16-byte rate, guide).
+// Buffer addressing: the loads sit in a polling loop -- bit 31 of aux marks them volatile for the compiler, bit 4 is sc1.
+#define SRL_OWN_ROW_OFFSET 13312              // LDS (behind everything the finisher stages, inside the phase-1 areas): the finishing workgroup's own row (32 doubles), handed over without a trip through memory
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(unsigned long long *granules) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)granules, 0, SRL_FUSED_MAX_BLOCKS * SRL_ROW_GRANULES * 8, 0x00020000);
+}
+__device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t rs, int block, int comp, unsigned epoch, double v) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    v4u32 x;
+    x.x = (unsigned)bits; x.y = epoch; x.z = (unsigned)(bits >> 32); x.w = epoch;
+    __builtin_amdgcn_raw_buffer_store_b128(x, rs, (block * SRL_ROW_GRANULES + 2 * comp) * 8, 0, 16);
+}
+__device__ __forceinline__ v4u32 row_load(__amdgpu_buffer_rsrc_t rs, int block, int comp) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (block * SRL_ROW_GRANULES + 2 * comp) * 8, 0, (int)0x80000010);
+}
+#endif
+
 // debug time line of an ARMED pass (srl_debug_pass_stamps, tools/arm_timeline.py): workgroup 0 files slots 0..7, the finishing
 // workgroup slots 8..15 of row (seq & 63); the pointer is re-read from the kernarg segment at every site (nothing stays live)
-#if defined(__HIP_DEVICE_COMPILE__)
+// Compiled in only with -DSRL_ARM_STAMPS (tools/build_variant.sh stamps "-DSRL_ARM_STAMPS -DSRL_STAMP_DETAIL"): the ten sites cost the
+// armed pass 0.2-0.4 us even with a null buffer (measured A/B), so the product build carries none.  Slots >= 16 (inside the finisher
+// and inside phase 2) additionally need -DSRL_STAMP_DETAIL.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SRL_ARM_STAMPS)
 __device__ __forceinline__ void arm_stamp(KargBytes karg, int slot) {
+#if !defined(SRL_STAMP_DETAIL)
+    if (slot >= 16) return;
+#endif
     typedef const __attribute__((address_space(4))) SrlAssocArgs *KP;
     KP q = (KP)karg;
     asm volatile("" : "+s"(q));
@@ -1066,7 +1094,17 @@ __device__ inline void arm_stamp(KargBytes, int) {}
 // Phase 2 geometry: lanes per keypoint and keypoints per phase-2 wave for a workgroup of kpb keypoints.  One lane per
 // keypoint from 48 keypoints on.  (Half-filled phase-2 waves -- 32 keypoints each, twice as many waves so that two dependent
 // FP64 chains interleave per SIMD -- were measured in round 3: no gain)
-__host__ __device__ constexpr int p2_lanes_per_keypoint(int kpb) { return kpb >= 48 ? 1 : (kpb >= 32 ? 2 : 4); }
+#ifndef SRL_P2_POLICY
+#define SRL_P2_POLICY 1
+#endif
+#if SRL_P2_POLICY == 0
+__host__ __device__ constexpr int p2_lanes_per_keypoint(int kpb) { return kpb >= 48 ? 1 : (kpb >= 32 ? 2 : 4); }     // rounds 2-3
+#else
+// Round 4: small workgroups spread a keypoint over four lanes (the neighbour loops are a 20-deep FP64 dependency chain on a wave that
+// has its SIMD to itself; with four lanes it is 5 deep + two quad-permute steps, and the phase occupies 4-6 of the 16 waves instead
+// of 1-2).  Workgroups of >= 192 keypoints keep one lane per keypoint: there the phase is bound by instruction issue, not by the chain.
+__host__ __device__ constexpr int p2_lanes_per_keypoint(int kpb) { return kpb >= 192 ? 1 : (kpb >= 128 ? 2 : 4); }
+#endif
 __host__ __device__ constexpr int p2_keypoints_per_wave(int kpb) { return 64 / p2_lanes_per_keypoint(kpb); }
 
 // ARMED = 1: the pass as an armed launch (assoc_body's prologue): the pose sits in LDS, not in the kernarg segment.
@@ -1128,14 +1166,21 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         const int kq = wave * KPW + lane;                                  // index inside the workgroup
         const int g = wbase_kp + lane;
         D3 p_imu = d3(0, 0, 0), p_w = d3(0, 0, 0);
-        if (g < A.n) {
-            const D3 raw = d3(A.raw_x[g], A.raw_y[g], A.raw_z[g]);
-            p_imu = add(matvec(A.R_il, raw), d3(A.t_il[0], A.t_il[1], A.t_il[2]));
-            if constexpr (POSE_LDS) p_w = add(matvec(s_pose, p_imu), d3(s_pose[18], s_pose[19], s_pose[20]));
-            else p_w = add(matvec(A.Rn, p_imu), d3(A.t[0], A.t[1], A.t[2]));
+        if constexpr (ARMED) {
+            // the body-frame point does not depend on the pose: this lane computed it while the launch was waiting (assoc_body's prologue)
+            if (g < A.n) {
+                p_imu = d3(s_pimu[kq * 3 + 0], s_pimu[kq * 3 + 1], s_pimu[kq * 3 + 2]);
+                p_w = add(matvec(s_pose, p_imu), d3(s_pose[18], s_pose[19], s_pose[20]));
+            }
+        } else {
+            if (g < A.n) {
+                const D3 raw = d3(A.raw_x[g], A.raw_y[g], A.raw_z[g]);
+                p_imu = add(matvec(A.R_il, raw), d3(A.t_il[0], A.t_il[1], A.t_il[2]));
+                p_w = add(matvec(A.Rn, p_imu), d3(A.t[0], A.t[1], A.t[2]));
+            }
+            s_pimu[kq * 3 + 0] = p_imu.x; s_pimu[kq * 3 + 1] = p_imu.y; s_pimu[kq * 3 + 2] = p_imu.z;
         }
         s_pw[kq * 3 + 0] = p_w.x; s_pw[kq * 3 + 1] = p_w.y; s_pw[kq * 3 + 2] = p_w.z;
-        s_pimu[kq * 3 + 0] = p_imu.x; s_pimu[kq * 3 + 1] = p_imu.y; s_pimu[kq * 3 + 2] = p_imu.z;
         {
             // FP32 prefilter constants of this keypoint (used once per keypoint by every lane of the wave later):
             // error model of select_topk_f32_r, m(T) = 4 a (T + 1)/2 + 8 u T + 4 a^2 at T = 2 tau + 1e-6, thr = (tau + 2 m)(1 + 1e-6)
@@ -1324,9 +1369,20 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     const bool owner_lane = p2_wave && klw < KP2 && kl < KPB;
     const int g = owner_lane ? bbase_kp + kl : b.n;
     // sum over the LPK lanes of a keypoint (butterfly: all of them end with the same bits)
-    auto lpk_sum = [](double v) {
-        if (LPK >= 2) v += __shfl_xor(v, 1);
-        if (LPK >= 4) v += __shfl_xor(v, 2);
+    // (quad permutes on the 32-bit halves: two v_mov_dpp per step -- __shfl_xor goes through the LDS crossbar, ds_bpermute x 2)
+    auto quad_xor = [](double v, auto ctrl) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, decltype(ctrl)::value, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)b >> 32), decltype(ctrl)::value, 0xF, 0xF, true);
+        return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+#else
+        return v;
+#endif
+    };
+    auto lpk_sum = [&](double v) {
+        if (LPK >= 2) v += quad_xor(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1, 0, 3, 2]: lane ^ 1
+        if (LPK >= 4) v += quad_xor(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2, 3, 0, 1]: lane ^ 2
         return v;
     };
     int status = 3;
@@ -1364,10 +1420,12 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         C[0][0] = lpk_sum(c00); C[0][1] = lpk_sum(c01); C[0][2] = lpk_sum(c02);
         C[1][1] = lpk_sum(c11); C[1][2] = lpk_sum(c12); C[2][2] = lpk_sum(c22);
         C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
+        if constexpr (ARMED) arm_stamp(karg, 21);
         double ev[3];
         D3 nrm;
         if (b.select_mode == 4) { eig3_jacobi(C, ev, nrm); nrm = normalized3(nrm); }   // .col(0).normalized() (optimize.cpp:340)
         else eig3_closed(C, ev, nrm);                              // already unit length (re-normalised once more at :93 below)
+        if constexpr (ARMED) arm_stamp(karg, 22);
         const double sigma_1 = sqrt(fabs(ev[2]));
         const double sigma_2 = sqrt(fabs(ev[1]));
         const double sigma_3 = sqrt(fabs(ev[0]));
@@ -1411,6 +1469,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
             J[3] = s0 * weight; J[4] = s1 * weight; J[5] = s2 * weight;
         }
     }
+    if constexpr (ARMED) arm_stamp(karg, 23);
     if (g < b.n && b.write_rec && sl == 0) {
         // per-keypoint record {J[6], distance, weight} (ordered cut-off path + taps; never on the throughput path)
         double2 *r = reinterpret_cast<double2 *>(b.rec + (size_t)g * 8);
@@ -1472,6 +1531,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
             s_wpart[w2 * 32 + lane] = acc;
         }
     }
+    if constexpr (ARMED) arm_stamp(karg, 24);
     {
         // one bit per keypoint: the ballot has the keypoint's bit at lane klw * LPK
         auto per_keypoint = [](unsigned long long m) {
@@ -1645,19 +1705,25 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
             auto fresh = [epoch](unsigned long long x) { return (unsigned)(x >> 32) == epoch; };
             auto as_double = [](unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
             // (a) four granules per thread, requested together (every poll round is one memory round trip, not four)
+            const __amdgpu_buffer_rsrc_t rs = rows_rsrc(b.granules);
+            const double *s_own = reinterpret_cast<const double *>(smem + SRL_OWN_ROW_OFFSET);      // this workgroup's own row (assoc_body)
             long long my_acc = 0;
             if (tid < nbk) {
-                const unsigned long long *row = b.granules + (size_t)tid * SRL_ROW_GRANULES;
-                unsigned long long x0, x1, x2, x3;
-                unsigned spins = 0;
-                for (;;) {
-                    x0 = ld(row + 28); x1 = ld(row + 60); x2 = ld(row + 30); x3 = ld(row + 62);
-                    if (fresh(x0) && fresh(x1) && fresh(x2) && fresh(x3)) break;
-                    if (++spins > (1u << 18)) { timed_out = true; x0 = x1 = x2 = x3 = 0ull; break; }
-                    __builtin_amdgcn_s_sleep(8);
+                double d_acc, d_nan;
+                if (tid == nbk - 1) { d_acc = s_own[28]; d_nan = s_own[30]; }
+                else {
+                    v4u32 x0, x1;
+                    unsigned spins = 0;
+                    for (;;) {
+                        x0 = row_load(rs, tid, 28); x1 = row_load(rs, tid, 30);
+                        if (x0.y == epoch && x0.w == epoch && x1.y == epoch && x1.w == epoch) break;
+                        if (++spins > (1u << 18)) { timed_out = true; x0 = x1 = v4u32{0u, 0u, 0u, 0u}; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    d_acc = as_double(x0.x, x0.z); d_nan = as_double(x1.x, x1.z);
                 }
-                my_acc = (long long)as_double((unsigned)x0, (unsigned)x1);
-                const int nanf = (int)as_double((unsigned)x2, (unsigned)x3);
+                my_acc = (long long)d_acc;
+                const int nanf = (int)d_nan;
                 if (nanf > 0) atomicMin(&s_i[4], tid * KPB + nanf - 1);
             }
             long long incl = my_acc;
@@ -1692,11 +1758,13 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
 #pragma unroll
                     for (int k = 0; k < INF; ++k) {
                         const int r = r0 + NPART * k;
-                        if (r < nbk && (comp >= 28 || r < c)) {
-                            const unsigned long long x0 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * SRL_ROW_GRANULES + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const unsigned long long x1 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * SRL_ROW_GRANULES + 32 + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = ok && (unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch;
-                            lo[k] = (unsigned)x0; hi[k] = (unsigned)x1;
+                        if (r < nbk - 1 && (comp >= 28 || r < c)) {
+                            const v4u32 x = row_load(rs, r, comp);
+                            ok = ok && x.y == epoch && x.w == epoch;
+                            lo[k] = x.x; hi[k] = x.z;
+                        } else if (r == nbk - 1 && (comp >= 28 || r < c)) {        // the own row: from LDS
+                            const unsigned long long ob = (unsigned long long)__double_as_longlong(s_own[comp]);
+                            lo[k] = (unsigned)ob; hi[k] = (unsigned)(ob >> 32);
                         } else { lo[k] = 0u; hi[k] = 0u; }
                     }
                     if (ok) break;
@@ -1790,6 +1858,8 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
         if (tid == 0) *s_bad = 0;
         const int comp = tid & 31, part = tid >> 5;
         const int nbk = (int)gridDim.x;
+        const __amdgpu_buffer_rsrc_t rs = rows_rsrc(b.granules);
+        const double *s_own = reinterpret_cast<const double *>(smem + SRL_OWN_ROW_OFFSET);          // this workgroup's own row (assoc_body)
         double s0 = 0.0;
         bool timed_out = false;
         for (int r0 = part; r0 < nbk; r0 += NPART * INF) {
@@ -1800,16 +1870,18 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
 #pragma unroll
                 for (int k = 0; k < INF; ++k) {
                     const int r = r0 + NPART * k;
-                    if (r < nbk) {
-                        const unsigned long long x0 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * SRL_ROW_GRANULES + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long x1 = __hip_atomic_load((gu64 *)(b.granules + (size_t)r * SRL_ROW_GRANULES + 32 + comp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = ok && (unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch;
-                        lo[k] = (unsigned)x0; hi[k] = (unsigned)x1;
+                    if (r < nbk - 1) {
+                        const v4u32 x = row_load(rs, r, comp);
+                        ok = ok && x.y == epoch && x.w == epoch;
+                        lo[k] = x.x; hi[k] = x.z;
+                    } else if (r == nbk - 1) {                                 // the own row: from LDS
+                        const unsigned long long ob = (unsigned long long)__double_as_longlong(s_own[comp]);
+                        lo[k] = (unsigned)ob; hi[k] = (unsigned)(ob >> 32);
                     } else { lo[k] = 0u; hi[k] = 0u; }
                 }
                 if (ok) break;
                 if (++spins > (1u << 18)) { timed_out = true; break; }     // ~0.3 s: something died; do not hang the GPU
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(4);
             }
 #pragma unroll
             for (int k = 0; k < INF; ++k) s0 += __longlong_as_double((long long)(((unsigned long long)hi[k] << 32) | lo[k]));
@@ -1914,6 +1986,19 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);
         int *s_ctrl = reinterpret_cast<int *>(s_pose + SRL_POSE_DOUBLES);
         arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 0);
+        {
+            // what phase 0 can do without the pose is done now: raw point -> body frame (optimize.cpp:83), every lane for the keypoint
+            // it owns in phase 0 (it reads its own LDS words back there: no barrier in between)
+            const int lane0 = tid & 63, wave0 = tid >> 6;
+            if (lane0 < KPW) {
+                const int kq = wave0 * KPW + lane0;
+                const int g = (int)blockIdx.x * KPB + kq;
+                double *s_pimu = reinterpret_cast<double *>(smem + L.off_pimu);
+                D3 p_imu = d3(0, 0, 0);
+                if (g < a.n) p_imu = add(matvec(a.R_il, d3(a.raw_x[g], a.raw_y[g], a.raw_z[g])), d3(a.t_il[0], a.t_il[1], a.t_il[2]));
+                s_pimu[kq * 3 + 0] = p_imu.x; s_pimu[kq * 3 + 1] = p_imu.y; s_pimu[kq * 3 + 2] = p_imu.z;
+            }
+        }
         if (tid < 64) {
             const int lane = tid;
             const unsigned epoch = a.pose_epoch;
@@ -2008,14 +2093,14 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
     const unsigned epoch = (unsigned)b.seq;
     constexpr int KP2 = p2_keypoints_per_wave(KPB);                       // keypoints per phase-2 wave (as in phase 2)
     constexpr int P2W = (KPB + KP2 - 1) / KP2;
-    if (tid < 64) {
-        // lane l publishes granule l of the row: half l >> 5 of component l & 31
-        const double vs = __shfl(row_v, tid & 31);
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(vs);
-        const unsigned half = (tid < 32) ? (unsigned)bits : (unsigned)(bits >> 32);
-        __hip_atomic_store((gu64 *)(b.granules + (size_t)blockIdx.x * SRL_ROW_GRANULES + tid), ((unsigned long long)epoch << 32) | half,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (tid < 72 && b.cut_max > 0) {
+    if (tid < 32) {
+        // lane l publishes component l of the row (row_store: one 16-byte write-through store); the finishing workgroup keeps its own
+        // row in LDS -- read back through memory it was the row the finisher's first poll always missed
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (blockIdx.x == gridDim.x - 1) reinterpret_cast<double *>(smem + SRL_OWN_ROW_OFFSET)[tid] = row_v;
+        else row_store(rows_rsrc(b.granules), (int)blockIdx.x, tid, epoch, row_v);
+#endif
+    } else if (tid >= 64 && tid < 72 && b.cut_max > 0) {
         // granules 64..71: which keypoints of this workgroup were accepted (bit i = keypoint i), 32 per granule
         const int j = tid - 64;
         unsigned word = 0u;

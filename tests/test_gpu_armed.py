@@ -83,7 +83,7 @@ def test_armed_launches_change_no_bit(scene, max_res, frame_id, box):
         assert s1["armed"] - s0["armed"] == 5 * iters and s1["fired"] - s0["fired"] == 5 * iters - 1
         assert s1["expired"] == s0["expired"]
     finally:
-        lio.ctx.set_pose_box(0)
+        lio.ctx.set_pose_box(-1)
         lio.ctx.set_armed_launch(True)
 
 

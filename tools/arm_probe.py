@@ -77,7 +77,7 @@ def run(name, workload, max_res, frame_id, solves):
         ref = leg("per_iteration", lambda: lio.ctx.set_armed_launch(False))
         a0 = leg("armed_hostbox", lambda: (lio.ctx.set_armed_launch(True), lio.ctx.set_pose_box(0)))
         a1 = leg("armed_barbox", lambda: (lio.ctx.set_armed_launch(True), lio.ctx.set_pose_box(1)))
-        lio.ctx.set_pose_box(0)
+        lio.ctx.set_pose_box(-1)
         out["armed_hostbox_bitwise_equal"] = bool(a0 is not None and np.array_equal(ref, a0))
         out["armed_barbox_bitwise_equal"] = None if a1 is None else bool(np.array_equal(ref, a1))
     finally:

@@ -1,7 +1,10 @@
 """Time line of armed passes (srl_debug_pass_stamps): where one ESIKF iteration goes, from the device's 100 MHz clock (workgroup 0
 and the finishing workgroup) and the host's steady clock.  Medians over the fired passes of back-to-back solves.
 
-    python tools/arm_timeline.py [--configs HEADLINE,C2,C3,HEADLINE@600] [--box 1]
+The product build carries no stamp sites (they cost 0.2-0.4 us per pass): build the stamped variant first and point the library at it,
+
+    tools/build_variant.sh stamps "-DSRL_ARM_STAMPS -DSRL_STAMP_DETAIL"
+    SRL_LIB_PATH=$PWD/gpurun_in/lib_stamps.so python tools/arm_timeline.py [--configs HEADLINE,C2,C3,HEADLINE@600] [--box 1]
 """
 import argparse
 import json
@@ -59,7 +62,7 @@ def run(name, box):
                     rows.append(dict(
                         w0_wait=(w0[1] - w0[0]), w0_phase0=(w0[3] - w0[1]), w0_phase1=(w0[4] - w0[3]), w0_phase2=(w0[5] - w0[4]), w0_publish=(w0[6] - w0[5]),
                         fin_wait=(fn[1] - fn[0]), fin_phase0=(fn[3] - fn[1]), fin_phase1=(fn[4] - fn[3]), fin_phase2=(fn[5] - fn[4]), fin_publish=(fn[6] - fn[5]),
-                        fin_gather_mailbox=(fn[7] - fn[6]), fin_loads=(fx[0] - fn[6]), fin_bar1=(fx[1] - fx[0]), fin_sum=(fx[2] - fx[1]), fin_stores=(fx[3] - fx[2]), fin_drain=(fx[4] - fx[3]), fin_seq=(fn[7] - fx[4]), active=(fn[7] - min(w0[1], fn[1])),
+                        fin_gather_mailbox=(fn[7] - fn[6]), fin_loads=(fx[0] - fn[6]), fin_bar1=(fx[1] - fx[0]), fin_sum=(fx[2] - fx[1]), fin_stores=(fx[3] - fx[2]), fin_drain=(fx[4] - fx[3]), fin_seq=(fn[7] - fx[4]), p2_loops=(fx[5] - fn[4]), p2_eigen=(fx[6] - fx[5]), p2_gate_J=(fx[7] - fx[6]), p2_rows_walk=(g[i, 24] * 10.0 - fx[7]), p2_tail=(fn[5] - g[i, 24] * 10.0), active=(fn[7] - min(w0[1], fn[1])),
                         hop_gpu=(min(nxt[1], nxt[9]) * 10.0 - fn[7]),               # mailbox written -> next pose received (device clock)
                         period_gpu=(nxt[15] - g[i, 15]) * 10.0,
                         pose_skew=(fn[1] - w0[1]),
