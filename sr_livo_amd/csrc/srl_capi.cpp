@@ -612,6 +612,7 @@ inline void pose_box_write(srl_ctx *ctx, const double *Rn, const double *R, cons
 int srl_ctx_disarm(srl_ctx *ctx) {
     if (!ctx || !ctx->armed) return SRL_OK;
     pose_box_write(ctx, nullptr, nullptr, nullptr, (unsigned)ctx->armed_sig.seq, SRL_ARM_CANCEL);
+    if (ctx->seq < ctx->armed_sig.seq) ctx->seq = ctx->armed_sig.seq;      // the cancelled launch's sequence number is spent
     ctx->armed = false;
     if (ctx->armed_ring >= 0) ctx->ring_void[ctx->armed_ring] = true;
     ctx->armed_ring = -1;
@@ -826,7 +827,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
 
     can_fuse_cut = can_fuse_cut && wpb == 16 && kpb <= SRL_FUSED_CUT_MAX_KPB && nblocks <= SRL_FUSED_MAX_BLOCKS;
     const bool fused = (can_fuse && wpb == 16 && nblocks <= SRL_FUSED_MAX_BLOCKS) || can_fuse_cut;
-    const unsigned long long seq_now = ++ctx->seq;
+    unsigned long long seq_now = ++ctx->seq;          // (a cancelled armed launch below takes this number with it: see there)
     const bool coll = ctx->comm && (ctx->nranks > 1 || ctx->force_coll) && !ctx->peer_on;
     const bool peer = ctx->peer_on && ctx->nranks > 1;
     unsigned peer_epoch = 0;
@@ -885,8 +886,13 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             ctx->arm_stats[1]++;
             fired = true;
         } else {
+            // not this pass's launch: cancel it.  It carried THIS pass's sequence number, and if it has already given up on its own it
+            // has left its "expired" report under that number in the mailbox -- so the pass takes the next one (a launch that
+            // reuses the number would read that report as its own result)
             const int rcd = srl_ctx_disarm(ctx);
             if (rcd) return rcd;
+            seq_now = ++ctx->seq;
+            if (fused) a.seq = seq_now;
         }
     }
     const auto t_prep = std::chrono::steady_clock::now();

@@ -361,8 +361,22 @@ __device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, cons
     }
     found = found && (int)cnt >= thr_cap && cnt > 0;            // NumPoints() < threshold -> skipped (optimize.cpp:389)
     // P_k of the two keypoints (the candidates the reference's loop visits, optimize.cpp:391-404) = the resident points of the
-    // voxels found: added up here, once per voxel, instead of by ballots over every candidate round
-    if (found) atomicAdd(ncand_pair + (lane >> 5), (int)cnt);
+    // voxels found: added up here, once per voxel, instead of by ballots over every candidate round.  Summed across the lanes of
+    // each half-wave in registers (DPP row shifts + row broadcasts: the standard wave reduction; lane 31 ends with the low half's
+    // sum, lane 63 with the wave's) and filed by ONE store per keypoint -- as an LDS atomic per found voxel, ~12 lanes on one
+    // address, it was 80 % of the kernel's LDS bank-conflict cycles (SQ_LDS_ADDR_CONFLICT 11.0 / SQ_LDS_BANK_CONFLICT 12.9 of 16.2
+    // cycles per keypoint, tools/ablate_pmc.py).
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        int v = found ? (int)cnt : 0;
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);      // row_shr:1
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);      // row_shr:2
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);      // row_shr:4   (inclusive prefix over 1 + 2 + 4 ... lanes of a row)
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);      // row_shr:8   -> lane 15 of every row: the row's sum
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3 -> lane 31: rows 0 + 1, lane 63: rows 2 + 3
+        if ((lane & 31) == 31) ncand_pair[lane >> 5] = v;
+#endif
+    }
     const unsigned long long m = __ballot(found);
     const unsigned m_lo = (unsigned)m, m_hi = (unsigned)(m >> 32);
     const int nv_a = __popc(m_lo), nv_b = __popc(m_hi);

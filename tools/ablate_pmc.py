@@ -20,9 +20,10 @@ if len(sys.argv) > 2 and sys.argv[1] == "--report":
     for i, b in enumerate(BITS):
         ds = disp[i * REPS:(i + 1) * REPS]
         c = {k: sum(per[d].get(k, 0.0) for d in ds) / len(ds) for k in per[ds[0]]}
-        line = f"{NAMES[b]:42s} VALU {c.get('SQ_INSTS_VALU', 0) / n:7.1f}  SALU {c.get('SQ_INSTS_SALU', 0) / n:7.1f}  LDS {c.get('SQ_INSTS_LDS', 0) / n:6.1f}  VMEM {c.get('SQ_INSTS_VMEM_RD', 0) / n:5.1f}  per keypoint"
+        keys = sorted(c)
+        line = f"{NAMES[b]:42s} " + "  ".join(f"{k.replace('SQ_', '')} {c[k] / n:8.2f}" for k in keys) + "  per keypoint"
         if prev:
-            line += f"   | removed vs previous row: VALU {(prev.get('SQ_INSTS_VALU', 0) - c.get('SQ_INSTS_VALU', 0)) / n:6.1f} SALU {(prev.get('SQ_INSTS_SALU', 0) - c.get('SQ_INSTS_SALU', 0)) / n:6.1f} LDS {(prev.get('SQ_INSTS_LDS', 0) - c.get('SQ_INSTS_LDS', 0)) / n:5.1f}"
+            line += "   | removed vs previous row: " + " ".join(f"{k.replace('SQ_', '')} {(prev.get(k, 0) - c[k]) / n:7.2f}" for k in keys)
         print(line)
         prev = c
     sys.exit(0)

@@ -49,8 +49,9 @@ def run(name, workload, max_res, frame_id, solves):
             for _ in range(5):
                 rc, it, nr = solve()
                 assert rc == 0, rc
-            s0 = lio.ctx.arm_stats()
+            lio.ctx.disarm()
             torch.cuda.synchronize()
+            s0 = lio.ctx.arm_stats()
             per = np.empty(solves)
             t = time.perf_counter()
             for k in range(solves):
