@@ -238,6 +238,12 @@ int srl_transform_points(srl_ctx *ctx, const double *raw_xyz, int n, const doubl
  * one context per process/GPU; the only exchange step is the all-reduce of the normal equations. */
 #define SRL_COMM_ID_BYTES 128
 int srl_comm_unique_id(void *id /* SRL_COMM_ID_BYTES */);
+/* debug / test hook: take the nccl* entry points of this process from the given shared object instead of the process's RCCL.  Only
+ * before the first communicator call (SRL_ERR_BAD_ARG afterwards: one instance per process).  tests/fake_rccl/libfake_rccl.so -- ranks
+ * as processes meeting in shared memory, collectives stream-ordered through host callbacks -- lets the N > 1 sequencing of
+ * srl_build_residuals (count all-gather -> reduce kernel -> all-reduce of 50 doubles -> publish, src/optimize.cpp:107,235,239 across
+ * shards) run on a one-GPU box, where RCCL itself refuses two ranks per device. */
+int srl_comm_set_library(const char *path);
 int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id);
 int srl_comm_destroy(srl_ctx *ctx);
 /* Which RCCL the communicator calls run on.  The library does not link librccl: it uses the RCCL instance the process has

@@ -8,5 +8,5 @@ CPU fallback: every compute entry point fails loudly when the HIP extension or a
 from .capi import (  # noqa: F401
     LIB_PATH, SrlError, IcpOpts, Frame, NormalEq, Timing, Context, Lio,
     load_library, library_symbols, declared_symbols, default_opts, shard_range, shard_budget,
-    grid_sampling, heap_topk, PinnedArray, comm_backend_info, tr1_order,
+    grid_sampling, heap_topk, PinnedArray, comm_backend_info, comm_set_library, tr1_order,
 )

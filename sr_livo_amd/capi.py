@@ -140,6 +140,7 @@ def load_library():
         "srl_comm_unique_id": ([p], C.c_int),
         "srl_comm_init_rank": ([p, C.c_int, C.c_int, p], C.c_int),
         "srl_comm_destroy": ([p], C.c_int),
+        "srl_comm_set_library": ([C.c_char_p], C.c_int),
         "srl_comm_suspend": ([p, C.c_int], C.c_int),
         "srl_comm_set_host_callbacks": ([p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, p], C.c_int),
         "srl_debug_set_gather_counts": ([p, C.c_int, C.c_int, C.POINTER(C.c_int64)], C.c_int),
@@ -290,6 +291,13 @@ class PinnedArray:
             self.close()
         except Exception:
             pass
+
+def comm_set_library(path):
+    """debug / test hook (srl_comm_set_library): resolve the nccl* entry points from `path`; only before the first communicator call"""
+    rc = load_library().srl_comm_set_library(os.fsencode(path))
+    if rc:
+        raise SrlError(rc, "srl_comm_set_library", "a communicator call has already resolved this process's RCCL")
+
 
 def comm_backend_info():
     """(path of the RCCL shared object in use, ncclGetVersion, found-already-loaded-in-the-process) or raises."""

@@ -1399,6 +1399,10 @@ int srl_comm_unique_id(void *id) {
     return SRL_OK;
 }
 
+int srl_comm_set_library(const char *path) {
+    return srl_rccl_set_library(path) ? SRL_OK : SRL_ERR_BAD_ARG;
+}
+
 int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id) {
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return SRL_ERR_BAD_ARG;
     SRL_DISARM(ctx);

@@ -13,6 +13,8 @@ SrlRccl g_tab;
 bool g_ok = false;
 std::string g_err;
 std::once_flag g_once;
+std::string g_override;          // srl_rccl_set_library: resolve from THIS shared object only (test stand-ins)
+bool g_resolved = false;
 
 template <class F>
 bool sym(void *handle, const char *name, F &out) {
@@ -30,6 +32,22 @@ bool fill(void *handle) {
 
 void resolve() {
     std::memset(&g_tab, 0, sizeof g_tab);
+    g_resolved = true;
+    if (!g_override.empty()) {
+        void *h = dlopen(g_override.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h || !fill(h)) {
+            const char *why = dlerror();
+            g_err = "srl_comm_set_library(" + g_override + "): " + (why ? why : "an nccl entry point is missing");
+            return;
+        }
+        g_tab.preloaded = false;
+        int v = 0;
+        if (g_tab.GetVersion(&v) != ncclSuccess) { g_err = "ncclGetVersion failed"; return; }
+        g_tab.version = v;
+        std::snprintf(g_tab.origin, sizeof g_tab.origin, "%s", g_override.c_str());
+        g_ok = true;
+        return;
+    }
     // 1. an RCCL the process already carries (global symbol scope)
     if (dlsym(RTLD_DEFAULT, "ncclCommInitRank") && fill(RTLD_DEFAULT)) {
         g_tab.preloaded = true;
@@ -70,3 +88,8 @@ const SrlRccl *srl_rccl() {
     return g_ok ? &g_tab : nullptr;
 }
 const char *srl_rccl_error() { return g_err.c_str(); }
+bool srl_rccl_set_library(const char *path) {
+    if (g_resolved || !path || !*path) return false;       // before the first communicator call only: one RCCL instance per process
+    g_override = path;
+    return true;
+}

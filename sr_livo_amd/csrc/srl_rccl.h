@@ -24,3 +24,6 @@ struct SrlRccl {
 // nullptr when no RCCL can be found (srl_rccl_error() says why)
 const SrlRccl *srl_rccl();
 const char *srl_rccl_error();
+// Resolve the entry points from this shared object instead (before the first communicator call; false afterwards): the test-only
+// stand-in tests/fake_rccl/libfake_rccl.so, through srl_comm_set_library -- an explicit call, never an environment variable.
+bool srl_rccl_set_library(const char *path);
