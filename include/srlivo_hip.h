@@ -351,6 +351,13 @@ int srl_debug_set_arm_linger(srl_ctx *ctx, double host_linger_us, double kernel_
  * 16..24 inside the finisher and phase 2 (-DSRL_STAMP_DETAIL);
  * host_out[64 * 4] (optional): steady-clock ns at {call entry, pose written or launch returned, result seen} and a fired flag. */
 int srl_debug_pass_stamps(srl_ctx *ctx, int enable, long long *gpu_out, long long *host_out);
+/* Stage times of the frame pipeline (bench.py's `pipeline` leg, tools/pipeline_probe.py).  While enabled the stream is synchronised at
+ * every stage boundary and the wall time of each stage is ACCUMULATED in us; out16 (optional) receives the sums since the last call,
+ * which also clears them: [0] srl_frame_upload; srl_frame_select_keypoints: [1] grouping kernels (transform, voxel key, first point per
+ * voxel), [2] download of the voxel list, [3] host: std::tr1::unordered_map iteration order, [4] gather into the resident sweep;
+ * srl_frame_commit: [5] re-transform, [6] download of point3D::point; the map insertion behind it (also srl_map_insert): [7] keys +
+ * (key, index) sort, [8] segments, [9] lookup + creation of new voxels, [10] per-voxel replay + counters. */
+int srl_debug_frame_timing(srl_ctx *ctx, int enable, double out16[16]);
 /* tuning experiments: force the association kernel's launch shape -- keypoints per wave (16-wave workgroups: 2 / 3 / 4 / 6 / 8 /
  * 12 / 16; 4-wave workgroups: 4 / 8 / 16) and waves per workgroup (4 / 16); 0, 0 = automatic (by sweep size).  Results do not
  * depend on the shape beyond FP64 summation order. */

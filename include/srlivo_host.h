@@ -29,6 +29,9 @@ int srl_lio_set_laser_point_cov(srl_lio *lio, double cov);
 /* srl_lio_last_solve_launches: kernel launches the last solve enqueued for its passes (one per ESIKF iteration; with armed launches
  * all but the first are enqueued ahead of time, include/srlivo_hip.h). */
 int srl_lio_last_solve_launches(srl_lio *lio, int *launches);
+/* eskfEstimator::observe() calls of the last solve (src/optimize.cpp:253).  0 = every pass ran into the step guard (:248-251) or
+ * failed before it: the reference then never wrote p_frame->p_state, G, G_norm (:255-261) -- a binding must not either. */
+int srl_lio_last_solve_observed(srl_lio *lio, int *observed);
 
 /* eskfEstimator accessors (eskfEstimator.h:74-108).  state = p(3) q(wxyz,4) v(3) ba(3) bg(3) g(3) */
 int srl_lio_eskf_get_state(srl_lio *lio, double s[19]);

@@ -14,16 +14,22 @@
 // The filter stays the node's own eskfEstimator: its state and covariance are handed to the call and read back
 // (eskfEstimator.h:86-108), p_frame->p_state and the globals G / G_norm are written as optimize.cpp:255-261 writes them.
 //
-// The voxel map.  The node keeps inserting sweeps into its tsl::robin_map (addPointsToMap, lioOptimization.cpp:1027 -- still
-// needed by the colour map / rendering side); the path reads the DEVICE map.  Both are fed the same points in the same order:
-// before a solve, every frame of the sliding window that the node has inserted since the last solve -- the frames before
-// frame_id 2, which stateEstimation inserts without calling optimize, and every frame whose optimize() succeeded
-// (lioOptimization.cpp:1003-1027) -- is inserted on the device with the parameters stateEstimation uses (srl_map_insert
-// reproduces addPointToMap's order-dependent semantics bit for bit).  mapSize() of the two maps is compared after every
-// sync: a difference is a hard error, not a silent drift.
+// The frame stays on the device.  optimize() uploads the frame's raw points ONCE, from a page-locked buffer the binding keeps across
+// calls; keypoints are selected on the device (same keypoints, same order as gridSampling, utility.cpp:167-201), the ESIKF runs on
+// them in place, and the frame is re-transformed with the solved pose (optimize.cpp:441-445) and inserted into the DEVICE map without
+// leaving HBM (srl_lio_optimize_resident / srl_lio_commit_frame); one download returns point3D::point for the node.
+//
+// The voxel map.  The node keeps inserting sweeps into its own tsl::robin_map (addPointsToMap, lioOptimization.cpp:1027 -- the colour
+// map / rendering side needs it); the path reads the DEVICE map.  Both receive the same points in the same order: a frame whose
+// optimize() succeeded is committed on the device inside optimize(), from the very world points the node inserts right after it
+// (lioOptimization.cpp:1003-1027); the frames before frame_id 2, which stateEstimation inserts without calling optimize, are
+// uploaded and inserted before the next solve (srl_map_insert reproduces addPointToMap's order-dependent semantics bit for bit).
+// mapSize() of the two maps is compared during the first calls and every 32nd afterwards (the node's mapSize walks every voxel):
+// a difference is a hard error, not a silent drift.
 //
 // tests/test_gpu_integration.py compiles this file together with the reference's own translation units
 // (oracle/Makefile, target refnode_hip) and drives the reference's run() over the 40-sweep replay stream.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <map>
@@ -49,10 +55,22 @@ struct HipBinding {
     srl_lio *lio = nullptr;
     int last_frame_handled = -1;              // frame_id up to which the window's frames have been looked at for the map sync
     std::map<int, bool> solved;               // frame_id -> optimize() succeeded (the node inserts exactly those, lioOptimization.cpp:1011-1027)
+    std::map<int, bool> committed;            // frame_id -> already inserted into the device map by optimize() itself
+    double *pinned_raw = nullptr;             // page-locked upload buffer for the frame's raw points, kept across calls (srl_pinned_alloc)
+    size_t pinned_cap = 0;                    // points
+    double *pinned_world = nullptr;           // point3D::point of the committed frame (download target), page-locked, kept across calls
+    long calls = 0;
+    // (freed by srl_integration_release, not by a destructor: a binding still alive at process exit would call into a HIP runtime that is
+    // already shutting down)
+    void free_buffers() { if (pinned_raw) srl_pinned_free(pinned_raw); if (pinned_world) srl_pinned_free(pinned_world); pinned_raw = pinned_world = nullptr; pinned_cap = 0; }
 };
 
 std::mutex g_mutex;
 std::unordered_map<const lioOptimization *, HipBinding> g_bindings;
+// the node calls from ONE thread (the ROS main thread, lioOptimization.cpp:1596-1604): the binding of the node seen last is remembered,
+// so that a call costs neither the lock nor the map lookup
+thread_local const lioOptimization *t_self = nullptr;
+thread_local HipBinding *t_binding = nullptr;
 
 [[noreturn]] void fail(srl_lio *lio, int rc, const char *what) {
     std::string msg = std::string(what) + ": " + srl_status_str(rc);
@@ -61,13 +79,50 @@ std::unordered_map<const lioOptimization *, HipBinding> g_bindings;
 }
 
 HipBinding &binding_of(const lioOptimization *self) {
+    if (t_self == self && t_binding) return *t_binding;
     std::lock_guard<std::mutex> lk(g_mutex);
-    HipBinding &b = g_bindings[self];
+    HipBinding &b = g_bindings[self];                      // (references into an unordered_map stay valid across insertions)
     if (!b.lio) {
         const int rc = srl_lio_create(0, &b.lio);          // no CPU fallback: without a GPU the node cannot run this path
         if (rc != SRL_OK) fail(nullptr, rc, "srl_lio_create");
     }
+    t_self = self; t_binding = &b;
     return b;
+}
+
+// the node's members the path reads (lioOptimization.h:216-228) and its filter, handed to the mirror before a solve ...
+void push_node_state(lioOptimization *self, srl_lio *lio, const Eigen::Matrix3d &R_imu_lidar, const Eigen::Vector3d &t_imu_lidar, double laser_point_cov,
+                     eskfEstimator *eskf_pro) {
+    (void)self;
+    double R_il[9], t_il[3];
+    for (int i = 0; i < 3; i++) { t_il[i] = t_imu_lidar[i]; for (int j = 0; j < 3; j++) R_il[3 * i + j] = R_imu_lidar(i, j); }
+    srl_lio_set_extrinsics(lio, R_il, t_il);
+    srl_lio_set_laser_point_cov(lio, laser_point_cov);
+    double es[19], P[289];
+    const Eigen::Vector3d p = eskf_pro->getTranslation(), v = eskf_pro->getVelocity(), ba = eskf_pro->getBa(), bg = eskf_pro->getBg(), g = eskf_pro->getGravity();
+    const Eigen::Quaterniond q = eskf_pro->getRotation();
+    for (int a = 0; a < 3; a++) { es[a] = p[a]; es[7 + a] = v[a]; es[10 + a] = ba[a]; es[13 + a] = bg[a]; es[16 + a] = g[a]; }
+    es[3] = q.w(); es[4] = q.x(); es[5] = q.y(); es[6] = q.z();
+    const Eigen::Matrix<double, 17, 17> cov = eskf_pro->getCovariance();
+    for (int i = 0; i < 17; i++) for (int j = 0; j < 17; j++) P[17 * i + j] = cov(i, j);
+    srl_lio_eskf_set_state(lio, es);
+    srl_lio_eskf_set_cov(lio, P);
+}
+// ... and what the loop leaves behind read back: the filter (observe(), optimize.cpp:253; setCovariance, :307) -- ALWAYS, also when
+// the solve ended in the NaN throw of optimize.cpp:348-350 (the reference keeps the observe() calls of the passes before it)
+void pull_filter(srl_lio *lio, eskfEstimator *eskf_pro) {
+    double es[19], P[289];
+    srl_lio_eskf_get_state(lio, es);
+    srl_lio_eskf_get_cov(lio, P);
+    eskf_pro->setTranslation(Eigen::Vector3d(es[0], es[1], es[2]));
+    eskf_pro->setRotation(Eigen::Quaterniond(es[3], es[4], es[5], es[6]));
+    eskf_pro->setVelocity(Eigen::Vector3d(es[7], es[8], es[9]));
+    eskf_pro->setBa(Eigen::Vector3d(es[10], es[11], es[12]));
+    eskf_pro->setBg(Eigen::Vector3d(es[13], es[14], es[15]));
+    eskf_pro->setGravity(Eigen::Vector3d(es[16], es[17], es[18]));
+    Eigen::Matrix<double, 17, 17> cov;
+    for (int i = 0; i < 17; i++) for (int j = 0; j < 17; j++) cov(i, j) = P[17 * i + j];
+    eskf_pro->setCovariance(cov);
 }
 
 srl_icp_opts to_abi(const icpOptions &o) {
@@ -121,7 +176,9 @@ extern "C" void srl_integration_release(const void *node) {
     std::lock_guard<std::mutex> lk(g_mutex);
     auto it = g_bindings.find(static_cast<const lioOptimization *>(node));
     if (it == g_bindings.end()) return;
+    it->second.free_buffers();
     if (it->second.lio) srl_lio_destroy(it->second.lio);
+    if (t_binding == &it->second) { t_self = nullptr; t_binding = nullptr; }
     g_bindings.erase(it);
 }
 
@@ -131,7 +188,8 @@ static void sync_device_map(lioOptimization *self, HipBinding &b, const std::vec
     for (const cloudFrame *f : window) {
         if (f == current || f->frame_id <= b.last_frame_handled) continue;
         const bool inserted_by_node = f->frame_id <= 1 || (b.solved.count(f->frame_id) && b.solved[f->frame_id]);
-        if (inserted_by_node && !f->point_frame.empty()) {
+        const bool already_on_device = b.committed.count(f->frame_id) != 0;       // optimize() committed it itself
+        if (inserted_by_node && !already_on_device && !f->point_frame.empty()) {
             std::vector<double> xyz(3 * f->point_frame.size());
             for (size_t k = 0; k < f->point_frame.size(); ++k) for (int d = 0; d < 3; d++) xyz[3 * k + d] = f->point_frame[k].point[d];
             const int rc = srl_lio_add_points_to_map(b.lio, xyz.data(), (int)f->point_frame.size(), oo.optimize_options.size_voxel_map,
@@ -140,6 +198,7 @@ static void sync_device_map(lioOptimization *self, HipBinding &b, const std::vec
         }
         b.last_frame_handled = f->frame_id;
     }
+    if (!(b.calls < 16 || b.calls % 32 == 0)) return;       // the node's mapSize() walks every voxel of its map
     int64_t on_device = 0;
     const int rc = srl_lio_map_size(b.lio, &on_device);
     if (rc != SRL_OK) fail(b.lio, rc, "srl_lio_map_size");
@@ -154,29 +213,71 @@ static void sync_device_map(lioOptimization *self, HipBinding &b, const std::vec
 optimizeSummary lioOptimization::optimize(cloudFrame *p_frame, const icpOptions &cur_icp_options, double sample_voxel_size)
 {
     HipBinding &b = binding_of(this);
+    srl_lio *lio = b.lio;
     sync_device_map(this, b, all_cloud_frame, p_frame, odometry_options, voxel_map);
+    b.calls++;
 
-    std::vector<point3D> keypoints;
-    gridSampling(p_frame->point_frame, keypoints, sample_voxel_size);                 // utility.cpp:188-201 (the node's own)
+    // the frame's raw points into the page-locked buffer (the upload is one DMA out of it)
+    const int n = (int)p_frame->point_frame.size();
+    if ((size_t)n > b.pinned_cap) {
+        if (b.pinned_raw) srl_pinned_free(b.pinned_raw);
+        if (b.pinned_world) srl_pinned_free(b.pinned_world);
+        b.pinned_raw = b.pinned_world = nullptr;
+        b.pinned_cap = (size_t)n + (size_t)n / 2 + 1024;
+        void *p = nullptr, *w = nullptr;
+        const int rca = srl_pinned_alloc(b.pinned_cap * 3 * sizeof(double), &p);
+        const int rcw = rca == SRL_OK ? srl_pinned_alloc(b.pinned_cap * 3 * sizeof(double), &w) : rca;
+        if (rca != SRL_OK || rcw != SRL_OK) { if (p) srl_pinned_free(p); b.pinned_cap = 0; fail(lio, rca != SRL_OK ? rca : rcw, "srl_pinned_alloc"); }
+        b.pinned_raw = static_cast<double *>(p);
+        b.pinned_world = static_cast<double *>(w);
+    }
+    for (int k = 0; k < n; k++) for (int d = 0; d < 3; d++) b.pinned_raw[3 * (size_t)k + d] = p_frame->point_frame[k].raw_point[d];
 
-    optimizeSummary optimize_summary = updateIEKF(cur_icp_options, voxel_map, keypoints, p_frame);
+    push_node_state(this, lio, R_imu_lidar, t_imu_lidar, laser_point_cov, eskf_pro);
+    const srl_icp_opts abi = to_abi(cur_icp_options);
+    double st[16], t_last[3];
+    pack_state16(p_frame->p_state, st);
+    const state *last_state = all_cloud_frame[p_frame->id - 1]->p_state;             // optimize.cpp:25
+    for (int a = 0; a < 3; a++) t_last[a] = last_state->translation[a];
+
+    // gridSampling (utility.cpp:188-201: same keypoints, same order, selected on the device from point = R(q)(R_il raw + t_il) + t at the
+    // prior pose -- what point3D::point holds here) + updateIEKF on them in place
+    int iters = 0, num_residuals = 0, observed = 0;
+    const int rc = srl_lio_optimize_resident(lio, &abi, sample_voxel_size, b.pinned_raw, n, st, t_last, p_frame->frame_id, nullptr, nullptr, &iters,
+                                             &num_residuals);
+    pull_filter(lio, eskf_pro);
+    srl_lio_last_solve_observed(lio, &observed);
+    if (observed > 0) {                                                              // optimize.cpp:255-261 ran at least once
+        unpack_state16(st, p_frame->p_state);
+        G = eskf_pro->getGravity();
+        G_norm = G.norm();
+    }
+    if (rc == SRL_ERR_NAN_PLANARITY) throw std::runtime_error("error");              // optimize.cpp:348-350
+    if (rc != SRL_OK && rc != SRL_ERR_NOT_ENOUGH_RESIDUALS) fail(lio, rc, "srl_lio_optimize_resident");
+
+    optimizeSummary optimize_summary;
+    optimize_summary.num_residuals_used = num_residuals;
+    optimize_summary.success = rc == SRL_OK;
     b.solved[p_frame->frame_id] = optimize_summary.success;
     if (b.solved.size() > 64) b.solved.erase(b.solved.begin());
-    if (!optimize_summary.success) return optimize_summary;
-
-    // transformPoint over the whole frame with the final pose (optimize.cpp:441-445 -> utility.cpp:314-318), on the device
-    const int n = (int)p_frame->point_frame.size();
-    if (n > 0) {
-        const std::vector<double> raw = raw_points_of(p_frame->point_frame);
-        std::vector<double> world(3 * (size_t)n);
-        const Eigen::Quaterniond &q_end = p_frame->p_state->rotation;
-        const double qv[4] = {q_end.w(), q_end.x(), q_end.y(), q_end.z()};
-        double t[3], R_il[9], t_il[3];
-        for (int i = 0; i < 3; i++) { t[i] = p_frame->p_state->translation[i]; t_il[i] = t_imu_lidar[i]; for (int j = 0; j < 3; j++) R_il[3 * i + j] = R_imu_lidar(i, j); }
-        const int rc = srl_transform_points(srl_lio_ctx(b.lio), raw.data(), n, qv, t, R_il, t_il, world.data());
-        if (rc != SRL_OK) fail(b.lio, rc, "srl_transform_points");
-        for (int k = 0; k < n; k++) p_frame->point_frame[k].point = Eigen::Vector3d(world[3 * (size_t)k], world[3 * (size_t)k + 1], world[3 * (size_t)k + 2]);
+    if (!optimize_summary.success) {                                                 // optimize.cpp:110-123
+        std::stringstream ss_out;
+        ss_out << "[Optimization] Error : not enough keypoints selected in ct-icp !" << std::endl;
+        ss_out << "[Optimization] number_of_residuals : " << num_residuals << std::endl;
+        optimize_summary.error_log = ss_out.str();
+        return optimize_summary;
     }
+
+    // transformPoint over the whole frame with the final pose (optimize.cpp:441-445 -> utility.cpp:314-318) and the insertion the node
+    // performs right after this call (addPointsToMap, lioOptimization.cpp:1027), both on the frame resident in HBM; the world points
+    // come back once, for point3D::point
+    int added = 0;
+    const int rcc = srl_lio_commit_frame(lio, st, odometry_options.optimize_options.size_voxel_map, odometry_options.max_num_points_in_voxel,
+                                         odometry_options.min_distance_points, 0, n > 0 ? b.pinned_world : nullptr, &added);
+    if (rcc != SRL_OK) fail(lio, rcc, "srl_lio_commit_frame");
+    b.committed[p_frame->frame_id] = true;
+    if (b.committed.size() > 64) b.committed.erase(b.committed.begin());
+    for (int k = 0; k < n; k++) p_frame->point_frame[k].point = Eigen::Vector3d(b.pinned_world[3 * (size_t)k], b.pinned_world[3 * (size_t)k + 1], b.pinned_world[3 * (size_t)k + 2]);
     return optimize_summary;
 }
 
@@ -187,24 +288,7 @@ optimizeSummary lioOptimization::updateIEKF(const icpOptions &cur_icp_options, v
     HipBinding &b = binding_of(this);
     srl_lio *lio = b.lio;
 
-    // members of the node the path reads (lioOptimization.h:216-228)
-    double R_il[9], t_il[3];
-    for (int i = 0; i < 3; i++) { t_il[i] = t_imu_lidar[i]; for (int j = 0; j < 3; j++) R_il[3 * i + j] = R_imu_lidar(i, j); }
-    srl_lio_set_extrinsics(lio, R_il, t_il);
-    srl_lio_set_laser_point_cov(lio, laser_point_cov);
-
-    // the filter: eskf_pro's state and covariance in, the updated ones out
-    double es[19], P[289];
-    {
-        const Eigen::Vector3d p = eskf_pro->getTranslation(), v = eskf_pro->getVelocity(), ba = eskf_pro->getBa(), bg = eskf_pro->getBg(), g = eskf_pro->getGravity();
-        const Eigen::Quaterniond q = eskf_pro->getRotation();
-        for (int a = 0; a < 3; a++) { es[a] = p[a]; es[7 + a] = v[a]; es[10 + a] = ba[a]; es[13 + a] = bg[a]; es[16 + a] = g[a]; }
-        es[3] = q.w(); es[4] = q.x(); es[5] = q.y(); es[6] = q.z();
-        const Eigen::Matrix<double, 17, 17> cov = eskf_pro->getCovariance();
-        for (int i = 0; i < 17; i++) for (int j = 0; j < 17; j++) P[17 * i + j] = cov(i, j);
-    }
-    srl_lio_eskf_set_state(lio, es);
-    srl_lio_eskf_set_cov(lio, P);
+    push_node_state(this, lio, R_imu_lidar, t_imu_lidar, laser_point_cov, eskf_pro);
 
     const srl_icp_opts abi = to_abi(cur_icp_options);
     const std::vector<double> raw = raw_points_of(keypoints);
@@ -214,29 +298,18 @@ optimizeSummary lioOptimization::updateIEKF(const icpOptions &cur_icp_options, v
     for (int a = 0; a < 3; a++) t_last[a] = last_state->translation[a];
     int iters = 0, num_residuals = 0;
     const int rc = srl_lio_update_iekf(lio, &abi, raw.data(), (int)keypoints.size(), st, t_last, p_frame->frame_id, nullptr, 0, &iters, &num_residuals);
-    if (rc == SRL_ERR_NAN_PLANARITY) throw std::runtime_error("error");              // optimize.cpp:348-350
-    if (rc != SRL_OK && rc != SRL_ERR_NOT_ENOUGH_RESIDUALS) fail(lio, rc, "srl_lio_update_iekf");
-
-    // what the loop leaves behind: the filter (observe(), optimize.cpp:253; setCovariance, :307), the frame's state (:255-259),
-    // the gravity globals (:260-261)
-    srl_lio_eskf_get_state(lio, es);
-    srl_lio_eskf_get_cov(lio, P);
-    eskf_pro->setTranslation(Eigen::Vector3d(es[0], es[1], es[2]));
-    eskf_pro->setRotation(Eigen::Quaterniond(es[3], es[4], es[5], es[6]));
-    eskf_pro->setVelocity(Eigen::Vector3d(es[7], es[8], es[9]));
-    eskf_pro->setBa(Eigen::Vector3d(es[10], es[11], es[12]));
-    eskf_pro->setBg(Eigen::Vector3d(es[13], es[14], es[15]));
-    eskf_pro->setGravity(Eigen::Vector3d(es[16], es[17], es[18]));
-    {
-        Eigen::Matrix<double, 17, 17> cov;
-        for (int i = 0; i < 17; i++) for (int j = 0; j < 17; j++) cov(i, j) = P[17 * i + j];
-        eskf_pro->setCovariance(cov);
-    }
-    unpack_state16(st, p_frame->p_state);
-    if (iters > 0) {
+    // what the loop leaves behind: the filter -- also behind the NaN throw --, the frame's state (:255-259) and the gravity globals
+    // (:260-261), the last two only if observe() ran at all (a solve whose every step hit the guard of :248-251 writes neither)
+    pull_filter(lio, eskf_pro);
+    int observed = 0;
+    srl_lio_last_solve_observed(lio, &observed);
+    if (observed > 0) {
+        unpack_state16(st, p_frame->p_state);
         G = eskf_pro->getGravity();
         G_norm = G.norm();
     }
+    if (rc == SRL_ERR_NAN_PLANARITY) throw std::runtime_error("error");              // optimize.cpp:348-350
+    if (rc != SRL_OK && rc != SRL_ERR_NOT_ENOUGH_RESIDUALS) fail(lio, rc, "srl_lio_update_iekf");
 
     optimizeSummary summary;
     summary.num_residuals_used = num_residuals;

@@ -475,6 +475,28 @@ void ref_param_set_str(const char *name, const char *v) { ros::standin::str_para
 
 struct ref_node { ParamGuard guard; lioOptimization lio; };
 
+// ---- wall time of every lioOptimization::optimize call the node makes (tests/test_gpu_integration.py compares the all-CPU node with
+// the node that carries integration/optimize_hip.cpp).  Both node libraries are linked with
+//   -Wl,--wrap=_ZN15lioOptimization8optimizeEP10cloudFrameRK10icpOptionsd
+// so that stateEstimation's call (src/lioOptimization.cpp:1009, in another object file) lands in __wrap_..., which stamps the clock
+// around __real_... = whichever optimize() the library was built with.  A non-static member function is called like a free function
+// with `this` first (Itanium C++ ABI), including the hidden result pointer of the class it returns.
+#include <chrono>
+static std::vector<double> g_optimize_us;
+extern "C" optimizeSummary __real__ZN15lioOptimization8optimizeEP10cloudFrameRK10icpOptionsd(lioOptimization *, cloudFrame *, const icpOptions &, double);
+extern "C" optimizeSummary __wrap__ZN15lioOptimization8optimizeEP10cloudFrameRK10icpOptionsd(lioOptimization *self, cloudFrame *f, const icpOptions &o, double s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    optimizeSummary r = __real__ZN15lioOptimization8optimizeEP10cloudFrameRK10icpOptionsd(self, f, o, s);
+    g_optimize_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    return r;
+}
+int ref_optimize_times(double *out, int cap) {
+    const int n = (int)g_optimize_us.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = g_optimize_us[i];
+    return n;
+}
+void ref_optimize_times_reset(void) { g_optimize_us.clear(); }
+
 // point_time_enable: what cloudProcessing derives from the message fields (given_offset_time, src/cloudProcessing.cpp:228-233)
 ref_node *ref_node_create(int point_time_enable) {
     std::streambuf *old = std::cout.rdbuf(nullptr);

@@ -156,6 +156,7 @@ def load_library():
         "srl_debug_set_pose_box": ([p, C.c_int], C.c_int),
         "srl_debug_set_arm_linger": ([p, C.c_double, C.c_double], C.c_int),
         "srl_debug_pass_stamps": ([p, C.c_int, p, p], C.c_int),
+        "srl_debug_frame_timing": ([p, C.c_int, p], C.c_int),
         "srl_set_armed_launch": ([p, C.c_int], C.c_int),
         "srl_disarm": ([p], C.c_int),
         "srl_get_arm_stats": ([p, C.POINTER(C.c_uint64)], C.c_int),
@@ -508,6 +509,15 @@ class Context:
     def set_pose_box(self, kind):
         """0: pinned host memory + device relay; 1: fine-grained device memory written through the BAR (raises if not CPU-visible)"""
         self._chk(self.lib.srl_debug_set_pose_box(self.h, int(kind)), "srl_debug_set_pose_box")
+
+    FRAME_STAGES = ("upload", "select_group", "select_download", "select_host_order", "select_gather", "commit_transform", "commit_download",
+                    "insert_sort", "insert_segments", "insert_lookup_create", "insert_replay")
+
+    def frame_timing(self, enable=True):
+        """accumulated stage times (us) of the frame pipeline since the last call (which clears them); see srl_debug_frame_timing"""
+        out = np.zeros(16)
+        self._chk(self.lib.srl_debug_frame_timing(self.h, 1 if enable else 0, _ptr(out)), "srl_debug_frame_timing")
+        return dict(zip(self.FRAME_STAGES, (float(v) for v in out)))
 
     def pass_stamps(self, enable=True, read=True):
         """(gpu[64, 16] device-clock ticks of 10 ns, host[64, 4] steady-clock ns) of the last 64 passes; see srl_debug_pass_stamps"""

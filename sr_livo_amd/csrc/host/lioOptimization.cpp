@@ -220,6 +220,7 @@ optimizeSummary lioOptimization::solveIEKF(const icpOptions &cur_icp_options, cl
     optimizeSummary summary;
     iteration_log.clear();
     last_num_iterations = 0;
+    last_num_observed = 0;
     last_solve_launches = 0;
 
     // covariance projection helpers (optimize.cpp:220-232): rows then columns of the so3 / S2 blocks
@@ -354,6 +355,7 @@ optimizeSummary lioOptimization::solveIEKF(const icpOptions &cur_icp_options, cl
         }
 
         eskf_pro->observe(d_x);                                                  // optimize.cpp:253
+        last_num_observed++;
 
         p_frame->p_state->translation = eskf_pro->getTranslation();              // optimize.cpp:255-261
         p_frame->p_state->rotation = eskf_pro->getRotation();

@@ -210,6 +210,7 @@ public:
     bool record_iterations = false;
     std::vector<iterationLog> iteration_log;
     int last_num_iterations = 0;
+    int last_num_observed = 0;         // eskf_pro->observe() calls of the last solve (optimize.cpp:253): 0 = p_state / G were never written (:255-261)
     int last_solve_launches = 0;       // passes (= association kernel launches) of the last solve
 
 private:

@@ -81,7 +81,10 @@ int run_update(srl_lio *h, const srl_icp_opts *opts, std::vector<point3D> &keypo
     try {
         s = resident ? h->lio->solveIEKF(o, &w.cur) : h->lio->updateIEKF(o, h->lio->voxel_map, keypoints, &w.cur);
     } catch (const std::exception &e) {
+        // the NaN throw of optimize.cpp:348-350 leaves p_frame->p_state as the passes before it wrote it (:255-259): hand that back too
         h->lio->all_cloud_frame.clear();
+        state_to(h->cur_state, state_io);
+        if (iters) *iters = h->lio->last_num_iterations;
         return status_from_exception(h, e);
     }
     h->lio->all_cloud_frame.clear();
@@ -129,6 +132,11 @@ int srl_lio_set_extrinsics(srl_lio *h, const double R_il[9], const double t_il[3
     return SRL_OK;
 }
 int srl_lio_set_laser_point_cov(srl_lio *h, double cov) { if (!h) return SRL_ERR_BAD_ARG; h->lio->laser_point_cov = cov; return SRL_OK; }
+int srl_lio_last_solve_observed(srl_lio *h, int *observed) {
+    if (!h || !observed) return SRL_ERR_BAD_ARG;
+    *observed = h->lio->last_num_observed;
+    return SRL_OK;
+}
 int srl_lio_last_solve_launches(srl_lio *h, int *launches) { if (!h || !launches) return SRL_ERR_BAD_ARG; *launches = h->lio->last_solve_launches; return SRL_OK; }
 
 int srl_lio_eskf_get_state(srl_lio *h, double s[19]) {
@@ -431,9 +439,11 @@ int srl_lio_optimize_resident(srl_lio *h, const srl_icp_opts *opts, double sampl
     optimizeSummary s;
     std::vector<int> kidx;
     try {
-        s = h->lio->optimizeResident(&w.cur, frame_raw, n, o, sample_voxel_size, &kidx);
+        s = h->lio->optimizeResident(&w.cur, frame_raw, n, o, sample_voxel_size, keypoint_index || num_keypoints ? &kidx : nullptr);
     } catch (const std::exception &e) {
         h->lio->all_cloud_frame.clear();
+        state_to(h->cur_state, state_io);
+        if (iters) *iters = h->lio->last_num_iterations;
         return status_from_exception(h, e);
     }
     h->lio->all_cloud_frame.clear();

@@ -78,6 +78,7 @@ int ensure_taps(srl_ctx *ctx, int n, int K) {
 }  // namespace
 
 int srl_ctx_ensure_work(srl_ctx *ctx, int n) { return ensure_work(ctx, n); }   // used by srl_frame_kernels.hip
+bool srl_ctx_is_pinned(const void *p) { return srl_is_pinned(p); }             // used by srl_frame_kernels.hip
 
 // shared with srl_map_kernels.hip
 int srl_ctx_grow_map(srl_ctx *ctx, unsigned need_slabs, unsigned need_slots);
@@ -665,6 +666,15 @@ int srl_debug_pass_stamps(srl_ctx *ctx, int enable, long long *gpu_out, long lon
     if (gpu_out && ctx->h_arm_stamps) std::memcpy(gpu_out, ctx->h_arm_stamps, 64 * 32 * sizeof(long long));
     if (host_out) std::memcpy(host_out, ctx->arm_host_stamps, sizeof ctx->arm_host_stamps);
     if (!enable && ctx->h_arm_stamps) { hipHostFree(ctx->h_arm_stamps); ctx->h_arm_stamps = nullptr; }
+    return SRL_OK;
+}
+
+int srl_debug_frame_timing(srl_ctx *ctx, int enable, double out16[16]) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
+    if (out16) std::memcpy(out16, ctx->frame_stage_us, sizeof ctx->frame_stage_us);
+    std::memset(ctx->frame_stage_us, 0, sizeof ctx->frame_stage_us);
+    ctx->frame_timing = enable != 0;
     return SRL_OK;
 }
 

@@ -54,6 +54,11 @@ struct srl_ctx {
     int corr_cap = 0;
     int corr_n = -1;
 
+    // srl_debug_frame_timing: per-stage wall time of the frame pipeline (the stream is synchronised at every stage boundary while on)
+    bool frame_timing = false;
+    double frame_stage_us[16] = {};
+    long long frame_stage_last_ns = 0;
+
     // page-locked sources: event behind the last DMA that read a caller's buffer (srl_sweep_wait)
     hipEvent_t upload_ev = nullptr;
     bool upload_pending = false;
@@ -184,6 +189,21 @@ struct srl_ctx {
 // that nobody fires would hold the stream until its bound)
 extern "C" int srl_ctx_disarm(srl_ctx *ctx);
 #define SRL_DISARM(ctx) do { if ((ctx)->armed) { int rcd__ = srl_ctx_disarm(ctx); if (rcd__) return rcd__; } } while (0)
+
+// frame pipeline stage stamps (only while srl_debug_frame_timing is on): close stage `slot` here
+#include <chrono>
+inline void srl_stage_begin(srl_ctx *ctx) {
+    if (!ctx->frame_timing) return;
+    hipStreamSynchronize(ctx->stream);
+    ctx->frame_stage_last_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline void srl_stage_end(srl_ctx *ctx, int slot) {
+    if (!ctx->frame_timing) return;
+    hipStreamSynchronize(ctx->stream);
+    const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    ctx->frame_stage_us[slot] += (double)(now - ctx->frame_stage_last_ns) * 1e-3;
+    ctx->frame_stage_last_ns = now;
+}
 
 inline int ensure_host_scratch(srl_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->h_scratch_bytes) return SRL_OK;

@@ -77,6 +77,46 @@ __global__ void k_run_heads(const unsigned long long *keys_sorted, const unsigne
     }
 }
 
+// gridSampling keeps the FIRST point of every sampling voxel (utility.cpp:175-183): group the points by voxel key in a scratch hash
+// table (open addressing, keys claimed by compare-and-swap) and keep the smallest point index per key (atomicMin) -- no sort: the
+// order of the voxels is decided on the host anyway (std::tr1::unordered_map iteration order), from the first indices.
+__global__ void k_select_group(const double *raw, int n, const Xf X, double size, unsigned long long *tkeys, unsigned *tfirst, unsigned mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double rx = raw[(size_t)i * 3], ry = raw[(size_t)i * 3 + 1], rz = raw[(size_t)i * 3 + 2];
+    const double ix = (X.R_il[0] * rx + X.R_il[1] * ry) + X.R_il[2] * rz + X.t_il[0];
+    const double iy = (X.R_il[3] * rx + X.R_il[4] * ry) + X.R_il[5] * rz + X.t_il[1];
+    const double iz = (X.R_il[6] * rx + X.R_il[7] * ry) + X.R_il[8] * rz + X.t_il[2];
+    const double wx = (X.R[0] * ix + X.R[1] * iy) + X.R[2] * iz + X.t[0];
+    const double wy = (X.R[3] * ix + X.R[4] * iy) + X.R[5] * iz + X.t[1];
+    const double wz = (X.R[6] * ix + X.R[7] * iy) + X.R[8] * iz + X.t[2];
+    const unsigned long long key = srl_pack_key((short)(int)(wx / size), (short)(int)(wy / size), (short)(int)(wz / size));
+    unsigned h = srl_hash_key(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        unsigned long long k = tkeys[h];
+        if (k == SRL_EMPTY_KEY) k = atomicCAS(&tkeys[h], SRL_EMPTY_KEY, key);          // returns what was there: EMPTY = claimed
+        if (k == SRL_EMPTY_KEY || k == key) { atomicMin(&tfirst[h], (unsigned)i); return; }
+        h = (h + 1) & mask;
+    }
+}
+// ... then the voxels in FIRST-OCCURRENCE order (the order subSampleFrame's loop creates them in, utility.cpp:175-183 -- what the
+// host's replay of the container's iteration order starts from): every occupied slot marks the index of its first point, an
+// exclusive scan over the marks ranks the voxels, and the keys are written out by rank.
+__global__ void k_select_mark(const unsigned long long *tkeys, const unsigned *tfirst, unsigned cap, int *flag, unsigned long long *key_at) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap || tkeys[i] == SRL_EMPTY_KEY) return;
+    const unsigned f = tfirst[i];
+    flag[f] = 1;
+    key_at[f] = tkeys[i];
+}
+__global__ void k_select_emit(const int *flag, const int *rank, const unsigned long long *key_at, int n, unsigned long long *out_key,
+                              unsigned *out_first, int *count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) { out_key[rank[i]] = key_at[i]; out_first[rank[i]] = (unsigned)i; }
+    if (i == n - 1) *count = rank[i] + flag[i];
+}
+
 __global__ void k_gather_soa(const double *raw, const int *sel, int m, double *x, double *y, double *z) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
@@ -108,6 +148,7 @@ void fill_xf(Xf &X, const double q[4], const double t[3], const double R_il[9], 
 }  // namespace
 
 int srl_ctx_ensure_work(srl_ctx *ctx, int n);   // srl_capi.cpp
+bool srl_ctx_is_pinned(const void *p);          // srl_capi.cpp
 
 namespace {
 
@@ -359,10 +400,15 @@ int srl_frame_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     int rc0 = ensure_frame(ctx, n);
     if (rc0) return rc0;
     ctx->frame_n = n;
+    srl_stage_begin(ctx);
     if (n > 0) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_raw, raw_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        // a page-locked source (srl_pinned_alloc) is read by the DMA engine behind this call: the caller may refill it once a later call
+        // on this context has returned results (like srl_sweep_upload; srl_sweep_wait waits explicitly); pageable sources are consumed here
+        if (!srl_ctx_is_pinned(raw_xyz)) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        else { if (!ctx->upload_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming)); HIPCHK(ctx, hipEventRecord(ctx->upload_ev, ctx->stream)); ctx->upload_pending = true; }
     }
+    srl_stage_end(ctx, 0);
     return SRL_OK;
 }
 
@@ -386,28 +432,31 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
     static const bool trace = std::getenv("SRL_FRAME_TIMING") != nullptr;      // stage times on stderr (tools/pipeline_probe.py)
     const auto tp0 = std::chrono::steady_clock::now();
     auto tp1 = tp0, tp2 = tp0, tp3 = tp0;
+    srl_stage_begin(ctx);
     if (n > 0) {
         Xf X;
         fill_xf(X, q, t, R_il, t_il);
-        DevBuf b_keys, b_keys2, b_idx, b_idx2, b_ukeys, b_first, b_cnt, b_tmp;
-        HIPCHK(ctx, b_keys.alloc(ctx, (size_t)n * 8)); HIPCHK(ctx, b_keys2.alloc(ctx, (size_t)n * 8));
-        HIPCHK(ctx, b_idx.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_idx2.alloc(ctx, (size_t)n * 4));
+        // group by sampling voxel in a scratch table of >= 2 n slots (keys | first indices: one block, one memset)
+        unsigned cap = 1024;
+        while (cap < 2u * (unsigned)n) cap <<= 1;
+        DevBuf b_table, b_ukeys, b_first, b_cnt, b_flag, b_rank, b_keyat, b_tmp;
+        HIPCHK(ctx, b_flag.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_rank.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_keyat.alloc(ctx, (size_t)n * 8));
+        HIPCHK(ctx, b_table.alloc(ctx, (size_t)cap * 12));
         HIPCHK(ctx, b_ukeys.alloc(ctx, (size_t)n * 8)); HIPCHK(ctx, b_first.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_cnt.alloc(ctx, 16));
-        hipLaunchKernelGGL(k_frame_keys, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, n, X, sample_voxel_size,
-                           (double *)nullptr, b_keys.as<unsigned long long>(), b_idx.as<unsigned>());
-        HIPCHK(ctx, hipGetLastError());
-        // stable sort by voxel key: inside a voxel the point indices stay ascending, so a run's head is its FIRST point
-        size_t tmp_bytes = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
-                                           b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st);
-        HIPCHK(ctx, b_tmp.alloc(ctx, tmp_bytes + 256));
-        size_t tb = tmp_bytes;
-        HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
-                                                       b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st));
-        HIPCHK(ctx, hipMemsetAsync(b_cnt.p, 0, 4, st));
-        hipLaunchKernelGGL(k_run_heads, dim3((n + 255) / 256), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_idx2.as<unsigned>(), n,
+        unsigned long long *tkeys = b_table.as<unsigned long long>();
+        unsigned *tfirst = reinterpret_cast<unsigned *>(tkeys + cap);
+        HIPCHK(ctx, hipMemsetAsync(b_table.p, 0xFF, (size_t)cap * 12, st));            // SRL_EMPTY_KEY everywhere, first index = UINT_MAX
+        HIPCHK(ctx, hipMemsetAsync(b_flag.p, 0, (size_t)n * 4, st));
+        hipLaunchKernelGGL(k_select_group, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, n, X, sample_voxel_size, tkeys, tfirst, cap - 1);
+        hipLaunchKernelGGL(k_select_mark, dim3((cap + 255) / 256), dim3(256), 0, st, tkeys, tfirst, cap, b_flag.as<int>(), b_keyat.as<unsigned long long>());
+        size_t scan_bytes = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, b_flag.as<int>(), b_rank.as<int>(), n, st);
+        HIPCHK(ctx, b_tmp.alloc(ctx, scan_bytes + 256));
+        HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, scan_bytes, b_flag.as<int>(), b_rank.as<int>(), n, st));
+        hipLaunchKernelGGL(k_select_emit, dim3((n + 255) / 256), dim3(256), 0, st, b_flag.as<int>(), b_rank.as<int>(), b_keyat.as<unsigned long long>(), n,
                            b_ukeys.as<unsigned long long>(), b_first.as<unsigned>(), b_cnt.as<int>());
         HIPCHK(ctx, hipGetLastError());
+        srl_stage_end(ctx, 1);
         tp1 = std::chrono::steady_clock::now();
         // one round trip for small frames (count + all n slots), two for large ones (count first); into pinned scratch
         int rcs = ensure_host_scratch(ctx, (size_t)n * 16 + 64);
@@ -416,7 +465,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         unsigned long long *ukeys = reinterpret_cast<unsigned long long *>(ctx->h_scratch + 64);
         unsigned *first = reinterpret_cast<unsigned *>(ctx->h_scratch + 64 + (size_t)n * 8);
         int S = 0;
-        const bool one_trip = n <= 65536;
+        const bool one_trip = n <= 16384;
         if (one_trip) {
             HIPCHK(ctx, hipMemcpyAsync(ukeys, b_ukeys.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipMemcpyAsync(first, b_first.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -430,23 +479,16 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
             HIPCHK(ctx, hipStreamSynchronize(st));
         }
 
+        srl_stage_end(ctx, 2);
         tp2 = std::chrono::steady_clock::now();
-        // voxels in FIRST-OCCURRENCE order (= the order subSampleFrame's loop creates them): first indices are distinct
-        // integers below n, so a scatter / compact pass orders them in O(n)
-        std::vector<int> slot_of((size_t)n, -1);
-        for (int i = 0; i < S; i++) slot_of[(size_t)first[i]] = i;
+        // the voxels arrive in FIRST-OCCURRENCE order (= the order subSampleFrame's loop creates them): ordered on the device
         std::vector<std::size_t> hashes((size_t)S);
-        std::vector<unsigned> first_sorted((size_t)S);
-        int w = 0;
-        for (int p = 0; p < n; p++) {
-            const int i = slot_of[(size_t)p];
-            if (i < 0) continue;
+        for (int i = 0; i < S; i++) {
             vkey k;
             srl_unpack_key(ukeys[i], &k.x, &k.y, &k.z);
-            hashes[(size_t)w] = vkey_hash()(k);
-            first_sorted[(size_t)w] = (unsigned)p;
-            w++;
+            hashes[(size_t)i] = vkey_hash()(k);
         }
+        const unsigned *first_sorted = first;
         // iteration order of the std::tr1::unordered_map of subSampleFrame, by replaying its bucket moves on flat arrays
         // (host/tr1_order.h) for the S distinct voxels (not the N points)
         std::vector<int> perm((size_t)S);
@@ -454,6 +496,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         order.resize((size_t)S);
         for (int r = 0; r < S; r++) order[(size_t)r] = (int)first_sorted[(size_t)perm[(size_t)r]];
     }
+    srl_stage_end(ctx, 3);
     tp3 = std::chrono::steady_clock::now();
     const int m = (int)order.size();
     if (num_keypoints) *num_keypoints = m;
@@ -481,6 +524,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(st));
     }
+    srl_stage_end(ctx, 4);
     if (trace) {
         const auto tp4 = std::chrono::steady_clock::now();
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -502,10 +546,13 @@ int srl_frame_commit(srl_ctx *ctx, const double q[4], const double t[3], const d
     if (n == 0) return SRL_OK;
     Xf X;
     fill_xf(X, q, t, R_il, t_il);
+    srl_stage_begin(ctx);
     hipLaunchKernelGGL(k_frame_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_frame_raw, n, X, 1.0, ctx->d_frame_world,
                        (unsigned long long *)nullptr, (unsigned *)nullptr);
     HIPCHK(ctx, hipGetLastError());
+    srl_stage_end(ctx, 5);
     if (world_out) HIPCHK(ctx, hipMemcpyAsync(world_out, ctx->d_frame_world, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    srl_stage_end(ctx, 6);
     return srl_map_insert_impl(ctx, ctx->d_frame_world, true, n, voxel_size, min_distance_points, min_num_points, num_added);
 }
 

@@ -31,12 +31,30 @@ __global__ void k_point_keys(const double *xyz, int n, double voxel_size, unsign
     idx[i] = (unsigned)i;
 }
 
-// per touched voxel: table slot (or -1), flag new, first point index
-__global__ void k_lookup(const unsigned long long *ukeys, const int *seg_start, const unsigned *sorted_idx, int S,
-                         const SrlMapSlot *table, unsigned mask, int *seg_slot, unsigned char *is_new, unsigned *first_idx) {
+// ---- segments of the (key, index)-sorted batch.  A segment = the points of one voxel, in their original order (stable sort).
+// head flag of sorted position i, as an iterator the scan reads directly (no flag array)
+struct HeadFlag {
+    const unsigned long long *keys;
+    __host__ __device__ int operator()(int i) const { return (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0; }
+};
+// seg_start[s] = sorted position of the first point of segment s (s = exclusive prefix of the head flags); counters[0] = S
+__global__ void k_seg_starts(const unsigned long long *keys_sorted, const int *head_prefix, int n, int *seg_start, int *counters) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool head = i == 0 || keys_sorted[i] != keys_sorted[i - 1];
+    if (head) seg_start[head_prefix[i]] = i;
+    if (i == n - 1) counters[0] = head_prefix[i] + (head ? 1 : 0);
+}
+
+// per touched voxel: table slot (or -1), flag new, first point index; a NEW voxel marks the index of its first point in new_flag:
+// the exclusive prefix over those marks is the voxel's creation rank (the sequential loop of lioOptimization.cpp:520-554 creates
+// voxels in the order their first points arrive)
+__global__ void k_lookup(const unsigned long long *keys_sorted, const int *seg_start, const unsigned *sorted_idx, const int *counters,
+                         const SrlMapSlot *table, unsigned mask, int *seg_slot, unsigned char *is_new, unsigned *first_idx, int *new_flag) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    const unsigned long long key = ukeys[s];
+    if (s >= counters[0]) return;
+    const int j0 = seg_start[s];
+    const unsigned long long key = keys_sorted[j0];
     unsigned h = srl_hash_key(key) & mask;
     int slot = -1;
     for (unsigned probe = 0; probe <= mask; ++probe) {
@@ -45,19 +63,22 @@ __global__ void k_lookup(const unsigned long long *ukeys, const int *seg_start, 
         if (k == SRL_EMPTY_KEY) break;
         h = (h + 1) & mask;
     }
+    const unsigned first = sorted_idx[j0];
     seg_slot[s] = slot;
     is_new[s] = slot < 0 ? 1 : 0;
-    first_idx[s] = sorted_idx[seg_start[s]];
+    first_idx[s] = first;
+    if (slot < 0 && new_flag) new_flag[first] = 1;
 }
 
-// new voxels in creation order r: slab = V + r; header written, key CAS-inserted into the table
-__global__ void k_create(const int *new_segs_sorted, int n_new, const unsigned long long *ukeys, int V,
-                         SrlMapSlot *table, unsigned mask, unsigned char *slabs, int *seg_slot) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_new) return;
-    const int s = new_segs_sorted[r];
-    const unsigned long long key = ukeys[s];
-    const unsigned slab = (unsigned)(V + r);
+// new voxels: slab = V + creation rank; header written, key CAS-inserted into the table.  counters[1] = number of new voxels.
+__global__ void k_create(const unsigned long long *keys_sorted, const int *seg_start, const int *counters_in, const unsigned char *is_new,
+                         const unsigned *first_idx, const int *new_rank, const int *new_flag, int n, int V,
+                         SrlMapSlot *table, unsigned mask, unsigned char *slabs, int *seg_slot, int *counters) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) counters[1] = new_rank[n - 1] + new_flag[n - 1];
+    if (s >= counters_in[0] || !is_new[s]) return;
+    const unsigned long long key = keys_sorted[seg_start[s]];
+    const unsigned slab = (unsigned)(V + new_rank[first_idx[s]]);
     SrlSlab *sl = reinterpret_cast<SrlSlab *>(slabs + (size_t)slab * SRL_SLAB_BYTES);
     sl->count = 0;
     sl->pad = 0;
@@ -88,10 +109,11 @@ __global__ void k_create(const int *new_segs_sorted, int n_new, const unsigned l
 // of 64 points resolved in order with ballots) -- 157 + 131 us and 2.5 + 1.2 ms: the long segments were never the tail (a
 // dense voxel fills to 20 and stops), the per-point latency of the many short ones was.
 #define SRL_REPLAY_BATCH 8
-__global__ void __launch_bounds__(128) k_replay(const int *seg_start, const int *seg_len, const unsigned *sorted_idx, int S, const double *xyz,
+__global__ void __launch_bounds__(128) k_replay(const int *seg_start, const unsigned *sorted_idx, const int *counters, int n, const double *xyz,
                          const int *seg_slot, const unsigned char *is_new, SrlMapSlot *table, unsigned char *slabs,
                          double voxel_size, double min_distance_points, int min_num_points, int *added_total) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = counters[0];
     if (s >= S) return;
     const int slot = seg_slot[s];
     if (slot < 0) return;                       // voxel absent and min_num_points > 0: nothing is created
@@ -99,7 +121,7 @@ __global__ void __launch_bounds__(128) k_replay(const int *seg_start, const int 
     SrlSlab *sl = reinterpret_cast<SrlSlab *>(slabs + (size_t)slab * SRL_SLAB_BYTES);
     int count = (int)sl->count;
     const bool fresh = is_new[s] != 0;
-    const int j0 = seg_start[s], j1 = j0 + seg_len[s];
+    const int j0 = seg_start[s], j1 = s + 1 < S ? seg_start[s + 1] : n;
     int added = 0;
     const double min_d2 = min_distance_points * min_distance_points;
     // the voxel's stored points live in REGISTERS for the whole replay (statically indexed: every loop over them is unrolled
@@ -221,7 +243,15 @@ int srl_map_insert_device(srl_ctx *ctx, const double *world_xyz, int n, double v
     return srl_map_insert_impl(ctx, world_xyz, false, n, voxel_size, min_distance_points, min_num_points, num_added);
 }
 
-// world_xyz: host pointer, or (on_device) a device pointer that stays valid for the duration of the call
+// world_xyz: host pointer, or (on_device) a device pointer that stays valid for the duration of the call.
+//
+// addPointsToMap's order semantics (lioOptimization.cpp:400-446,520-554) on the device, ONE host synchronisation per call (round 3:
+// four, two of them through pageable copies):
+//   keys -> stable radix sort (key, index) -> head flags scanned into segment ids -> segment starts -> table lookup per segment ->
+//   new voxels ranked by the index of their first point (a scan over marks in point-index space = the sequential loop's creation
+//   order) -> created (slab = V + rank, key CAS-inserted) -> one thread per touched voxel replays its segment sequentially.
+// Nothing is read back before the end: the kernels take the segment count from device memory, storage is grown beforehand for the
+// worst case (every point a new voxel) when the batch is a frame (n <= 131072); a bulk load reads the segment count once to size the map.
 int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, int n, double voxel_size,
                         double min_distance_points, int min_num_points, int *num_added) {
     if (num_added) *num_added = 0;
@@ -234,8 +264,16 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
         int rc = srl_ctx_grow_map(ctx, 4096u, 8192u);
         if (rc) return rc;
     }
+    const bool frame_sized = n <= 131072;
+    if (frame_sized) {
+        const unsigned need_slabs = (unsigned)ctx->num_voxels + (unsigned)n;
+        if (need_slabs > ctx->slab_cap || SRL_TABLE_FACTOR * need_slabs > ctx->table_cap) {
+            int rc = srl_ctx_grow_map(ctx, need_slabs, SRL_TABLE_FACTOR * need_slabs);
+            if (rc) return rc;
+        }
+    }
 
-    DevBuf b_xyz, b_keys, b_keys2, b_idx, b_idx2, b_ukeys, b_len, b_start, b_nruns, b_tmp;
+    DevBuf b_xyz, b_keys, b_keys2, b_idx, b_idx2, b_prefix, b_start, b_cnt, b_tmp, b_slot, b_isnew, b_first, b_newflag, b_newrank;
     const double *d_xyz = world_xyz;
     if (!on_device) {
         HIPCHK(ctx, b_xyz.alloc(ctx, (size_t)n * 3 * sizeof(double)));
@@ -246,102 +284,82 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
     HIPCHK(ctx, b_keys2.alloc(ctx, (size_t)n * 8));
     HIPCHK(ctx, b_idx.alloc(ctx, (size_t)n * 4));
     HIPCHK(ctx, b_idx2.alloc(ctx, (size_t)n * 4));
-    HIPCHK(ctx, b_ukeys.alloc(ctx, (size_t)n * 8));
-    HIPCHK(ctx, b_len.alloc(ctx, (size_t)n * 4));
+    HIPCHK(ctx, b_prefix.alloc(ctx, (size_t)n * 4));
     HIPCHK(ctx, b_start.alloc(ctx, (size_t)n * 4));
-    HIPCHK(ctx, b_nruns.alloc(ctx, 16));
+    HIPCHK(ctx, b_cnt.alloc(ctx, 64));                       // counters: [0] segments, [1] new voxels, [2] points added
+    HIPCHK(ctx, b_slot.alloc(ctx, (size_t)n * 4));
+    HIPCHK(ctx, b_isnew.alloc(ctx, (size_t)n));
+    HIPCHK(ctx, b_first.alloc(ctx, (size_t)n * 4));
+    HIPCHK(ctx, b_newflag.alloc(ctx, (size_t)n * 4));
+    HIPCHK(ctx, b_newrank.alloc(ctx, (size_t)n * 4));
+    int *cnt = b_cnt.as<int>();
+    srl_stage_begin(ctx);
+    HIPCHK(ctx, hipMemsetAsync(cnt, 0, 64, st));
+    HIPCHK(ctx, hipMemsetAsync(b_newflag.p, 0, (size_t)n * 4, st));
     hipLaunchKernelGGL(k_point_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, voxel_size,
                        b_keys.as<unsigned long long>(), b_idx.as<unsigned>());
     HIPCHK(ctx, hipGetLastError());
 
     // stable sort by key (48 significant bits): original order survives inside each voxel
+    hipcub::CountingInputIterator<int> positions(0);
+    hipcub::TransformInputIterator<int, HeadFlag, hipcub::CountingInputIterator<int>> heads(positions, HeadFlag{b_keys2.as<unsigned long long>()});
     size_t tmp_bytes = 0, need = 0;
     hipcub::DeviceRadixSort::SortPairs(nullptr, need, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
                                        b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st);
     tmp_bytes = need;
-    hipcub::DeviceRunLengthEncode::Encode(nullptr, need, b_keys2.as<unsigned long long>(), b_ukeys.as<unsigned long long>(),
-                                          b_len.as<int>(), b_nruns.as<int>(), n, st);
+    hipcub::DeviceScan::ExclusiveSum(nullptr, need, heads, b_prefix.as<int>(), n, st);
     tmp_bytes = std::max(tmp_bytes, need);
-    hipcub::DeviceScan::ExclusiveSum(nullptr, need, b_len.as<int>(), b_start.as<int>(), n, st);
-    tmp_bytes = std::max(tmp_bytes, need);
-    tmp_bytes += 4096;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, need, b_newflag.as<int>(), b_newrank.as<int>(), n, st);
+    tmp_bytes = std::max(tmp_bytes, need) + 4096;
     HIPCHK(ctx, b_tmp.alloc(ctx, tmp_bytes));
     size_t tb = tmp_bytes;
     HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
                                                    b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st));
+    srl_stage_end(ctx, 7);                                    // keys + sort
     tb = tmp_bytes;
-    HIPCHK(ctx, hipcub::DeviceRunLengthEncode::Encode(b_tmp.p, tb, b_keys2.as<unsigned long long>(), b_ukeys.as<unsigned long long>(),
-                                                      b_len.as<int>(), b_nruns.as<int>(), n, st));
-    int S = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&S, b_nruns.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    tb = tmp_bytes;
-    HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, b_len.as<int>(), b_start.as<int>(), S, st));
+    HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, heads, b_prefix.as<int>(), n, st));
+    hipLaunchKernelGGL(k_seg_starts, dim3((n + 255) / 256), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_prefix.as<int>(), n,
+                       b_start.as<int>(), cnt);
+    HIPCHK(ctx, hipGetLastError());
 
-    // make room for the worst case (every touched voxel new) before slot indices are taken
-    {
-        const unsigned need_slabs = (unsigned)ctx->num_voxels + (unsigned)S;
+    srl_stage_end(ctx, 8);                                    // segments
+    int rcs = ensure_host_scratch(ctx, 64);
+    if (rcs) return rcs;
+    int *h_cnt = reinterpret_cast<int *>(ctx->h_scratch);
+    if (!frame_sized) {
+        // a bulk load: the number of touched voxels sizes the map (worst-case sizing would reserve a slab per point)
+        HIPCHK(ctx, hipMemcpyAsync(h_cnt, cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        const unsigned need_slabs = (unsigned)ctx->num_voxels + (unsigned)h_cnt[0];
         if (need_slabs > ctx->slab_cap || SRL_TABLE_FACTOR * need_slabs > ctx->table_cap) {
             int rc = srl_ctx_grow_map(ctx, need_slabs, SRL_TABLE_FACTOR * need_slabs);
             if (rc) return rc;
         }
     }
     const unsigned mask = ctx->table_cap - 1;
-
-    DevBuf b_slot, b_isnew, b_first, b_first2, b_seg, b_seg2, b_nsel, b_added;
-    HIPCHK(ctx, b_slot.alloc(ctx, (size_t)S * 4));
-    HIPCHK(ctx, b_isnew.alloc(ctx, (size_t)S));
-    HIPCHK(ctx, b_first.alloc(ctx, (size_t)S * 4));
-    HIPCHK(ctx, b_first2.alloc(ctx, (size_t)S * 4));
-    HIPCHK(ctx, b_seg.alloc(ctx, (size_t)S * 4));
-    HIPCHK(ctx, b_seg2.alloc(ctx, (size_t)S * 4));
-    HIPCHK(ctx, b_nsel.alloc(ctx, 16));
-    HIPCHK(ctx, b_added.alloc(ctx, 16));
-    HIPCHK(ctx, hipMemsetAsync(b_added.p, 0, 16, st));
-    hipLaunchKernelGGL(k_lookup, dim3((S + 255) / 256), dim3(256), 0, st, b_ukeys.as<unsigned long long>(), b_start.as<int>(),
-                       b_idx2.as<unsigned>(), S, ctx->d_table, mask, b_slot.as<int>(), b_isnew.as<unsigned char>(), b_first.as<unsigned>());
+    const bool create_new = min_num_points <= 0;             // min_num_points > 0: a point never opens a voxel (lioOptimization.cpp:437)
+    const int seg_grid = (n + 255) / 256;                    // (one thread per POSSIBLE segment; the kernels stop at the device-side count)
+    hipLaunchKernelGGL(k_lookup, dim3(seg_grid), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_start.as<int>(), b_idx2.as<unsigned>(), cnt,
+                       ctx->d_table, mask, b_slot.as<int>(), b_isnew.as<unsigned char>(), b_first.as<unsigned>(), create_new ? b_newflag.as<int>() : (int *)nullptr);
     HIPCHK(ctx, hipGetLastError());
-
-    int n_new = 0;
-    if (min_num_points <= 0) {
-        // new voxels, ranked by the index of their first point = creation order of the sequential loop
-        DevBuf b_tmp2, b_newfirst;
-        HIPCHK(ctx, b_newfirst.alloc(ctx, (size_t)S * 4));
-        hipcub::CountingInputIterator<int> seg_ids(0);
-        size_t need2 = 0, t2 = 0;
-        hipcub::DeviceSelect::Flagged(nullptr, need2, seg_ids, b_isnew.as<unsigned char>(), b_seg.as<int>(), b_nsel.as<int>(), S, st);
-        t2 = need2;
-        hipcub::DeviceSelect::Flagged(nullptr, need2, b_first.as<unsigned>(), b_isnew.as<unsigned char>(), b_newfirst.as<unsigned>(), b_nsel.as<int>(), S, st);
-        t2 = std::max(t2, need2);
-        hipcub::DeviceRadixSort::SortPairs(nullptr, need2, b_newfirst.as<unsigned>(), b_first2.as<unsigned>(), b_seg.as<int>(), b_seg2.as<int>(), S, 0, 32, st);
-        t2 = std::max(t2, need2) + 4096;
-        HIPCHK(ctx, b_tmp2.alloc(ctx, t2));
-        size_t tt = t2;
-        HIPCHK(ctx, hipcub::DeviceSelect::Flagged(b_tmp2.p, tt, seg_ids, b_isnew.as<unsigned char>(), b_seg.as<int>(), b_nsel.as<int>(), S, st));
-        tt = t2;
-        HIPCHK(ctx, hipcub::DeviceSelect::Flagged(b_tmp2.p, tt, b_first.as<unsigned>(), b_isnew.as<unsigned char>(), b_newfirst.as<unsigned>(), b_nsel.as<int>(), S, st));
-        HIPCHK(ctx, hipMemcpyAsync(&n_new, b_nsel.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        if (n_new > 0) {
-            tt = t2;
-            HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp2.p, tt, b_newfirst.as<unsigned>(), b_first2.as<unsigned>(),
-                                                           b_seg.as<int>(), b_seg2.as<int>(), n_new, 0, 32, st));
-            hipLaunchKernelGGL(k_create, dim3((n_new + 255) / 256), dim3(256), 0, st, b_seg2.as<int>(), n_new,
-                               b_ukeys.as<unsigned long long>(), ctx->num_voxels, ctx->d_table, mask, ctx->d_slabs, b_slot.as<int>());
-            HIPCHK(ctx, hipGetLastError());
-        }
-        HIPCHK(ctx, hipStreamSynchronize(st));
+    if (create_new) {
+        tb = tmp_bytes;
+        HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, b_newflag.as<int>(), b_newrank.as<int>(), n, st));
+        hipLaunchKernelGGL(k_create, dim3(seg_grid), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_start.as<int>(), cnt, b_isnew.as<unsigned char>(),
+                           b_first.as<unsigned>(), b_newrank.as<int>(), b_newflag.as<int>(), n, ctx->num_voxels, ctx->d_table, mask, ctx->d_slabs,
+                           b_slot.as<int>(), cnt);
+        HIPCHK(ctx, hipGetLastError());
     }
-
-    hipLaunchKernelGGL(k_replay, dim3((S + 127) / 128), dim3(128), 0, st, b_start.as<int>(), b_len.as<int>(), b_idx2.as<unsigned>(), S,
+    srl_stage_end(ctx, 9);                                    // lookup + creation
+    hipLaunchKernelGGL(k_replay, dim3((n + 127) / 128), dim3(128), 0, st, b_start.as<int>(), b_idx2.as<unsigned>(), cnt, n,
                        d_xyz, b_slot.as<int>(), b_isnew.as<unsigned char>(), ctx->d_table, ctx->d_slabs, voxel_size,
-                       min_distance_points, min_num_points, b_added.as<int>());
+                       min_distance_points, min_num_points, cnt + 2);
     HIPCHK(ctx, hipGetLastError());
-    int added = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&added, b_added.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(h_cnt, cnt, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    ctx->num_voxels += n_new;
-    ctx->num_points += added;
-    if (num_added) *num_added = added;
+    srl_stage_end(ctx, 10);                                   // replay + counters
+    ctx->num_voxels += h_cnt[1];
+    ctx->num_points += h_cnt[2];
+    if (num_added) *num_added = h_cnt[2];
     return SRL_OK;
 }

@@ -182,11 +182,12 @@ REPLAY_OO = dict(init_voxel_size=0.2, init_sample_voxel_size=1.0, init_num_frame
 REPLAY_SEQ = dict(map_seed=555, map_target=60_000, seq_seed=31, n_moving=7, n_pts=6000, max_num_residuals=600)
 
 
-def replay_inputs():
+def replay_inputs(seq=None):
     """The sensor streams of the replay goldens (regenerated from seeds wherever they are needed), the same streams cut
-    into measurements the way getMeasurements does, and the ground-truth poses."""
+    into measurements the way getMeasurements does, and the ground-truth poses.  seq: another sequence description (default REPLAY_SEQ)."""
     from sr_livo_amd import synth
-    _, L = synth.map_candidates(REPLAY_SEQ["map_seed"], REPLAY_SEQ["map_target"])
-    meas, gt, _ = synth.make_sequence(REPLAY_SEQ["seq_seed"], REPLAY_SEQ["n_moving"], REPLAY_SEQ["n_pts"], L)
+    seq = REPLAY_SEQ if seq is None else seq
+    _, L = synth.map_candidates(seq["map_seed"], seq["map_target"])
+    meas, gt, _ = synth.make_sequence(seq["seq_seed"], seq["n_moving"], seq["n_pts"], L)
     st = streams_from_sequence(meas)
     return st, partition_like_get_measurements(st), gt

@@ -1,38 +1,81 @@
-"""Per-stage wall time of the frame-resident pipeline on a 1M-point map (informational; not the headline metric)."""
-import os, sys, time
+"""Per-stage wall time of the frame-resident pipeline (upload -> keypoint selection -> solve -> commit) on a 1 M-point map, for frames
+spread over the scene like a reconstructed sweep.  Stage times come from srl_debug_frame_timing (stream synchronised at every stage
+boundary: the sum of the stages is an upper bound of the un-instrumented call, printed beside it).
+
+    python tools/pipeline_probe.py [--frames 6000,24000,65536]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
 import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import sr_livo_amd as srl
-from sr_livo_amd import capi, synth
+import sr_livo_amd as srl  # noqa: E402
+from sr_livo_amd import capi, synth  # noqa: E402
 
-n_frame = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
-cands, L = synth.map_candidates(7, 1_000_000)
-sw = synth.make_sweep(8, n_frame, L)
-lio = srl.Lio(0)
-lio.add_points_to_map(cands)
-ctx = lio.ctx
-q, t = sw["q_pred"], sw["t_pred"]
-st = np.zeros((12, 17)); st[:, 0] = 100.0 + 0.01 * np.arange(12); st[:, 10] = 1.0
-rel = np.sort(np.random.default_rng(0).uniform(0, 100, n_frame))
-def timed(f, reps=5):
-    f(); ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter(); r = f(); ts.append(time.perf_counter() - t0)
-    return r, 1e3 * float(np.median(ts))
-_, t_und = timed(lambda: ctx.frame_undistort(sw["raw"], rel, st, 100.0, capi.MC_CONSTANT_VELOCITY))
-_, t_up = timed(lambda: ctx.frame_upload(sw["raw"]))
-kidx, t_sel = timed(lambda: ctx.frame_select_keypoints(q, t, 1.5))
-f = capi.make_frame(q, t, sw["t_last"]); opts = srl.default_opts(max_num_residuals=2**31 - 1)
-_, t_it = timed(lambda: ctx.build_residuals(f, opts))
-_, t_commit = timed(lambda: ctx.frame_commit(sw["q_gt"], sw["t_gt"], want_world=False), reps=3)
-print(f"frame {n_frame} pts: undistort {t_und:.2f} ms, upload {t_up:.2f} ms, select_keypoints {t_sel:.2f} ms -> {len(kidx)} keypoints, "
-      f"one ESIKF pass {t_it * 1e3:.0f} us, commit (transform + map insert) {t_commit:.2f} ms")
 
-# a frame spread over the scene like a real reconstructed sweep (24k points drawn from the map's surface candidates)
-rng = np.random.default_rng(3)
-frame = cands[rng.choice(len(cands), 24_000, replace=False)] + rng.normal(0, 0.03, (24_000, 3))
-ident_q = np.array([1.0, 0, 0, 0]); zero = np.zeros(3)
-_, t_up2 = timed(lambda: ctx.frame_upload(frame))
-k2, t_sel2 = timed(lambda: ctx.frame_select_keypoints(ident_q, zero, 1.5))
-_, t_commit2 = timed(lambda: ctx.frame_commit(ident_q, zero, want_world=False), reps=3)
-print(f"scene-spread frame 24000 pts: upload {t_up2:.2f} ms, select_keypoints {t_sel2:.2f} ms -> {len(k2)} keypoints, commit {t_commit2:.2f} ms")
+def run(ctx, cands, n_frame, reps=7):
+    rng = np.random.default_rng(3 + n_frame)
+    frame = cands[rng.choice(len(cands), n_frame, replace=False)] + rng.normal(0, 0.03, (n_frame, 3))
+    pin = srl.PinnedArray(frame.shape)
+    pin.array[:] = frame
+    q, t = np.array([1.0, 0, 0, 0]), np.zeros(3)
+    f = capi.make_frame(q, t, t)
+    opts = srl.default_opts(max_num_residuals=2**31 - 1)
+    out = {"frame_points": n_frame}
+
+    def one(timing):
+        ctx.frame_timing(timing)
+        t0 = time.perf_counter()
+        ctx.frame_upload(pin.array)
+        t1 = time.perf_counter()
+        k = ctx.frame_select_keypoints(q, t, 1.5)
+        t2 = time.perf_counter()
+        neq, _ = ctx.build_residuals(f, opts)
+        neq, _ = ctx.build_residuals(f, opts)
+        ctx.disarm()
+        t3 = time.perf_counter()
+        ctx.frame_commit(q, t, want_world=True)
+        t4 = time.perf_counter()
+        st = ctx.frame_timing(False)
+        return len(k), (t1 - t0, t2 - t1, t3 - t2, t4 - t3), st
+
+    one(False); one(True)
+    plain = np.array([one(False)[1] for _ in range(reps)]) * 1e6
+    stages = [one(True) for _ in range(reps)]
+    out["keypoints"] = stages[0][0]
+    med = np.median(plain, axis=0)
+    out["us"] = dict(upload=float(med[0]), select=float(med[1]), two_passes=float(med[2]), commit=float(med[3]), total=float(med.sum()))
+    out["sweeps_per_s"] = 1e6 / float(med.sum())
+    out["stage_us"] = {k: float(np.median([s[2][k] for s in stages])) for k in stages[0][2]}
+    pin.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", default="6000,24000,65536")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "pipeline_probe.json"))
+    args = ap.parse_args()
+    cands, L = synth.map_candidates(7, 1_000_000)
+    lio = srl.Lio(0)
+    lio.ctx.pin_thread_to_gpu_numa()
+    lio.add_points_to_map(cands)
+    res = []
+    for n in [int(x) for x in args.frames.split(",")]:
+        r = run(lio.ctx, cands, n)
+        res.append(r)
+        u = r["us"]
+        print(f"frame {n:6d} pts -> {r['keypoints']:5d} keypoints: upload {u['upload']:.0f}  select {u['select']:.0f}  two passes {u['two_passes']:.0f}  commit {u['commit']:.0f}"
+              f"  = {u['total']:.0f} us  ({r['sweeps_per_s']:.0f} frames/s)")
+        print("      stages (synchronised):", "  ".join(f"{k} {v:.0f}" for k, v in r["stage_us"].items()))
+    lio.close()
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
