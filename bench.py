@@ -275,6 +275,55 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         lio.close()
 
 
+def run_pipeline(device, frame_points=(24_000, 65_536), reps=9):
+    """The frame-resident pipeline either side of the solve: per frame upload of the raw points (page-locked) ->
+    keypoint selection on the device in gridSampling order (1.5 m sampling) -> two ESIKF passes on the selected keypoints -> commit
+    (re-transform + addPointsToMap on the device, world points downloaded), on a 1 M-point map, for frames spread over the scene.
+    Wall time per stage (median), frames/s of the whole chain, and the synchronised stage breakdown of srl_debug_frame_timing."""
+    from sr_livo_amd import capi
+    cands, L = synth.map_candidates(7, 1_000_000)
+    lio = srl.Lio(device)
+    out = []
+    try:
+        lio.add_points_to_map(cands)
+        ctx = lio.ctx
+        q, t = np.array([1.0, 0, 0, 0]), np.zeros(3)
+        f = capi.make_frame(q, t, t)
+        opts = srl.default_opts(max_num_residuals=INT_MAX)
+        for n_frame in frame_points:
+            rng = np.random.default_rng(3 + n_frame)
+            frame = cands[rng.choice(len(cands), n_frame, replace=False)] + rng.normal(0, 0.03, (n_frame, 3))
+            pin = srl.PinnedArray(frame.shape)
+            pin.array[:] = frame
+
+            def one(timing):
+                ctx.frame_timing(timing)
+                t0 = time.perf_counter()
+                ctx.frame_upload(pin.array)
+                t1 = time.perf_counter()
+                k = ctx.frame_select_keypoints(q, t, 1.5)
+                t2 = time.perf_counter()
+                ctx.build_residuals(f, opts)
+                ctx.build_residuals(f, opts)
+                ctx.disarm()
+                t3 = time.perf_counter()
+                ctx.frame_commit(q, t, want_world=True)
+                t4 = time.perf_counter()
+                return len(k), (t1 - t0, t2 - t1, t3 - t2, t4 - t3), ctx.frame_timing(False)
+
+            one(False); one(True)
+            plain = np.array([one(False)[1] for _ in range(reps)]) * 1e6
+            staged = [one(True) for _ in range(5)]
+            med = np.median(plain, axis=0)
+            out.append({"frame_points": n_frame, "keypoints": staged[0][0], "map_points": lio.map_size(), "frames_per_s": 1e6 / float(med.sum()),
+                        "us": {"upload": float(med[0]), "select": float(med[1]), "two_passes": float(med[2]), "commit": float(med[3]), "total": float(med.sum())},
+                        "stage_us_synchronised": {k: float(np.median([s_[2][k] for s_ in staged])) for k in staged[0][2]}})
+            pin.close()
+    finally:
+        lio.close()
+    return out
+
+
 def eo_last_cov(po, backend, omap, oo, prior_state, prior_cov, sweep, state0, frame_id):
     """covariance the oracle leaves after the same solve (for the bitwise oracle-vs-reference-TU flag of the bench line)"""
     eo = po.Eskf(backend)
@@ -918,6 +967,14 @@ def main():
             except Exception as e:  # noqa: BLE001
                 cfgs.append({"name": name, "error": repr(e)})
         out["configs"] = cfgs
+        try:
+            pl = run_pipeline(local_rank)
+            out["pipeline_detail"] = pl
+            out["pipeline"] = {"what": "frames/s of upload + device keypoint selection + two passes + device commit, 1M-pt map",
+                               "frames": [{"points": e["frame_points"], "keypoints": e["keypoints"], "frames_per_s": e["frames_per_s"],
+                                           "us": e["us"]} for e in pl]}
+        except Exception as e:  # noqa: BLE001
+            out["pipeline"] = {"error": repr(e)[:160]}
     if rank == 0:
         write_detail(out)
         print(compact_line(out), flush=True)
