@@ -1052,12 +1052,27 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             return true;
         };
         unsigned long long spins = 0;
+        bool arm_expired = false;
         while (!arrived()) {
+            if (fired && __atomic_load_n(&ctx->h_mail->expired, __ATOMIC_ACQUIRE) == ra.seq) { arm_expired = true; break; }   // the launch this pass fired had left
             if ((++spins & 0xFFFFF) == 0) {           // every ~1M polls: make sure the stream has not faulted
                 const hipError_t qe = hipStreamQuery(ctx->stream);
                 if (qe != hipSuccess && qe != hipErrorNotReady) { ctx->err = std::string("reduce kernel: ") + hipGetErrorString(qe); return SRL_ERR_HIP; }
-                if (qe == hipSuccess && !arrived()) { ctx->err = "reduce kernel finished without publishing"; return SRL_ERR_HIP; }
+                if (qe == hipSuccess && !arrived()) {
+                    char dbg[256];
+                    int bad = -1; unsigned bad_tag = 0;
+                    if (tagged_mail) for (int i = 0; i < 2 * NW; i++) if ((unsigned)(gran[i] >> 32) != tag32) { bad = i; bad_tag = (unsigned)(gran[i] >> 32); break; }
+                    std::snprintf(dbg, sizeof dbg, "reduce kernel finished without publishing (seq %llu, tagged %d, fired %d, fused %d, blocks %d, first stale granule %d tag %u, plain seq %llu)",
+                                  (unsigned long long)ra.seq, (int)tagged_mail, (int)fired, (int)fused, nblocks, bad, bad_tag, (unsigned long long)ctx->h_mail->seq);
+                    ctx->err = dbg;
+                    return SRL_ERR_HIP;
+                }
             }
+        }
+        if (arm_expired) {
+            ctx->arm_stats[3]++;
+            ctx->err = "armed launch expired";
+            return SRL_INTERNAL_ARM_EXPIRED;
         }
         if (tagged_mail) {
             unsigned long long *w = reinterpret_cast<unsigned long long *>(ctx->h_out);
@@ -1070,11 +1085,6 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         if (host_reduce) {
             if (!ctx->cb_ar) { ctx->err = "nranks > 1 without communicator"; return SRL_ERR_COMM; }
             if (ctx->cb_ar(reinterpret_cast<double *>(ctx->h_out), n_red, ctx->cb_user) != 0) { ctx->err = "allreduce callback failed"; return SRL_ERR_COMM; }
-        }
-        if (ctx->h_out->pad == SRL_ARM_EXPIRED_MARK) {       // the armed launch had stopped waiting before this pass fired it
-            ctx->arm_stats[3]++;
-            ctx->err = "armed launch expired";
-            return SRL_INTERNAL_ARM_EXPIRED;
         }
         if (ctx->h_out->pad == SRL_PEER_TIMEOUT_MARK) { ctx->err = "direct peer exchange: a rank's row never arrived"; return SRL_ERR_COMM; }
         if (ctx->h_out->pad != 0 || ctx->h_out->d_timeout > 0.5) {     // (summed over the ranks: all of them repeat the pass together)

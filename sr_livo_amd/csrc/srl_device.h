@@ -81,7 +81,9 @@ struct SrlDevOut {             // result of the reduce kernel (device, then copi
 struct SrlMailbox {            // host-mapped (fine-grained) memory the reduce kernel publishes into (single rank)
     SrlDevOut out;             // plain form: the record ...
     unsigned long long seq;    // ... = launch sequence number once `out` is complete
-    unsigned long long pad[11];   // (g starts on a 64-byte line)
+    unsigned long long expired;   // sequence number of the last ARMED launch that gave up waiting for its pose (its own word: an armed
+                                  // launch expires on its own schedule and must not touch the result a slower host has not read yet)
+    unsigned long long pad[10];   // (g starts on a 64-byte line)
     // tagged form (the fused finisher of a single-context pass): word w of the record as granules g[2w], g[2w + 1] = {low 32 bits of the
     // sequence number, 32-bit half} -- "the data is the flag": no drain and no second PCIe write behind the data
     unsigned long long g[2 * (sizeof(SrlDevOut) / 8)];
@@ -96,7 +98,6 @@ static_assert(offsetof(SrlMailbox, g) % 64 == 0, "the tagged record starts on a 
 #define SRL_ARM_GO 1u
 #define SRL_ARM_CANCEL 2u
 #define SRL_ARM_EXPIRED 3u
-#define SRL_ARM_EXPIRED_MARK 0xA53Dll   // SrlDevOut::pad: an armed launch gave up waiting before it was fired
 
 #define SRL_REDUCED_DOUBLES 50 // leading doubles of SrlDevOut that are summed over the shards (HtH .. d_timeout)
 

@@ -2048,12 +2048,11 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         {
             const int code = *s_ctrl;
             if (code != (int)SRL_ARM_GO) {
-                if (code == (int)SRL_ARM_EXPIRED && blockIdx.x == gridDim.x - 1 && tid < 64) {
-                    // nobody is listening any more: a host that fires this launch after all learns it from the mailbox and relaunches
-                    // (an armed launch always reports into the tagged host mailbox: zeros + the marker in SrlDevOut::pad, the last word)
-                    constexpr int NW = (int)(sizeof(SrlDevOut) / 8);
-                    const unsigned long long w = tid == NW - 1 ? (unsigned long long)SRL_ARM_EXPIRED_MARK : 0ull;
-                    if (tid < NW) store_granule_pair(&a.mailbox->g[2 * tid], (unsigned)a.seq, w);
+                if (code == (int)SRL_ARM_EXPIRED && blockIdx.x == gridDim.x - 1 && tid == 0) {
+                    // nobody is listening any more: a host that fires this launch after all learns it from the mailbox's `expired` word and
+                    // relaunches.  (NOT through the result record: this launch leaves on its own schedule, possibly while the host -- descheduled
+                    // for longer than the bound -- has not yet read the result of the pass before it; found by the 10^6-launch soak.)
+                    __hip_atomic_store(&a.mailbox->expired, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 return;
             }

@@ -138,14 +138,26 @@ def test_compact_line_survives_nan_and_an_oversized_result():
 
 def test_gpus_n_without_a_launcher_becomes_its_own_launcher(monkeypatch):
     """`python bench.py --gpus N` (how the driver starts the scaling runs) must not exit with "use torch.distributed.run": it re-runs
-    itself under torch.distributed.run with N ranks on loopback.  The command line is checked here; the GPU suite runs it for real."""
+    itself under torch.distributed.run with N ranks on loopback, and falls back RCCL -> peer exchange -> replicas when a form fails.
+    The command lines are checked here; the GPU suite runs the launcher for real."""
     import subprocess
+    import types
     bench = _bench()
-    seen = {}
-    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    seen = []
+
+    def fake_run(cmd, env=None, stdout=None, timeout=None):
+        seen.append((cmd, env))
+        ok = "--mode" in cmd                                            # the two sharded forms "fail", the replicas succeed
+        return types.SimpleNamespace(returncode=0 if ok else 1, stdout=b'{"value":1.0,"n_gpus":4}\n' if ok else b"")
+    monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.setattr("sys.argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    printed = []
+    monkeypatch.setattr("builtins.print", lambda *a, **k: printed.append((a, k)))
     assert bench.self_launch(4) == 0
-    cmd = seen["cmd"]
+    cmd, env = seen[0]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
-    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert [c[-2:] for c, _ in seen[1:]] == [["--transport", "peer"], ["--mode", "replay"]]
+    out = [a[0] for a, k in printed if k.get("file") is None]
+    assert len(out) == 1 and json.loads(out[0])["fallback"].startswith("sharded forms failed") and json.loads(out[0])["n_gpus"] == 4

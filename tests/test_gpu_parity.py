@@ -1539,6 +1539,7 @@ def test_replay_driver_matches_reference_loop(oracle_lib, oracle_backend, mc):
         lio.set_initial_flag(False)
         lio.set_odometry_options(icp=icp_p, **oo)
         processed = 0
+        margins = []
         for i, ms in enumerate(meas):
             want = ref.run_measurement(ms)
             got = lio.run_measurement(ms["time_frame"], ms["imu_t"], ms["imu_acc"], ms["imu_gyr"], ms["pts_raw"], ms["pts_timestamp"],
@@ -1558,11 +1559,33 @@ def test_replay_driver_matches_reference_loop(oracle_lib, oracle_backend, mc):
             assert rel(f["raw_point"], fo["raw"]) < 1e-11 and rel(f["imu_point"], fo["imu_point"]) < 1e-11
             assert rel(f["point"], fo["point"]) < 1e-9
             assert rel(lio.eskf_get_cov(), ref.e.get_cov()) < 1e-8
+            # The final maps are compared BIT for bit below although the device's undistortion agrees with the host's only to ~1e-12
+            # (device sin / cos / acos): that holds as long as no inserted point sits closer to a decision boundary of the insertion than
+            # the device / host difference -- (a) a voxel seam of the map (key = short(float(p) / 1.0), lioOptimization.cpp:403-405) and
+            # (b) a rounding boundary of the FP32 position that is stored (cloudMap.cpp:7).  Asserted here, per frame, not left to luck.
+            pd, ph = np.asarray(f["point"], np.float64), np.asarray(fo["point"], np.float64)
+            delta = float(np.max(np.abs(pd - ph)))
+            seam = float(np.min(np.abs(ph - np.round(ph))))                          # voxel size 1.0: seams at the integers
+            f32 = ph.astype(np.float32)
+            up = np.nextafter(f32, np.float32(np.inf)).astype(np.float64); dn = np.nextafter(f32, np.float32(-np.inf)).astype(np.float64)
+            mid = np.minimum(np.abs(ph - 0.5 * (f32.astype(np.float64) + up)), np.abs(ph - 0.5 * (f32.astype(np.float64) + dn)))
+            flips = int(np.count_nonzero(pd.astype(np.float32) != f32))
+            margins.append((delta, seam, float(np.min(mid)), flips))
+            assert seam > 100.0 * delta, (delta, seam)                               # (a): no key can flip -- the maps have the same voxels
+            assert flips <= 3 and (flips == 0 or float(np.min(mid)) <= delta)        # (b): a flip needs a point within delta of a boundary
         assert processed == ref.index_frame - 1 and processed >= 9
+        print("device/host point difference, distance to the nearest voxel seam, to the nearest FP32 rounding boundary, FP32 flips per frame:", margins)
+        total_flips = sum(m_[3] for m_ in margins)
         # the estimate follows the motion (odometry frame = first sensor pose)
         assert np.linalg.norm(got["state"][4:7] - gt[-1][1]) < 0.05
         kg, cg, xg = lio.ctx.map_download(); ko, co, xo = ref.m.export()
-        assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
+        assert np.array_equal(kg, ko) and np.array_equal(cg, co)
+        # stored positions: bit-identical, except where a frame point's FP32 rounding differed between device and host (counted above:
+        # ~1e-6 per coordinate at a 1e-11 device / host difference -- a handful per replay at most, none in most) -- there, one ulp
+        differ = xg != xo
+        assert int(np.count_nonzero(differ)) <= total_flips
+        if differ.any():
+            assert np.all(np.abs(xg[differ].astype(np.float64) - xo[differ].astype(np.float64)) <= np.spacing(np.abs(xo[differ]))), "more than one FP32 ulp"
     finally:
         lio.set_initial_flag(False)
         lio.close()

@@ -32,4 +32,6 @@ for r in range(rounds):
             launches += 1
             if not np.array_equal(h, first[n]):
                 raise SystemExit(f"MISMATCH at round {r} size {n}")
-print(f"soak ok: {launches} fused launches over {len(sizes)} sweep sizes in {time.time() - t0:.1f} s, all bitwise reproducible")
+st = ctx.arm_stats()
+print(f"soak ok: {launches} fused launches over {len(sizes)} sweep sizes in {time.time() - t0:.1f} s, every result bitwise equal to the first of its size; "
+      f"armed launches: {st}")
