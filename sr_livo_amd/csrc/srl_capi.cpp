@@ -1436,7 +1436,7 @@ int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id) {
     ctx->rank = rank;
     ctx->cb_ar = nullptr; ctx->cb_ag = nullptr; ctx->cb_user = nullptr;
     { const char *fc = std::getenv("SRL_FORCE_COLLECTIVES"); ctx->force_coll = fc && std::atoi(fc) != 0; }
-    int rc = ensure(ctx, ctx->d_gather, (size_t)nranks);
+    int rc = ensure_gather(ctx, (size_t)nranks);
     return rc;
 }
 
@@ -1544,7 +1544,7 @@ int srl_peer_attach(srl_ctx *ctx, int nranks, int rank, const void *ipc_handles,
     }
     if (!ctx->d_peer) { int rcp = ensure(ctx, ctx->d_peer, 1); if (rcp) return rcp; }
     HIPCHK(ctx, hipMemcpy(ctx->d_peer, &t, sizeof t, hipMemcpyHostToDevice));
-    { int rcg = ensure(ctx, ctx->d_gather, (size_t)nranks); if (rcg) return rcg; }
+    { int rcg = ensure_gather(ctx, (size_t)nranks); if (rcg) return rcg; }
     ctx->nranks = nranks; ctx->rank = rank;
     ctx->peer_on = nranks > 1;
     ctx->peer_seq = 0;                       // every rank starts counting from the same attach
@@ -1560,7 +1560,7 @@ int srl_debug_set_gather_counts(srl_ctx *ctx, int nranks, int rank, const int64_
     if (ctx->comm) { ctx->err = "srl_debug_set_gather_counts: a communicator is attached"; return SRL_ERR_BAD_ARG; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!counts) { ctx->dbg_gather = false; ctx->nranks = 1; ctx->rank = 0; ctx->cb_ar = nullptr; ctx->cb_ag = nullptr; return SRL_OK; }
-    int rc = ensure(ctx, ctx->d_gather, (size_t)nranks);
+    int rc = ensure_gather(ctx, (size_t)nranks);
     if (rc) return rc;
     std::vector<long long> c64(counts, counts + nranks);
     HIPCHK(ctx, hipMemcpy(ctx->d_gather, c64.data(), (size_t)nranks * sizeof(long long), hipMemcpyHostToDevice));

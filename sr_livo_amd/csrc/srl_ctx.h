@@ -137,7 +137,8 @@ struct srl_ctx {
     srl_allreduce_fn cb_ar = nullptr;
     srl_allgather_i64_fn cb_ag = nullptr;
     void *cb_user = nullptr;
-    long long *d_gather = nullptr;     // nranks
+    long long *d_gather = nullptr;     // nranks (capacity d_gather_cap: grow-only, see ensure_gather)
+    size_t d_gather_cap = 0;
     // direct peer exchange (srl_peer_export / srl_peer_attach): the sharded sum without an RCCL call on the data path
     unsigned long long *d_inbox = nullptr;     // fine-grained device memory the peers store into (SRL_PEER_INBOX_GRANULES)
     SrlPeerTable *d_peer = nullptr;            // the table the kernels read (device copy)
@@ -207,7 +208,10 @@ inline void srl_stage_end(srl_ctx *ctx, int slot) {
 
 inline int ensure_host_scratch(srl_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->h_scratch_bytes) return SRL_OK;
-    if (ctx->h_scratch) { HIPCHK(ctx, hipHostFree(ctx->h_scratch)); ctx->h_scratch = nullptr; ctx->h_scratch_bytes = 0; }
+    if (ctx->h_scratch) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // a DMA out of the old block may still be queued (srl_frame_select_keypoints' index list)
+        HIPCHK(ctx, hipHostFree(ctx->h_scratch)); ctx->h_scratch = nullptr; ctx->h_scratch_bytes = 0;
+    }
     const size_t cap = ((bytes + bytes / 2 + 4095) / 4096) * 4096;
     HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_scratch, cap, hipHostMallocDefault));
     ctx->h_scratch_bytes = cap;
@@ -219,6 +223,18 @@ int ensure(srl_ctx *ctx, T *&p, size_t count) {
     if (p) { HIPCHK(ctx, hipFree(p)); p = nullptr; }
     if (count == 0) count = 1;
     HIPCHK(ctx, hipMalloc((void **)&p, count * sizeof(T)));
+    return SRL_OK;
+}
+
+// The per-rank counts of the ordered cut.  Grow-only and never re-allocated for a size that fits: hipFree waits for the WHOLE
+// device, and a second rank of the same process may already sit in a pass that waits for THIS rank's row (a second peer
+// session on live contexts: its attach used to free + re-allocate here and stalled until the peer's bounded spin gave up).
+inline int ensure_gather(srl_ctx *ctx, size_t nranks) {
+    if (ctx->d_gather && nranks <= ctx->d_gather_cap) return SRL_OK;
+    const size_t cap = nranks < 64 ? 64 : nranks;
+    int rc = ensure(ctx, ctx->d_gather, cap);
+    if (rc) { ctx->d_gather_cap = 0; return rc; }
+    ctx->d_gather_cap = cap;
     return SRL_OK;
 }
 

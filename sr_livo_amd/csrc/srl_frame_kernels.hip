@@ -465,17 +465,17 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         unsigned long long *ukeys = reinterpret_cast<unsigned long long *>(ctx->h_scratch + 64);
         unsigned *first = reinterpret_cast<unsigned *>(ctx->h_scratch + 64 + (size_t)n * 8);
         int S = 0;
-        const bool one_trip = n <= 16384;
-        if (one_trip) {
-            HIPCHK(ctx, hipMemcpyAsync(ukeys, b_ukeys.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipMemcpyAsync(first, b_first.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-        }
+        // one round trip: the count and the first `pre` voxels together (a frame rarely has more occupied sampling voxels than that);
+        // a second trip only for what is left
+        const int pre = std::min(n, 32768);
+        HIPCHK(ctx, hipMemcpyAsync(ukeys, b_ukeys.p, (size_t)pre * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(first, b_first.p, (size_t)pre * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipMemcpyAsync(h_cnt, b_cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         S = *h_cnt;
-        if (!one_trip) {
-            HIPCHK(ctx, hipMemcpyAsync(ukeys, b_ukeys.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipMemcpyAsync(first, b_first.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+        if (S > pre) {
+            HIPCHK(ctx, hipMemcpyAsync(ukeys + pre, b_ukeys.as<unsigned long long>() + pre, (size_t)(S - pre) * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(first + pre, b_first.as<unsigned>() + pre, (size_t)(S - pre) * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
         }
 
@@ -522,7 +522,8 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         hipLaunchKernelGGL(k_gather_soa, dim3((m + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, b_sel.as<int>(), m,
                            ctx->d_raw, ctx->d_raw + ctx->sweep_cap, ctx->d_raw + 2 * (size_t)ctx->sweep_cap);
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipStreamSynchronize(st));
+        // no synchronisation: the solve that follows is ordered behind the gather on the stream, and the pinned scratch the index list
+        // was copied from is next written by a DMA of the same stream or, on the host, behind a later synchronisation
     }
     srl_stage_end(ctx, 4);
     if (trace) {

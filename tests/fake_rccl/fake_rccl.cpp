@@ -64,7 +64,11 @@ void exchange_cb(void *p) {
     const auto t0 = std::chrono::steady_clock::now();
     for (int r = 0; r < c->nranks; r++) {
         while (s.posted[r].load(std::memory_order_acquire) != a->op + 1) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { c->timed_out = 1; delete a; return; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                std::fprintf(stderr, "fake_rccl: rank %d of %d, collective %llu (kind %d): rank %d has not posted after 120 s (its last post: %llu)\n", c->rank, c->nranks,
+                             a->op, a->kind, r, s.posted[r].load());
+                c->timed_out = 1; delete a; return;
+            }
             std::this_thread::yield();
         }
     }

@@ -2,9 +2,10 @@
 # Run on the GPU box (via gpurun): the un-profiled bench line + rocprofv3 (kernel trace + separate PMC passes) of every
 # configuration quoted in DESIGN.md section 5.  Summaries land in gpurun_out/prof_<tag>/ and gpurun_out/bench_final.json.
 R=${1:-r04}
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; cp gpurun_out/bench_detail.json gpurun_out/bench_final_detail.json
 tools/profile_gpu.sh ${R}_headline 10 "" > /dev/null 2>&1
-tools/profile_gpu.sh ${R}_headline_unfused 10 "--no-fused-reduce" > /dev/null 2>&1
+tools/profile_gpu.sh ${R}_headline_unarmed 10 "--no-armed" > /dev/null 2>&1
+tools/profile_gpu.sh ${R}_headline_unfused 10 "--no-fused-reduce --no-armed" > /dev/null 2>&1
 tools/profile_gpu.sh ${R}_c1 10 "--workload C1" > /dev/null 2>&1
 tools/profile_gpu.sh ${R}_c2 10 "--workload C2" > /dev/null 2>&1
 tools/profile_gpu.sh ${R}_c3 10 "--workload C3" > /dev/null 2>&1
