@@ -179,7 +179,10 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
                                int32_t *keypoint_index /* capacity n, or NULL */, int *num_keypoints);
 int srl_frame_commit(srl_ctx *ctx, const double q[4], const double t[3], const double R_il[9], const double t_il[3],
                      double voxel_size, int cap, double min_distance_points, int min_num_points,
-                     double *world_out /* n x 3 or NULL */, int *num_added);
+                     double *world_out /* n x 3 or NULL */, int *num_added /* or NULL */);
+/* num_added == NULL (addPointsToMap returns nothing either): the insertion is enqueued behind the re-transform and the call returns as
+ * soon as world_out (if asked for) has arrived; the passes of the next sweep are ordered behind the insertion on the context's stream,
+ * and the map's totals are brought up to date by the next call that reads them (srl_map_size, srl_map_download, the next insertion). */
 
 /* ------------------------------------------------------------------ hot path
  * replaces: lioOptimization::buildPlaneResiduals (optimize.cpp:18-131) incl. searchNeighbors

@@ -136,7 +136,7 @@ int srl_lio_optimize_resident(srl_lio *lio, const srl_icp_opts *opts, double sam
                               int n, double state_io[16], const double t_last[3], int frame_id, int32_t *keypoint_index,
                               int *num_keypoints, int *iters, int *num_residuals_used);
 int srl_lio_commit_frame(srl_lio *lio, const double state[16], double voxel_size, int max_num_points_in_voxel,
-                         double min_distance_points, int min_num_points, double *world_out, int *num_added);
+                         double min_distance_points, int min_num_points, double *world_out, int *num_added /* or NULL: see srl_frame_commit */);
 
 /* lioOptimization::searchNeighbors / computeNeighborhoodDistribution single-call forms */
 int srl_lio_search_neighbors(srl_lio *lio, const double point[3], int nb_voxels_visited, double size_voxel_map,

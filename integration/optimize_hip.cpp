@@ -271,9 +271,9 @@ optimizeSummary lioOptimization::optimize(cloudFrame *p_frame, const icpOptions 
     // transformPoint over the whole frame with the final pose (optimize.cpp:441-445 -> utility.cpp:314-318) and the insertion the node
     // performs right after this call (addPointsToMap, lioOptimization.cpp:1027), both on the frame resident in HBM; the world points
     // come back once, for point3D::point
-    int added = 0;
+    // (num_added = NULL: addPointsToMap returns nothing; the insertion runs on behind this call, the next sweep's passes are ordered behind it)
     const int rcc = srl_lio_commit_frame(lio, st, odometry_options.optimize_options.size_voxel_map, odometry_options.max_num_points_in_voxel,
-                                         odometry_options.min_distance_points, 0, n > 0 ? b.pinned_world : nullptr, &added);
+                                         odometry_options.min_distance_points, 0, n > 0 ? b.pinned_world : nullptr, nullptr);
     if (rcc != SRL_OK) fail(lio, rcc, "srl_lio_commit_frame");
     b.committed[p_frame->frame_id] = true;
     if (b.committed.size() > 64) b.committed.erase(b.committed.begin());

@@ -578,15 +578,22 @@ class Context:
                                                       float(sample_voxel_size), _ptr(idx), C.byref(m)), "srl_frame_select_keypoints")
         return idx[: m.value].copy()
 
-    def frame_commit(self, q, t, voxel_size=1.0, cap=20, min_dist=0.15, min_num_points=0, R_il=None, t_il=None, want_world=True):
+    def frame_commit(self, q, t, voxel_size=1.0, cap=20, min_dist=0.15, min_num_points=0, R_il=None, t_il=None, want_world=True, want_added=True,
+                     world_out=None):
+        """want_added=False: num_added = NULL (the insertion is only enqueued, see include/srlivo_hip.h); world_out: a caller-owned
+        (n, 3) float64 array to receive the world points (page-locked for the fastest path) instead of a fresh one"""
         R_il = _f64(np.eye(3) if R_il is None else R_il).ravel()
         t_il = _f64(np.zeros(3) if t_il is None else t_il)
-        world = np.empty((self.frame_size(), 3)) if want_world else None
+        world = None
+        if want_world:
+            world = world_out if world_out is not None else np.empty((self.frame_size(), 3))
+            assert world.dtype == np.float64 and world.flags.c_contiguous and world.shape == (self.frame_size(), 3)
         added = C.c_int()
         self._chk(self.lib.srl_frame_commit(self.h, _dptr(_f64(q)), _dptr(_f64(t)), _dptr(R_il), _dptr(t_il), float(voxel_size), cap,
-                                            float(min_dist), min_num_points, _ptr(world) if want_world else None, C.byref(added)),
+                                            float(min_dist), min_num_points, _ptr(world) if want_world else None,
+                                            C.byref(added) if want_added else None),
                   "srl_frame_commit")
-        return world, added.value
+        return world, (added.value if want_added else None)
 
     # --- multi-GPU
     @staticmethod
@@ -874,12 +881,12 @@ class Lio:
                                                           C.byref(nres)), "optimize_resident", ok=allow)
         return dict(rc=rc, state=st, keypoint_index=kidx[: nk.value].copy(), iters=iters.value, num_residuals=nres.value)
 
-    def commit_frame(self, state, voxel_size=1.0, cap=20, min_dist=0.15, min_num_points=0, want_world=True):
+    def commit_frame(self, state, voxel_size=1.0, cap=20, min_dist=0.15, min_num_points=0, want_world=True, want_added=True):
         world = np.empty((self.ctx.frame_size(), 3)) if want_world else None
         added = C.c_int()
         self._chk(self.lib.srl_lio_commit_frame(self.h, _dptr(_f64(state)), float(voxel_size), cap, float(min_dist), min_num_points,
-                                                _ptr(world) if want_world else None, C.byref(added)), "commit_frame")
-        return world, added.value
+                                                _ptr(world) if want_world else None, C.byref(added) if want_added else None), "commit_frame")
+        return world, (added.value if want_added else None)
 
     def search_neighbors(self, point, nb=1, size=1.0, K=20, thr=1):
         out = np.zeros((K, 3)); vox = np.zeros((K, 3), dtype=np.int16); nf = C.c_int()

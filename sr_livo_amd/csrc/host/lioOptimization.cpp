@@ -810,13 +810,13 @@ optimizeSummary lioOptimization::optimizeResident(cloudFrame *p_frame, const dou
 }
 
 int lioOptimization::commitFrame(const state *p_state, double voxel_size, int max_num_points_in_voxel, double min_distance_points,
-                                 int min_num_points, double *world_out) {
+                                 int min_num_points, double *world_out, bool want_added) {
     srl_ctx *ctx = voxel_map.ctx;
     if (!ctx) throw std::runtime_error("addPointsToMap: no HIP context (the product has no CPU path)");
     const double qv[4] = {p_state->rotation.w, p_state->rotation.x, p_state->rotation.y, p_state->rotation.z};
-    int added = 0;
+    int added = -1;
     check(ctx, srl_frame_commit(ctx, qv, p_state->translation.a, R_imu_lidar.a, t_imu_lidar.a, voxel_size, max_num_points_in_voxel,
-                                min_distance_points, min_num_points, world_out, &added), "srl_frame_commit");
+                                min_distance_points, min_num_points, world_out, want_added ? &added : nullptr), "srl_frame_commit");
     return added;
 }
 

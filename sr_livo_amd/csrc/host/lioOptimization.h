@@ -194,8 +194,9 @@ public:
     optimizeSummary optimizeResident(cloudFrame *p_frame, const double *frame_raw, int n, const icpOptions &cur_icp_options,
                                      double sample_voxel_size, std::vector<int> *keypoint_index = nullptr);
     // transformPoint over the uploaded frame with p_state's pose + addPointsToMap, all on the device
+    // (want_added = false: the insertion is only enqueued -- srl_frame_commit with num_added = NULL -- and -1 is returned)
     int commitFrame(const state *p_state, double voxel_size, int max_num_points_in_voxel, double min_distance_points,
-                    int min_num_points, double *world_out = nullptr);
+                    int min_num_points, double *world_out = nullptr, bool want_added = true);
     void setNormalEqProvider(normal_eq_provider fn, void *user) { provider = fn; provider_user = user; }
     srl_ctx *context() { return voxel_map.ctx; }
 

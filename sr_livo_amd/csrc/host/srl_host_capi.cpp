@@ -463,7 +463,7 @@ int srl_lio_commit_frame(srl_lio *h, const double state[16], double voxel_size, 
     srlivo::state st;
     state_from(state, st);
     try {
-        const int added = h->lio->commitFrame(&st, voxel_size, max_num_points_in_voxel, min_distance_points, min_num_points, world_out);
+        const int added = h->lio->commitFrame(&st, voxel_size, max_num_points_in_voxel, min_distance_points, min_num_points, world_out, num_added != nullptr);
         if (num_added) *num_added = added;
     } catch (const std::exception &e) { return status_from_exception(h, e); }
     return SRL_OK;

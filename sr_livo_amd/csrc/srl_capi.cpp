@@ -176,6 +176,12 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->h_mail) hipHostFree(ctx->h_mail);
     if (ctx->h_arm_stamps) hipHostFree(ctx->h_arm_stamps);
     if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
+    if (ctx->h_frame_x) hipHostFree(ctx->h_frame_x);
+    for (SrlEpochTable *t : {&ctx->sel_table, &ctx->ins_table}) { if (t->keyw) hipFree(t->keyw); if (t->minw) hipFree(t->minw); }
+    if (ctx->d_frame_sync) hipFree(ctx->d_frame_sync);
+    if (ctx->h_insert_cnt) hipHostFree(ctx->h_insert_cnt);
+    if (ctx->ev_insert) hipEventDestroy(ctx->ev_insert);
+    if (ctx->ev_world) hipEventDestroy(ctx->ev_world);
     if (ctx->h_ring) { hipHostFree(ctx->h_ring); for (int i = 0; i < srl_ctx::RING_SLOTS; i++) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]); }
     for (auto &b : ctx->pool_free) hipFree(b.p);
     ctx->pool_free.clear();
@@ -197,6 +203,7 @@ int srl_map_upload(srl_ctx *ctx, const int16_t *keys_xyz, const int32_t *counts,
     SRL_DISARM(ctx);
     if (cap != SRL_VOXEL_CAP) { ctx->err = "max_num_points_in_voxel must be 20"; return SRL_ERR_UNSUPPORTED; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    { const int rcs = srl_map_settle(ctx); if (rcs) return rcs; }
     // capacity with headroom so that srl_map_insert can add voxels without an immediate rebuild
     const unsigned slab_cap = std::max<unsigned>(1024u, (unsigned)V + (unsigned)V / 2u + 4096u);
     if (slab_cap > SRL_MAX_SLABS) { ctx->err = "map too large: slab byte offsets are 32-bit (16.7 M voxels)"; return SRL_ERR_UNSUPPORTED; }
@@ -243,6 +250,7 @@ int srl_map_upload(srl_ctx *ctx, const int16_t *keys_xyz, const int32_t *counts,
 
 int srl_map_size(srl_ctx *ctx, int64_t *num_points, int32_t *num_voxels) {
     if (!ctx) return SRL_ERR_BAD_ARG;
+    { const int rcs = srl_map_settle(ctx); if (rcs) return rcs; }      // (a deferred insert's counters: srl_frame_commit without num_added)
     if (num_points) *num_points = ctx->num_points;
     if (num_voxels) *num_voxels = ctx->num_voxels;
     return SRL_OK;
@@ -252,6 +260,7 @@ int srl_map_download(srl_ctx *ctx, int16_t *keys_xyz, int32_t *counts, float *xy
     if (!ctx) return SRL_ERR_BAD_ARG;
     SRL_DISARM(ctx);
     if (!ctx->d_slabs) return SRL_ERR_NO_MAP;
+    { const int rcs = srl_map_settle(ctx); if (rcs) return rcs; }
     const int V = ctx->num_voxels;
     if (max_voxels < V) return SRL_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -9,6 +9,15 @@
 #include <string>
 #include <vector>
 
+// scratch hash table of the per-frame kernels that is never cleared between frames (srl_frame_scratch.h)
+struct SrlEpochTable {
+    unsigned long long *keyw = nullptr;       // (epoch16 << 48) | key48
+    unsigned long long *minw = nullptr;       // optional companion: {~frame counter, smallest index}
+    unsigned cap = 0;                         // slots allocated (power of two)
+    unsigned epoch16 = 0;
+    unsigned counter32 = 0;
+};
+
 struct srl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -75,6 +84,17 @@ struct srl_ctx {
     // synchronously by the runtime and cost more than the kernels around them
     char *h_scratch = nullptr;
     size_t h_scratch_bytes = 0;
+    // frame pipeline <-> host exchange (page-locked, coherent, device-mapped): the selection kernels write the voxel list straight into
+    // it and the gather reads the ordered index list out of it -- no copy commands, the host waits on a tagged word, not on the stream
+    char *h_frame_x = nullptr;
+    size_t h_frame_x_bytes = 0;
+    unsigned *d_frame_sync = nullptr;            // [0]: blocks of the emitting kernel that are done (reset by the last one)
+    unsigned frame_tag = 0;                      // tag of the last exchange (never 0)
+    // addPointsToMap on the device: counters of the last insert, folded into num_voxels / num_points lazily (srl_map_settle)
+    int *h_insert_cnt = nullptr;                 // pinned: [0] segments, [1] new voxels, [2] points added
+    hipEvent_t ev_insert = nullptr, ev_world = nullptr;
+    bool insert_pending = false;
+    SrlEpochTable sel_table, ins_table;          // keypoint selection (with first-index words) / frame insertion
 
     // work buffers
     double *d_rec = nullptr;
@@ -204,6 +224,32 @@ inline void srl_stage_end(srl_ctx *ctx, int slot) {
     const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     ctx->frame_stage_us[slot] += (double)(now - ctx->frame_stage_last_ns) * 1e-3;
     ctx->frame_stage_last_ns = now;
+}
+
+// fold the counters of a deferred insert into the map's totals (every reader of num_voxels / num_points calls this first)
+inline int srl_map_settle(srl_ctx *ctx) {
+    if (!ctx->insert_pending) return SRL_OK;
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_insert));
+    ctx->num_voxels += ctx->h_insert_cnt[1];
+    ctx->num_points += ctx->h_insert_cnt[2];
+    ctx->insert_pending = false;
+    return SRL_OK;
+}
+
+inline int ensure_frame_exchange(srl_ctx *ctx, size_t bytes) {
+    if (!ctx->d_frame_sync) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_frame_sync, 256));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_frame_sync, 0, 256, ctx->stream));
+    }
+    if (bytes <= ctx->h_frame_x_bytes) return SRL_OK;
+    if (ctx->h_frame_x) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // a gather may still be reading its index list out of the old block
+        HIPCHK(ctx, hipHostFree(ctx->h_frame_x)); ctx->h_frame_x = nullptr; ctx->h_frame_x_bytes = 0;
+    }
+    const size_t cap = ((bytes + bytes / 2 + 4095) / 4096) * 4096;
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_frame_x, cap, hipHostMallocCoherent | hipHostMallocMapped));
+    ctx->h_frame_x_bytes = cap;
+    return SRL_OK;
 }
 
 inline int ensure_host_scratch(srl_ctx *ctx, size_t bytes) {

@@ -12,6 +12,7 @@
 //   srl_frame_commit            the re-transform loop of optimize() (optimize.cpp:441-445) + addPointsToMap
 //                               (lioOptimization.cpp:520-554) chained on the device.
 #include "srl_ctx.h"
+#include "srl_frame_scratch.h"
 #include "srl_hash.h"
 #include "host/srl_la.h"
 #include "host/tr1_order.h"
@@ -27,7 +28,7 @@
 #include <vector>
 
 int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, int n, double voxel_size,
-                        double min_distance_points, int min_num_points, int *num_added);
+                        double min_distance_points, int min_num_points, int *num_added, bool defer_counters);
 
 namespace {
 
@@ -80,9 +81,11 @@ __global__ void k_run_heads(const unsigned long long *keys_sorted, const unsigne
 // gridSampling keeps the FIRST point of every sampling voxel (utility.cpp:175-183): group the points by voxel key in a scratch hash
 // table (open addressing, keys claimed by compare-and-swap) and keep the smallest point index per key (atomicMin) -- no sort: the
 // order of the voxels is decided on the host anyway (std::tr1::unordered_map iteration order), from the first indices.
-__global__ void k_select_group(const double *raw, int n, const Xf X, double size, unsigned long long *tkeys, unsigned *tfirst, unsigned mask) {
+__global__ void k_select_group(const double *raw, int n, const Xf X, double size, unsigned long long *keyw, unsigned long long *minw, unsigned mask,
+                               unsigned epoch16, unsigned counter32, int *flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    flag[i] = 0;                           // (k_select_mark, the next kernel, sets the marks: no fill in front of this one)
     const double rx = raw[(size_t)i * 3], ry = raw[(size_t)i * 3 + 1], rz = raw[(size_t)i * 3 + 2];
     const double ix = (X.R_il[0] * rx + X.R_il[1] * ry) + X.R_il[2] * rz + X.t_il[0];
     const double iy = (X.R_il[3] * rx + X.R_il[4] * ry) + X.R_il[5] * rz + X.t_il[1];
@@ -91,30 +94,48 @@ __global__ void k_select_group(const double *raw, int n, const Xf X, double size
     const double wy = (X.R[3] * ix + X.R[4] * iy) + X.R[5] * iz + X.t[1];
     const double wz = (X.R[6] * ix + X.R[7] * iy) + X.R[8] * iz + X.t[2];
     const unsigned long long key = srl_pack_key((short)(int)(wx / size), (short)(int)(wy / size), (short)(int)(wz / size));
-    unsigned h = srl_hash_key(key) & mask;
-    for (unsigned probe = 0; probe <= mask; ++probe) {
-        unsigned long long k = tkeys[h];
-        if (k == SRL_EMPTY_KEY) k = atomicCAS(&tkeys[h], SRL_EMPTY_KEY, key);          // returns what was there: EMPTY = claimed
-        if (k == SRL_EMPTY_KEY || k == key) { atomicMin(&tfirst[h], (unsigned)i); return; }
-        h = (h + 1) & mask;
-    }
+    const unsigned h = srl_epoch_claim(keyw, mask, epoch16, key, srl_hash_key(key));
+    // smallest point index of the voxel: {~frame counter, index}, only ever lowered -- a word of an earlier frame loses against any of this one
+    atomicMin(&minw[h], ((unsigned long long)(0xFFFFFFFFu - counter32) << 32) | (unsigned)i);
 }
 // ... then the voxels in FIRST-OCCURRENCE order (the order subSampleFrame's loop creates them in, utility.cpp:175-183 -- what the
 // host's replay of the container's iteration order starts from): every occupied slot marks the index of its first point, an
 // exclusive scan over the marks ranks the voxels, and the keys are written out by rank.
-__global__ void k_select_mark(const unsigned long long *tkeys, const unsigned *tfirst, unsigned cap, int *flag, unsigned long long *key_at) {
+__global__ void k_select_mark(const unsigned long long *keyw, const unsigned long long *minw, unsigned cap, unsigned epoch16, int *flag,
+                              unsigned long long *key_at) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cap || tkeys[i] == SRL_EMPTY_KEY) return;
-    const unsigned f = tfirst[i];
+    if (i >= cap) return;
+    const unsigned long long k = keyw[i];
+    if ((unsigned)(k >> 48) != epoch16) return;
+    const unsigned f = (unsigned)minw[i];
     flag[f] = 1;
-    key_at[f] = tkeys[i];
+    key_at[f] = k & SRL_KEY48_MASK;
 }
-__global__ void k_select_emit(const int *flag, const int *rank, const unsigned long long *key_at, int n, unsigned long long *out_key,
-                              unsigned *out_first, int *count) {
+// The voxels leave the device HERE: {std::hash<voxel> (cloudMap.h:173-184, what the host's replay of the container needs), index of the
+// first point} by rank, stored straight into page-locked host memory; the last block to finish publishes {tag, count} in one 8-byte
+// word the host waits on.  No copy command, no stream synchronisation (a D2H copy + hipStreamSynchronize cost ~25 us per frame).
+__global__ void k_select_emit(const int *flag, const int *rank, const unsigned long long *key_at, int n, unsigned long long *host_hash,
+                              unsigned *host_first, unsigned *done, unsigned long long *host_ctrl, unsigned tag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flag[i]) { out_key[rank[i]] = key_at[i]; out_first[rank[i]] = (unsigned)i; }
-    if (i == n - 1) *count = rank[i] + flag[i];
+    if (i < n && flag[i]) {
+        short x, y, z;
+        srl_unpack_key(key_at[i], &x, &y, &z);
+        const unsigned long long kP1 = 73856093ull, kP2 = 19349669ull, kP3 = 83492791ull;       // size_t arithmetic of the reference's hash
+        const int r = rank[i];
+        host_hash[r] = (unsigned long long)(long long)x * kP1 + (unsigned long long)(long long)y * kP2 + (unsigned long long)(long long)z * kP3;
+        host_first[r] = (unsigned)i;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // ready for the next frame
+            const unsigned count = (unsigned)(rank[n - 1] + flag[n - 1]);
+            __threadfence_system();
+            __hip_atomic_store(host_ctrl, ((unsigned long long)tag << 32) | count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 __global__ void k_gather_soa(const double *raw, const int *sel, int m, double *x, double *y, double *z) {
@@ -436,65 +457,63 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
     if (n > 0) {
         Xf X;
         fill_xf(X, q, t, R_il, t_il);
-        // group by sampling voxel in a scratch table of >= 2 n slots (keys | first indices: one block, one memset)
+        // group by sampling voxel in a scratch table of >= 2 n slots (epoch-tagged: never cleared between frames, srl_frame_scratch.h)
         unsigned cap = 1024;
         while (cap < 2u * (unsigned)n) cap <<= 1;
-        DevBuf b_table, b_ukeys, b_first, b_cnt, b_flag, b_rank, b_keyat, b_tmp;
+        DevBuf b_flag, b_rank, b_keyat, b_tmp;
         HIPCHK(ctx, b_flag.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_rank.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_keyat.alloc(ctx, (size_t)n * 8));
-        HIPCHK(ctx, b_table.alloc(ctx, (size_t)cap * 12));
-        HIPCHK(ctx, b_ukeys.alloc(ctx, (size_t)n * 8)); HIPCHK(ctx, b_first.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_cnt.alloc(ctx, 16));
-        unsigned long long *tkeys = b_table.as<unsigned long long>();
-        unsigned *tfirst = reinterpret_cast<unsigned *>(tkeys + cap);
-        HIPCHK(ctx, hipMemsetAsync(b_table.p, 0xFF, (size_t)cap * 12, st));            // SRL_EMPTY_KEY everywhere, first index = UINT_MAX
-        HIPCHK(ctx, hipMemsetAsync(b_flag.p, 0, (size_t)n * 4, st));
-        hipLaunchKernelGGL(k_select_group, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, n, X, sample_voxel_size, tkeys, tfirst, cap - 1);
-        hipLaunchKernelGGL(k_select_mark, dim3((cap + 255) / 256), dim3(256), 0, st, tkeys, tfirst, cap, b_flag.as<int>(), b_keyat.as<unsigned long long>());
-        size_t scan_bytes = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, b_flag.as<int>(), b_rank.as<int>(), n, st);
-        HIPCHK(ctx, b_tmp.alloc(ctx, scan_bytes + 256));
-        HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, scan_bytes, b_flag.as<int>(), b_rank.as<int>(), n, st));
+        int rct = srl_epoch_table_begin(ctx, ctx->sel_table, cap, true);
+        if (rct) return rct;
+        const SrlEpochTable &T = ctx->sel_table;
+        // host exchange block: [0] control word {tag, count} | hashes (8 B) | first indices (4 B) | ordered index list for the gather (4 B)
+        int rcx = ensure_frame_exchange(ctx, 64 + (size_t)n * 16);
+        if (rcx) return rcx;
+        unsigned long long *h_ctrl = reinterpret_cast<unsigned long long *>(ctx->h_frame_x);
+        unsigned long long *h_hash = reinterpret_cast<unsigned long long *>(ctx->h_frame_x + 64);
+        unsigned *first = reinterpret_cast<unsigned *>(ctx->h_frame_x + 64 + (size_t)n * 8);
+        if (++ctx->frame_tag == 0) ++ctx->frame_tag;
+        const unsigned tag = ctx->frame_tag;
+        __atomic_store_n(h_ctrl, 0ull, __ATOMIC_RELEASE);
+        hipLaunchKernelGGL(k_select_group, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, n, X, sample_voxel_size, T.keyw, T.minw, cap - 1, T.epoch16,
+                           T.counter32, b_flag.as<int>());
+        hipLaunchKernelGGL(k_select_mark, dim3((cap + 255) / 256), dim3(256), 0, st, T.keyw, T.minw, cap, T.epoch16, b_flag.as<int>(), b_keyat.as<unsigned long long>());
+        if (n <= SRL_SCAN_SMALL_MAX) {
+            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, SrlIntArraySink>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, SrlIntArrayIn{b_flag.as<int>()},
+                               SrlIntArraySink{b_rank.as<int>()}, n);
+        } else {
+            size_t scan_bytes = 0;
+            hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, b_flag.as<int>(), b_rank.as<int>(), n, st);
+            HIPCHK(ctx, b_tmp.alloc(ctx, scan_bytes + 256));
+            HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, scan_bytes, b_flag.as<int>(), b_rank.as<int>(), n, st));
+        }
         hipLaunchKernelGGL(k_select_emit, dim3((n + 255) / 256), dim3(256), 0, st, b_flag.as<int>(), b_rank.as<int>(), b_keyat.as<unsigned long long>(), n,
-                           b_ukeys.as<unsigned long long>(), b_first.as<unsigned>(), b_cnt.as<int>());
+                           h_hash, first, ctx->d_frame_sync, h_ctrl, tag);
         HIPCHK(ctx, hipGetLastError());
         srl_stage_end(ctx, 1);
         tp1 = std::chrono::steady_clock::now();
-        // one round trip for small frames (count + all n slots), two for large ones (count first); into pinned scratch
-        int rcs = ensure_host_scratch(ctx, (size_t)n * 16 + 64);
-        if (rcs) return rcs;
-        int *h_cnt = reinterpret_cast<int *>(ctx->h_scratch);
-        unsigned long long *ukeys = reinterpret_cast<unsigned long long *>(ctx->h_scratch + 64);
-        unsigned *first = reinterpret_cast<unsigned *>(ctx->h_scratch + 64 + (size_t)n * 8);
-        int S = 0;
-        // one round trip: the count and the first `pre` voxels together (a frame rarely has more occupied sampling voxels than that);
-        // a second trip only for what is left
-        const int pre = std::min(n, 32768);
-        HIPCHK(ctx, hipMemcpyAsync(ukeys, b_ukeys.p, (size_t)pre * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(first, b_first.p, (size_t)pre * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(h_cnt, b_cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        S = *h_cnt;
-        if (S > pre) {
-            HIPCHK(ctx, hipMemcpyAsync(ukeys + pre, b_ukeys.as<unsigned long long>() + pre, (size_t)(S - pre) * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipMemcpyAsync(first + pre, b_first.as<unsigned>() + pre, (size_t)(S - pre) * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
+        // wait for the control word (the stream is looked at every ~1M polls: a fault must not become a hang)
+        unsigned long long ctrl = 0, spins = 0;
+        while ((unsigned)((ctrl = __atomic_load_n(h_ctrl, __ATOMIC_ACQUIRE)) >> 32) != tag) {
+            if ((++spins & 0xFFFFF) == 0) {
+                const hipError_t qe = hipStreamQuery(st);
+                if (qe != hipSuccess && qe != hipErrorNotReady) { ctx->err = std::string("keypoint selection: ") + hipGetErrorString(qe); return SRL_ERR_HIP; }
+                if (qe == hipSuccess && (unsigned)(__atomic_load_n(h_ctrl, __ATOMIC_ACQUIRE) >> 32) != tag) {
+                    ctx->err = "keypoint selection finished without publishing its voxel list";
+                    return SRL_ERR_HIP;
+                }
+            }
         }
-
+        const int S = (int)(unsigned)ctrl;
         srl_stage_end(ctx, 2);
         tp2 = std::chrono::steady_clock::now();
-        // the voxels arrive in FIRST-OCCURRENCE order (= the order subSampleFrame's loop creates them): ordered on the device
-        std::vector<std::size_t> hashes((size_t)S);
-        for (int i = 0; i < S; i++) {
-            vkey k;
-            srl_unpack_key(ukeys[i], &k.x, &k.y, &k.z);
-            hashes[(size_t)i] = vkey_hash()(k);
-        }
-        const unsigned *first_sorted = first;
-        // iteration order of the std::tr1::unordered_map of subSampleFrame, by replaying its bucket moves on flat arrays
+        // the voxels arrive in FIRST-OCCURRENCE order (= the order subSampleFrame's loop creates them): ordered on the device.
+        // Iteration order of the std::tr1::unordered_map of subSampleFrame, by replaying its bucket moves on flat arrays
         // (host/tr1_order.h) for the S distinct voxels (not the N points)
+        static_assert(sizeof(std::size_t) == sizeof(unsigned long long), "hashes are exchanged as 64-bit words");
         std::vector<int> perm((size_t)S);
-        srl::Tr1Order::order(hashes.data(), S, perm.data());
+        srl::Tr1Order::order(reinterpret_cast<const std::size_t *>(h_hash), S, perm.data());
         order.resize((size_t)S);
-        for (int r = 0; r < S; r++) order[(size_t)r] = (int)first_sorted[(size_t)perm[(size_t)r]];
+        for (int r = 0; r < S; r++) order[(size_t)r] = (int)first[(size_t)perm[(size_t)r]];
     }
     srl_stage_end(ctx, 3);
     tp3 = std::chrono::steady_clock::now();
@@ -513,17 +532,13 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
     int rc = srl_ctx_ensure_work(ctx, m);
     if (rc) return rc;
     if (m > 0) {
-        DevBuf b_sel;
-        HIPCHK(ctx, b_sel.alloc(ctx, (size_t)m * 4));
-        int rch = ensure_host_scratch(ctx, (size_t)m * 4);          // (the downloads above have been consumed)
-        if (rch) return rch;
-        std::memcpy(ctx->h_scratch, order.data(), (size_t)m * 4);
-        HIPCHK(ctx, hipMemcpyAsync(b_sel.p, ctx->h_scratch, (size_t)m * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_gather_soa, dim3((m + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, b_sel.as<int>(), m,
+        // the gather reads the ordered index list straight out of the exchange block (its own region: nothing is written there before
+        // the next frame's list, and that is produced behind a wait on a later kernel of this stream)
+        int *h_sel = reinterpret_cast<int *>(ctx->h_frame_x + 64 + (size_t)n * 12);
+        std::memcpy(h_sel, order.data(), (size_t)m * 4);
+        hipLaunchKernelGGL(k_gather_soa, dim3((m + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, h_sel, m,
                            ctx->d_raw, ctx->d_raw + ctx->sweep_cap, ctx->d_raw + 2 * (size_t)ctx->sweep_cap);
         HIPCHK(ctx, hipGetLastError());
-        // no synchronisation: the solve that follows is ordered behind the gather on the stream, and the pinned scratch the index list
-        // was copied from is next written by a DMA of the same stream or, on the host, behind a later synchronisation
     }
     srl_stage_end(ctx, 4);
     if (trace) {
@@ -552,9 +567,17 @@ int srl_frame_commit(srl_ctx *ctx, const double q[4], const double t[3], const d
                        (unsigned long long *)nullptr, (unsigned *)nullptr);
     HIPCHK(ctx, hipGetLastError());
     srl_stage_end(ctx, 5);
-    if (world_out) HIPCHK(ctx, hipMemcpyAsync(world_out, ctx->d_frame_world, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (world_out) {
+        HIPCHK(ctx, hipMemcpyAsync(world_out, ctx->d_frame_world, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (!ctx->ev_world) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_world, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_world, ctx->stream));
+    }
     srl_stage_end(ctx, 6);
-    return srl_map_insert_impl(ctx, ctx->d_frame_world, true, n, voxel_size, min_distance_points, min_num_points, num_added);
+    // num_added == NULL: the insert is only enqueued (its counters are folded in later, srl_map_settle); the caller's world points are
+    // waited for on their own event, which fires long before the insert behind them is done
+    const int rci = srl_map_insert_impl(ctx, ctx->d_frame_world, true, n, voxel_size, min_distance_points, min_num_points, num_added, num_added == nullptr);
+    if (world_out) HIPCHK(ctx, hipEventSynchronize(ctx->ev_world));
+    return rci;
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 //      first point (= creation order) -> slab ids; CAS-insert into the open-addressing table
 //   4. one thread per touched voxel replays its segment sequentially (IsFull, min-distance, cap).
 #include "srl_ctx.h"
+#include "srl_frame_scratch.h"
 #include "srl_hash.h"
 
 #include <hipcub/hipcub.hpp>
@@ -30,6 +31,44 @@ __global__ void k_point_keys(const double *xyz, int n, double voxel_size, unsign
     keys[i] = srl_pack_key(kx, ky, kz);
     idx[i] = (unsigned)i;
 }
+
+// Frame-sized batches: the sort only has to bring the points of a voxel TOGETHER, in their original order -- not the voxels into
+// key order.  So the 48-bit key is first replaced by the slot the voxel claims in a scratch table of >= 2 n slots (open
+// addressing, compare-and-swap; one slot per distinct key), and the stable radix sort runs over log2(slots) bits: 2 passes for a
+// 24k-point frame instead of 6.  Which segment comes first is irrelevant downstream (creation order = first-point rank, replay =
+// per segment).
+__global__ void k_point_slots(const double *xyz, int n, double voxel_size, unsigned long long *keyw, unsigned mask, unsigned epoch16, unsigned *slot_out,
+                              unsigned *idx, int *new_flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float fx = (float)xyz[(size_t)i * 3], fy = (float)xyz[(size_t)i * 3 + 1], fz = (float)xyz[(size_t)i * 3 + 2];
+    const short kx = (short)(int)((double)fx / voxel_size);
+    const short ky = (short)(int)((double)fy / voxel_size);
+    const short kz = (short)(int)((double)fz / voxel_size);
+    const unsigned long long key = srl_pack_key(kx, ky, kz);
+    slot_out[i] = srl_epoch_claim(keyw, mask, epoch16, key, srl_hash_key(key));     // (epoch-tagged scratch table: no fill per frame)
+    idx[i] = (unsigned)i;
+    new_flag[i] = 0;                       // (k_lookup, three kernels on, sets the marks: no fill in front of this one)
+}
+// head flag of sorted position i / the per-element work of the scan over them: segment starts, and the voxel key of every sorted
+// position restored from the scratch table (in the pass of the scan itself: k_scan_small)
+struct HeadFlag32 {
+    const unsigned *slots;
+    __host__ __device__ int operator()(int i) const { return (i == 0 || slots[i] != slots[i - 1]) ? 1 : 0; }
+};
+struct SegmentSink {
+    const unsigned *slots_sorted;
+    const unsigned long long *keyw;
+    int *seg_start;
+    unsigned long long *keys_sorted;
+    int *counters;
+    int n;
+    __device__ void operator()(int i, int head, int excl) const {
+        keys_sorted[i] = keyw[slots_sorted[i]] & SRL_KEY48_MASK;
+        if (head) seg_start[excl] = i;
+        if (i == n - 1) { counters[0] = excl + head; counters[1] = 0; counters[2] = 0; }      // segments | new voxels (k_create) | points added (k_replay)
+    }
+};
 
 // ---- segments of the (key, index)-sorted batch.  A segment = the points of one voxel, in their original order (stable sort).
 // head flag of sorted position i, as an iterator the scan reads directly (no flag array)
@@ -235,12 +274,12 @@ int srl_ctx_grow_map(srl_ctx *ctx, unsigned need_slabs, unsigned need_slots) {
 }
 
 int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, int n, double voxel_size,
-                        double min_distance_points, int min_num_points, int *num_added);
+                        double min_distance_points, int min_num_points, int *num_added, bool defer_counters);
 
 int srl_map_insert_device(srl_ctx *ctx, const double *world_xyz, int n, double voxel_size, int cap,
                           double min_distance_points, int min_num_points, int *num_added) {
     (void)cap;
-    return srl_map_insert_impl(ctx, world_xyz, false, n, voxel_size, min_distance_points, min_num_points, num_added);
+    return srl_map_insert_impl(ctx, world_xyz, false, n, voxel_size, min_distance_points, min_num_points, num_added, false);
 }
 
 // world_xyz: host pointer, or (on_device) a device pointer that stays valid for the duration of the call.
@@ -252,13 +291,21 @@ int srl_map_insert_device(srl_ctx *ctx, const double *world_xyz, int n, double v
 //   order) -> created (slab = V + rank, key CAS-inserted) -> one thread per touched voxel replays its segment sequentially.
 // Nothing is read back before the end: the kernels take the segment count from device memory, storage is grown beforehand for the
 // worst case (every point a new voxel) when the batch is a frame (n <= 131072); a bulk load reads the segment count once to size the map.
+// defer_counters (frame-sized batches, num_added == NULL): return once everything is enqueued; the counters are folded into the
+// map's totals by srl_map_settle() -- at the next insert, srl_map_size, srl_map_download.  The solve that follows needs none of them
+// and is ordered behind the insert on the stream.
 int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, int n, double voxel_size,
-                        double min_distance_points, int min_num_points, int *num_added) {
+                        double min_distance_points, int min_num_points, int *num_added, bool defer_counters) {
     if (num_added) *num_added = 0;
     if (n == 0) return SRL_OK;
     if (!(voxel_size > 0.0)) return SRL_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    { const int rcs = srl_map_settle(ctx); if (rcs) return rcs; }
+    if (!ctx->h_insert_cnt) {
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_insert_cnt, 64, hipHostMallocDefault));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_insert, hipEventDisableTiming));
+    }
     if (!ctx->d_table) {            // empty map: create storage
         ctx->slab_cap = 0; ctx->table_cap = 0; ctx->num_voxels = 0; ctx->num_points = 0;
         int rc = srl_ctx_grow_map(ctx, 4096u, 8192u);
@@ -294,33 +341,60 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
     HIPCHK(ctx, b_newrank.alloc(ctx, (size_t)n * 4));
     int *cnt = b_cnt.as<int>();
     srl_stage_begin(ctx);
-    HIPCHK(ctx, hipMemsetAsync(cnt, 0, 64, st));
-    HIPCHK(ctx, hipMemsetAsync(b_newflag.p, 0, (size_t)n * 4, st));
-    hipLaunchKernelGGL(k_point_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, voxel_size,
-                       b_keys.as<unsigned long long>(), b_idx.as<unsigned>());
-    HIPCHK(ctx, hipGetLastError());
-
-    // stable sort by key (48 significant bits): original order survives inside each voxel
+    if (!frame_sized) {             // (a frame's kernels initialise what they accumulate into themselves: k_point_slots, SegmentSink)
+        HIPCHK(ctx, hipMemsetAsync(cnt, 0, 64, st));
+        HIPCHK(ctx, hipMemsetAsync(b_newflag.p, 0, (size_t)n * 4, st));
+    }
     hipcub::CountingInputIterator<int> positions(0);
-    hipcub::TransformInputIterator<int, HeadFlag, hipcub::CountingInputIterator<int>> heads(positions, HeadFlag{b_keys2.as<unsigned long long>()});
     size_t tmp_bytes = 0, need = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, need, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
-                                       b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st);
-    tmp_bytes = need;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, need, heads, b_prefix.as<int>(), n, st);
-    tmp_bytes = std::max(tmp_bytes, need);
-    hipcub::DeviceScan::ExclusiveSum(nullptr, need, b_newflag.as<int>(), b_newrank.as<int>(), n, st);
-    tmp_bytes = std::max(tmp_bytes, need) + 4096;
-    HIPCHK(ctx, b_tmp.alloc(ctx, tmp_bytes));
-    size_t tb = tmp_bytes;
-    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
-                                                   b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st));
-    srl_stage_end(ctx, 7);                                    // keys + sort
-    tb = tmp_bytes;
-    HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, heads, b_prefix.as<int>(), n, st));
-    hipLaunchKernelGGL(k_seg_starts, dim3((n + 255) / 256), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_prefix.as<int>(), n,
-                       b_start.as<int>(), cnt);
-    HIPCHK(ctx, hipGetLastError());
+    size_t tb = 0;
+    if (frame_sized) {
+        // group by scratch-table slot, stable sort over log2(slots) bits (k_point_slots); the scan over the head flags writes
+        // the segment starts in the same pass
+        unsigned cap2 = 1024, bits = 10;
+        while (cap2 < 2u * (unsigned)n) { cap2 <<= 1; ++bits; }
+        int rct = srl_epoch_table_begin(ctx, ctx->ins_table, cap2, false);
+        if (rct) return rct;
+        const SrlEpochTable &T = ctx->ins_table;
+        DevBuf b_slot_in, b_slot_sorted;
+        HIPCHK(ctx, b_slot_in.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_slot_sorted.alloc(ctx, (size_t)n * 4));
+        hipLaunchKernelGGL(k_point_slots, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, voxel_size, T.keyw, cap2 - 1, T.epoch16,
+                           b_slot_in.as<unsigned>(), b_idx.as<unsigned>(), b_newflag.as<int>());
+        HIPCHK(ctx, hipGetLastError());
+        hipcub::DeviceRadixSort::SortPairs(nullptr, need, b_slot_in.as<unsigned>(), b_slot_sorted.as<unsigned>(), b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, (int)bits, st);
+        tmp_bytes = need + 4096;
+        HIPCHK(ctx, b_tmp.alloc(ctx, tmp_bytes));
+        tb = tmp_bytes;
+        HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_slot_in.as<unsigned>(), b_slot_sorted.as<unsigned>(), b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0,
+                                                       (int)bits, st));
+        srl_stage_end(ctx, 7);                                    // slots + sort
+        hipLaunchKernelGGL((k_scan_small<HeadFlag32, SegmentSink>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, HeadFlag32{b_slot_sorted.as<unsigned>()},
+                           SegmentSink{b_slot_sorted.as<unsigned>(), T.keyw, b_start.as<int>(), b_keys2.as<unsigned long long>(), cnt, n}, n);
+        HIPCHK(ctx, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_point_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, voxel_size,
+                           b_keys.as<unsigned long long>(), b_idx.as<unsigned>());
+        HIPCHK(ctx, hipGetLastError());
+        // stable sort by key (48 significant bits): original order survives inside each voxel
+        hipcub::TransformInputIterator<int, HeadFlag, hipcub::CountingInputIterator<int>> heads(positions, HeadFlag{b_keys2.as<unsigned long long>()});
+        hipcub::DeviceRadixSort::SortPairs(nullptr, need, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
+                                           b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st);
+        tmp_bytes = need;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, need, heads, b_prefix.as<int>(), n, st);
+        tmp_bytes = std::max(tmp_bytes, need);
+        hipcub::DeviceScan::ExclusiveSum(nullptr, need, b_newflag.as<int>(), b_newrank.as<int>(), n, st);
+        tmp_bytes = std::max(tmp_bytes, need) + 4096;
+        HIPCHK(ctx, b_tmp.alloc(ctx, tmp_bytes));
+        tb = tmp_bytes;
+        HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
+                                                       b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st));
+        srl_stage_end(ctx, 7);                                    // keys + sort
+        tb = tmp_bytes;
+        HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, heads, b_prefix.as<int>(), n, st));
+        hipLaunchKernelGGL(k_seg_starts, dim3((n + 255) / 256), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_prefix.as<int>(), n,
+                           b_start.as<int>(), cnt);
+        HIPCHK(ctx, hipGetLastError());
+    }
 
     srl_stage_end(ctx, 8);                                    // segments
     int rcs = ensure_host_scratch(ctx, 64);
@@ -343,8 +417,13 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
                        ctx->d_table, mask, b_slot.as<int>(), b_isnew.as<unsigned char>(), b_first.as<unsigned>(), create_new ? b_newflag.as<int>() : (int *)nullptr);
     HIPCHK(ctx, hipGetLastError());
     if (create_new) {
-        tb = tmp_bytes;
-        HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, b_newflag.as<int>(), b_newrank.as<int>(), n, st));
+        if (frame_sized) {
+            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, SrlIntArraySink>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, SrlIntArrayIn{b_newflag.as<int>()},
+                               SrlIntArraySink{b_newrank.as<int>()}, n);
+        } else {
+            tb = tmp_bytes;
+            HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, b_newflag.as<int>(), b_newrank.as<int>(), n, st));
+        }
         hipLaunchKernelGGL(k_create, dim3(seg_grid), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_start.as<int>(), cnt, b_isnew.as<unsigned char>(),
                            b_first.as<unsigned>(), b_newrank.as<int>(), b_newflag.as<int>(), n, ctx->num_voxels, ctx->d_table, mask, ctx->d_slabs,
                            b_slot.as<int>(), cnt);
@@ -355,11 +434,12 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
                        d_xyz, b_slot.as<int>(), b_isnew.as<unsigned char>(), ctx->d_table, ctx->d_slabs, voxel_size,
                        min_distance_points, min_num_points, cnt + 2);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(h_cnt, cnt, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_insert_cnt, cnt, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_insert, st));
+    ctx->insert_pending = true;
+    if (defer_counters && frame_sized && !num_added && !ctx->frame_timing) return SRL_OK;
+    { const int rcs = srl_map_settle(ctx); if (rcs) return rcs; }
     srl_stage_end(ctx, 10);                                   // replay + counters
-    ctx->num_voxels += h_cnt[1];
-    ctx->num_points += h_cnt[2];
-    if (num_added) *num_added = h_cnt[2];
+    if (num_added) *num_added = ctx->h_insert_cnt[2];
     return SRL_OK;
 }

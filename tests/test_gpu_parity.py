@@ -1320,6 +1320,52 @@ def test_extrinsics_unnormalised_quaternion_and_voxel_size(oracle_lib, oracle_ba
 
 
 # ----------------------------------------------------------------------------- frame-resident pipeline (rows f1/f2)
+def test_deferred_commit_equals_the_synchronous_one_over_a_stream_of_frames():
+    """srl_frame_commit with num_added = NULL only enqueues the insertion (the map's totals are folded in by the next reader); the
+    passes of the next frame are ordered behind it on the stream.  Eight frames of different sizes (so that the host exchange block and
+    the scratch tables change size and the pool blocks are recycled while the previous insertion may still run): selection, normal
+    equations of two passes, world points, map totals and the final map are bit-identical to the synchronous form."""
+    pts, L = synth.map_candidates(1301, 60_000)
+    a = srl.Context(0); b = srl.Context(0)
+    pinned = []
+    try:
+        for c in (a, b):
+            c.map_insert(pts[:20_000])
+        opts = srl.default_opts(max_num_residuals=INT_MAX)
+        rng = np.random.default_rng(5)
+        total_added = 0
+        for k, n in enumerate((9_000, 3_000, 24_000, 700, 24_000, 12_345, 1, 6_000)):
+            sw = synth.make_sweep(1310 + k, n, L)
+            q, t = sw["q_pred"], sw["t_pred"]
+            f = capi.make_frame(q, t, sw["t_last"])
+            pin = srl.PinnedArray((n, 3)); pinned.append(pin)
+            out = []
+            for c, deferred in ((a, False), (b, True)):
+                c.frame_upload(sw["raw"])
+                kp = c.frame_select_keypoints(q, t, 1.2)
+                n1, _ = c.build_residuals(f, opts)
+                n2, _ = c.build_residuals(f, opts)
+                if deferred:
+                    world, added = c.frame_commit(sw["q_gt"], sw["t_gt"], want_added=False, world_out=pin.array)
+                    assert added is None
+                    world = world.copy()
+                else:
+                    world, added = c.frame_commit(sw["q_gt"], sw["t_gt"])
+                    total_added += added
+                out.append((kp, np.array(n1.HtH), np.array(n2.Hth), n1.num_residuals, world))
+            for x, y in zip(out[0], out[1]):
+                assert np.array_equal(x, y), f"frame {k}: deferred and synchronous commits diverge"
+            if k == 4:
+                assert a.map_size() == b.map_size()            # a reader in the middle of the stream settles the totals
+        assert a.map_size() == b.map_size() and a.map_size()[0] > 20_000 and total_added > 0
+        ka, ca, xa = a.map_download(); kb, cb, xb = b.map_download()
+        assert np.array_equal(ka, kb) and np.array_equal(ca, cb) and np.array_equal(xa, xb)
+    finally:
+        for pin in pinned:
+            pin.close()
+        a.close(); b.close()
+
+
 def test_frame_pipeline_selects_reference_keypoints_and_commits(oracle_lib, oracle_backend):
     """srl_frame_upload -> srl_frame_select_keypoints -> srl_build_residuals -> srl_frame_commit against
     transformPoint + gridSampling + buildPlaneResiduals + addPointsToMap of the oracle: same keypoints in the
