@@ -182,6 +182,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->h_insert_cnt) hipHostFree(ctx->h_insert_cnt);
     if (ctx->ev_insert) hipEventDestroy(ctx->ev_insert);
     if (ctx->ev_world) hipEventDestroy(ctx->ev_world);
+    if (ctx->ev_frame_read) hipEventDestroy(ctx->ev_frame_read);
     if (ctx->h_ring) { hipHostFree(ctx->h_ring); for (int i = 0; i < srl_ctx::RING_SLOTS; i++) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]); }
     for (auto &b : ctx->pool_free) hipFree(b.p);
     ctx->pool_free.clear();
@@ -377,10 +378,8 @@ int srl_sweep_prefetch(srl_ctx *ctx, const double *raw_xyz, int n) {
     if (!ctx || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
     SRL_DISARM(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!ctx->copy_stream) {
-        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->next_ready, hipEventDisableTiming));
-    }
+    { const int rcc = ensure_copy_stream(ctx); if (rcc) return rcc; }
+    if (!ctx->next_ready) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->next_ready, hipEventDisableTiming));
     int b = 0, cnt = 0;
     srl_shard_range(n, ctx->nranks, ctx->rank, &b, &cnt);
     if (cnt > ctx->next_cap || cnt > ctx->stage_next_cap) {

@@ -94,6 +94,7 @@ struct srl_ctx {
     int *h_insert_cnt = nullptr;                 // pinned: [0] segments, [1] new voxels, [2] points added
     hipEvent_t ev_insert = nullptr, ev_world = nullptr;
     bool insert_pending = false;
+    hipEvent_t ev_frame_read = nullptr;          // main stream: the last kernel reading d_frame_raw (the next upload, on the copy stream, waits for it)
     SrlEpochTable sel_table, ins_table;          // keypoint selection (with first-index words) / frame insertion
 
     // work buffers
@@ -233,6 +234,17 @@ inline int srl_map_settle(srl_ctx *ctx) {
     ctx->num_voxels += ctx->h_insert_cnt[1];
     ctx->num_points += ctx->h_insert_cnt[2];
     ctx->insert_pending = false;
+    return SRL_OK;
+}
+
+inline int ensure_copy_stream(srl_ctx *ctx) {
+    if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    return SRL_OK;
+}
+// the frame's raw points have just been read for the last time by what is enqueued so far
+inline int srl_mark_frame_read(srl_ctx *ctx) {
+    if (!ctx->ev_frame_read) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_frame_read, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_frame_read, ctx->stream));
     return SRL_OK;
 }
 

@@ -423,11 +423,24 @@ int srl_frame_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     ctx->frame_n = n;
     srl_stage_begin(ctx);
     if (n > 0) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_raw, raw_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        // a page-locked source (srl_pinned_alloc) is read by the DMA engine behind this call: the caller may refill it once a later call
-        // on this context has returned results (like srl_sweep_upload; srl_sweep_wait waits explicitly); pageable sources are consumed here
-        if (!srl_ctx_is_pinned(raw_xyz)) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        else { if (!ctx->upload_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming)); HIPCHK(ctx, hipEventRecord(ctx->upload_ev, ctx->stream)); ctx->upload_pending = true; }
+        if (!srl_ctx_is_pinned(raw_xyz)) {
+            // a pageable source is consumed here
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_raw, raw_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+            // a page-locked source (srl_pinned_alloc) is read by the DMA engine behind this call: the caller may refill it once a later call
+            // on this context has returned results (like srl_sweep_upload; srl_sweep_wait waits explicitly).  The copy runs on the COPY
+            // stream, behind the last kernel that read the previous frame's raw points and beside whatever the compute stream still has to
+            // do for that frame (its deferred map insertion); the compute stream picks up behind the copy.
+            int rcc = ensure_copy_stream(ctx);
+            if (rcc) return rcc;
+            if (ctx->ev_frame_read) HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_frame_read, 0));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_raw, raw_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->copy_stream));
+            if (!ctx->upload_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventRecord(ctx->upload_ev, ctx->copy_stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
+            ctx->upload_pending = true;
+        }
     }
     srl_stage_end(ctx, 0);
     return SRL_OK;
@@ -540,6 +553,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
                            ctx->d_raw, ctx->d_raw + ctx->sweep_cap, ctx->d_raw + 2 * (size_t)ctx->sweep_cap);
         HIPCHK(ctx, hipGetLastError());
     }
+    if (n > 0) { const int rcm = srl_mark_frame_read(ctx); if (rcm) return rcm; }
     srl_stage_end(ctx, 4);
     if (trace) {
         const auto tp4 = std::chrono::steady_clock::now();
@@ -567,10 +581,15 @@ int srl_frame_commit(srl_ctx *ctx, const double q[4], const double t[3], const d
                        (unsigned long long *)nullptr, (unsigned *)nullptr);
     HIPCHK(ctx, hipGetLastError());
     srl_stage_end(ctx, 5);
+    { const int rcm = srl_mark_frame_read(ctx); if (rcm) return rcm; }       // (= the world points are ready)
     if (world_out) {
-        HIPCHK(ctx, hipMemcpyAsync(world_out, ctx->d_frame_world, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        // point3D::point leaves on the copy stream, beside the insertion
+        int rcc = ensure_copy_stream(ctx);
+        if (rcc) return rcc;
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_frame_read, 0));
+        HIPCHK(ctx, hipMemcpyAsync(world_out, ctx->d_frame_world, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
         if (!ctx->ev_world) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_world, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_world, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_world, ctx->copy_stream));
     }
     srl_stage_end(ctx, 6);
     // num_added == NULL: the insert is only enqueued (its counters are folded in later, srl_map_settle); the caller's world points are
