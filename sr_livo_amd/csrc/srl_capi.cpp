@@ -848,6 +848,10 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     unsigned long long seq_now = ++ctx->seq;          // (a cancelled armed launch below takes this number with it: see there)
     const bool coll = ctx->comm && (ctx->nranks > 1 || ctx->force_coll) && !ctx->peer_on;
     const bool peer = ctx->peer_on && ctx->nranks > 1;
+    if (peer && ctx->peer_failed) {
+        ctx->err = "direct peer exchange: this session has failed (a rank's row never arrived); srl_peer_detach, srl_peer_export and srl_peer_attach on every rank start a new one";
+        return SRL_ERR_COMM;
+    }
     unsigned peer_epoch = 0;
     int peer_slot = 0;
     auto next_exchange = [&]() {           // one tag per exchange, the same on every rank (never 0: an untouched inbox holds zeros)
@@ -1094,7 +1098,13 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             if (!ctx->cb_ar) { ctx->err = "nranks > 1 without communicator"; return SRL_ERR_COMM; }
             if (ctx->cb_ar(reinterpret_cast<double *>(ctx->h_out), n_red, ctx->cb_user) != 0) { ctx->err = "allreduce callback failed"; return SRL_ERR_COMM; }
         }
-        if (ctx->h_out->pad == SRL_PEER_TIMEOUT_MARK) { ctx->err = "direct peer exchange: a rank's row never arrived"; return SRL_ERR_COMM; }
+        if (ctx->h_out->pad == SRL_PEER_TIMEOUT_MARK) {
+            // The peers may have completed this exchange (a late rank still finds every row): this rank must not run ahead of them into the
+            // slot they may still be reading, so the session ends here -- they find no row of the next exchange and end theirs.
+            ctx->peer_failed = true;
+            ctx->err = "direct peer exchange: a rank's row never arrived";
+            return SRL_ERR_COMM;
+        }
         if (ctx->h_out->pad != 0 || ctx->h_out->d_timeout > 0.5) {     // (summed over the ranks: all of them repeat the pass together)
             // the finishing workgroup gave up waiting for a row (bounded spin: another process holding compute units back, a
             // preempted queue): not an error of the data -- the caller repeats the pass with the reduction in its own kernel
@@ -1556,6 +1566,7 @@ int srl_peer_attach(srl_ctx *ctx, int nranks, int rank, const void *ipc_handles,
     ctx->nranks = nranks; ctx->rank = rank;
     ctx->peer_on = nranks > 1;
     ctx->peer_seq = 0;                       // every rank starts counting from the same attach
+    ctx->peer_failed = false;
     ctx->dbg_gather = false;
     return SRL_OK;
 }

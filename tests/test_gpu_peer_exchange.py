@@ -168,6 +168,48 @@ def test_a_missing_peer_is_an_error_not_a_hang(golden):
     assert "peer" in str(errors[0])
 
 
+def test_a_failed_session_stays_failed_until_it_is_started_again(golden):
+    """After a row never arrived the rank must not run ahead into the slot its peers may still be reading: every further pass of the
+    session fails at once (no second bounded spin), and export + attach on every rank starts a working session on the same contexts."""
+    import time
+    ctxs = [srl.Context(0) for _ in range(2)]
+    f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    try:
+        for c in ctxs:
+            c.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        ptrs = [c.peer_export()[1] for c in ctxs]
+        for r, c in enumerate(ctxs):
+            c.peer_attach(2, r, local_ptrs=ptrs)
+            c.sweep_upload(golden["raw"])
+        with pytest.raises(srl.SrlError) as e1:
+            ctxs[0].build_residuals(f, opts)                               # rank 1 never calls
+        assert e1.value.status == capi.SRL_ERR_COMM
+        t0 = time.perf_counter()
+        with pytest.raises(srl.SrlError) as e2:
+            ctxs[0].build_residuals(f, opts)
+        assert e2.value.status == capi.SRL_ERR_COMM and "session" in str(e2.value) and time.perf_counter() - t0 < 0.2
+        for c in ctxs:
+            c.peer_detach()
+        ptrs = [c.peer_export()[1] for c in ctxs]
+        out = [None, None]
+
+        def worker(r):
+            ctxs[r].peer_attach(2, r, local_ptrs=ptrs)
+            ctxs[r].sweep_upload(golden["raw"])
+            out[r] = ctxs[r].build_residuals(f, opts)[0]
+
+        ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        ref = _single(golden, golden["raw"], INT_MAX)
+        assert out[0] is not None and out[1] is not None and out[0].num_residuals == ref.num_residuals == out[1].num_residuals
+        assert np.array_equal(np.array(out[0].HtH), np.array(out[1].HtH))
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_peer_attach_refuses_a_second_transport(golden):
     ctx = srl.Context(0)
     other = srl.Context(0)
