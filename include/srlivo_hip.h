@@ -361,6 +361,10 @@ int srl_debug_pass_stamps(srl_ctx *ctx, int enable, long long *gpu_out, long lon
  * srl_frame_commit: [5] re-transform, [6] download of point3D::point; the map insertion behind it (also srl_map_insert): [7] keys +
  * (key, index) sort, [8] segments, [9] lookup + creation of new voxels, [10] per-voxel replay + counters. */
 int srl_debug_frame_timing(srl_ctx *ctx, int enable, double out16[16]);
+/* The scratch hash tables of the frame pipeline are never cleared per frame: entries carry a 16-bit epoch (csrc/srl_frame_scratch.h) and
+ * the tables are cleared when it wraps, every 65 535 frames (1.8 h of a 10 Hz sensor).  Test hook: set the epoch counters of both tables so
+ * that the wrap happens `frames_to_wrap` frames from now. */
+int srl_debug_set_frame_epoch(srl_ctx *ctx, int frames_to_wrap);
 /* tuning experiments: force the association kernel's launch shape -- keypoints per wave (16-wave workgroups: 2 / 3 / 4 / 6 / 8 /
  * 12 / 16; 4-wave workgroups: 4 / 8 / 16) and waves per workgroup (4 / 16); 0, 0 = automatic (by sweep size).  Results do not
  * depend on the shape beyond FP64 summation order. */

@@ -157,6 +157,7 @@ def load_library():
         "srl_debug_set_arm_linger": ([p, C.c_double, C.c_double], C.c_int),
         "srl_debug_pass_stamps": ([p, C.c_int, p, p], C.c_int),
         "srl_debug_frame_timing": ([p, C.c_int, p], C.c_int),
+        "srl_debug_set_frame_epoch": ([p, C.c_int], C.c_int),
         "srl_set_armed_launch": ([p, C.c_int], C.c_int),
         "srl_disarm": ([p], C.c_int),
         "srl_get_arm_stats": ([p, C.POINTER(C.c_uint64)], C.c_int),
@@ -512,6 +513,10 @@ class Context:
 
     FRAME_STAGES = ("upload", "select_group", "select_download", "select_host_order", "select_gather", "commit_transform", "commit_download",
                     "insert_sort", "insert_segments", "insert_lookup_create", "insert_replay")
+
+    def set_frame_epoch(self, frames_to_wrap):
+        """test hook: the epoch of the frame pipeline's scratch tables wraps `frames_to_wrap` frames from now (srl_debug_set_frame_epoch)"""
+        self._chk(self.lib.srl_debug_set_frame_epoch(self.h, int(frames_to_wrap)), "srl_debug_set_frame_epoch")
 
     def frame_timing(self, enable=True):
         """accumulated stage times (us) of the frame pipeline since the last call (which clears them); see srl_debug_frame_timing"""

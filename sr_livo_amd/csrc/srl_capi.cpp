@@ -677,6 +677,20 @@ int srl_debug_pass_stamps(srl_ctx *ctx, int enable, long long *gpu_out, long lon
     return SRL_OK;
 }
 
+int srl_debug_set_frame_epoch(srl_ctx *ctx, int frames_to_wrap) {
+    if (!ctx || frames_to_wrap < 0 || frames_to_wrap > 0xFFFF) return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (SrlEpochTable *t : {&ctx->sel_table, &ctx->ins_table}) {
+        // entries written so far carry epochs <= the old counter: moving the counter forward keeps all of them stale
+        const unsigned target = 0xFFFFu - (unsigned)frames_to_wrap;
+        if (t->epoch16 > target) return SRL_ERR_BAD_ARG;
+        t->epoch16 = target;
+    }
+    return SRL_OK;
+}
+
 int srl_debug_frame_timing(srl_ctx *ctx, int enable, double out16[16]) {
     if (!ctx) return SRL_ERR_BAD_ARG;
     SRL_DISARM(ctx);

@@ -1319,6 +1319,35 @@ def test_extrinsics_unnormalised_quaternion_and_voxel_size(oracle_lib, oracle_ba
             ctx.close()
 
 
+def test_scratch_table_epoch_wrap_changes_nothing():
+    """The frame pipeline's scratch hash tables are never cleared per frame: entries carry a 16-bit epoch and the tables are cleared when
+    it wraps (every 65 535 frames).  A context whose epoch wraps in the middle of a 7-frame stream selects the same keypoints and builds
+    the same map as one far from the wrap -- through the frames before the wrap (stale entries of higher epochs), the wrapping frame
+    (tables cleared, epoch 1) and the frames after it."""
+    pts, L = synth.map_candidates(1401, 40_000)
+    a = srl.Context(0); b = srl.Context(0)
+    try:
+        for c in (a, b):
+            c.map_insert(pts[:15_000])
+        for k, n in enumerate((8_000, 8_000, 5_000, 12_000, 8_000, 300, 9_000)):
+            if k == 1:
+                a.set_frame_epoch(2)                      # frames 1, 2 use the last two epochs, frame 3 wraps
+            sw = synth.make_sweep(1410 + k, n, L)
+            q, t = sw["q_pred"], sw["t_pred"]
+            got = []
+            for c in (a, b):
+                c.frame_upload(sw["raw"])
+                kp = c.frame_select_keypoints(q, t, 0.9)
+                world, _ = c.frame_commit(sw["q_gt"], sw["t_gt"], want_added=(k % 2 == 0))
+                got.append((kp, world))
+            assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]), f"frame {k}"
+            assert a.map_size() == b.map_size(), f"frame {k}"
+        ka, ca, xa = a.map_download(); kb, cb, xb = b.map_download()
+        assert np.array_equal(ka, kb) and np.array_equal(ca, cb) and np.array_equal(xa, xb)
+    finally:
+        a.close(); b.close()
+
+
 # ----------------------------------------------------------------------------- frame-resident pipeline (rows f1/f2)
 def test_deferred_commit_equals_the_synchronous_one_over_a_stream_of_frames():
     """srl_frame_commit with num_added = NULL only enqueues the insertion (the map's totals are folded in by the next reader); the
