@@ -103,6 +103,54 @@ def test_reference_node_with_the_hip_binding_matches_the_all_cpu_reference_node(
         node.close()
 
 
+def test_the_binding_rebuilds_a_device_map_that_fell_out_of_step(hip_node_lib):
+    """The device map is a mirror of the node's voxel_map.  If the two ever differ (here: half of the device map is thrown away behind the
+    binding's back in the middle of the replay), the next optimize() rebuilds the device copy from voxel_map instead of failing, and the
+    node lands where the all-CPU reference node landed."""
+    pr, lib = hip_node_lib
+    from oracle import pyoracle as po
+    from replay_reference import REPLAY_OO, REPLAY_SEQ, replay_inputs
+    lib.srl_integration_resyncs.argtypes = [C.c_void_p]; lib.srl_integration_resyncs.restype = C.c_long
+    gref = dict(np.load(os.path.join(HERE, "golden", "golden_ref_tu.npz"), allow_pickle=False))
+    st, parts, _ = replay_inputs()
+    pr.set_params(*pr.params_from_options(dict(REPLAY_OO, motion_compensation=1), po.default_opts(max_num_residuals=REPLAY_SEQ["max_num_residuals"])))
+    node = pr.Node(True)
+    node_ptr = lib.ref_node_lio_ptr(node.h)
+    try:
+        node.push_imu(st["imu_t"], st["imu_acc"], st["imu_gyr"])
+        node.push_points(st["pts_raw"], st["pts_timestamp"])
+        for t in st["image_times"]:
+            node.push_image_time(t)
+        row, last_fid, damaged = 0, None, False
+        for i in range(len(parts)):
+            info = node.run()
+            assert info["rc"] == 0
+            f = node.last_frame()
+            if f is None or f["frame_id"] == last_fid:
+                continue
+            last_fid = f["frame_id"]
+            assert rel(f["state"], gref["run1_state"][row]) < TIGHT, f"row {row}"
+            assert info["map_points"] == int(gref["run1_map_points"][row])
+            row += 1
+            if row == 4 and not damaged:
+                ctx = srl.Context(handle=C.c_void_p(lib.srl_integration_ctx(node_ptr)))
+                k, c, x = ctx.map_download()
+                half = len(k) // 2
+                ctx.map_upload(k[:half], c[:half], x[:half])
+                assert ctx.map_size()[0] < info["map_points"]
+                damaged = True
+        assert row == 9 and damaged and lib.srl_integration_resyncs(node_ptr) == 1
+        k, c, x = node.map_export()
+        ctx = srl.Context(handle=C.c_void_p(lib.srl_integration_ctx(node_ptr)))
+        dk, dc, dx = ctx.map_download()
+        dev = {tuple(key): (cnt, xyz[:cnt].tobytes()) for key, cnt, xyz in zip(dk.tolist(), dc.tolist(), dx)}
+        host = {tuple(key): (cnt, xyz[:cnt].tobytes()) for key, cnt, xyz in zip(k.tolist(), c.tolist(), x)}
+        assert dev == host
+    finally:
+        lib.srl_integration_release(node_ptr)
+        node.close()
+
+
 # the replay stream at BASELINE scale: 24k-point sweeps, every point a keypoint candidate at a 0.2 m sampling voxel, every accepted
 # residual counts (BASELINE.json configs[1]: "R3Live Livox Avia sweep (~24k pts after reconstruction) ... full ESIKF solve")
 HEAVY_SEQ = dict(map_seed=556, map_target=400_000, seq_seed=32, n_moving=4, n_pts=24_000, max_num_residuals=2**31 - 1)
