@@ -1,4 +1,4 @@
-"""The committed bench lines (profiles/r02_bench.json, profiles/r03_bench.json: un-edited outputs of `python bench.py` on an MI355X
+"""The committed bench lines (profiles/r02_bench.json, r03_bench.json, r04_bench.json: un-edited outputs of `python bench.py` on an MI355X
 box) carry every field the driver's contract names, with consistent values; the round-3 line and the committed profile summaries
 belong to the kernel sources in the tree (SHA stamp).  CPU only: it guards the shape of the lines, not the numbers."""
 import json
@@ -121,6 +121,36 @@ def test_the_printed_line_fits_the_drivers_capture_window_and_is_strict_json(nam
     assert [x["name"] for x in d["configs"]][:4] == ["C1", "C2", "C3", "C4"]
     for x in d["configs"]:
         assert set(x) >= {"name", "us_per_iter", "kernel_us", "frac", "parity_ok"} and x["parity_ok"] is True
+    assert d["detail"] == "gpurun_out/bench_detail.json"
+
+
+def test_round4_committed_line_is_what_the_driver_can_parse_and_points_to_its_detail_file():
+    """profiles/r04_bench.json is the line exactly as printed (one line, < 8 KB, strict JSON); r04_bench_detail.json the full result it was
+    cut from.  Contract keys, the value / ms_per_step pair, roofline arithmetic, the round's targets (headline <= 55, C2 <= 31,
+    C3 <= 27, @600 <= 24 us per iteration; pipeline >= 2 500 frames/s at 24k points) and agreement of line and detail file."""
+    path = os.path.join(ROOT, "profiles", "r04_bench.json")
+    raw = open(path).read()
+    assert raw.count("\n") <= 1 and len(raw) < 8192
+
+    def no_constants(x):
+        raise AssertionError(f"non-strict JSON constant {x}")
+    d = json.loads(raw, parse_constant=no_constants)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_detail.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "sweeps/s" and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - full["value"]) / d["value"] < 1e-6 and abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-9
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and r["profile_stale"] is False and r["traffic"] < r["algorithmic_bytes_per_launch"]
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-4
+    assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["cores"] == 1 and d["value"] > 1000 * d["cpu_baseline"]["value"]
+    assert d["parity"]["oracle_equals_reference_tu_bitwise"] is True and d["parity"]["state_rel_err_vs_oracle"] < 1e-12
+    assert d["launch_ab"]["state_bitwise_equal"] is True and d["launch_ab"]["armed_us_per_iter"] < d["launch_ab"]["launch_per_iteration_us_per_iter"]
+    us = {c["name"]: c["us_per_iter"] for c in d["configs"]}
+    assert all(c["parity_ok"] is True for c in d["configs"])
+    assert d["ms_per_esikf_iter"] * 1e3 <= 55 and us["C2"] <= 31 and us["C3"] <= 27 and us["HEADLINE@600"] <= 24
+    frames = {f["points"]: f["frames_per_s"] for f in d["pipeline"]["frames"]}
+    assert frames[24000] >= 2500
     assert d["detail"] == "gpurun_out/bench_detail.json"
 
 
