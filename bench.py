@@ -878,7 +878,7 @@ def main():
                                   else ("replicas x%d" % world if world > 1 else "single GPU"),
                    "esikf_iterations_per_solve": iters, "residuals_used": r["num_residuals"],
                    "kernel_launches_per_solve": launches_per_solve,
-                   "launch_mode": "one launch per ESIKF iteration" if args.no_armed else "armed launches: the kernel of pass k+1 is enqueued while pass k runs and receives its pose through the pose box",
+                   "launch_mode": "one launch per ESIKF iteration" + ("" if args.no_armed else " (sharded passes are never armed)") if (args.no_armed or sharded) else "armed launches: the kernel of pass k+1 is enqueued while pass k runs and receives its pose through the pose box",
                    "value_is": "the HBM-resident rate (sweep uploaded before the timed region); SURVEY 8(d)'s metric includes the H2D of the sweep:",
                    "pcie_inclusive_sweeps_per_s": {"pipelined_prefetch": rates["pipelined"], "pinned_upload_then_solve": rates["pinned"],
                                                    "pageable_upload_then_solve": rates["pageable"]}},
