@@ -1,0 +1,64 @@
+"""Randomised parity of one pass through the C-ABI against the live oracle: scene size, sweep size and pattern, search radius (init mode),
+K, budget, selection path and a pose error larger than the generator's all drawn per case.  Same bars as tests/test_gpu_parity.py:
+neighbour ids and status bit-exact, counts equal, residual fields and normal equations to 1e-9 relative.
+
+The default run draws SRL_FUZZ_CASES = 24 cases (seconds); `SRL_FUZZ_CASES=400 python -m pytest tests/test_gpu_fuzz.py -m gpu` is the
+longer form whose output is kept under profiles/."""
+import os
+
+import numpy as np
+import pytest
+
+import sr_livo_amd as srl
+from sr_livo_amd import synth
+
+from test_gpu_parity import INT_MAX, check_pass_against, gpu_pass
+
+pytestmark = pytest.mark.gpu
+
+CASES = int(os.environ.get("SRL_FUZZ_CASES", "24"))
+
+
+def _draw(case):
+    rng = np.random.default_rng(9000 + case)
+    return dict(
+        map_pts=int(rng.choice([3_000, 12_000, 40_000, 90_000])),
+        n=int(rng.choice([1, 7, 63, 64, 65, 500, 1_500, 4_096, 6_001])),
+        pattern=str(rng.choice(["livox", "ouster16"])),
+        frame_id=int(rng.choice([5, 100])),                                   # 5: init mode (r = 2), 100: r = 1
+        K=int(rng.choice([5, 20, 20, 32])),
+        max_res=int(rng.choice([INT_MAX, INT_MAX, 600, 37, 5, 0, -1])),
+        select_mode=int(rng.choice([0, 0, 0, 1, 2])),
+        extra_rot=rng.normal(0, 0.01, 3), extra_t=rng.normal(0, 0.05, 3),
+        seed=int(rng.integers(1, 2**31 - 1)),
+    )
+
+
+@pytest.mark.parametrize("case", range(CASES))
+def test_random_pass_against_the_oracle(oracle_lib, oracle_backend, case):
+    p = _draw(case)
+    pts, L = synth.map_candidates(p["seed"], p["map_pts"])
+    sw = synth.make_sweep(p["seed"] + 1, p["n"], L, pattern=p["pattern"])
+    q = synth.quat_mul(synth.quat_from_rotvec(p["extra_rot"]), sw["q_pred"])
+    t = sw["t_pred"] + p["extra_t"]
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(pts)
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(*m.export())
+        kw = dict(max_num_residuals=p["max_res"], max_number_neighbors=p["K"])
+        g = gpu_pass(ctx, sw["raw"], q, t, sw["t_last"], frame_id=p["frame_id"], select_mode=p["select_mode"], **kw)
+        o = m.build_plane_residuals(oracle_lib.default_opts(**kw), sw["raw"], q, t, sw["t_last"], frame_id=p["frame_id"])
+        if o["neq"].nan_error:
+            pytest.skip("the oracle met a NaN planarity in this draw (covered by the dedicated NaN tests)")
+        ref = {f"x_one_{k}": v for k, v in o.items() if isinstance(v, np.ndarray)}
+        ref.update(x_one_num_ties=o["neq"].num_ties, x_one_num_residuals=o["neq"].num_residuals, x_one_success=o["neq"].success, x_one_loss=o["neq"].loss_sum)
+        try:
+            check_pass_against(g, ref, "x")
+            assert g["neq"].last_visited == o["neq"].num_visited - 1
+            if p["max_res"] == INT_MAX:
+                assert g["neq"].sum_candidates == o["neq"].sum_candidates
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {p}: {e}") from e
+    finally:
+        ctx.close()
