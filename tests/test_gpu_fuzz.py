@@ -62,3 +62,49 @@ def test_random_pass_against_the_oracle(oracle_lib, oracle_backend, case):
             raise AssertionError(f"case {case}: {p}: {e}") from e
     finally:
         ctx.close()
+
+
+SOLVES = max(CASES // 2, 1)
+
+
+@pytest.mark.parametrize("case", range(SOLVES))
+def test_random_full_solve_against_the_oracle(oracle_lib, oracle_backend, case):
+    """The whole ESIKF loop (armed launches, host update) on a random scene against the oracle's updateIEKF: same iteration count, same
+    number of residuals, state to 1e-9, covariance to 1e-8 -- for a random budget, K and a pose error up to several iterations' worth."""
+    from test_gpu_parity import rel, state16
+    rng = np.random.default_rng(77_000 + case)
+    map_pts = int(rng.choice([8_000, 30_000, 80_000]))
+    n = int(rng.choice([200, 1_000, 3_000, 5_000]))
+    pattern = str(rng.choice(["livox", "ouster16"]))
+    max_res = int(rng.choice([INT_MAX, 600, 150]))
+    K = int(rng.choice([10, 20, 20, 32]))
+    frame_id = int(rng.choice([5, 100]))
+    seed = int(rng.integers(1, 2**31 - 1))
+    pts, L = synth.map_candidates(seed, map_pts)
+    sw = synth.make_sweep(seed + 1, n, L, pattern=pattern)
+    sw["q_pred"] = synth.quat_mul(synth.quat_from_rotvec(rng.normal(0, 0.004, 3)), sw["q_pred"])
+    sw["t_pred"] = sw["t_pred"] + rng.normal(0, 0.03, 3)
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(pts)
+    lio = srl.Lio(0)
+    try:
+        lio.ctx.map_upload(*m.export())
+        e = oracle_lib.Eskf(oracle_backend)
+        synth.eskf_prior(e, sw["q_pred"], sw["t_pred"], sw["vel"])
+        lio.eskf_set_state(e.get_state()); lio.eskf_set_cov(e.get_cov())
+        st = state16(sw)
+        opts = srl.default_opts(max_num_residuals=max_res, max_number_neighbors=K)
+        what = f"case {case}: map {map_pts}, n {n}, {pattern}, max_res {max_res}, K {K}, frame_id {frame_id}, seed {seed}"
+        try:
+            r = lio.update_iekf(opts, sw["raw"], st, sw["t_last"], frame_id=frame_id)
+        except srl.SrlError as err:                                         # NaN planarity: the reference throws
+            r = dict(rc=err.status)
+        u = oracle_lib.update_iekf(m, e, oracle_lib.opts_from_product(opts), sw["raw"], st, sw["t_last"], frame_id=frame_id)
+        if u["rc"] < 0 or r["rc"] != 0:
+            assert u["rc"] < 0 and r["rc"] != 0, (what, u["rc"], r["rc"])     # a failed solve (too few residuals / NaN planarity) fails on both sides
+            return
+        assert r["rc"] == 0 and r["iters"] == u["rc"] and r["num_residuals"] == u["num_residuals"], (what, r["rc"], r["iters"], u["rc"])
+        assert rel(r["state"], u["state"]) < 1e-9, what
+        assert rel(lio.eskf_get_cov(), e.get_cov()) < 1e-8, what
+    finally:
+        lio.close()
