@@ -108,3 +108,43 @@ def test_random_full_solve_against_the_oracle(oracle_lib, oracle_backend, case):
         assert rel(lio.eskf_get_cov(), e.get_cov()) < 1e-8, what
     finally:
         lio.close()
+
+
+@pytest.mark.parametrize("case", range(SOLVES))
+def test_random_frame_pipeline_against_the_oracle(oracle_lib, oracle_backend, case):
+    """upload -> device keypoint selection -> commit (deferred or not) on random frames: the keypoints equal gridSampling's in set AND order
+    (std::tr1::unordered_map iteration order), the world points equal transformPoint's bit for bit, the map equals the sequential
+    addPointsToMap -- for random frame sizes, sampling voxel sizes, extrinsics, un-normalised quaternions and two frames in a row."""
+    rng = np.random.default_rng(55_000 + case)
+    map_pts = int(rng.choice([5_000, 40_000]))
+    seed = int(rng.integers(1, 2**31 - 1))
+    pts, L = synth.map_candidates(seed, map_pts)
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(pts[: map_pts // 2])
+    ctx = srl.Context(0)
+    try:
+        ctx.map_insert(pts[: map_pts // 2])
+        for k in range(2):
+            n = int(rng.choice([1, 2, 100, 1_023, 1_024, 1_025, 7_000, 20_000, 40_000]))
+            size = float(rng.choice([0.2, 0.5, 1.0, 1.5, 3.0]))
+            sw = synth.make_sweep(seed + 10 + k, n, L, pattern=str(rng.choice(["livox", "ouster16"])))
+            R_il = synth.quat_to_rot(synth.quat_from_rotvec(rng.normal(0, 0.05, 3))); t_il = rng.normal(0, 0.05, 3)
+            raw = (sw["raw"] - t_il) @ R_il
+            q = sw["q_pred"] * float(rng.uniform(0.999, 1.001)); t = sw["t_pred"]
+            what = f"case {case}.{k}: map {map_pts}, n {n}, size {size}, seed {seed}"
+            world = oracle_lib.transform_points(raw, q, t, R_il, t_il, backend=oracle_backend)
+            want = oracle_lib.grid_sampling(world, size, backend=oracle_backend)
+            ctx.frame_upload(raw)
+            got = ctx.frame_select_keypoints(q, t, size, R_il, t_il)
+            assert np.array_equal(got, want), what
+            q2 = sw["q_gt"]; t2 = sw["t_gt"]
+            deferred = bool(rng.integers(0, 2))
+            world2, added = ctx.frame_commit(q2, t2, R_il=R_il, t_il=t_il, want_added=not deferred)
+            assert np.array_equal(world2, oracle_lib.transform_points(raw, q2, t2, R_il, t_il, backend=oracle_backend)), what
+            before = m.size()
+            m.add_points(world2)
+            assert ctx.map_size()[0] == m.size() and (deferred or added == m.size() - before), what
+        kg, cg, xg = ctx.map_download(); ko, co, xo = m.export()
+        assert np.array_equal(kg, ko) and np.array_equal(cg, co) and np.array_equal(xg, xo)
+    finally:
+        ctx.close()
