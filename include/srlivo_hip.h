@@ -147,7 +147,10 @@ int srl_sweep_shard(srl_ctx *ctx, int *begin, int *count, int *total);
  *                             point = R(q) (R_il raw + t_il) + t (utility.cpp:314-318): same keypoints in the same
  *                             (std::tr1::unordered_map iteration) order; they become the resident sweep.
  * srl_frame_commit            replaces the re-transform loop (optimize.cpp:441-445) + addPointsToMap
- *                             (lioOptimization.cpp:520-554) with the final pose, without leaving the device. */
+ *                             (lioOptimization.cpp:520-554) with the final pose, without leaving the device.
+ * A page-locked raw_xyz (srl_pinned_alloc) is copied by the DMA engine on the context's copy stream, beside whatever the compute stream
+ * still does for the previous frame; the buffer may be refilled once a later call on the context has returned results (or after
+ * srl_sweep_wait).  A pageable raw_xyz is consumed before the call returns. */
 int srl_frame_upload(srl_ctx *ctx, const double *raw_xyz, int n);
 
 /* Sweep reconstruction: the per-point stages of buildFrame (lioOptimization.cpp:833-850).
