@@ -138,6 +138,40 @@ __global__ void k_select_emit(const int *flag, const int *rank, const unsigned l
     }
 }
 
+// ... the same hand-over as the per-element work (EmitSink) and the "tile done" step (EmitFin) of the one-launch scan over the marks
+// (frames up to SRL_SCAN_SMALL_MAX points): no rank array, no launch of its own
+struct EmitSink {
+    const unsigned long long *key_at;
+    unsigned long long *host_hash;
+    unsigned *host_first;
+    __device__ void operator()(int i, int is_first, int r) const {
+        if (!is_first) return;
+        short x, y, z;
+        srl_unpack_key(key_at[i], &x, &y, &z);
+        const unsigned long long kP1 = 73856093ull, kP2 = 19349669ull, kP3 = 83492791ull;
+        host_hash[r] = (unsigned long long)(long long)x * kP1 + (unsigned long long)(long long)y * kP2 + (unsigned long long)(long long)z * kP3;
+        host_first[r] = (unsigned)i;
+    }
+};
+struct EmitFin {
+    unsigned *sync;                           // [0] workgroups done (reset by the last one), [1] the count (written by the workgroup holding the last tile)
+    unsigned long long *host_ctrl;
+    unsigned tag;
+    __device__ void operator()(int tile_end) const {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x != 0) return;
+        if (blockIdx.x == gridDim.x - 1) __hip_atomic_store(sync + 1, (unsigned)tile_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned prev = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned count = __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(host_ctrl, ((unsigned long long)tag << 32) | count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+};
+
 __global__ void k_gather_soa(const double *raw, const int *sel, int m, double *x, double *y, double *z) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
@@ -491,16 +525,17 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
                            T.counter32, b_flag.as<int>());
         hipLaunchKernelGGL(k_select_mark, dim3((cap + 255) / 256), dim3(256), 0, st, T.keyw, T.minw, cap, T.epoch16, b_flag.as<int>(), b_keyat.as<unsigned long long>());
         if (n <= SRL_SCAN_SMALL_MAX) {
-            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, SrlIntArraySink>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, SrlIntArrayIn{b_flag.as<int>()},
-                               SrlIntArraySink{b_rank.as<int>()}, n);
+            // ranks, hand-over to the host and the completion word in ONE launch
+            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, EmitSink, EmitFin>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, SrlIntArrayIn{b_flag.as<int>()},
+                               EmitSink{b_keyat.as<unsigned long long>(), h_hash, first}, n, EmitFin{ctx->d_frame_sync, h_ctrl, tag});
         } else {
             size_t scan_bytes = 0;
             hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, b_flag.as<int>(), b_rank.as<int>(), n, st);
             HIPCHK(ctx, b_tmp.alloc(ctx, scan_bytes + 256));
             HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, scan_bytes, b_flag.as<int>(), b_rank.as<int>(), n, st));
+            hipLaunchKernelGGL(k_select_emit, dim3((n + 255) / 256), dim3(256), 0, st, b_flag.as<int>(), b_rank.as<int>(), b_keyat.as<unsigned long long>(), n,
+                               h_hash, first, ctx->d_frame_sync, h_ctrl, tag);
         }
-        hipLaunchKernelGGL(k_select_emit, dim3((n + 255) / 256), dim3(256), 0, st, b_flag.as<int>(), b_rank.as<int>(), b_keyat.as<unsigned long long>(), n,
-                           h_hash, first, ctx->d_frame_sync, h_ctrl, tag);
         HIPCHK(ctx, hipGetLastError());
         srl_stage_end(ctx, 1);
         tp1 = std::chrono::steady_clock::now();

@@ -73,8 +73,13 @@ __device__ __forceinline__ unsigned srl_epoch_claim(unsigned long long *keyw, un
 // look-back scan initialises its tile states in a kernel of its own) or a chain of waits (one workgroup walking the array measured
 // 15 us at 24k, this form ~4 us).  sink(i, value, exclusive prefix) is called once per element.
 #define SRL_SCAN_SMALL_MAX 131072
-template <class In, class Sink>
-__global__ void __launch_bounds__(1024) k_scan_small(In in, Sink sink, int n) {
+struct SrlNoFin {
+    __device__ void operator()(int) const {}
+};
+// fin(inclusive total up to the end of this workgroup's tile) is called by every thread of the workgroup after its sink calls (the last
+// workgroup's value is the grand total): a place for "this tile is done" protocols
+template <class In, class Sink, class Fin = SrlNoFin>
+__global__ void __launch_bounds__(1024) k_scan_small(In in, Sink sink, int n, Fin fin = Fin()) {
     __shared__ int wave_part[16], wave_front[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int base = blockIdx.x * 1024;
@@ -98,6 +103,9 @@ __global__ void __launch_bounds__(1024) k_scan_small(In in, Sink sink, int n) {
     for (int k = 0; k < 16; k++) run += wave_front[k];
     for (int k = 0; k < w; k++) run += wave_part[k];
     if (i < n) sink(i, v, run + incl - v);
+    int tile_end = 0;
+    for (int k = 0; k < 16; k++) tile_end += wave_front[k] + wave_part[k];
+    fin(tile_end);
 }
 inline int srl_scan_small_grid(int n) { return (n + 1023) / 1024; }
 struct SrlIntArrayIn {

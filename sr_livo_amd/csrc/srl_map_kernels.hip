@@ -48,7 +48,7 @@ __global__ void k_point_slots(const double *xyz, int n, double voxel_size, unsig
     const unsigned long long key = srl_pack_key(kx, ky, kz);
     slot_out[i] = srl_epoch_claim(keyw, mask, epoch16, key, srl_hash_key(key));     // (epoch-tagged scratch table: no fill per frame)
     idx[i] = (unsigned)i;
-    new_flag[i] = 0;                       // (k_lookup, three kernels on, sets the marks: no fill in front of this one)
+    new_flag[i] = 0;                       // (the segment scan, behind the sort, sets the marks: no fill in front of this one)
 }
 // head flag of sorted position i / the per-element work of the scan over them: segment starts, and the voxel key of every sorted
 // position restored from the scratch table (in the pass of the scan itself: k_scan_small)
@@ -58,15 +58,77 @@ struct HeadFlag32 {
 };
 struct SegmentSink {
     const unsigned *slots_sorted;
+    const unsigned *idx_sorted;
     const unsigned long long *keyw;
     int *seg_start;
-    unsigned long long *keys_sorted;
+    unsigned long long *keys_sorted;          // written at segment heads only: the voxel key of the segment
+    const SrlMapSlot *table;                  // the map's table: the lookup of k_lookup happens here, at the head of every segment
+    unsigned mask;
+    int *seg_slot;
+    unsigned char *is_new;
+    int *new_flag;                            // or nullptr (min_num_points > 0: nothing is created)
+    int *seg_of_first;                        // [first point index of a NEW voxel] -> its segment (for CreateSink)
     int *counters;
     int n;
     __device__ void operator()(int i, int head, int excl) const {
-        keys_sorted[i] = keyw[slots_sorted[i]] & SRL_KEY48_MASK;
-        if (head) seg_start[excl] = i;
-        if (i == n - 1) { counters[0] = excl + head; counters[1] = 0; counters[2] = 0; }      // segments | new voxels (k_create) | points added (k_replay)
+        if (head) {
+            const unsigned long long key = keyw[slots_sorted[i]] & SRL_KEY48_MASK;
+            keys_sorted[i] = key;
+            seg_start[excl] = i;
+            unsigned h = srl_hash_key(key) & mask;
+            int slot = -1;
+            for (unsigned probe = 0; probe <= mask; ++probe) {
+                const unsigned long long k = table[h].key;
+                if (k == key) { slot = (int)h; break; }
+                if (k == SRL_EMPTY_KEY) break;
+                h = (h + 1) & mask;
+            }
+            seg_slot[excl] = slot;
+            is_new[excl] = slot < 0 ? 1 : 0;
+            if (slot < 0 && new_flag) {
+                const unsigned first = idx_sorted[i];              // stable sort: the segment's first element is its earliest point
+                new_flag[first] = 1;
+                seg_of_first[first] = excl;
+            }
+        }
+        if (i == n - 1) { counters[0] = excl + head; counters[1] = 0; counters[2] = 0; }      // segments | new voxels (CreateSink) | points added (k_replay)
+    }
+};
+// ... and the per-element work of the scan over the new-voxel marks (point-index space): the exclusive prefix IS the creation rank
+// (the sequential loop of lioOptimization.cpp:520-554 creates voxels in the order their first points arrive) -- k_create's work
+struct CreateSink {
+    const int *seg_of_first;
+    const int *seg_start;
+    const unsigned long long *keys_sorted;
+    int V;
+    SrlMapSlot *table;
+    unsigned mask;
+    unsigned char *slabs;
+    int *seg_slot;
+    int *counters;
+    int n;
+    __device__ void operator()(int i, int is_first_of_new, int rank) const {
+        if (is_first_of_new) {
+            const int s = seg_of_first[i];
+            const unsigned long long key = keys_sorted[seg_start[s]];
+            const unsigned slab = (unsigned)(V + rank);
+            SrlSlab *sl = reinterpret_cast<SrlSlab *>(slabs + (size_t)slab * SRL_SLAB_BYTES);
+            sl->count = 0;
+            sl->pad = 0;
+            sl->key = key;
+            unsigned h = srl_hash_key(key) & mask;
+            for (unsigned probe = 0; probe <= mask; ++probe) {
+                const unsigned long long prev = atomicCAS(&table[h].key, SRL_EMPTY_KEY, key);
+                if (prev == SRL_EMPTY_KEY) {
+                    table[h].slab = slab;
+                    table[h].count = 0;
+                    seg_slot[s] = (int)h;
+                    break;
+                }
+                h = (h + 1) & mask;
+            }
+        }
+        if (i == n - 1) counters[1] = rank + is_first_of_new;
     }
 };
 
@@ -369,7 +431,9 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
                                                        (int)bits, st));
         srl_stage_end(ctx, 7);                                    // slots + sort
         hipLaunchKernelGGL((k_scan_small<HeadFlag32, SegmentSink>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, HeadFlag32{b_slot_sorted.as<unsigned>()},
-                           SegmentSink{b_slot_sorted.as<unsigned>(), T.keyw, b_start.as<int>(), b_keys2.as<unsigned long long>(), cnt, n}, n);
+                           SegmentSink{b_slot_sorted.as<unsigned>(), b_idx2.as<unsigned>(), T.keyw, b_start.as<int>(), b_keys2.as<unsigned long long>(), ctx->d_table,
+                                       ctx->table_cap - 1, b_slot.as<int>(), b_isnew.as<unsigned char>(), min_num_points <= 0 ? b_newflag.as<int>() : (int *)nullptr,
+                                       b_first.as<int>(), cnt, n}, n);
         HIPCHK(ctx, hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_point_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, voxel_size,
@@ -413,21 +477,26 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
     const unsigned mask = ctx->table_cap - 1;
     const bool create_new = min_num_points <= 0;             // min_num_points > 0: a point never opens a voxel (lioOptimization.cpp:437)
     const int seg_grid = (n + 255) / 256;                    // (one thread per POSSIBLE segment; the kernels stop at the device-side count)
-    hipLaunchKernelGGL(k_lookup, dim3(seg_grid), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_start.as<int>(), b_idx2.as<unsigned>(), cnt,
-                       ctx->d_table, mask, b_slot.as<int>(), b_isnew.as<unsigned char>(), b_first.as<unsigned>(), create_new ? b_newflag.as<int>() : (int *)nullptr);
-    HIPCHK(ctx, hipGetLastError());
-    if (create_new) {
-        if (frame_sized) {
-            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, SrlIntArraySink>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, SrlIntArrayIn{b_newflag.as<int>()},
-                               SrlIntArraySink{b_newrank.as<int>()}, n);
-        } else {
+    if (frame_sized) {
+        // the lookup has happened at the segment heads of the scan above; creation = the per-element work of the scan over the new-voxel marks
+        if (create_new) {
+            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, CreateSink>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, SrlIntArrayIn{b_newflag.as<int>()},
+                               CreateSink{b_first.as<int>(), b_start.as<int>(), b_keys2.as<unsigned long long>(), ctx->num_voxels, ctx->d_table, mask, ctx->d_slabs,
+                                          b_slot.as<int>(), cnt, n}, n);
+            HIPCHK(ctx, hipGetLastError());
+        }
+    } else {
+        hipLaunchKernelGGL(k_lookup, dim3(seg_grid), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_start.as<int>(), b_idx2.as<unsigned>(), cnt,
+                           ctx->d_table, mask, b_slot.as<int>(), b_isnew.as<unsigned char>(), b_first.as<unsigned>(), create_new ? b_newflag.as<int>() : (int *)nullptr);
+        HIPCHK(ctx, hipGetLastError());
+        if (create_new) {
             tb = tmp_bytes;
             HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, b_newflag.as<int>(), b_newrank.as<int>(), n, st));
+            hipLaunchKernelGGL(k_create, dim3(seg_grid), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_start.as<int>(), cnt, b_isnew.as<unsigned char>(),
+                               b_first.as<unsigned>(), b_newrank.as<int>(), b_newflag.as<int>(), n, ctx->num_voxels, ctx->d_table, mask, ctx->d_slabs,
+                               b_slot.as<int>(), cnt);
+            HIPCHK(ctx, hipGetLastError());
         }
-        hipLaunchKernelGGL(k_create, dim3(seg_grid), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_start.as<int>(), cnt, b_isnew.as<unsigned char>(),
-                           b_first.as<unsigned>(), b_newrank.as<int>(), b_newflag.as<int>(), n, ctx->num_voxels, ctx->d_table, mask, ctx->d_slabs,
-                           b_slot.as<int>(), cnt);
-        HIPCHK(ctx, hipGetLastError());
     }
     srl_stage_end(ctx, 9);                                    // lookup + creation
     hipLaunchKernelGGL(k_replay, dim3((n + 127) / 128), dim3(128), 0, st, b_start.as<int>(), b_idx2.as<unsigned>(), cnt, n,
