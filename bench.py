@@ -484,6 +484,9 @@ def write_detail(out):
         print(f"bench.py: could not write {DETAIL_PATH}: {e}", file=sys.stderr)
 
 
+SELF_LAUNCH_TIMEOUT_S = 600
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher around it: re-run this command line as N ranks under torch.distributed.run
     (one process per GPU, rendezvous over loopback) and pass rank 0's line through.  The sharded path has never met a real N-GPU node
@@ -505,13 +508,22 @@ def self_launch(n_gpus):
             port = s.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + base + extra
+        # the launcher and its ranks form a process group of their own: an attempt that hangs is ended as a whole (killing only the launcher
+        # would leave its ranks spinning on the GPUs under the next attempt)
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
         try:
-            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=900)
+            out, _ = p.communicate(timeout=SELF_LAUNCH_TIMEOUT_S)
         except subprocess.TimeoutExpired:
-            print(f"bench.py: {' '.join(extra) or 'default transport'} timed out", file=sys.stderr)
+            import signal
+            try:
+                os.killpg(p.pid, signal.SIGKILL)               # exactly the group started above
+            except ProcessLookupError:
+                pass
+            p.communicate()
+            print(f"bench.py: {' '.join(extra) or 'default transport'} timed out after {SELF_LAUNCH_TIMEOUT_S} s", file=sys.stderr)
             continue
         last_rc = p.returncode
-        lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
         if p.returncode == 0 and lines:
             line = lines[-1]
             if note:

@@ -175,11 +175,24 @@ def test_gpus_n_without_a_launcher_becomes_its_own_launcher(monkeypatch):
     bench = _bench()
     seen = []
 
-    def fake_run(cmd, env=None, stdout=None, timeout=None):
-        seen.append((cmd, env))
-        ok = "--mode" in cmd                                            # the two sharded forms "fail", the replicas succeed
-        return types.SimpleNamespace(returncode=0 if ok else 1, stdout=b'{"value":1.0,"n_gpus":4}\n' if ok else b"")
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    killed = []
+
+    class FakePopen:
+        # RCCL form: hangs (the launcher's whole process group must be killed); peer form: fails; replicas: succeed
+        def __init__(self, cmd, env=None, stdout=None, start_new_session=False):
+            assert start_new_session is True                           # a group of its own, so that a hung attempt can be ended with its ranks
+            seen.append((cmd, env))
+            self.pid = 4242 + len(seen)
+            self.hang = "--transport" not in cmd and "--mode" not in cmd
+            self.ok = "--mode" in cmd
+            self.returncode = 0 if self.ok else 1
+
+        def communicate(self, timeout=None):
+            if self.hang and timeout is not None:
+                raise subprocess.TimeoutExpired("x", timeout)
+            return (b'{"value":1.0,"n_gpus":4}\n' if self.ok else b""), None
+    monkeypatch.setattr(subprocess, "Popen", FakePopen)
+    monkeypatch.setattr(os, "killpg", lambda pid, sig: killed.append(pid))
     monkeypatch.setattr("sys.argv", ["bench.py", "--gpus", "4", "--steps", "3"])
     printed = []
     monkeypatch.setattr("builtins.print", lambda *a, **k: printed.append((a, k)))
@@ -189,5 +202,6 @@ def test_gpus_n_without_a_launcher_becomes_its_own_launcher(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert [c[-2:] for c, _ in seen[1:]] == [["--transport", "peer"], ["--mode", "replay"]]
+    assert killed == [4243]                                             # the hung first attempt: its process group, nothing else
     out = [a[0] for a, k in printed if k.get("file") is None]
     assert len(out) == 1 and json.loads(out[0])["fallback"].startswith("sharded forms failed") and json.loads(out[0])["n_gpus"] == 4
