@@ -134,7 +134,8 @@ int srl_thread_pin_to_gpu_numa(srl_ctx *ctx, int *numa_node);
 /* The NEXT sweep while the current one is being solved (a node receives sweep k + 1 during the solve of sweep k):
  * srl_sweep_prefetch uploads it on the context's copy stream into a second sweep buffer and returns at once; the current
  * sweep stays valid.  srl_sweep_swap makes the prefetched sweep current -- the compute stream waits for the upload's event,
- * the host does not.  Same buffer rules as srl_sweep_upload (a page-locked source must stay untouched until the first
+ * the host does not; when the upload has already landed, a launch armed behind the previous sweep's last pass is kept and serves
+ * as the new sweep's first pass (see ARMED LAUNCHES).  Same buffer rules as srl_sweep_upload (a page-locked source must stay untouched until the first
  * result computed on the swapped-in sweep has been returned). */
 int srl_sweep_prefetch(srl_ctx *ctx, const double *raw_xyz, int n);
 int srl_sweep_swap(srl_ctx *ctx);
@@ -202,19 +203,29 @@ int srl_build_residuals_overlap(srl_ctx *ctx, const srl_frame *frame, const srl_
                                 srl_overlap_fn fn, void *user);
 /* ARMED LAUNCHES.  The loop of updateIEKF (src/optimize.cpp:147-312) alternates kernel and host: buildPlaneResiduals' normal
  * equations (:153,:235,:239) -> 17-dim update (:172-261) -> next pose -> buildPlaneResiduals.  With armed launches on (the
- * default) every srl_build_residuals call on an unsharded context, besides running its own pass, enqueues the kernel of the NEXT
- * pass while the current one is in flight -- same sweep, map and options; the pose, which does not exist yet, arrives later
- * through a small host-written "pose box" the waiting workgroups poll.  The next call, if its arguments are those of the armed
- * launch (the pose may differ: that is the point), only writes the pose: the launch call, the dispatch and the ramp of the kernel
- * are off the per-iteration critical path.  Any other call on the context, or a pass with other arguments, cancels the armed
- * launch first (one 384-byte write; the waiting kernel exits), so nothing observable changes: same kernels, same arithmetic,
- * same results.  An armed launch that is neither fired nor cancelled leaves by itself after 300 us (so a device-wide
- * synchronisation issued from outside this library waits that long at most), and a call arriving more than 150 us after arming
- * cancels instead of firing.
- *   srl_set_armed_launch(ctx, 0 | 1)   turn the mechanism off / on (default on)
+ * default) an srl_build_residuals call on an unsharded context, besides running its own pass, enqueues the kernel of the NEXT
+ * pass while the current one is in flight -- same map and options; the pose, which does not exist yet, arrives later through a
+ * small host-written "pose box" the waiting workgroups poll, together with the keypoint count and which of the context's two
+ * sweep buffers (srl_sweep_prefetch / srl_sweep_swap) the pass runs on.  The next call, if its arguments are those of the armed
+ * launch (pose, sweep buffer and count may differ: that is the point), only writes the box: the launch call, the dispatch and the
+ * ramp of the kernel are off the per-iteration critical path -- also across srl_sweep_swap, where the launch armed behind the last
+ * pass of sweep k becomes the first pass of sweep k + 1 (src/lioOptimization.cpp:1003-1027: one optimize() per sweep).  Any other
+ * call on the context, or a pass with other arguments, cancels the armed launch first (one 384-byte write; the waiting kernel
+ * exits), so nothing observable changes: same kernels, same arithmetic, same results.
+ * PROCESS-WIDE EFFECT: a waiting launch keeps one workgroup per compute unit resident.  Other work for the same GPU -- another
+ * context or process, a foreign hipDeviceSynchronize / hipFree -- waits until the launch is fired, cancelled or leaves by itself
+ * (300 us after it started waiting; a call arriving more than 150 us after arming cancels instead of firing).  Therefore a launch
+ * is only armed where it is likely to fire: not behind the pass expected to be the last of a solve (the pass count of the
+ * previous solve, told by srl_solve_end) unless a prefetched sweep is waiting, and not while a second context of this process
+ * lives on the device.
+ *   srl_set_armed_launch(ctx, 0 | 1 | 2)  off / on with the policy above (default) / armed behind every eligible pass
+ *   srl_solve_end(ctx)                 the caller's ESIKF loop on the current sweep has ended (converged, iteration cap, failure):
+ *                                      remembers how many passes it took and cancels an armed launch unless a prefetched sweep
+ *                                      is waiting.  Optional (without it every eligible pass arms, as with mode 2).
  *   srl_disarm(ctx)                    cancel an armed launch now (optional: e.g. before the thread goes idle)
  *   srl_get_arm_stats                  counters {armed, fired, cancelled, expired} since context creation */
 int srl_set_armed_launch(srl_ctx *ctx, int mode);
+int srl_solve_end(srl_ctx *ctx);
 int srl_disarm(srl_ctx *ctx);
 int srl_get_arm_stats(srl_ctx *ctx, uint64_t out[4]);
 

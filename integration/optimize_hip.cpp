@@ -30,6 +30,7 @@
 // tests/test_gpu_integration.py compiles this file together with the reference's own translation units
 // (oracle/Makefile, target refnode_hip) and drives the reference's run() over the 40-sweep replay stream.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdint>
@@ -71,8 +72,12 @@ std::mutex g_mutex;
 std::unordered_map<const lioOptimization *, HipBinding> g_bindings;
 // the node calls from ONE thread (the ROS main thread, lioOptimization.cpp:1596-1604): the binding of the node seen last is remembered,
 // so that a call costs neither the lock nor the map lookup
+// -- valid only while no binding has been released since it was remembered: srl_integration_release (any thread) advances g_generation,
+// and a thread whose cached generation is stale looks the binding up under the lock again (a released node's address may be reused)
+std::atomic<unsigned long> g_generation{1};
 thread_local const lioOptimization *t_self = nullptr;
 thread_local HipBinding *t_binding = nullptr;
+thread_local unsigned long t_generation = 0;
 
 [[noreturn]] void fail(srl_lio *lio, int rc, const char *what) {
     std::string msg = std::string(what) + ": " + srl_status_str(rc);
@@ -81,14 +86,14 @@ thread_local HipBinding *t_binding = nullptr;
 }
 
 HipBinding &binding_of(const lioOptimization *self) {
-    if (t_self == self && t_binding) return *t_binding;
+    if (t_self == self && t_binding && t_generation == g_generation.load(std::memory_order_acquire)) return *t_binding;
     std::lock_guard<std::mutex> lk(g_mutex);
     HipBinding &b = g_bindings[self];                      // (references into an unordered_map stay valid across insertions)
     if (!b.lio) {
         const int rc = srl_lio_create(0, &b.lio);          // no CPU fallback: without a GPU the node cannot run this path
         if (rc != SRL_OK) fail(nullptr, rc, "srl_lio_create");
     }
-    t_self = self; t_binding = &b;
+    t_self = self; t_binding = &b; t_generation = g_generation.load(std::memory_order_acquire);
     return b;
 }
 
@@ -186,6 +191,7 @@ extern "C" void srl_integration_release(const void *node) {
     it->second.free_buffers();
     if (it->second.lio) srl_lio_destroy(it->second.lio);
     if (t_binding == &it->second) { t_self = nullptr; t_binding = nullptr; }
+    g_generation.fetch_add(1, std::memory_order_acq_rel);          // every thread's remembered binding is void from here on
     g_bindings.erase(it);
 }
 

@@ -160,6 +160,7 @@ def load_library():
         "srl_debug_set_frame_epoch": ([p, C.c_int], C.c_int),
         "srl_set_armed_launch": ([p, C.c_int], C.c_int),
         "srl_disarm": ([p], C.c_int),
+        "srl_solve_end": ([p], C.c_int),
         "srl_get_arm_stats": ([p, C.POINTER(C.c_uint64)], C.c_int),
         "srl_debug_set_launch_shape": ([p, C.c_int, C.c_int], C.c_int),
         "srl_debug_set_search_select_mode": ([p, C.c_int], C.c_int),
@@ -497,7 +498,12 @@ class Context:
 
     def set_armed_launch(self, on):
         """armed launches (the next pass's kernel enqueued while the current one runs): on by default"""
-        self._chk(self.lib.srl_set_armed_launch(self.h, 1 if on else 0), "srl_set_armed_launch")
+        mode = int(on) if on in (0, 1, 2) and not isinstance(on, bool) else (1 if on else 0)      # 2: armed behind every eligible pass (no policy)
+        self._chk(self.lib.srl_set_armed_launch(self.h, mode), "srl_set_armed_launch")
+
+    def solve_end(self):
+        """the caller's ESIKF loop on the current sweep has ended (srl_solve_end)"""
+        self._chk(self.lib.srl_solve_end(self.h), "srl_solve_end")
 
     def disarm(self):
         self._chk(self.lib.srl_disarm(self.h), "srl_disarm")

@@ -222,6 +222,9 @@ optimizeSummary lioOptimization::solveIEKF(const icpOptions &cur_icp_options, cl
     last_num_iterations = 0;
     last_num_observed = 0;
     last_solve_launches = 0;
+    // whichever way the loop below is left (converged, iteration cap, failure, exception): tell the context that this solve is over --
+    // it remembers the pass count for its arming policy and keeps a launch armed behind the last pass only for a prefetched sweep
+    struct SolveEnd { srl_ctx *c; ~SolveEnd() { if (c) srl_solve_end(c); } } solve_end_guard{provider ? nullptr : voxel_map.ctx};
 
     // covariance projection helpers (optimize.cpp:220-232): rows then columns of the so3 / S2 blocks
     auto left3 = [](Mat17 &dst, const Mat3 &J, const Mat17 &src) {

@@ -11,13 +11,13 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
-#include <csetjmp>
-#include <csignal>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,6 +31,13 @@ int srl_map_insert_device(struct srl_ctx *ctx, const double *world_xyz, int n, d
 namespace {
 
 unsigned next_pow2(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return p; }
+
+// Live contexts per device.  An armed launch keeps one workgroup per CU resident until its pose arrives: with a second context on the
+// same device each side would stall the other for the full linger, so launches are only armed while the context has its device to
+// itself inside this process (arm_mode 1; srl_set_armed_launch(ctx, 2) overrides).
+constexpr int SRL_MAX_DEVICES = 64;
+std::atomic<int> g_live_ctx[SRL_MAX_DEVICES];
+inline int live_contexts(int device) { return (device >= 0 && device < SRL_MAX_DEVICES) ? g_live_ctx[device].load(std::memory_order_relaxed) : 1; }
 
 int ensure_work(srl_ctx *ctx, int n) {
     if (n <= ctx->work_cap) return SRL_OK;
@@ -150,6 +157,8 @@ int srl_ctx_create(int device, srl_ctx **out) {
     }
     std::memset(ctx->h_mail, 0, sizeof(SrlMailbox));
     for (int i = 0; i < 4; i++) hipEventCreate(&ctx->ev[i]);
+    if (device < SRL_MAX_DEVICES) g_live_ctx[device].fetch_add(1, std::memory_order_relaxed);
+    ctx->counted = true;
     *out = ctx;
     return SRL_OK;
 }
@@ -157,6 +166,7 @@ int srl_ctx_create(int device, srl_ctx **out) {
 int srl_ctx_destroy(srl_ctx *ctx) {
     if (!ctx) return SRL_OK;
     hipSetDevice(ctx->device);
+    if (ctx->counted && ctx->device < SRL_MAX_DEVICES) g_live_ctx[ctx->device].fetch_sub(1, std::memory_order_relaxed);
     if (ctx->armed) srl_ctx_disarm(ctx);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
@@ -340,6 +350,7 @@ int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     ctx->n = cnt;
     ctx->sweep_loaded = true;
     ctx->taps_valid = false;
+    ctx->passes_in_solve = 0;
     if (cnt > ctx->sweep_cap) {
         const int cap = std::max(cnt, 1024);
         int rc = ensure(ctx, ctx->d_raw, (size_t)cap * 3);
@@ -376,14 +387,18 @@ int srl_sweep_wait(srl_ctx *ctx) {
 
 int srl_sweep_prefetch(srl_ctx *ctx, const double *raw_xyz, int n) {
     if (!ctx || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
-    SRL_DISARM(ctx);
+    // An armed launch stays: the upload runs on the copy stream into the context's OTHER sweep buffer, which the launch only reads when
+    // it is fired for that sweep (srl_sweep_swap).  (Its prologue may read the buffer it was armed on while this upload rewrites it:
+    // those values are discarded -- a launch fired for another sweep recomputes them, assoc_body's prologue.)
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_stream || !ctx->next_ready) SRL_DISARM(ctx);       // first use: stream / event creation may synchronise the device
     { const int rcc = ensure_copy_stream(ctx); if (rcc) return rcc; }
     if (!ctx->next_ready) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->next_ready, hipEventDisableTiming));
     int b = 0, cnt = 0;
     srl_shard_range(n, ctx->nranks, ctx->rank, &b, &cnt);
     if (cnt > ctx->next_cap || cnt > ctx->stage_next_cap) {
         const int cap = std::max(cnt, 1024);
+        SRL_DISARM(ctx);                                                // the buffers move (hipFree waits for the whole device)
         HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
         int rc;
         if (cnt > ctx->next_cap) { if ((rc = ensure(ctx, ctx->d_raw_next, (size_t)cap * 3))) return rc; ctx->next_cap = cap; }
@@ -402,10 +417,17 @@ int srl_sweep_prefetch(srl_ctx *ctx, const double *raw_xyz, int n) {
 
 int srl_sweep_swap(srl_ctx *ctx) {
     if (!ctx) return SRL_ERR_BAD_ARG;
-    SRL_DISARM(ctx);
-    if (ctx->next_n < 0) { ctx->err = "srl_sweep_swap: nothing prefetched"; return SRL_ERR_NO_SWEEP; }
+    if (ctx->next_n < 0) { SRL_DISARM(ctx); ctx->err = "srl_sweep_swap: nothing prefetched"; return SRL_ERR_NO_SWEEP; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->next_ready, 0));       // compute waits for the upload; the host does not
+    // A launch armed behind the last pass of the sweep that ends here carries BOTH sweep buffers: if the upload has already landed (the
+    // usual case: it was issued a whole solve ago) the launch stays and becomes the first pass of the sweep swapped in -- fired through
+    // the pose box with SRL_ARM_ALT, no launch on the critical path of the new solve.  An upload still in flight is awaited by the
+    // compute stream as before, and a launch already waiting in front of that dependency is cancelled (it could start too early).
+    const hipError_t up = hipEventQuery(ctx->next_ready);
+    if (up != hipSuccess && up != hipErrorNotReady) { ctx->err = std::string("hipEventQuery: ") + hipGetErrorString(up); return SRL_ERR_HIP; }
+    if (up != hipSuccess || ctx->next_n > ctx->work_cap) SRL_DISARM(ctx);   // (growing the work buffers frees them: never under a waiting launch)
+    if (up != hipSuccess) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->next_ready, 0));       // compute waits for the upload; the host does not
+    ctx->passes_in_solve = 0;
     std::swap(ctx->d_raw, ctx->d_raw_next);
     std::swap(ctx->sweep_cap, ctx->next_cap);
     ctx->n = ctx->next_n; ctx->shard_begin = ctx->next_begin; ctx->total_n = ctx->next_total;
@@ -554,20 +576,22 @@ int srl_get_timing(srl_ctx *ctx, srl_timing *t) {
 namespace {
 inline long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// CPU-visibility probe of a device allocation (pose box kind 1): one store under a temporary SIGSEGV / SIGBUS handler
-sigjmp_buf g_probe_jmp;
-void probe_handler(int) { siglongjmp(g_probe_jmp, 1); }
-bool host_can_write(volatile unsigned long long *p) {
-    struct sigaction sa, old_segv, old_bus;
-    std::memset(&sa, 0, sizeof sa);
-    sa.sa_handler = probe_handler;
-    sigemptyset(&sa.sa_mask);
-    sigaction(SIGSEGV, &sa, &old_segv);
-    sigaction(SIGBUS, &sa, &old_bus);
-    bool ok = false;
-    if (sigsetjmp(g_probe_jmp, 1) == 0) { p[0] = 0ull; ok = (p[0] == 0ull); }
-    sigaction(SIGSEGV, &old_segv, nullptr);
-    sigaction(SIGBUS, &old_bus, nullptr);
+// Can the CPU store into device memory (pose box kind 1)?  Asked of the runtime, never probed by faulting: the device must report a
+// large PCIe BAR (hipDeviceAttributeIsLargeBar: the whole of its memory is CPU-addressable) and the runtime must know the
+// allocation as device memory with a host-usable address.  One answer per device, computed once under a lock.
+bool device_memory_is_host_writable(int device, const void *p) {
+    static std::mutex mu;
+    static int cached[SRL_MAX_DEVICES];            // 0 unknown, 1 yes, -1 no
+    std::lock_guard<std::mutex> lk(mu);
+    if (device >= 0 && device < SRL_MAX_DEVICES && cached[device] != 0) return cached[device] > 0;
+    int large_bar = 0;
+    bool ok = hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar != 0;
+    if (ok) {
+        hipPointerAttribute_t at;
+        ok = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice && at.devicePointer == p;
+    }
+    (void)hipGetLastError();
+    if (device >= 0 && device < SRL_MAX_DEVICES) cached[device] = ok ? 1 : -1;
     return ok;
 }
 
@@ -584,7 +608,7 @@ int ensure_pose_box(srl_ctx *ctx) {
             HIPCHK(ctx, hipExtMallocWithFlags((void **)&ctx->pose_box_dev, 4096, hipDeviceMallocFinegrained));
             HIPCHK(ctx, hipMemset(ctx->pose_box_dev, 0, 4096));
             HIPCHK(ctx, hipDeviceSynchronize());
-            ctx->pose_box_dev_visible = host_can_write(ctx->pose_box_dev);
+            ctx->pose_box_dev_visible = device_memory_is_host_writable(ctx->device, ctx->pose_box_dev);
         }
         if (ctx->pose_box_dev_visible) { ctx->pose_box_kind = 1; ctx->h_pose_box = ctx->pose_box_dev; return SRL_OK; }
         if (ctx->pose_box_kind == 1) { ctx->err = "pose box: device memory is not CPU-visible on this system (no large BAR)"; return SRL_ERR_UNSUPPORTED; }
@@ -599,7 +623,7 @@ int ensure_pose_box(srl_ctx *ctx) {
 }
 
 // the pose of launch `epoch` (or its cancellation: code = SRL_ARM_CANCEL, pose ignored): 48 tagged granules = six 64-byte lines
-inline void pose_box_write(srl_ctx *ctx, const double *Rn, const double *R, const double *t, unsigned epoch, unsigned code) {
+inline void pose_box_write(srl_ctx *ctx, const double *Rn, const double *R, const double *t, unsigned epoch, unsigned code, unsigned n = 0u) {
     unsigned long long line[48];
     const unsigned long long tag = (unsigned long long)epoch << 32;
     auto put = [&](int d, double v) {
@@ -611,6 +635,7 @@ inline void pose_box_write(srl_ctx *ctx, const double *Rn, const double *R, cons
     for (int i = 0; i < 9; i++) { put(i, Rn ? Rn[i] : 0.0); put(9 + i, R ? R[i] : 0.0); }
     for (int i = 0; i < 3; i++) put(18 + i, t ? t[i] : 0.0);
     line[SRL_POSE_BOX_CTRL] = tag | code;
+    line[SRL_POSE_BOX_N] = tag | n;                          // keypoints of the pass (the launch may serve another sweep than it was armed on)
     for (int i = SRL_POSE_BOX_USED; i < 48; i++) line[i] = tag;
     volatile unsigned long long *box = ctx->h_pose_box;
     for (int i = 0; i < 48; i++) box[i] = line[i];          // every granule validates itself: no ordering between the stores is needed
@@ -635,7 +660,7 @@ int srl_disarm(srl_ctx *ctx) {
 }
 
 int srl_set_armed_launch(srl_ctx *ctx, int mode) {
-    if (!ctx || mode < 0 || mode > 1) return SRL_ERR_BAD_ARG;
+    if (!ctx || mode < 0 || mode > 2) return SRL_ERR_BAD_ARG;
     SRL_DISARM(ctx);
     ctx->arm_mode = mode;
     return SRL_OK;
@@ -909,14 +934,20 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         SrlAssocArgs sg = src;
         std::memset(sg.Rn, 0, sizeof sg.Rn); std::memset(sg.R, 0, sizeof sg.R); std::memset(sg.t, 0, sizeof sg.t);
         sg.pose_box = nullptr; sg.pose_relay = nullptr; sg.pose_epoch = 0; sg.arm_linger_ticks = 0;
+        // the sweep (either buffer of the context) and its keypoint count travel with the pose: compared separately below
+        sg.raw_x = sg.raw_y = sg.raw_z = nullptr; sg.alt_x = sg.alt_y = sg.alt_z = nullptr; sg.n = 0;
         return sg;
     };
     bool fired = false;
     if (ctx->armed) {
         const SrlAssocArgs sg = signature(a);
         const double age_us = (double)(steady_ns() - ctx->armed_at_ns) * 1e-3;
-        if (arm_ok && age_us < ctx->arm_host_linger_us && nb == ctx->armed_nb && kpw == ctx->armed_kpw && std::memcmp(&sg, &ctx->armed_sig, sizeof sg) == 0) {
-            pose_box_write(ctx, a.Rn, a.R, a.t, (unsigned)seq_now, SRL_ARM_GO);
+        // which of the launch's two sweep buffers holds this pass's sweep (the one it was armed on, or -- after srl_sweep_swap -- the other)
+        const bool on_raw = a.raw_x == ctx->armed_raw && ctx->sweep_cap == ctx->armed_raw_cap;
+        const bool on_alt = !on_raw && ctx->armed_alt != nullptr && a.raw_x == ctx->armed_alt && ctx->sweep_cap == ctx->armed_alt_cap;
+        if (arm_ok && age_us < ctx->arm_host_linger_us && nb == ctx->armed_nb && kpw == ctx->armed_kpw && nblocks <= ctx->armed_nblocks && (on_raw || on_alt) &&
+            std::memcmp(&sg, &ctx->armed_sig, sizeof sg) == 0) {
+            pose_box_write(ctx, a.Rn, a.R, a.t, (unsigned)seq_now, SRL_ARM_GO | (on_alt ? SRL_ARM_ALT : 0u), (unsigned)a.n);
             ctx->armed = false;
             ctx->armed_ring = -1;
             ctx->arm_stats[1]++;
@@ -946,12 +977,24 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         hs[1] = std::chrono::duration_cast<std::chrono::nanoseconds>(t_launched.time_since_epoch()).count();
         hs[3] = fired ? 1 : 0;
     }
-    if (arm_ok) {
+    // Arm only where the launch is likely to be fired (an armed launch nobody fires holds one workgroup per CU until it is cancelled or
+    // leaves by itself): not behind the pass that is expected to be the last of this solve -- the previous solve's pass count,
+    // srl_solve_end -- unless a prefetched sweep is waiting, in which case the launch becomes the first pass of THAT sweep
+    // (srl_sweep_swap); and not while another context of this process lives on the same device.  arm_mode 2: always.
+    const bool arm_wanted = ctx->arm_mode == 2 ||
+                            (live_contexts(ctx->device) <= 1 &&
+                             (ctx->next_n >= 0 || ctx->expected_passes == 0 || ctx->passes_in_solve + 1 < ctx->expected_passes));
+    if (arm_ok && arm_wanted) {
         // ... and arm the next pass now, while this one runs: same arguments, the sequence number this context hands out next
         int rcp = ensure_pose_box(ctx);
         if (rcp) return rcp;
         SrlAssocArgs nx = a;
         nx.seq = ctx->seq + 1;
+        // the context's other sweep buffer, if it exists: the launch can then be fired for the sweep srl_sweep_swap makes current
+        const bool has_alt = ctx->d_raw_next != nullptr && ctx->next_cap > 0 && ctx->nranks == 1;
+        nx.alt_x = has_alt ? ctx->d_raw_next : nullptr;
+        nx.alt_y = has_alt ? ctx->d_raw_next + ctx->next_cap : nullptr;
+        nx.alt_z = has_alt ? ctx->d_raw_next + 2 * (size_t)ctx->next_cap : nullptr;
         nx.pose_box = ctx->h_pose_box;                    // (host-mapped pinned memory and CPU-visible device memory: one address for both sides)
         nx.pose_relay = ctx->pose_box_kind == 1 ? nullptr : ctx->d_pose_relay;
         nx.pose_epoch = (unsigned)nx.seq;
@@ -976,7 +1019,9 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             ctx->ring_head++;
         }
         ctx->armed_sig = signature(nx);
-        ctx->armed_nb = nb; ctx->armed_kpw = kpw;
+        ctx->armed_nb = nb; ctx->armed_kpw = kpw; ctx->armed_nblocks = nblocks;
+        ctx->armed_raw = nx.raw_x; ctx->armed_raw_cap = ctx->sweep_cap;
+        ctx->armed_alt = nx.alt_x; ctx->armed_alt_cap = has_alt ? ctx->next_cap : 0;
         ctx->armed_at_ns = steady_ns();
         ctx->armed = true;
         ctx->arm_stats[0]++;
@@ -1426,7 +1471,17 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     int rc = pass(n_eff);
     if ((rc == SRL_OK || rc == SRL_ERR_NAN_PLANARITY) && n_eff < ctx->n && out->num_residuals < o->max_num_residuals)
         rc = pass(ctx->n);
+    ctx->passes_in_solve++;
     return rc;
+}
+
+int srl_solve_end(srl_ctx *ctx) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (ctx->passes_in_solve > 0) ctx->expected_passes = ctx->passes_in_solve;
+    ctx->passes_in_solve = 0;
+    // a launch armed behind the last pass is only worth keeping when the next sweep is already on its way (it will be that sweep's first pass)
+    if (ctx->armed && ctx->next_n < 0 && ctx->arm_mode != 2) return srl_ctx_disarm(ctx);
+    return SRL_OK;
 }
 
 int srl_build_residuals_overlap(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o, srl_normal_eq *out, srl_overlap_fn fn, void *user) {

@@ -20,6 +20,7 @@ struct SrlEpochTable {
 
 struct srl_ctx {
     int device = 0;
+    bool counted = false;              // this context is in the per-device census (srl_capi.cpp: g_live_ctx)
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -118,7 +119,10 @@ struct srl_ctx {
 
     // ARMED launches (srl_capi.cpp: arm_next / pose_box_write / srl_ctx_disarm): the kernel of the NEXT pass is enqueued while the
     // current one runs and waits, resident, for its pose
-    int arm_mode = 1;                           // srl_set_armed_launch: 0 off, 1 on
+    int arm_mode = 1;                           // srl_set_armed_launch: 0 off, 1 on (armed where it is likely to fire: arm_wanted in srl_capi.cpp), 2 always
+    int passes_in_solve = 0;                    // srl_build_residuals calls since the last srl_solve_end / sweep change
+    int expected_passes = 0;                    // passes the previous solve took (0: unknown): no launch is armed behind the pass expected to be the
+                                                // last one unless a prefetched sweep is waiting (the armed launch then becomes ITS first pass)
     int pose_box_kind = -1;                     // -1: not chosen yet (1 where possible); 0: pinned host memory, workgroup 0 relays into device memory; 1: fine-grained device memory the host writes through the PCIe BAR
     bool pose_box_dev_visible = false;
     unsigned long long *h_pose_box = nullptr;   // where the HOST writes the pose granules (kind 1: the CPU-visible device pointer)
@@ -128,6 +132,9 @@ struct srl_ctx {
     bool armed = false;
     SrlAssocArgs armed_sig;                     // the armed launch's arguments with the pose zeroed: a pass must equal them to fire it
     int armed_nb = 0, armed_kpw = 0;
+    int armed_nblocks = 0;                      // grid of the armed launch (a pass over fewer keypoints may fire it: the surplus workgroups find empty tiles)
+    const double *armed_raw = nullptr, *armed_alt = nullptr;   // x planes of the sweep buffer the launch was armed on / of the context's other buffer
+    int armed_raw_cap = 0, armed_alt_cap = 0;   // ... and their strides (capacity in points)
     int armed_ring = -1;                        // light profiling: ring slot of the armed launch's event pair (-1: none)
     long long armed_at_ns = 0;                  // steady clock at arm time
     double arm_host_linger_us = 150.0;          // an armed launch older than this is cancelled, never fired (the kernel's own bound is longer)

@@ -92,12 +92,15 @@ static_assert(sizeof(SrlDevOut) == 52 * 8 && offsetof(SrlDevOut, pad) == 51 * 8,
 static_assert(offsetof(SrlMailbox, g) % 64 == 0, "the tagged record starts on a cache line");
 
 // ---- armed launches: the pose box
-#define SRL_POSE_BOX_CTRL 42       // granule index of the control word {epoch, code}; granules 2d, 2d + 1 = halves of pose double d (Rn R t)
-#define SRL_POSE_BOX_USED 43       // granules a launch waits for
+#define SRL_POSE_BOX_CTRL 42       // granule index of the control word {epoch, code | SRL_ARM_ALT}; granules 2d, 2d + 1 = halves of pose double d (Rn R t)
+#define SRL_POSE_BOX_N 43          // granule {epoch, n}: keypoints of the pass (an armed launch can be fired for ANOTHER sweep: srl_sweep_swap)
+#define SRL_POSE_BOX_USED 44       // granules a launch waits for
 #define SRL_POSE_BOX_GRANULES 64   // allocated (the host writes whole 64-byte lines: 48 granules)
 #define SRL_ARM_GO 1u
 #define SRL_ARM_CANCEL 2u
 #define SRL_ARM_EXPIRED 3u
+#define SRL_ARM_CODE_MASK 3u
+#define SRL_ARM_ALT 4u             // flag beside SRL_ARM_GO: the pass runs on the launch's ALTERNATE sweep buffer (alt_x / alt_y / alt_z)
 
 #define SRL_REDUCED_DOUBLES 50 // leading doubles of SrlDevOut that are summed over the shards (HtH .. d_timeout)
 
@@ -155,7 +158,9 @@ struct SrlAssocArgs {
     int pad_mail;
     unsigned long long seq;     // launch sequence number published with the result
     // ARMED launch (enqueued before its pose exists; null = the pose is Rn / R / t above): see assoc_body's prologue
-    const unsigned long long *pose_box;   // tagged granules the host writes: 2 x 21 pose halves + the control granule
+    const unsigned long long *pose_box;   // tagged granules the host writes: 2 x 21 pose halves + the control granule + the keypoint count
+    const double *alt_x, *alt_y, *alt_z;  // the context's OTHER sweep buffer (srl_sweep_prefetch / srl_sweep_swap): an armed launch fired with
+                                          // SRL_ARM_ALT runs on it -- the first pass of the next sweep without a launch on its critical path
     unsigned long long *pose_relay;       // device memory workgroup 0 republishes the box into for the others (null: everybody polls the box)
     unsigned pose_epoch;                  // tag of THIS launch's pose (low 32 bits of its sequence number, never 0)
     unsigned arm_linger_ticks;            // 100 MHz ticks an armed launch waits at most (safety net)

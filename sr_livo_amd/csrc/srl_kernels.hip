@@ -1160,6 +1160,13 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     typedef const __attribute__((address_space(4))) SrlAssocArgs *KernargPtr;
 #endif
     double *s_pose = reinterpret_cast<double *>(smem + L.off_pose);       // armed launch: Rn[9] | R[9] | t[3] of this pass
+    // keypoints of this pass: an armed launch learns the count with its pose (it may have been fired for ANOTHER sweep than the one it was
+    // armed on -- srl_sweep_swap --, the grid stays the one it was launched with: workgroups behind the sweep's end find empty tiles).
+    // Re-read where it is needed: nothing stays live across phase 1.
+    auto n_pass = [&]() -> int {
+        if constexpr (ARMED) return __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(s_pose + SRL_POSE_DOUBLES)[1]);
+        else return A.n;
+    };
     int n_fallback = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     auto tile_stamp = [&](int slot) {
@@ -1182,7 +1189,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         D3 p_imu = d3(0, 0, 0), p_w = d3(0, 0, 0);
         if constexpr (ARMED) {
             // the body-frame point does not depend on the pose: this lane computed it while the launch was waiting (assoc_body's prologue)
-            if (g < A.n) {
+            if (g < n_pass()) {
                 p_imu = d3(s_pimu[kq * 3 + 0], s_pimu[kq * 3 + 1], s_pimu[kq * 3 + 2]);
                 p_w = add(matvec(s_pose, p_imu), d3(s_pose[18], s_pose[19], s_pose[20]));
             }
@@ -1227,8 +1234,8 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
 
     // ---------------- phase 1: searchNeighbors, the whole wave on one keypoint at a time
     {
-        const int left = A.n - bbase_kp;
-        const int n_here = __builtin_amdgcn_readfirstlane(left < KPB ? left : KPB);   // keypoints of this workgroup that exist
+        const int left = n_pass() - bbase_kp;
+        const int n_here = __builtin_amdgcn_readfirstlane(left < KPB ? left : KPB);   // keypoints of this workgroup that exist (<= 0: an empty tile)
         auto make_sink = [&](int kl) {
             LdsSink sink;
             sink.col = s_nb + kl;
@@ -1259,7 +1266,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
             // Keypoints the fast path cannot finish (> 64 survivors, or a tie among the K+1 smallest distances) are only
             // NOTED here (workgroup list) and handled after the loop: the hot loop carries no general-path code.
             const LaneRole role = lane_role(lane);
-            const int npairs = (n_here + 1) >> 1;
+            const int npairs = n_here > 0 ? (n_here + 1) >> 1 : 0;            // (an empty tile: a workgroup behind the end of a shorter sweep)
             auto take = [&]() { int p = 0; if (lane == 0) p = atomicAdd(s_next, 1); return __builtin_amdgcn_readfirstlane(p); };
             int cur = take();
             ProbeReq preq;
@@ -1381,7 +1388,8 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     const int klw = lane / LPK, sl = lane % LPK;                                    // keypoint inside this wave, sub-lane
     const int kl = (p2_wave ? w2 : 0) * KP2 + klw;                                  // keypoint inside the workgroup
     const bool owner_lane = p2_wave && klw < KP2 && kl < KPB;
-    const int g = owner_lane ? bbase_kp + kl : b.n;
+    const int n2 = ARMED ? n_pass() : b.n;                                          // keypoints of this pass (phase 2's copy)
+    const int g = owner_lane ? bbase_kp + kl : n2;
     // sum over the LPK lanes of a keypoint (butterfly: all of them end with the same bits)
     // (quad permutes on the 32-bit halves: two v_mov_dpp per step -- __shfl_xor goes through the LDS crossbar, ds_bpermute x 2)
     auto quad_xor = [](double v, auto ctrl) {
@@ -1406,8 +1414,8 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     // neighbours found = min(candidates visited, K): every path leaves the candidate count in s_ncand
     const int nc2 = owner_lane ? s_ncand[kl] : 0;
     const int nf = nc2 < Kn ? nc2 : Kn;
-    if (g < b.n) status = 0;
-    const bool fit = (g < b.n) && (nf >= b.min_nb) && !(DBG && (b.ablate & 1));
+    if (g < n2) status = 0;
+    const bool fit = (g < n2) && (nf >= b.min_nb) && !(DBG && (b.ablate & 1));
     if (fit) {
 #pragma clang fp contract(fast)      // plane fit / weights / Jacobian are tolerance-bound (1e-9 vs the oracle): products may fuse
         const D3 p_imu = d3(s_pimu[kl * 3 + 0], s_pimu[kl * 3 + 1], s_pimu[kl * 3 + 2]);
@@ -1484,7 +1492,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         }
     }
     if constexpr (ARMED) arm_stamp(karg, 23);
-    if (g < b.n && b.write_rec && sl == 0) {
+    if (g < n2 && b.write_rec && sl == 0) {
         // per-keypoint record {J[6], distance, weight} (ordered cut-off path + taps; never on the throughput path)
         double2 *r = reinterpret_cast<double2 *>(b.rec + (size_t)g * 8);
         double2 v;
@@ -1568,7 +1576,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         const unsigned long long acc_mask = __ballot(status == 2 && sl == 0);
         const unsigned long long nan_mask = __ballot(nan_bad);
         const unsigned long long pln_mask = __ballot((status == 1 || status == 2) && sl == 0);
-        int pk = (g < b.n && sl == 0) ? s_ncand[kl] : 0;
+        int pk = (g < n2 && sl == 0) ? s_ncand[kl] : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) pk += __shfl_xor(pk, off);
         if (lane == 0) {
@@ -1662,7 +1670,7 @@ __device__ __forceinline__ bool peer_exchange(const SrlPeerTable *pt, unsigned e
 // bind) and sends the normal equations to the host mailbox.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int KPW, int WPB>
-__device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch) {
+__device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch, const int n_total) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KPB = WPB * KPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1849,7 +1857,7 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
             } else if (tid == 27) {
                 put_f(&out->loss, s_part[27]);
             } else if (tid == 32) {
-                const long long last_visited = cut ? (long long)c * KPB + s_i[3] : (long long)b.n - 1;
+                const long long last_visited = cut ? (long long)c * KPB + s_i[3] : (long long)n_total - 1;
                 put_f(&out->d_num_res, cut ? (double)cut_max : s_part[28]);
                 put_f(&out->d_total_accepted, s_part[28]);
                 put_f(&out->d_sum_pk, s_part[29]);
@@ -1931,14 +1939,14 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
                     else if (tid == 45) v = s_part[29];
                     else if (tid == 46) v = s_part[30] > 0.0 ? 1.0 : 0.0;
                     else if (tid == 47) v = s_part[31];
-                    else if (tid == 48) v = (double)b.n;
+                    else if (tid == 48) v = (double)n_total;
                     else if (tid == 49) v = *s_bad ? 1.0 : 0.0;
                     double sum = 0.0;
                     const bool ok = peer_exchange(b.peer, b.peer_epoch, b.peer_slot, lane, SRL_REDUCED_DOUBLES, (unsigned long long)__double_as_longlong(v),
                                                   [&](int, unsigned long long w) { sum += __longlong_as_double((long long)w); });
                     double *od = reinterpret_cast<double *>(out);
                     if (tid < SRL_REDUCED_DOUBLES) put_f(od + tid, sum);
-                    else if (tid == SRL_REDUCED_DOUBLES) put_i(&out->last_visited, (long long)b.n - 1);
+                    else if (tid == SRL_REDUCED_DOUBLES) put_i(&out->last_visited, (long long)n_total - 1);
                     else if (tid == SRL_REDUCED_DOUBLES + 1) put_i(&out->pad, ok ? 0ll : SRL_PEER_TIMEOUT_MARK);
                 }
             }
@@ -1960,9 +1968,9 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
             put_f(&out->d_sum_pk, s_part[29]);
             put_f(&out->d_nan, s_part[30] > 0.0 ? 1.0 : 0.0);              // every keypoint is visited
             put_f(&out->d_fallback, s_part[31]);
-            put_f(&out->d_visited, (double)b.n);
+            put_f(&out->d_visited, (double)n_total);
             put_f(&out->d_timeout, *s_bad ? 1.0 : 0.0);
-            put_i(&out->last_visited, (long long)b.n - 1);
+            put_i(&out->last_visited, (long long)n_total - 1);
             put_i(&out->pad, *s_bad ? 0x7117ll : 0ll);          // time-out marker
         }
         arm_stamp(karg, 19);
@@ -2041,12 +2049,32 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
             }
             const unsigned hi = (unsigned)__shfl_down((unsigned)x, 1);
             if (lane < 2 * (SRL_POSE_DOUBLES - 1) && !(lane & 1)) s_pose[lane >> 1] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned)x));
-            if (lane == 0) *s_ctrl = (int)code;
+            if (lane == 0) { s_ctrl[0] = (int)(code & SRL_ARM_CODE_MASK); s_ctrl[2] = (code & SRL_ARM_ALT) ? 1 : 0; }
+            if (lane == SRL_POSE_BOX_N) s_ctrl[1] = (code & SRL_ARM_CODE_MASK) == SRL_ARM_GO ? (int)(unsigned)x : a.n;     // keypoints of this pass
         }
         __syncthreads();
         arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 1);
         {
             const int code = *s_ctrl;
+            if (code == (int)SRL_ARM_GO) {
+                // Fired for the context's OTHER sweep buffer (srl_sweep_swap kept this launch: it is the first pass of the NEXT sweep) or with
+                // another keypoint count: the body-frame points precomputed above belong to the sweep this launch was armed on -- redo them.
+                // (Same lane, same LDS words as above and as phase 0 reads back: no barrier.)
+                const int n_new = s_ctrl[1];
+                const bool alt = s_ctrl[2] != 0;
+                if (alt || n_new != a.n) {
+                    const int lane0 = tid & 63, wave0 = tid >> 6;
+                    if (lane0 < KPW) {
+                        const int kq = wave0 * KPW + lane0;
+                        const int g = (int)blockIdx.x * KPB + kq;
+                        double *s_pimu = reinterpret_cast<double *>(smem + L.off_pimu);
+                        const double *rx = alt ? a.alt_x : a.raw_x, *ry = alt ? a.alt_y : a.raw_y, *rz = alt ? a.alt_z : a.raw_z;
+                        D3 p_imu = d3(0, 0, 0);
+                        if (g < n_new) p_imu = add(matvec(a.R_il, d3(rx[g], ry[g], rz[g])), d3(a.t_il[0], a.t_il[1], a.t_il[2]));
+                        s_pimu[kq * 3 + 0] = p_imu.x; s_pimu[kq * 3 + 1] = p_imu.y; s_pimu[kq * 3 + 2] = p_imu.z;
+                    }
+                }
+            }
             if (code != (int)SRL_ARM_GO) {
                 if (code == (int)SRL_ARM_EXPIRED && blockIdx.x == gridDim.x - 1 && tid == 0) {
                     // nobody is listening any more: a host that fires this launch after all learns it from the mailbox's `expired` word and
@@ -2132,7 +2160,9 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
     }
     if constexpr (ARMED) arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 6);
     if (blockIdx.x != gridDim.x - 1) return;
-    finish_rows<KPW, WPB>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), epoch);
+    int n_total = b.n;
+    if constexpr (ARMED) n_total = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(smem + L.off_pose + SRL_POSE_DOUBLES * 8)[1]);   // the count that came with the pose
+    finish_rows<KPW, WPB>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), epoch, n_total);
     if constexpr (ARMED) arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 7);
 }
 

@@ -47,9 +47,12 @@ def _solver(sc, max_res=INT_MAX, frame_id=100, **kw):
     return sc["lio"].bound_solver(opts, sc["prior_state"], sc["prior_cov"], sc["state0"], sc["sweep"]["t_last"], frame_id, sc["n"])
 
 
+ALWAYS = 2      # srl_set_armed_launch(ctx, 2): a launch armed behind EVERY eligible pass (the mechanism, without the policy of mode 1)
+
+
 def _run(sc, solve, armed, n=4):
     lio = sc["lio"]
-    lio.ctx.set_armed_launch(armed)
+    lio.ctx.set_armed_launch(ALWAYS if armed else 0)
     out = []
     for _ in range(n):
         rc, it, nr = solve()
@@ -89,7 +92,7 @@ def test_armed_launches_change_no_bit(scene, max_res, frame_id, box):
 
 def test_another_call_or_other_arguments_cancel_the_armed_launch(scene):
     lio = scene["lio"]
-    lio.ctx.set_armed_launch(True)
+    lio.ctx.set_armed_launch(ALWAYS)
     a = _solver(scene, INT_MAX)
     b = _solver(scene, 600)
     c = _solver(scene, INT_MAX, weight_alpha=0.8, weight_neighborhood=0.2)
@@ -97,7 +100,7 @@ def test_another_call_or_other_arguments_cancel_the_armed_launch(scene):
     lio.ctx.set_armed_launch(False)
     for k, s in (("a", a), ("b", b), ("c", c)):
         s(); ref[k] = s.state.copy()
-    lio.ctx.set_armed_launch(True)
+    lio.ctx.set_armed_launch(ALWAYS)
     s0 = lio.ctx.arm_stats()
     for k, s in (("a", a), ("b", b), ("a", a), ("c", c), ("c", c), ("b", b)):     # other budget / other weights: the waiting launch is not theirs
         rc, it, nr = s()
@@ -111,6 +114,7 @@ def test_another_call_or_other_arguments_cancel_the_armed_launch(scene):
     assert np.array_equal(a.state, ref["a"])
     lio.ctx.disarm(); a()
     assert np.array_equal(a.state, ref["a"]) and lio.ctx.arm_stats()["expired"] == s0["expired"]
+    lio.ctx.set_armed_launch(True)
 
 
 def test_an_armed_launch_too_old_for_the_host_is_cancelled_not_fired(scene):
@@ -118,7 +122,7 @@ def test_an_armed_launch_too_old_for_the_host_is_cancelled_not_fired(scene):
     lio.ctx.set_armed_launch(False)
     a = _solver(scene)
     a(); ref = a.state.copy()
-    lio.ctx.set_armed_launch(True)
+    lio.ctx.set_armed_launch(ALWAYS)
     lio.ctx.set_arm_linger(host_linger_us=0.0)                             # every waiting launch is "too old"
     try:
         s0 = lio.ctx.arm_stats()
@@ -129,6 +133,7 @@ def test_an_armed_launch_too_old_for_the_host_is_cancelled_not_fired(scene):
         assert s1["fired"] == s0["fired"] and s1["cancelled"] - s0["cancelled"] >= 3 * 2 - 1
     finally:
         lio.ctx.set_arm_linger()
+        lio.ctx.set_armed_launch(True)
 
 
 def test_an_armed_launch_that_gave_up_on_the_device_is_replaced_by_a_normal_one(scene):
@@ -138,7 +143,7 @@ def test_an_armed_launch_that_gave_up_on_the_device_is_replaced_by_a_normal_one(
     lio.ctx.set_armed_launch(False)
     a = _solver(scene)
     a(); ref = a.state.copy()
-    lio.ctx.set_armed_launch(True)
+    lio.ctx.set_armed_launch(ALWAYS)
     lio.ctx.set_arm_linger(host_linger_us=3.6e9, kernel_linger_us=200.0)
     try:
         a()
@@ -151,13 +156,14 @@ def test_an_armed_launch_that_gave_up_on_the_device_is_replaced_by_a_normal_one(
     finally:
         lio.ctx.set_arm_linger()
         lio.ctx.disarm()
+        lio.ctx.set_armed_launch(True)
 
 
 def test_frame_pipeline_and_map_growth_between_armed_solves(scene):
     """insert points (the map's table and slabs may move: other kernel arguments), solve again: equal to the un-armed solve on the same map"""
     lio = scene["lio"]
     a = _solver(scene)
-    lio.ctx.set_armed_launch(True)
+    lio.ctx.set_armed_launch(ALWAYS)
     a(); a()
     rng = np.random.default_rng(5)
     extra = scene["cands"][rng.choice(len(scene["cands"]), 2000, replace=False)] + rng.normal(0, 0.3, (2000, 3))
@@ -168,3 +174,157 @@ def test_frame_pipeline_and_map_growth_between_armed_solves(scene):
     a()
     assert np.array_equal(a.state, got)
     lio.ctx.set_armed_launch(True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The arming policy of mode 1 (the default) and launches that survive srl_sweep_swap
+# ---------------------------------------------------------------------------------------------------------------------
+def _sweeps(sc, count, sizes=None):
+    """`count` distinct sweeps of the scene (own seeds, own predicted poses, hence own priors) in page-locked memory, each with the
+    solver that starts from ITS prior; sizes: keypoints per sweep (default: the scene's)"""
+    import gc
+    gc.collect()
+    lio = sc["lio"]
+    n_kp, map_pts, pattern, seed = synth.CONFIGS["C1"]
+    out = []
+    for j in range(count):
+        n = sizes[j] if sizes else n_kp
+        sw = synth.make_sweep(seed + 2000 + j, n, sc["L"], pattern=pattern)
+        ps = sc["prior_state"].copy()
+        ps[0:3] = sw["t_pred"]; ps[3:7] = sw["q_pred"]; ps[7:10] = sw["vel"]
+        st0 = np.concatenate([sw["q_pred"], sw["t_pred"], sw["vel"], np.zeros(6)])
+        pin = srl.PinnedArray(sw["raw"].shape)
+        pin.array[:] = sw["raw"]
+        out.append(dict(sweep=sw, pin=pin, n=n, prior_state=ps, state0=st0))
+    return out
+
+
+def _stream(sc, sweeps, opts, rounds, frame_id=100):
+    """the node's loop over a stream of sweeps: the next sweep is uploaded while the current one is solved (srl_sweep_prefetch), made
+    current behind the solve (srl_sweep_swap); returns the solved states in order"""
+    lio = sc["lio"]
+    solvers = [lio.bound_solver(opts, s["prior_state"], sc["prior_cov"], s["state0"], s["sweep"]["t_last"], frame_id, s["n"]) for s in sweeps]
+    S = len(sweeps)
+    lio.prefetch_sweep(sweeps[0]["pin"].array); lio.swap_sweep()
+    states = []
+    for k in range(rounds):
+        lio.prefetch_sweep(sweeps[(k + 1) % S]["pin"].array)
+        rc, it, nr = solvers[k % S]()
+        assert rc == 0
+        states.append((it, nr, solvers[k % S].state.copy(), lio.eskf_get_cov().copy()))
+        lio.swap_sweep()
+    lio.ctx.disarm()
+    return states
+
+
+@pytest.fixture(scope="module")
+def scene_L(scene):
+    n_kp, map_pts, pattern, seed = synth.CONFIGS["C1"]
+    _, L = synth.map_candidates(seed, map_pts)
+    scene["L"] = L
+    return scene
+
+
+@pytest.mark.parametrize("max_res", [INT_MAX, 600])
+def test_a_launch_armed_behind_the_last_pass_becomes_the_first_pass_of_the_next_sweep(scene_L, max_res):
+    """four distinct sweeps streamed through prefetch / swap: in steady state every pass -- the first pass of a sweep included -- fires
+    a waiting launch, nothing is cancelled, and every solved state and covariance equals, bit for bit, the one launch per
+    iteration produces on the same sweep"""
+    sc = scene_L
+    lio = sc["lio"]
+    sw = _sweeps(sc, 4)
+    opts = srl.default_opts(max_num_residuals=max_res)
+    try:
+        lio.ctx.set_armed_launch(False)
+        ref = _stream(sc, sw, opts, 8)
+        lio.ctx.set_armed_launch(True)
+        _stream(sc, sw, opts, 4)                                            # (the pass count of a solve is learnt from the solve before it)
+        s0 = lio.ctx.arm_stats()
+        got = _stream(sc, sw, opts, 16)
+        s1 = lio.ctx.arm_stats()
+        for k, g in enumerate(got):
+            r = ref[k % 8] if k < 8 else ref[k % 4 + 4]
+            assert g[0] == r[0] and g[1] == r[1], (k, g[:2], r[:2])
+            assert np.array_equal(g[2], r[2]) and np.array_equal(g[3], r[3]), k
+        passes = sum(g[0] for g in got)
+        # the very first pass of the series has no launch waiting; the disarm at the end of _stream cancels the one armed behind the last pass
+        assert s1["fired"] - s0["fired"] >= passes - 1, (s0, s1, passes)
+        assert s1["cancelled"] - s0["cancelled"] <= 1, (s0, s1)
+        assert s1["expired"] == s0["expired"]
+    finally:
+        lio.ctx.set_armed_launch(True)
+        lio.resident_sweep(sc["sweep"]["raw"])
+        for s in sw:
+            s["pin"].close()
+
+
+def test_a_waiting_launch_serves_a_shorter_sweep_and_is_cancelled_for_a_longer_one(scene_L):
+    """keypoint counts differ from sweep to sweep: the launch armed on 4 096 keypoints (128 workgroups) is fired for 4 000 (its last
+    workgroups find empty tiles), the one armed on 4 000 (125 workgroups) cannot hold 4 096 and is cancelled -- same bits either way"""
+    sc = scene_L
+    lio = sc["lio"]
+    sw = _sweeps(sc, 4, sizes=[4096, 4000, 4096, 3990])
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    try:
+        lio.ctx.set_armed_launch(False)
+        ref = _stream(sc, sw, opts, 4)
+        lio.ctx.set_armed_launch(True)
+        _stream(sc, sw, opts, 4)
+        s0 = lio.ctx.arm_stats()
+        got = _stream(sc, sw, opts, 12)
+        s1 = lio.ctx.arm_stats()
+        for k, g in enumerate(got):
+            r = ref[k % 4]
+            assert g[0] == r[0] and g[1] == r[1] and np.array_equal(g[2], r[2]) and np.array_equal(g[3], r[3]), k
+        assert s1["fired"] > s0["fired"] and s1["cancelled"] > s0["cancelled"] and s1["expired"] == s0["expired"]
+    finally:
+        lio.ctx.set_armed_launch(True)
+        lio.resident_sweep(sc["sweep"]["raw"])
+        for s in sw:
+            s["pin"].close()
+
+
+def test_no_launch_is_left_waiting_behind_a_solve_without_a_prefetched_sweep(scene):
+    """mode 1 on a resident sweep solved again and again: launches are armed only between the passes of a solve -- none behind the pass
+    expected to be the last --, so every armed launch is fired and nothing is cancelled; srl_solve_end cancels what a longer-than-
+    expected solve leaves behind"""
+    import gc
+    gc.collect()
+    lio = scene["lio"]
+    lio.resident_sweep(scene["sweep"]["raw"])
+    a = _solver(scene)
+    lio.ctx.set_armed_launch(False)
+    a(); ref = a.state.copy()
+    lio.ctx.set_armed_launch(True)
+    a(); a()
+    s0 = lio.ctx.arm_stats()
+    its = 0
+    for _ in range(6):
+        rc, it, nr = a()
+        its += it
+        assert rc == 0 and np.array_equal(a.state, ref)
+    s1 = lio.ctx.arm_stats()
+    assert s1["armed"] - s0["armed"] == its - 6 and s1["fired"] - s0["fired"] == its - 6, (s0, s1, its)
+    assert s1["cancelled"] == s0["cancelled"] and s1["expired"] == s0["expired"]
+
+
+def test_a_second_context_on_the_device_keeps_launches_from_being_armed(scene):
+    import gc
+    gc.collect()
+    lio = scene["lio"]
+    lio.resident_sweep(scene["sweep"]["raw"])
+    a = _solver(scene)
+    lio.ctx.set_armed_launch(True)
+    a(); ref = a.state.copy()
+    other = srl.Context(0)
+    try:
+        s0 = lio.ctx.arm_stats()
+        for _ in range(3):
+            a()
+            assert np.array_equal(a.state, ref)
+        s1 = lio.ctx.arm_stats()
+        assert s1["armed"] == s0["armed"]
+    finally:
+        other.close()
+    a(); a()
+    assert lio.ctx.arm_stats()["armed"] > s1["armed"] and np.array_equal(a.state, ref)

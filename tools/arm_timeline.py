@@ -43,6 +43,7 @@ def run(name, box):
         if box is not None:
             lio.ctx.set_pose_box(box)
         solve = lio.bound_solver(srl.default_opts(max_num_residuals=max_res), prior_state, prior_cov, state0, sweep["t_last"], frame_id, n_kp)
+        lio.ctx.set_armed_launch(2)      # a launch armed behind EVERY pass (the sweep is re-solved in place: the policy of mode 1 would leave each solve's first pass un-armed)
         lio.ctx.pass_stamps(True, read=False)
         rows = []
         for rep in range(12):
