@@ -189,17 +189,32 @@ def oracle_solve(po, backend, lio, opts, sweep, prior_state, prior_cov, state0, 
 CONFIG_CLOCK_WARMUP_S = 0.05
 
 
-def make_stream(sweep0, prior_state0, sweep_seed, n_kp, L, pattern, count):
+def make_stream(sweep0, prior_state0, sweep_seed, n_kp, L, pattern, count, iterations_of=None):
     """`count` distinct sweeps of one scene for the timed stream (one solve per sweep, never the same sweep twice in a row):
-    own seeds, own ground-truth and predicted poses, hence own priors (the prior covariance is the scene's); raw points in page-locked
-    host memory.  Entry 0 is the given sweep."""
-    stream = [dict(sweep=sweep0, prior_state=prior_state0,
+    own seeds (sweep_seed + 100 j), own ground-truth and predicted poses, hence own priors (the prior covariance is the scene's); raw
+    points in page-locked host memory.  Entry 0 is the given sweep.
+    iterations_of(entry) -> ESIKF iterations of its solve: when given, a candidate whose solve takes another number of iterations than
+    sweep 0's is skipped (its seed is recorded), so that "one step" is the same amount of algorithmic work for every sweep of the stream
+    and the rate stays comparable with the single-sweep figure of rounds 1-4.  At most 4 x count candidates are drawn."""
+    stream = [dict(sweep=sweep0, prior_state=prior_state0, seed=sweep_seed,
                    state0=np.concatenate([sweep0["q_pred"], sweep0["t_pred"], sweep0["vel"], np.zeros(6)]))]
-    for j in range(1, max(int(count), 1)):
+    want = iterations_of(stream[0]) if iterations_of else None
+    skipped = []
+    j = 0
+    while len(stream) < max(int(count), 1) and j < 4 * max(int(count), 1):
+        j += 1
         sw = synth.make_sweep(sweep_seed + 100 * j, n_kp, L, pattern=pattern)
         ps = prior_state0.copy()
         ps[0:3] = sw["t_pred"]; ps[3:7] = sw["q_pred"]; ps[7:10] = sw["vel"]
-        stream.append(dict(sweep=sw, prior_state=ps, state0=np.concatenate([sw["q_pred"], sw["t_pred"], sw["vel"], np.zeros(6)])))
+        e = dict(sweep=sw, prior_state=ps, seed=sweep_seed + 100 * j, state0=np.concatenate([sw["q_pred"], sw["t_pred"], sw["vel"], np.zeros(6)]))
+        if iterations_of is not None:
+            it = iterations_of(e)
+            if it != want:
+                skipped.append({"seed": e["seed"], "iterations": it})
+                continue
+        stream.append(e)
+    stream[0]["skipped"] = skipped
+    stream[0]["iterations"] = want
     for e in stream:
         e["pin"] = srl.PinnedArray(e["sweep"]["raw"].shape)
         e["pin"].array[:] = e["sweep"]["raw"]
@@ -251,7 +266,12 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         prior_cov = lio.eskf_get_cov().copy()
         state0 = np.concatenate([sweep["q_pred"], sweep["t_pred"], sweep["vel"], np.zeros(6)])
         opts = srl.default_opts(max_num_residuals=max_res)
-        streamer = Streamer(lio, make_stream(sweep, prior_state, seed + 1000, n_kp, L, pattern, stream_sweeps), opts, prior_cov, frame_id, n_kp)
+        def iterations_of(e):
+            lio.resident_sweep(e["sweep"]["raw"])
+            rc_, it_, _ = lio.bound_solver(opts, e["prior_state"], prior_cov, e["state0"], e["sweep"]["t_last"], frame_id, n_kp)()
+            return it_ if rc_ == 0 else -1
+
+        streamer = Streamer(lio, make_stream(sweep, prior_state, seed + 1000, n_kp, L, pattern, stream_sweeps, iterations_of), opts, prior_cov, frame_id, n_kp)
         step = streamer.step
         streamer.begin()
         for _ in range(warmup):
@@ -333,7 +353,7 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
                "sweeps_per_s": steps / el, "ms_per_solve": el / steps * 1e3, "esikf_iterations": it, "ms_per_esikf_iter": el * 1e3 / max(its, 1),
                "steps": steps, "ms_per_solve_median": float(np.median(per)) * 1e3, "ms_per_solve_max": float(per.max()) * 1e3,
                "residuals_used": nr, "kernel_launches_per_solve": launches_per_solve,
-               "arm_stats": arm, "armed": bool(arm["fired"] > 0),
+               "arm_stats": arm, "armed": bool(arm["fired"] > 0), "stream_sweeps": streamer.S, "stream_seeds_skipped": streamer.stream[0].get("skipped"),
                "launch_per_iteration_ab": {"ms_per_esikf_iter": el_un * 1e3 / max(its_un, 1), "state_bitwise_equal": un_equal,
                                            "what": "armed launches off (srl_set_armed_launch(0)), same stream"},
                "resident_resolve_us_per_iter": el_r / steps * 1e6 / max(it_r, 1),
@@ -716,8 +736,14 @@ def main():
     # THE STREAM (one full solve per sweep, "incl. H2D of the sweep"; src/lioOptimization.cpp:1003-1027 never solves a sweep
     # twice): S distinct sweeps of the scene -- own seeds, own ground-truth and predicted poses, hence own priors -- in page-locked host
     # memory.  Sweep 0 is the sweep every other leg (CPU baselines, parity, profiles) uses.
-    S = max(int(args.stream_sweeps), 1)
-    stream = make_stream(sweep, prior_state, sweep_seed, n_kp, L, pattern, S)
+    def iterations_of(e):
+        lio.resident_sweep(e["sweep"]["raw"])
+        sv = lio.bound_solver(opts, e["prior_state"], prior_cov, e["state0"], e["sweep"]["t_last"], args.frame_id, n_kp)
+        rc, it, _ = sv()
+        return it if rc == 0 else -1
+
+    stream = make_stream(sweep, prior_state, sweep_seed, n_kp, L, pattern, max(int(args.stream_sweeps), 1), iterations_of)
+    S = len(stream)
     lio.resident_sweep(sweep["raw"])
     setup_s = time.time() - t0
     # The interpreter's cyclic collector is host noise, not part of the path: with torch imported one full collection costs
@@ -1024,7 +1050,9 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: stream of {S} distinct {n_kp}-keypoint {pattern} sweeps (own poses and priors), {n_map}-pt voxel map "
                                f"({map_pts} target), max_num_residuals={args.max_num_residuals}, r={nb}, K=20; one full ESIKF solve per sweep, "
-                               f"every sweep crosses PCIe once (uploaded on the copy stream during the solve before it: resident in HBM when its solve starts)",
+                               f"every sweep crosses PCIe once (uploaded on the copy stream during the solve before it: resident in HBM when its solve starts); "
+                               f"sweeps drawn with seeds {stream[0]['seed']} + 100 j, keeping those that take sweep 0's {stream[0]['iterations']} ESIKF iterations "
+                               f"(skipped seeds: {[x['seed'] for x in stream[0]['skipped']]})",
                    "parallelism": ("point-range shards x%d + %s of the 6x6 normal equations" % (world, "direct peer exchange" if args.transport == "peer" else "RCCL all-reduce")) if sharded
                                   else ("replicas x%d" % world if world > 1 else "single GPU"),
                    "esikf_iterations_per_solve": iters_timed / max(args.steps, 1), "residuals_used": r["num_residuals"],
@@ -1185,7 +1213,7 @@ def main():
         cfgs = []
         for name, wl, mr, fid, st in plan:
             try:
-                cfgs.append(run_config(name, wl, mr, fid, st, 2, local_rank, po, backend, threads))
+                cfgs.append(run_config(name, wl, mr, fid, st, 2, local_rank, po, backend, threads, stream_sweeps=2 if st <= 20 else 4))
             except Exception as e:  # noqa: BLE001
                 cfgs.append({"name": name, "error": repr(e)})
         out["configs"] = cfgs

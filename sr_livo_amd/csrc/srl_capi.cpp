@@ -176,7 +176,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->comm);
     if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
-                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
+                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_stage_cur, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
                     ctx->d_tap_offset, ctx->d_gather, ctx->d_peer, ctx->d_mail};
     for (int r = 0; r < SRL_MAX_PEERS; r++) if (ctx->peer_mapped[r]) hipIpcCloseMemHandle(ctx->peer_mapped[r]);
     if (ctx->d_inbox) hipFree(ctx->d_inbox);
@@ -368,6 +368,7 @@ int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
         if (rcu) return rcu;
         HIPCHK(ctx, srl_launch_aos_to_soa(ctx->d_rec, cnt, ctx->d_raw, ctx->d_raw + ctx->sweep_cap, ctx->d_raw + 2 * (size_t)ctx->sweep_cap, ctx->stream));
     }
+    ctx->soa_valid_n = cnt;
     return SRL_OK;
 }
 
@@ -401,14 +402,15 @@ int srl_sweep_prefetch(srl_ctx *ctx, const double *raw_xyz, int n) {
         SRL_DISARM(ctx);                                                // the buffers move (hipFree waits for the whole device)
         HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
         int rc;
-        if (cnt > ctx->next_cap) { if ((rc = ensure(ctx, ctx->d_raw_next, (size_t)cap * 3))) return rc; ctx->next_cap = cap; }
+        if (cnt > ctx->next_cap) { if ((rc = ensure(ctx, ctx->d_raw_next, (size_t)cap * 3))) return rc; ctx->next_cap = cap; HIPCHK(ctx, hipMemsetAsync(ctx->d_raw_next, 0, (size_t)cap * 3 * sizeof(double), ctx->copy_stream)); }
         if (cnt > ctx->stage_next_cap) { if ((rc = ensure(ctx, ctx->d_stage_next, (size_t)cap * 3))) return rc; ctx->stage_next_cap = cap; }
     }
     if (cnt > 0) {
+        // DMA only: the points stay AoS in the staging buffer and are transposed by the first pass that reads them (SrlAssocArgs::aos) --
+        // a transpose kernel on the copy stream would wait for compute units the association kernels (resident back to back, armed
+        // launches included) do not release before the solve it is meant to overlap has ended
         int rcu = upload_aos(ctx, reinterpret_cast<const char *>(raw_xyz + (size_t)b * 3), (size_t)cnt * 3 * sizeof(double), ctx->d_stage_next, ctx->copy_stream);
         if (rcu) return rcu;
-        HIPCHK(ctx, srl_launch_aos_to_soa(ctx->d_stage_next, cnt, ctx->d_raw_next, ctx->d_raw_next + ctx->next_cap,
-                                          ctx->d_raw_next + 2 * (size_t)ctx->next_cap, ctx->copy_stream));
     }
     HIPCHK(ctx, hipEventRecord(ctx->next_ready, ctx->copy_stream));
     ctx->next_n = cnt; ctx->next_begin = b; ctx->next_total = n;
@@ -430,6 +432,9 @@ int srl_sweep_swap(srl_ctx *ctx) {
     ctx->passes_in_solve = 0;
     std::swap(ctx->d_raw, ctx->d_raw_next);
     std::swap(ctx->sweep_cap, ctx->next_cap);
+    std::swap(ctx->d_stage_cur, ctx->d_stage_next);
+    std::swap(ctx->stage_cur_cap, ctx->stage_next_cap);
+    ctx->soa_valid_n = 0;                                   // the planes of d_raw are filled by the first pass over the sweep
     ctx->n = ctx->next_n; ctx->shard_begin = ctx->next_begin; ctx->total_n = ctx->next_total;
     ctx->next_n = -1;
     ctx->sweep_loaded = true;
@@ -752,6 +757,7 @@ static int prepare_assoc_args(srl_ctx *ctx, const srl_frame *f, const srl_icp_op
     a.raw_y = ctx->d_raw + ctx->sweep_cap;
     a.raw_z = ctx->d_raw + 2 * (size_t)ctx->sweep_cap;
     a.n = n_eff;
+    a.aos = (n_eff > ctx->soa_valid_n) ? ctx->d_stage_cur : nullptr;     // the pass reads (all of) its points AoS and files the SoA planes
     a.table = ctx->d_table;
     a.table_mask = ctx->table_cap - 1;
     a.slabs = ctx->d_slabs;
@@ -935,7 +941,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         std::memset(sg.Rn, 0, sizeof sg.Rn); std::memset(sg.R, 0, sizeof sg.R); std::memset(sg.t, 0, sizeof sg.t);
         sg.pose_box = nullptr; sg.pose_relay = nullptr; sg.pose_epoch = 0; sg.arm_linger_ticks = 0;
         // the sweep (either buffer of the context) and its keypoint count travel with the pose: compared separately below
-        sg.raw_x = sg.raw_y = sg.raw_z = nullptr; sg.alt_x = sg.alt_y = sg.alt_z = nullptr; sg.n = 0;
+        sg.raw_x = sg.raw_y = sg.raw_z = nullptr; sg.alt_x = sg.alt_y = sg.alt_z = nullptr; sg.n = 0; sg.aos = nullptr; sg.alt_aos = nullptr;
         return sg;
     };
     bool fired = false;
@@ -943,8 +949,10 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         const SrlAssocArgs sg = signature(a);
         const double age_us = (double)(steady_ns() - ctx->armed_at_ns) * 1e-3;
         // which of the launch's two sweep buffers holds this pass's sweep (the one it was armed on, or -- after srl_sweep_swap -- the other)
-        const bool on_raw = a.raw_x == ctx->armed_raw && ctx->sweep_cap == ctx->armed_raw_cap;
-        const bool on_alt = !on_raw && ctx->armed_alt != nullptr && a.raw_x == ctx->armed_alt && ctx->sweep_cap == ctx->armed_alt_cap;
+        // (on the buffer it was armed on the launch reads the SoA planes: they must be valid; on the other one it reads the staging buffer)
+        const bool on_raw = a.raw_x == ctx->armed_raw && ctx->sweep_cap == ctx->armed_raw_cap && a.aos == nullptr;
+        const bool on_alt = !on_raw && ctx->armed_alt != nullptr && a.raw_x == ctx->armed_alt && ctx->sweep_cap == ctx->armed_alt_cap &&
+                            a.aos != nullptr && a.aos == ctx->armed_alt_aos;
         if (arm_ok && age_us < ctx->arm_host_linger_us && nb == ctx->armed_nb && kpw == ctx->armed_kpw && nblocks <= ctx->armed_nblocks && (on_raw || on_alt) &&
             std::memcmp(&sg, &ctx->armed_sig, sizeof sg) == 0) {
             pose_box_write(ctx, a.Rn, a.R, a.t, (unsigned)seq_now, SRL_ARM_GO | (on_alt ? SRL_ARM_ALT : 0u), (unsigned)a.n);
@@ -991,7 +999,9 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         SrlAssocArgs nx = a;
         nx.seq = ctx->seq + 1;
         // the context's other sweep buffer, if it exists: the launch can then be fired for the sweep srl_sweep_swap makes current
-        const bool has_alt = ctx->d_raw_next != nullptr && ctx->next_cap > 0 && ctx->nranks == 1;
+        const bool has_alt = ctx->d_raw_next != nullptr && ctx->next_cap > 0 && ctx->d_stage_next != nullptr && ctx->nranks == 1;
+        nx.aos = nullptr;                                  // (its own buffer's planes are valid once this pass has run)
+        nx.alt_aos = has_alt ? ctx->d_stage_next : nullptr;
         nx.alt_x = has_alt ? ctx->d_raw_next : nullptr;
         nx.alt_y = has_alt ? ctx->d_raw_next + ctx->next_cap : nullptr;
         nx.alt_z = has_alt ? ctx->d_raw_next + 2 * (size_t)ctx->next_cap : nullptr;
@@ -1021,7 +1031,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         ctx->armed_sig = signature(nx);
         ctx->armed_nb = nb; ctx->armed_kpw = kpw; ctx->armed_nblocks = nblocks;
         ctx->armed_raw = nx.raw_x; ctx->armed_raw_cap = ctx->sweep_cap;
-        ctx->armed_alt = nx.alt_x; ctx->armed_alt_cap = has_alt ? ctx->next_cap : 0;
+        ctx->armed_alt = nx.alt_x; ctx->armed_alt_cap = has_alt ? ctx->next_cap : 0; ctx->armed_alt_aos = nx.alt_aos;
         ctx->armed_at_ns = steady_ns();
         ctx->armed = true;
         ctx->arm_stats[0]++;
@@ -1200,6 +1210,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     out->nan_error = r.d_nan > 0.5 ? 1 : 0;
     out->num_fallback = (int32_t)(r.d_fallback + 0.5);
 
+    if (a.aos != nullptr && n_eff > ctx->soa_valid_n) ctx->soa_valid_n = n_eff;      // this pass filed the SoA planes of its keypoints
     ctx->last_K = K;
     ctx->last_nb = nb;
     ctx->last_visited_local = visited_local - 1;

@@ -46,8 +46,11 @@ struct srl_ctx {
 
     // the NEXT sweep (srl_sweep_prefetch / srl_sweep_swap): uploaded on its own stream while the current one is solved
     double *d_raw_next = nullptr;      // SoA, stride next_cap
-    double *d_stage_next = nullptr;    // AoS staging of the prefetch (d_rec belongs to the running solve)
-    int next_cap = 0, stage_next_cap = 0;      // capacities (points) of d_raw_next / d_stage_next: the sweep buffers swap, the staging does not
+    double *d_stage_next = nullptr;    // AoS staging of the prefetch: the DMA's target (no kernel runs on the copy stream)
+    double *d_stage_cur = nullptr;     // ... of the sweep that is current now (swapped with d_stage_next by srl_sweep_swap): its points are
+                                       // transposed into d_raw by the first pass that touches them (SrlAssocArgs::aos)
+    int soa_valid_n = 0;               // leading keypoints of the current sweep whose SoA planes in d_raw are filled
+    int next_cap = 0, stage_next_cap = 0, stage_cur_cap = 0;   // capacities (points) of d_raw_next / d_stage_next / d_stage_cur
     int next_n = -1, next_begin = 0, next_total = 0;   // next_n < 0: nothing prefetched
     hipStream_t copy_stream = nullptr;
     int num_cu = 256;                 // compute units of the device (launch-shape policy)
@@ -134,6 +137,7 @@ struct srl_ctx {
     int armed_nb = 0, armed_kpw = 0;
     int armed_nblocks = 0;                      // grid of the armed launch (a pass over fewer keypoints may fire it: the surplus workgroups find empty tiles)
     const double *armed_raw = nullptr, *armed_alt = nullptr;   // x planes of the sweep buffer the launch was armed on / of the context's other buffer
+    const double *armed_alt_aos = nullptr;      // the staging buffer the launch reads when it is fired for the other buffer
     int armed_raw_cap = 0, armed_alt_cap = 0;   // ... and their strides (capacity in points)
     int armed_ring = -1;                        // light profiling: ring slot of the armed launch's event pair (-1: none)
     long long armed_at_ns = 0;                  // steady clock at arm time

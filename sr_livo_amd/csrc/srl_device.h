@@ -123,6 +123,11 @@ struct SrlPeerTable {          // device memory, written once at srl_peer_attach
 struct SrlAssocArgs {
     // sweep
     const double *raw_x, *raw_y, *raw_z;
+    // A prefetched sweep arrives AoS (n x 3) by DMA alone -- no kernel on the copy stream: while the association kernels hold every
+    // compute unit a transpose kernel could not start before the solve it is meant to overlap had ended.  The first pass over such a
+    // sweep reads its points from `aos` and writes the SoA planes raw_x / raw_y / raw_z as it goes (every later pass reads the planes);
+    // null: the planes are valid.
+    const double *aos;
     int n;
     // map
     const SrlMapSlot *table;
@@ -161,6 +166,8 @@ struct SrlAssocArgs {
     const unsigned long long *pose_box;   // tagged granules the host writes: 2 x 21 pose halves + the control granule + the keypoint count
     const double *alt_x, *alt_y, *alt_z;  // the context's OTHER sweep buffer (srl_sweep_prefetch / srl_sweep_swap): an armed launch fired with
                                           // SRL_ARM_ALT runs on it -- the first pass of the next sweep without a launch on its critical path
+    const double *alt_aos;                // ... whose points still lie AoS (n x 3) in the prefetch's staging buffer: that pass reads them
+                                          // there and files the SoA planes alt_x / alt_y / alt_z itself (see `aos`)
     unsigned long long *pose_relay;       // device memory workgroup 0 republishes the box into for the others (null: everybody polls the box)
     unsigned pose_epoch;                  // tag of THIS launch's pose (low 32 bits of its sequence number, never 0)
     unsigned arm_linger_ticks;            // 100 MHz ticks an armed launch waits at most (safety net)

@@ -1195,7 +1195,15 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
             }
         } else {
             if (g < A.n) {
-                const D3 raw = d3(A.raw_x[g], A.raw_y[g], A.raw_z[g]);
+                D3 raw;
+                if (A.aos != nullptr) {
+                    // first pass over a prefetched sweep: the point still lies AoS in the staging buffer -- read it there and file the SoA planes
+                    const double *p = A.aos + 3 * (size_t)g;
+                    raw = d3(p[0], p[1], p[2]);
+                    const_cast<double *>(A.raw_x)[g] = raw.x; const_cast<double *>(A.raw_y)[g] = raw.y; const_cast<double *>(A.raw_z)[g] = raw.z;
+                } else {
+                    raw = d3(A.raw_x[g], A.raw_y[g], A.raw_z[g]);
+                }
                 p_imu = add(matvec(A.R_il, raw), d3(A.t_il[0], A.t_il[1], A.t_il[2]));
                 p_w = add(matvec(A.Rn, p_imu), d3(A.t[0], A.t[1], A.t[2]));
             }
@@ -2068,9 +2076,19 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
                         const int kq = wave0 * KPW + lane0;
                         const int g = (int)blockIdx.x * KPB + kq;
                         double *s_pimu = reinterpret_cast<double *>(smem + L.off_pimu);
-                        const double *rx = alt ? a.alt_x : a.raw_x, *ry = alt ? a.alt_y : a.raw_y, *rz = alt ? a.alt_z : a.raw_z;
                         D3 p_imu = d3(0, 0, 0);
-                        if (g < n_new) p_imu = add(matvec(a.R_il, d3(rx[g], ry[g], rz[g])), d3(a.t_il[0], a.t_il[1], a.t_il[2]));
+                        if (g < n_new) {
+                            D3 raw;
+                            if (alt) {
+                                // the other buffer's points arrived AoS by DMA (srl_sweep_prefetch): this pass files its SoA planes (SrlAssocArgs::aos)
+                                const double *p = a.alt_aos + 3 * (size_t)g;
+                                raw = d3(p[0], p[1], p[2]);
+                                const_cast<double *>(a.alt_x)[g] = raw.x; const_cast<double *>(a.alt_y)[g] = raw.y; const_cast<double *>(a.alt_z)[g] = raw.z;
+                            } else {
+                                raw = d3(a.raw_x[g], a.raw_y[g], a.raw_z[g]);
+                            }
+                            p_imu = add(matvec(a.R_il, raw), d3(a.t_il[0], a.t_il[1], a.t_il[2]));
+                        }
                         s_pimu[kq * 3 + 0] = p_imu.x; s_pimu[kq * 3 + 1] = p_imu.y; s_pimu[kq * 3 + 2] = p_imu.z;
                     }
                 }
