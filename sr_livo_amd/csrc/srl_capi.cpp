@@ -628,8 +628,9 @@ int ensure_pose_box(srl_ctx *ctx) {
 }
 
 // the pose of launch `epoch` (or its cancellation: code = SRL_ARM_CANCEL, pose ignored): 48 tagged granules = six 64-byte lines
-inline void pose_box_write(srl_ctx *ctx, const double *Rn, const double *R, const double *t, unsigned epoch, unsigned code, unsigned n = 0u) {
-    unsigned long long line[48];
+inline void pose_box_write(srl_ctx *ctx, const double *Rn, const double *R, const double *t, unsigned epoch, unsigned code, unsigned n = 0u,
+                           const double *t_last = nullptr) {
+    unsigned long long line[SRL_POSE_BOX_WRITTEN];
     const unsigned long long tag = (unsigned long long)epoch << 32;
     auto put = [&](int d, double v) {
         unsigned long long bits;
@@ -641,9 +642,15 @@ inline void pose_box_write(srl_ctx *ctx, const double *Rn, const double *R, cons
     for (int i = 0; i < 3; i++) put(18 + i, t ? t[i] : 0.0);
     line[SRL_POSE_BOX_CTRL] = tag | code;
     line[SRL_POSE_BOX_N] = tag | n;                          // keypoints of the pass (the launch may serve another sweep than it was armed on)
-    for (int i = SRL_POSE_BOX_USED; i < 48; i++) line[i] = tag;
+    for (int i = 0; i < 3; i++) {                            // t_last (optimize.cpp:25) belongs to the sweep, like the pose
+        unsigned long long bits = 0ull;
+        if (t_last) std::memcpy(&bits, &t_last[i], 8);
+        line[SRL_POSE_BOX_TLAST + 2 * i] = tag | (bits & 0xFFFFFFFFull);
+        line[SRL_POSE_BOX_TLAST + 2 * i + 1] = tag | (bits >> 32);
+    }
+    for (int i = SRL_POSE_BOX_USED; i < SRL_POSE_BOX_WRITTEN; i++) line[i] = tag;
     volatile unsigned long long *box = ctx->h_pose_box;
-    for (int i = 0; i < 48; i++) box[i] = line[i];          // every granule validates itself: no ordering between the stores is needed
+    for (int i = 0; i < SRL_POSE_BOX_WRITTEN; i++) box[i] = line[i];          // every granule validates itself: no ordering between the stores is needed
     __atomic_thread_fence(__ATOMIC_SEQ_CST);                // ... only that they leave the core now (mfence: drains write-combining buffers too)
 }
 }  // namespace
@@ -939,6 +946,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     auto signature = [](const SrlAssocArgs &src) {
         SrlAssocArgs sg = src;
         std::memset(sg.Rn, 0, sizeof sg.Rn); std::memset(sg.R, 0, sizeof sg.R); std::memset(sg.t, 0, sizeof sg.t);
+        std::memset(sg.t_last, 0, sizeof sg.t_last);       // (optimize.cpp:25: per sweep -- it travels through the pose box with the pose)
         sg.pose_box = nullptr; sg.pose_relay = nullptr; sg.pose_epoch = 0; sg.arm_linger_ticks = 0;
         // the sweep (either buffer of the context) and its keypoint count travel with the pose: compared separately below
         sg.raw_x = sg.raw_y = sg.raw_z = nullptr; sg.alt_x = sg.alt_y = sg.alt_z = nullptr; sg.n = 0; sg.aos = nullptr; sg.alt_aos = nullptr;
@@ -955,7 +963,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
                             a.aos != nullptr && a.aos == ctx->armed_alt_aos;
         if (arm_ok && age_us < ctx->arm_host_linger_us && nb == ctx->armed_nb && kpw == ctx->armed_kpw && nblocks <= ctx->armed_nblocks && (on_raw || on_alt) &&
             std::memcmp(&sg, &ctx->armed_sig, sizeof sg) == 0) {
-            pose_box_write(ctx, a.Rn, a.R, a.t, (unsigned)seq_now, SRL_ARM_GO | (on_alt ? SRL_ARM_ALT : 0u), (unsigned)a.n);
+            pose_box_write(ctx, a.Rn, a.R, a.t, (unsigned)seq_now, SRL_ARM_GO | (on_alt ? SRL_ARM_ALT : 0u), (unsigned)a.n, a.t_last);
             ctx->armed = false;
             ctx->armed_ring = -1;
             ctx->arm_stats[1]++;

@@ -94,8 +94,10 @@ static_assert(offsetof(SrlMailbox, g) % 64 == 0, "the tagged record starts on a 
 // ---- armed launches: the pose box
 #define SRL_POSE_BOX_CTRL 42       // granule index of the control word {epoch, code | SRL_ARM_ALT}; granules 2d, 2d + 1 = halves of pose double d (Rn R t)
 #define SRL_POSE_BOX_N 43          // granule {epoch, n}: keypoints of the pass (an armed launch can be fired for ANOTHER sweep: srl_sweep_swap)
-#define SRL_POSE_BOX_USED 44       // granules a launch waits for
-#define SRL_POSE_BOX_GRANULES 64   // allocated (the host writes whole 64-byte lines: 48 granules)
+#define SRL_POSE_BOX_TLAST 44      // granules 44..49: halves of t_last[3] (optimize.cpp:25: the previous frame's translation -- per sweep, like the pose)
+#define SRL_POSE_BOX_USED 50       // granules a launch waits for
+#define SRL_POSE_BOX_WRITTEN 56    // granules the host writes (whole 64-byte lines: seven)
+#define SRL_POSE_BOX_GRANULES 64   // allocated
 #define SRL_ARM_GO 1u
 #define SRL_ARM_CANCEL 2u
 #define SRL_ARM_EXPIRED 3u
@@ -188,7 +190,7 @@ struct SrlAssocArgs {
     double *tap_offset;     // n
 };
 
-#define SRL_POSE_DOUBLES 22    // armed launches: the LDS pose block Rn[9] R[9] t[3] (+ one spare), the control word behind it
+#define SRL_POSE_DOUBLES 24    // armed launches: the LDS pose block Rn[9] R[9] t[3] t_last[3], the control words behind it
 static_assert(sizeof(SrlAssocArgs) <= 4096, "the struct travels in the kernarg segment");
 
 struct SrlReduceArgs {

@@ -1463,7 +1463,7 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         if (a2D != a2D) nan_bad = true;                           // optimize.cpp:348-350 throws here: no residual from this keypoint
         const double w_plan = (b.power_planarity == 2.0) ? a2D * a2D : pow(a2D, b.power_planarity);
         // normal flip: world-frame last translation minus body-frame location (optimize.cpp:49-51)
-        const D3 tl = d3(b.t_last[0], b.t_last[1], b.t_last[2]);
+        const D3 tl = POSE_LDS ? d3(s_pose[21], s_pose[22], s_pose[23]) : d3(b.t_last[0], b.t_last[1], b.t_last[2]);   // (armed: t_last came with the pose)
         if (dot3(nrm, sub(tl, p_imu)) < 0.0) nrm = d3(-1.0 * nrm.x, -1.0 * nrm.y, -1.0 * nrm.z);
         const D3 nn0 = d3((double)s_nb[kl], (double)s_nb[nb_plane + kl], (double)s_nb[2 * nb_plane + kl]);
         const D3 dq = sub(nn0, p_w);
@@ -2056,7 +2056,9 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
                 __hip_atomic_store((gu64a *)(a.pose_relay + lane), y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const unsigned hi = (unsigned)__shfl_down((unsigned)x, 1);
-            if (lane < 2 * (SRL_POSE_DOUBLES - 1) && !(lane & 1)) s_pose[lane >> 1] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned)x));
+            // granules 2d, 2d + 1 -> pose double d (d < 21); granules 44..49 -> t_last = doubles 21..23
+            if (!(lane & 1) && (lane < SRL_POSE_BOX_CTRL || (lane >= SRL_POSE_BOX_TLAST && lane < SRL_POSE_BOX_USED)))
+                s_pose[lane < SRL_POSE_BOX_CTRL ? (lane >> 1) : 21 + ((lane - SRL_POSE_BOX_TLAST) >> 1)] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned)x));
             if (lane == 0) { s_ctrl[0] = (int)(code & SRL_ARM_CODE_MASK); s_ctrl[2] = (code & SRL_ARM_ALT) ? 1 : 0; }
             if (lane == SRL_POSE_BOX_N) s_ctrl[1] = (code & SRL_ARM_CODE_MASK) == SRL_ARM_GO ? (int)(unsigned)x : a.n;     // keypoints of this pass
         }
