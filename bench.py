@@ -784,6 +784,8 @@ def main():
 
     # setup, untimed: bring GPU and host core to their steady clocks (a timed region of 20 solves lasts 2 ms: measured right after the
     # map build, its steps kept getting faster until the end -- 107 -> 103 us per solve); the W warm-up steps of the contract follow
+    lio.ctx.set_profiling(2)          # the event pairs of the timed region exist and have been recorded once before it starts (first use of an
+                                      # event costs; 1 024 creations right before the region left the GPU idle long enough to drop its clocks)
     t_cw = time.perf_counter()
     n_cw = 0
     stream_begin()
