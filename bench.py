@@ -797,12 +797,14 @@ def main():
         for _ in range(int(args.clock_warmup_ms * 4)):        # ranks solve in lock-step (the exchange is collective): a count, not a clock
             stream_step()
             n_cw += 1
-    for _ in range(args.warmup):
-        r = stream_step()
     # HIP events on the context's own stream, inside the timed region: one pair around every association launch, read
     # back lazily after the region (mode 2) -- the full per-call breakdown (mode 1: four events + a sync per call, ~20 us
     # of host time per iteration) is taken on a few extra solves after the timed region instead.
-    lio.ctx.set_profiling(2)
+    lio.ctx.set_profiling(2)          # (reads back the clock warm-up's several hundred event pairs -- milliseconds of idle GPU -- BEFORE the W warm-up steps)
+    for _ in range(args.warmup):
+        r = stream_step()
+    tim_w = lio.ctx.timing()          # the warm-up steps' launches, subtracted below: the figures are those of the timed region alone
+    tim_w = {k: getattr(tim_w, k) for k in ("calls", "sum_assoc_ms", "sum_algorithmic_bytes", "sum_passes", "sum_keypoints")}
     step_end = np.empty(args.steps)
     barrier()
     arm_before = lio.ctx.arm_stats()
@@ -816,7 +818,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t1
     per_step_us = np.diff(np.concatenate([[t1], step_end])) * 1e6
-    tim = lio.ctx.timing()
+    import types
+    tim_t = lio.ctx.timing()
+    tim = types.SimpleNamespace(**{k: getattr(tim_t, k) - v for k, v in tim_w.items()})
     launches_timed = lio.last_solve_launches()
     arm_stats = {k: arm_after[k] - arm_before[k] for k in arm_after}
     lio.ctx.set_profiling(0)
