@@ -237,7 +237,8 @@ class Streamer:
     def step(self):
         k = self.pos
         e = self.stream[k % self.S]
-        self.lio.prefetch_sweep(self.stream[(k + 1) % self.S]["pin"].array)
+        # sweep k + 1 arrives during the solve of sweep k: its upload is issued by the solve itself, beside the kernel of the first pass
+        self.lio.prefetch_sweep_during_solve(self.stream[(k + 1) % self.S]["pin"].array)
         rc, it, nr = e["solve"]()
         if rc:
             raise RuntimeError(f"update_iekf failed with status {rc} on sweep {k % self.S} of the stream")

@@ -55,6 +55,11 @@ int srl_lio_resident_sweep(srl_lio *lio, const double *raw_xyz, int n);
  * solves the current one; the swapped-in sweep becomes the resident one. */
 int srl_lio_prefetch_sweep(srl_lio *lio, const double *raw_xyz, int n);
 int srl_lio_swap_sweep(srl_lio *lio);
+/* The same prefetch, issued BY the next srl_lio_update_iekf while the kernel of its first pass is in flight (a node receives sweep k + 1
+ * during the solve of sweep k, src/lioOptimization.cpp:1003-1027): the host time of the upload call (a memcpy enqueue and two event
+ * records, ~5 us) then lies beside the association kernel instead of between two solves.  raw_xyz must stay valid and untouched until that
+ * solve has returned (page-locked memory: until srl_sweep_wait / the first result on the swapped-in sweep, as for srl_sweep_prefetch). */
+int srl_lio_prefetch_sweep_during_solve(srl_lio *lio, const double *raw_xyz, int n);
 
 /* lioOptimization::updateIEKF (optimize.cpp:133-314).
  * state_io: p_frame->p_state = q(wxyz) t v ba bg (16 doubles) in/out; t_last = previous frame's

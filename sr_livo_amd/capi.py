@@ -189,6 +189,7 @@ def load_library():
         "srl_lio_resident_sweep": ([p, p, C.c_int], C.c_int),
         "srl_lio_prefetch_sweep": ([p, p, C.c_int], C.c_int),
         "srl_lio_swap_sweep": ([p], C.c_int),
+        "srl_lio_prefetch_sweep_during_solve": ([p, p, C.c_int], C.c_int),
         "srl_lio_update_iekf": ([p, C.POINTER(IcpOpts), p, C.c_int, dp, dp, C.c_int, p, C.c_int,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_lio_update_iekf_provided": ([p, C.POINTER(IcpOpts), PROVIDER_FN, p, C.c_int, dp, dp, C.c_int, p, C.c_int,
@@ -785,6 +786,12 @@ class Lio:
 
     def swap_sweep(self):
         self._chk(self.lib.srl_lio_swap_sweep(self.h), "swap_sweep")
+
+    def prefetch_sweep_during_solve(self, raw_xyz):
+        """the upload of the NEXT sweep, issued by the next update_iekf beside the kernel of its first pass (srl_lio_prefetch_sweep_during_solve)"""
+        r = _f64(raw_xyz, (-1, 3))
+        self._keep_prefetch = r
+        self._chk(self.lib.srl_lio_prefetch_sweep_during_solve(self.h, _ptr(r), len(r)), "prefetch_sweep_during_solve")
 
     def update_iekf(self, opts, raw_xyz, state, t_last, frame_id=100, log_iters=0, n_resident=None,
                     allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):

@@ -225,6 +225,16 @@ optimizeSummary lioOptimization::solveIEKF(const icpOptions &cur_icp_options, cl
     // whichever way the loop below is left (converged, iteration cap, failure, exception): tell the context that this solve is over --
     // it remembers the pass count for its arming policy and keeps a launch armed behind the last pass only for a prefetched sweep
     struct SolveEnd { srl_ctx *c; ~SolveEnd() { if (c) srl_solve_end(c); } } solve_end_guard{provider ? nullptr : voxel_map.ctx};
+    // a prefetch registered for this solve (prefetchSweepDuringSolve) is issued beside the kernel of the first pass -- or, should no pass
+    // get that far, when the solve is left
+    auto issue_pending_prefetch = [this]() {
+        if (pending_prefetch_n < 0) return;
+        const double *raw = pending_prefetch_raw;
+        const int n = pending_prefetch_n;
+        pending_prefetch_raw = nullptr; pending_prefetch_n = -1;
+        pending_prefetch_rc = voxel_map.ctx ? prefetchSweep(raw, n) : SRL_ERR_NO_DEVICE;
+    };
+    struct PrefetchGuard { decltype(issue_pending_prefetch) &f; ~PrefetchGuard() { f(); } } prefetch_guard{issue_pending_prefetch};
 
     // covariance projection helpers (optimize.cpp:220-232): rows then columns of the so3 / S2 blocks
     auto left3 = [](Mat17 &dst, const Mat3 &J, const Mat17 &src) {
@@ -254,6 +264,7 @@ optimizeSummary lioOptimization::solveIEKF(const icpOptions &cur_icp_options, cl
         Mat17 covariance, temp;
         bool prior_done = false;
         auto prior = [&]() {
+        issue_pending_prefetch();            // (first pass only: a no-op afterwards) the next sweep starts crossing PCIe while this pass's kernel runs
         // prior error state (optimize.cpp:172-211)
         const Vec3 d_p = eskf_pro->getTranslation() - p_predict;
         const Quat d_q = q_predict.inverse() * eskf_pro->getRotation();

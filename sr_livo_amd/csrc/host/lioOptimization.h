@@ -184,6 +184,8 @@ public:
     // upload the NEXT sweep on the copy stream while solveIEKF() works on the current one; swapSweep() makes it the pinned one
     int prefetchSweep(const double *raw_xyz, int n);
     int swapSweep();
+    // ... the same upload issued by the next solveIEKF() beside the kernel of its first pass (srl_lio_prefetch_sweep_during_solve)
+    void prefetchSweepDuringSolve(const double *raw_xyz, int n) { pending_prefetch_raw = raw_xyz; pending_prefetch_n = n; }
     bool sweepPinned(int n) const { return sweep_pinned && resident_n == n; }
     // updateIEKF on the sweep already resident in HBM (no keypoint vector needed)
     optimizeSummary solveIEKF(const icpOptions &cur_icp_options, cloudFrame *p_frame);
@@ -221,6 +223,9 @@ private:
     void *provider_user = nullptr;
     int resident_n = -1;
     int prefetched_n = -1;
+    const double *pending_prefetch_raw = nullptr;      // prefetchSweepDuringSolve: issued by the next solve's first pass
+    int pending_prefetch_n = -1;
+    int pending_prefetch_rc = 0;
     bool sweep_pinned = false;
 };
 

@@ -227,6 +227,12 @@ int srl_lio_prefetch_sweep(srl_lio *h, const double *raw_xyz, int n) {
     if (!h || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
     return h->lio->prefetchSweep(raw_xyz, n);
 }
+int srl_lio_prefetch_sweep_during_solve(srl_lio *h, const double *raw_xyz, int n) {
+    if (!h || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
+    if (!h->lio->context()) return SRL_ERR_NO_DEVICE;
+    h->lio->prefetchSweepDuringSolve(raw_xyz, n);
+    return SRL_OK;
+}
 int srl_lio_swap_sweep(srl_lio *h) {
     if (!h) return SRL_ERR_BAD_ARG;
     return h->lio->swapSweep();

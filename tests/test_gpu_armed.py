@@ -199,7 +199,7 @@ def _sweeps(sc, count, sizes=None):
     return out
 
 
-def _stream(sc, sweeps, opts, rounds, frame_id=100):
+def _stream(sc, sweeps, opts, rounds, frame_id=100, during_solve=False):
     """the node's loop over a stream of sweeps: the next sweep is uploaded while the current one is solved (srl_sweep_prefetch), made
     current behind the solve (srl_sweep_swap); returns the solved states in order"""
     lio = sc["lio"]
@@ -208,7 +208,8 @@ def _stream(sc, sweeps, opts, rounds, frame_id=100):
     lio.prefetch_sweep(sweeps[0]["pin"].array); lio.swap_sweep()
     states = []
     for k in range(rounds):
-        lio.prefetch_sweep(sweeps[(k + 1) % S]["pin"].array)
+        # the next sweep's upload: before the solve, or issued by the solve itself beside its first kernel (srl_lio_prefetch_sweep_during_solve)
+        (lio.prefetch_sweep_during_solve if during_solve else lio.prefetch_sweep)(sweeps[(k + 1) % S]["pin"].array)
         rc, it, nr = solvers[k % S]()
         assert rc == 0
         states.append((it, nr, solvers[k % S].state.copy(), lio.eskf_get_cov().copy()))
@@ -240,16 +241,16 @@ def test_a_launch_armed_behind_the_last_pass_becomes_the_first_pass_of_the_next_
         lio.ctx.set_armed_launch(True)
         _stream(sc, sw, opts, 4)                                            # (the pass count of a solve is learnt from the solve before it)
         s0 = lio.ctx.arm_stats()
-        got = _stream(sc, sw, opts, 16)
+        got = _stream(sc, sw, opts, 8) + _stream(sc, sw, opts, 8, during_solve=True)
         s1 = lio.ctx.arm_stats()
         for k, g in enumerate(got):
-            r = ref[k % 8] if k < 8 else ref[k % 4 + 4]
+            r = ref[k % 8]
             assert g[0] == r[0] and g[1] == r[1], (k, g[:2], r[:2])
             assert np.array_equal(g[2], r[2]) and np.array_equal(g[3], r[3]), k
         passes = sum(g[0] for g in got)
         # the very first pass of the series has no launch waiting; the disarm at the end of _stream cancels the one armed behind the last pass
-        assert s1["fired"] - s0["fired"] >= passes - 1, (s0, s1, passes)
-        assert s1["cancelled"] - s0["cancelled"] <= 1, (s0, s1)
+        assert s1["fired"] - s0["fired"] >= passes - 2, (s0, s1, passes)
+        assert s1["cancelled"] - s0["cancelled"] <= 2, (s0, s1)
         assert s1["expired"] == s0["expired"]
     finally:
         lio.ctx.set_armed_launch(True)

@@ -44,7 +44,7 @@ def run(name, n_solves=400):
             its = 0
             for k in range(n_solves + 50):
                 t0 = time.perf_counter()
-                lio.prefetch_sweep(stream[(k + 1) % S]["pin"].array)
+                lio.prefetch_sweep_during_solve(stream[(k + 1) % S]["pin"].array)
                 t1 = time.perf_counter()
                 rc, it, nr = stream[k % S]["solve"]()
                 t2 = time.perf_counter()
