@@ -226,9 +226,13 @@ class Streamer:
     one from its own prior -> swap.  Every sweep crosses PCIe exactly once per solve; no host synchronisation."""
 
     def __init__(self, lio, stream, opts, prior_cov, frame_id, n_kp):
+        import ctypes
         self.lio, self.stream, self.S, self.pos = lio, stream, len(stream), 0
         for e in stream:
             e["solve"] = lio.bound_solver(opts, e["prior_state"], prior_cov, e["state0"], e["sweep"]["t_last"], frame_id, n_kp)
+            e["ptr"] = e["pin"].array.ctypes.data_as(ctypes.c_void_p)          # arguments converted once: the loop below calls the C entry points directly
+            e["n"] = int(len(e["pin"].array))
+        self._prefetch, self._swap, self._h = lio.lib.srl_lio_prefetch_sweep_during_solve, lio.lib.srl_lio_swap_sweep, lio.h
 
     def begin(self):
         self.lio.prefetch_sweep(self.stream[self.pos % self.S]["pin"].array)
@@ -238,11 +242,12 @@ class Streamer:
         k = self.pos
         e = self.stream[k % self.S]
         # sweep k + 1 arrives during the solve of sweep k: its upload is issued by the solve itself, beside the kernel of the first pass
-        self.lio.prefetch_sweep_during_solve(self.stream[(k + 1) % self.S]["pin"].array)
-        rc, it, nr = e["solve"]()
+        nx = self.stream[(k + 1) % self.S]
+        rc = self._prefetch(self._h, nx["ptr"], nx["n"])
+        rc2, it, nr = e["solve"]()
+        rc = rc or rc2 or self._swap(self._h)
         if rc:
-            raise RuntimeError(f"update_iekf failed with status {rc} on sweep {k % self.S} of the stream")
-        self.lio.swap_sweep()
+            raise RuntimeError(f"stream step failed with status {rc} on sweep {k % self.S} of the stream")
         self.pos = k + 1
         return {"iters": it, "num_residuals": nr, "state": e["solve"].state, "sweep": k % self.S}
 

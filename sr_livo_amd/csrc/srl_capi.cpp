@@ -31,6 +31,7 @@ int srl_map_insert_device(struct srl_ctx *ctx, const double *world_xyz, int n, d
 namespace {
 
 unsigned next_pow2(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return p; }
+inline long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Live contexts per device.  An armed launch keeps one workgroup per CU resident until its pose arrives: with a second context on the
 // same device each side would stall the other for the full linger, so launches are only armed while the context has its device to
@@ -425,7 +426,14 @@ int srl_sweep_swap(srl_ctx *ctx) {
     // usual case: it was issued a whole solve ago) the launch stays and becomes the first pass of the sweep swapped in -- fired through
     // the pose box with SRL_ARM_ALT, no launch on the critical path of the new solve.  An upload still in flight is awaited by the
     // compute stream as before, and a launch already waiting in front of that dependency is cancelled (it could start too early).
-    const hipError_t up = hipEventQuery(ctx->next_ready);
+    hipError_t up = hipEventQuery(ctx->next_ready);
+    if (up == hipErrorNotReady && ctx->armed && ctx->next_n <= ctx->work_cap) {
+        // the last bytes of the upload are still on their way and a launch is waiting that could serve the new sweep: cancelling it and
+        // launching afresh costs ~8 us -- give the DMA up to 25 us first (a short solve behind a long sweep: the shipped max_num_residuals
+        // = 600 reads 4 480 keypoints of a sweep whose 64k points cross PCIe in ~40 us)
+        const long long t_give_up = steady_ns() + 25000;
+        while ((up = hipEventQuery(ctx->next_ready)) == hipErrorNotReady && steady_ns() < t_give_up) { }
+    }
     if (up != hipSuccess && up != hipErrorNotReady) { ctx->err = std::string("hipEventQuery: ") + hipGetErrorString(up); return SRL_ERR_HIP; }
     if (up != hipSuccess || ctx->next_n > ctx->work_cap) SRL_DISARM(ctx);   // (growing the work buffers frees them: never under a waiting launch)
     if (up != hipSuccess) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->next_ready, 0));       // compute waits for the upload; the host does not
@@ -579,7 +587,6 @@ int srl_get_timing(srl_ctx *ctx, srl_timing *t) {
 // prologue in srl_kernels.hip).  A pass whose arguments equal the armed launch's FIRES it (one 384-byte write instead of a launch);
 // anything else -- other options, another sweep, another entry point -- cancels it (control granule) and launches normally.
 namespace {
-inline long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Can the CPU store into device memory (pose box kind 1)?  Asked of the runtime, never probed by faulting: the device must report a
 // large PCIe BAR (hipDeviceAttributeIsLargeBar: the whole of its memory is CPU-addressable) and the runtime must know the
