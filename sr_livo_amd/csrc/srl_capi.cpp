@@ -177,7 +177,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->comm);
     if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
-                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_stage_cur, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
+                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_cut_guess, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_stage_cur, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
                     ctx->d_tap_offset, ctx->d_gather, ctx->d_peer, ctx->d_mail};
     for (int r = 0; r < SRL_MAX_PEERS; r++) if (ctx->peer_mapped[r]) hipIpcCloseMemHandle(ctx->peer_mapped[r]);
     if (ctx->d_inbox) hipFree(ctx->d_inbox);
@@ -902,7 +902,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         ring_ev = ctx->ring[ctx->ring_head % srl_ctx::PROF_RING];
     }
 
-    can_fuse_cut = can_fuse_cut && wpb == 16 && kpb <= SRL_FUSED_CUT_MAX_KPB && nblocks <= SRL_FUSED_MAX_BLOCKS;
+    can_fuse_cut = can_fuse_cut && wpb == 16 && kpb <= SRL_FUSED_CUT_MAX_KPB && nblocks <= 512;      // (the finisher reads one row's counters per thread)
     const bool fused = (can_fuse && wpb == 16 && nblocks <= SRL_FUSED_MAX_BLOCKS) || can_fuse_cut;
     unsigned long long seq_now = ++ctx->seq;          // (a cancelled armed launch below takes this number with it: see there)
     const bool coll = ctx->comm && (ctx->nranks > 1 || ctx->force_coll) && !ctx->peer_on;
@@ -941,6 +941,11 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             HIPCHK(ctx, hipMemsetAsync(ctx->d_rec_granules, 0, need * sizeof(unsigned long long), ctx->stream));   // no stale tag can match
             ctx->rec_granule_cap = need;
         }
+        if (!ctx->d_cut_guess) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_cut_guess, 64));
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_cut_guess, 0, 64, ctx->stream));
+        }
+        a.cut_guess = ctx->d_cut_guess;
         a.rec_granules = ctx->d_rec_granules;
         a.cut_max = o->max_num_residuals;
         a.write_rec = 0;                                    // nobody reads the global records: the finisher has the granules
@@ -948,13 +953,14 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
 
     // ---- armed launch: fire the kernel that is already waiting for this pass, if its arguments are this pass's
     const bool fast_sel = o->select_mode == 0 || o->select_mode == 4;
-    const bool arm_ok = ctx->arm_mode != 0 && fused && single_rank && !peer && !coll && wpb == 16 && nblocks <= ctx->num_cu && fast_sel &&
+    // (a grid larger than the chip is armed too: its first round waits resident, the later rounds find the pose in the box when they start)
+    const bool arm_ok = ctx->arm_mode != 0 && fused && single_rank && !peer && !coll && wpb == 16 && fast_sel &&
                         a.ablate == 0 && !prof && !ctx->taps;
     auto signature = [](const SrlAssocArgs &src) {
         SrlAssocArgs sg = src;
         std::memset(sg.Rn, 0, sizeof sg.Rn); std::memset(sg.R, 0, sizeof sg.R); std::memset(sg.t, 0, sizeof sg.t);
         std::memset(sg.t_last, 0, sizeof sg.t_last);       // (optimize.cpp:25: per sweep -- it travels through the pose box with the pose)
-        sg.pose_box = nullptr; sg.pose_relay = nullptr; sg.pose_epoch = 0; sg.arm_linger_ticks = 0;
+        sg.pose_box = nullptr; sg.pose_relay = nullptr; sg.pose_relayed = 0; sg.pose_epoch = 0; sg.arm_linger_ticks = 0;
         // the sweep (either buffer of the context) and its keypoint count travel with the pose: compared separately below
         sg.raw_x = sg.raw_y = sg.raw_z = nullptr; sg.alt_x = sg.alt_y = sg.alt_z = nullptr; sg.n = 0; sg.aos = nullptr; sg.alt_aos = nullptr;
         return sg;
@@ -1021,7 +1027,8 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         nx.alt_y = has_alt ? ctx->d_raw_next + ctx->next_cap : nullptr;
         nx.alt_z = has_alt ? ctx->d_raw_next + 2 * (size_t)ctx->next_cap : nullptr;
         nx.pose_box = ctx->h_pose_box;                    // (host-mapped pinned memory and CPU-visible device memory: one address for both sides)
-        nx.pose_relay = ctx->pose_box_kind == 1 ? nullptr : ctx->d_pose_relay;
+        nx.pose_relay = ctx->d_pose_relay;
+        nx.pose_relayed = ctx->pose_box_kind == 1 ? 0 : 1;
         nx.pose_epoch = (unsigned)nx.seq;
         nx.arm_linger_ticks = ctx->arm_linger_ticks;
         hipEvent_t *nev = nullptr;

@@ -35,7 +35,7 @@
 #define SRL_TABLE_FACTOR 4u   // hash slots per voxel capacity (load <= 0.25: a 2-slot probe almost always resolves)
 #define SRL_PART_STRIDE 32
 #define SRL_ROW_GRANULES 128  // published row of a workgroup (fused final reduction): 64 granules = 32 doubles, 8 = acceptance mask of <= 256 keypoints
-#define SRL_FUSED_MAX_BLOCKS 512
+#define SRL_FUSED_MAX_BLOCKS 2048    // workgroups of a fused pass (published rows): 256k keypoints in 256-keypoint workgroups = 1 024
 #define SRL_FUSED_CUT_MAX_KPB 64   // fused ordered cut: the finisher re-reads one workgroup's records, one granule per thread
 
 struct SrlMapSlot {
@@ -160,6 +160,8 @@ struct SrlAssocArgs {
     unsigned long long *granules;   // nblocks x SRL_ROW_GRANULES tagged 8-byte granules {epoch, 32-bit payload}: the published rows (null = not fused)
     unsigned long long *rec_granules;   // fused ORDERED CUT: per keypoint 16 tagged granules = the record {J[6], distance, weight} (else null)
     long long cut_max;              // fused ordered cut: max_num_residuals (> 0), the sequential loop's budget (optimize.cpp:107); 0 = no cut possible
+    int *cut_guess;                 // fused ordered cut: device word, the workgroup that held the max-th accepted residual in the previous pass (the
+                                    // finisher fetches that workgroup's records together with the rows, and leaves its own finding for the next pass)
     SrlMailbox *mailbox;        // host-mapped result mailbox (fused + RCCL: a device-side mailbox the all-reduce then works on)
     int mail_tagged;            // 1: the finisher reports in the mailbox's tagged form (host mailbox), 0: plain form + sequence word
     int pad_mail;
@@ -170,7 +172,10 @@ struct SrlAssocArgs {
                                           // SRL_ARM_ALT runs on it -- the first pass of the next sweep without a launch on its critical path
     const double *alt_aos;                // ... whose points still lie AoS (n x 3) in the prefetch's staging buffer: that pass reads them
                                           // there and files the SoA planes alt_x / alt_y / alt_z itself (see `aos`)
-    unsigned long long *pose_relay;       // device memory workgroup 0 republishes the box into for the others (null: everybody polls the box)
+    unsigned long long *pose_relay;       // device memory: pose_relayed != 0 -- workgroup 0 republishes the box into it for the others; else everybody
+                                          // polls the box and only a launch that gave up waiting leaves a note here (workgroups of later rounds leave at once)
+    int pose_relayed;
+    int pad_relay;
     unsigned pose_epoch;                  // tag of THIS launch's pose (low 32 bits of its sequence number, never 0)
     unsigned arm_linger_ticks;            // 100 MHz ticks an armed launch waits at most (safety net)
     long long *stamps;                    // debug time line of armed passes (host-mapped, 64 rows x 16 slots; null = off)

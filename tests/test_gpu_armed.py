@@ -329,3 +329,42 @@ def test_a_second_context_on_the_device_keeps_launches_from_being_armed(scene):
         other.close()
     a(); a()
     assert lio.ctx.arm_stats()["armed"] > s1["armed"] and np.array_equal(a.state, ref)
+
+
+@pytest.mark.parametrize("n_big", [70_000, 140_000])
+def test_a_sweep_of_more_workgroups_than_compute_units_stays_fused_and_armed(scene_L, n_big):
+    """70 000 / 140 000 keypoints = 274 / 547 workgroups of 256 on 256 compute units: the pass runs in rounds -- still one kernel per ESIKF
+    iteration (fused final reduction over up to 2 048 rows) and armed like any other pass: the first round waits resident for its pose,
+    the later rounds find it in the box when they start.  Bit-identical to the same pass launched per iteration, and equal to the
+    un-fused pass (reduce kernel) up to summation order"""
+    sc = scene_L
+    lio = sc["lio"]
+    n_kp, map_pts, pattern, seed = synth.CONFIGS["C1"]
+    sw = synth.make_sweep(seed + 3000, n_big, sc["L"], pattern=pattern)
+    ps = sc["prior_state"].copy()
+    ps[0:3] = sw["t_pred"]; ps[3:7] = sw["q_pred"]; ps[7:10] = sw["vel"]
+    st0 = np.concatenate([sw["q_pred"], sw["t_pred"], sw["vel"], np.zeros(6)])
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    try:
+        lio.resident_sweep(sw["raw"])
+        solve = lio.bound_solver(opts, ps, sc["prior_cov"], st0, sw["t_last"], 100, n_big)
+        lio.ctx.set_armed_launch(False)
+        rc, it, nr = solve()
+        assert rc == 0 and it >= 2
+        ref, ref_cov, launches = solve.state.copy(), lio.eskf_get_cov().copy(), lio.last_solve_launches()
+        assert launches == it                                               # one kernel per iteration: fused although the grid exceeds the chip
+        lio.ctx.set_fused_reduce(0)
+        solve()
+        unfused = solve.state.copy()
+        lio.ctx.set_fused_reduce(1)
+        assert np.max(np.abs(unfused - ref)) <= 1e-12 * np.max(np.abs(ref))
+        lio.ctx.set_armed_launch(ALWAYS)
+        s0 = lio.ctx.arm_stats()
+        for _ in range(4):
+            rc, it2, nr2 = solve()
+            assert rc == 0 and (it2, nr2) == (it, nr) and np.array_equal(solve.state, ref) and np.array_equal(lio.eskf_get_cov(), ref_cov)
+        s1 = lio.ctx.arm_stats()
+        assert s1["fired"] - s0["fired"] == 4 * it - 1 and s1["expired"] == s0["expired"]
+    finally:
+        lio.ctx.set_armed_launch(True)
+        lio.resident_sweep(sc["sweep"]["raw"])
