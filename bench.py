@@ -344,6 +344,16 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
             rc_r, it_r, _nr = solve()
         lio.ctx.disarm(); torch.cuda.synchronize()
         el_r = time.perf_counter() - t_r
+        # ... and with a launch armed behind EVERY pass (srl_set_armed_launch(2)): the loop rounds 1-4 quoted, in which the launch armed by the
+        # last pass of a solve is fired by the first pass of the next solve of the SAME sweep -- kept for comparison with those rounds only
+        lio.ctx.set_armed_launch(2)
+        solve(); solve()
+        t_r2 = time.perf_counter()
+        for _ in range(steps):
+            solve()
+        el_r2 = time.perf_counter() - t_r2
+        lio.ctx.disarm(); torch.cuda.synchronize()
+        lio.ctx.set_armed_launch(True)
         lio.ctx.set_fused_reduce(0)
         solve()
         lio.ctx.set_profiling(2)
@@ -363,6 +373,7 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
                "launch_per_iteration_ab": {"ms_per_esikf_iter": el_un * 1e3 / max(its_un, 1), "state_bitwise_equal": un_equal,
                                            "what": "armed launches off (srl_set_armed_launch(0)), same stream"},
                "resident_resolve_us_per_iter": el_r / steps * 1e6 / max(it_r, 1),
+               "resident_resolve_always_armed_us_per_iter": el_r2 / steps * 1e6 / max(it_r, 1),
                "kernel_us": assoc_ms * 1e3, "passes_per_launch": passes_per_launch, "kernel_us_per_pass": assoc_ms * 1e3 / passes_per_launch,
                "assoc_kernel_us": assoc_ms * 1e3 / passes_per_launch, "assoc_launches": tim.calls,
                "keypoints_per_launch": tim.sum_keypoints / calls, "algorithmic_MB_per_launch": bytes_per_launch / 1e6,
@@ -571,6 +582,7 @@ def compact_line(out):
         issue = ((c.get("profile") or {}).get("issue") or {}).get("frac")
         cfgs.append({"name": c["name"], "us_per_iter": c["ms_per_esikf_iter"] * 1e3, "kernel_us": c.get("kernel_us", c.get("assoc_kernel_us")), "frac": c.get("hbm_roofline_frac"),
                      "issue_frac": issue, "sweeps_per_s": c["sweeps_per_s"], "iters": c["esikf_iterations"], "armed": c.get("armed"),
+                     "us_per_iter_r04_loop": c.get("resident_resolve_always_armed_us_per_iter"),
                      "parity_ok": (c.get("parity") or {}).get("ok")})
     if cfgs:
         line["configs"] = cfgs
