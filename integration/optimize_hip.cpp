@@ -149,7 +149,6 @@ srl_icp_opts to_abi(const icpOptions &o) {
     s.max_num_residuals = o.max_num_residuals;
     s.weight_alpha = o.weight_alpha;
     s.weight_neighborhood = o.weight_neighborhood;
-    s.select_mode = 0;
     return s;
 }
 

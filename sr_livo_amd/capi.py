@@ -39,8 +39,10 @@ class IcpOpts(C.Structure):
         ("max_dist_to_plane_icp", C.c_double), ("threshold_orientation_norm", C.c_double),
         ("threshold_translation_norm", C.c_double), ("max_num_residuals", C.c_int32),
         ("weight_alpha", C.c_double), ("weight_neighborhood", C.c_double),
-        ("select_mode", C.c_int32),
     ]
+    # test hook, NOT part of the struct (srl_icp_opts = the reference's icpOptions fields only): default_opts(select_mode=...) keeps the
+    # wish as a Python attribute and the wrappers hand it to srl_debug_set_select_mode before the call
+    select_mode = 0
 
 
 class Frame(C.Structure):
@@ -164,6 +166,7 @@ def load_library():
         "srl_get_arm_stats": ([p, C.POINTER(C.c_uint64)], C.c_int),
         "srl_debug_set_launch_shape": ([p, C.c_int, C.c_int], C.c_int),
         "srl_debug_set_search_select_mode": ([p, C.c_int], C.c_int),
+        "srl_debug_set_select_mode": ([p, C.c_int], C.c_int),
         "srl_debug_heap_topk": ([p, C.c_int, C.c_int, p], C.c_int),
         "srl_debug_device_sqrt": ([p, p, C.c_int, p], C.c_int),
         "srl_set_profiling": ([p, C.c_int], C.c_int),
@@ -225,7 +228,7 @@ def load_library():
 def declared_symbols():
     """Every function name declared in include/srlivo_hip.h and include/srlivo_host.h."""
     names = []
-    for hdr in ("srlivo_hip.h", "srlivo_host.h"):
+    for hdr in ("srlivo_hip.h", "srlivo_hip_debug.h", "srlivo_host.h"):
         text = open(os.path.join(INCLUDE_DIR, hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names += re.findall(r"\b(srl_[a-z0-9_]+)\s*\(", text)
@@ -447,13 +450,22 @@ class Context:
         self._chk(self.lib.srl_get_timing(self.h, C.byref(t)), "srl_get_timing")
         return t
 
+    def _select(self, opts):
+        """test hook: the selection path wished for with default_opts(select_mode=...) (srl_debug_set_select_mode; sticky per context)"""
+        mode = int(getattr(opts, "select_mode", 0) or 0)
+        if mode != getattr(self, "_select_mode", 0):
+            self._chk(self.lib.srl_debug_set_select_mode(self.h, mode), "srl_debug_set_select_mode")
+            self._select_mode = mode
+
     def build_residuals(self, frame, opts, allow=(SRL_ERR_NAN_PLANARITY,)):
+        self._select(opts)
         out = NormalEq()
         rc = self._chk(self.lib.srl_build_residuals(self.h, C.byref(frame), C.byref(opts), C.byref(out)), "srl_build_residuals", ok=allow)
         return out, rc
 
     def build_residuals_overlap(self, frame, opts, fn, allow=(SRL_ERR_NAN_PLANARITY,)):
         """srl_build_residuals with a host callback (a Python callable without arguments) run while the kernels are in flight."""
+        self._select(opts)
         out = NormalEq()
         cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _u: fn())
         rc = self._chk(self.lib.srl_build_residuals_overlap(self.h, C.byref(frame), C.byref(opts), C.byref(out), cb, None),
@@ -796,6 +808,8 @@ class Lio:
     def update_iekf(self, opts, raw_xyz, state, t_last, frame_id=100, log_iters=0, n_resident=None,
                     allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):
         """raw_xyz=None uses the sweep pinned by resident_sweep (n_resident = its size)."""
+        if self.ctx is not None:
+            self.ctx._select(opts)
         st = _f64(state).copy()
         log = np.zeros((max(log_iters, 1), 61)) if log_iters else None
         iters, nres = C.c_int(), C.c_int()
@@ -813,6 +827,8 @@ class Lio:
         """A zero-allocation closure for repeated solves of the resident sweep from the same prior (bench / replay
         loops): every argument is converted once; each call = srl_lio_eskf_set_state + _set_cov + srl_lio_update_iekf.
         Returns (status, iterations, residuals); the solved state is left in `solver.state`."""
+        if self.ctx is not None:
+            self.ctx._select(opts)
         es = _f64(eskf_state).copy(); ec = _f64(eskf_cov).ravel().copy()
         st0 = _f64(state).copy(); st = st0.copy(); tl = _f64(t_last).copy()
         iters, nres = C.c_int(), C.c_int()
@@ -833,6 +849,8 @@ class Lio:
     def update_iekf_provided(self, opts, provider, n, state, t_last, frame_id=100, log_iters=0,
                              allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):
         """provider(frame: Frame, opts: IcpOpts, out: NormalEq) -> int status."""
+        if self.ctx is not None:
+            self.ctx._select(opts)
         def _p(fp, op, outp, _user):
             return int(provider(fp.contents, op.contents, outp.contents))
         self._provider = PROVIDER_FN(_p)
@@ -846,6 +864,8 @@ class Lio:
 
     def optimize(self, opts, sample_voxel_size, frame_raw, frame_world, state, t_last, frame_id=100,
                  allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):
+        if self.ctx is not None:
+            self.ctx._select(opts)
         raw = _f64(frame_raw, (-1, 3))
         world = _f64(frame_world, (-1, 3)).copy()
         st = _f64(state).copy()
@@ -890,6 +910,8 @@ class Lio:
 
     def optimize_resident(self, opts, sample_voxel_size, frame_raw, state, t_last, frame_id=100,
                           allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):
+        if self.ctx is not None:
+            self.ctx._select(opts)
         raw = _f64(frame_raw, (-1, 3))
         st = _f64(state).copy()
         kidx = np.empty(max(len(raw), 1), dtype=np.int32)
@@ -918,6 +940,8 @@ class Lio:
         return dict(center=c, normal=n, covariance=cov.reshape(3, 3), a2D=a.value)
 
     def build_plane_residuals(self, opts, raw_xyz, state, t_last, frame_id=100):
+        if self.ctx is not None:
+            self.ctx._select(opts)
         r = _f64(raw_xyz, (-1, 3))
         rows = np.zeros((len(r), 15)); world = np.zeros((len(r), 3))
         nout, succ = C.c_int(), C.c_int(); loss = C.c_double()

@@ -27,7 +27,6 @@ public:
     double weight_neighborhood = 0.1;
     bool debug_print = true;
     bool debug_viz = false;
-    int select_mode = 0;   // ours (test hook, see srl_icp_opts)
 
     srl_icp_opts toAbi() const {
         srl_icp_opts o;
@@ -45,7 +44,6 @@ public:
         o.max_num_residuals = max_num_residuals;
         o.weight_alpha = weight_alpha;
         o.weight_neighborhood = weight_neighborhood;
-        o.select_mode = select_mode;
         return o;
     }
     static icpOptions fromAbi(const srl_icp_opts &o) {
@@ -64,7 +62,6 @@ public:
         r.max_num_residuals = o.max_num_residuals;
         r.weight_alpha = o.weight_alpha;
         r.weight_neighborhood = o.weight_neighborhood;
-        r.select_mode = o.select_mode;
         return r;
     }
 };

@@ -2,6 +2,7 @@
 // Host plumbing only (buffers, stream, hash-table build, RCCL); all arithmetic of the hot path runs
 // in the HIP kernels of srl_kernels.hip / srl_map_kernels.hip.  No CPU fallback exists.
 #include "../../include/srlivo_hip.h"
+#include "../../include/srlivo_hip_debug.h"
 #include "host/srl_la.h"
 #include "srl_device.h"
 #include "srl_hash.h"
@@ -131,7 +132,6 @@ void srl_icp_opts_default(srl_icp_opts *o) {
     o->max_num_residuals = 600;
     o->weight_alpha = 0.9;
     o->weight_neighborhood = 0.1;
-    o->select_mode = 0;
 }
 
 int srl_ctx_create(int device, srl_ctx **out) {
@@ -806,7 +806,7 @@ static int prepare_assoc_args(srl_ctx *ctx, const srl_frame *f, const srl_icp_op
     a.K = K;
     a.min_nb = o->min_number_neighbors;
     a.thr_cap = thr;
-    a.select_mode = o->select_mode;
+    a.select_mode = ctx->select_mode;                           // 0 unless srl_debug_set_select_mode was called (tests)
     a.ablate = ctx->ablate;                                     // 0 unless srl_debug_set_ablate was called (profiling tools only)
     a.stamps = ctx->h_arm_stamps;                               // null unless srl_debug_pass_stamps is on
     a.rec = ctx->d_rec;
@@ -952,7 +952,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     }
 
     // ---- armed launch: fire the kernel that is already waiting for this pass, if its arguments are this pass's
-    const bool fast_sel = o->select_mode == 0 || o->select_mode == 4;
+    const bool fast_sel = ctx->select_mode == 0 || ctx->select_mode == 4;
     // (a grid larger than the chip is armed too: its first round waits resident, the later rounds find the pose in the box when they start)
     const bool arm_ok = ctx->arm_mode != 0 && fused && single_rank && !peer && !coll && wpb == 16 && fast_sel &&
                         a.ablate == 0 && !prof && !ctx->taps;
@@ -1390,6 +1390,12 @@ int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable) {
     if (!ctx) return SRL_ERR_BAD_ARG;
     SRL_DISARM(ctx);
     ctx->fuse_reduce = enable != 0;
+    return SRL_OK;
+}
+int srl_debug_set_select_mode(srl_ctx *ctx, int select_mode) {
+    if (!ctx || select_mode < 0 || select_mode > 5) return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
+    ctx->select_mode = select_mode;
     return SRL_OK;
 }
 int srl_debug_set_search_select_mode(srl_ctx *ctx, int select_mode) {

@@ -40,6 +40,7 @@ struct srl_ctx {
     int total_n = 0;
     bool sweep_loaded = false;         // a sweep (possibly empty) has been uploaded / selected
     int search_select_mode = 0;        // srl_debug_set_search_select_mode: selection path of srl_search_neighbors (tests)
+    int select_mode = 0;               // srl_debug_set_select_mode: selection path of srl_build_residuals (tests; 0 = automatic)
     int ablate = 0;                    // srl_debug_set_ablate (profiling tools only; never set by the product)
     void (*overlap_fn)(void *) = nullptr;   // srl_build_residuals_overlap: host work to run while the kernels are in flight
     void *overlap_user = nullptr;
