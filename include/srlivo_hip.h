@@ -104,6 +104,28 @@ int srl_map_insert(srl_ctx *ctx, const double *world_xyz, int n, double voxel_si
 int srl_map_size(srl_ctx *ctx, int64_t *num_points, int32_t *num_voxels);
 /* copies the device map back in creation order (same layout as srl_map_upload) */
 int srl_map_download(srl_ctx *ctx, int16_t *keys_xyz, int32_t *counts, float *xyz, int max_voxels);
+/* A cheap fingerprint of the part of the map a set of points falls into -- what a caller that keeps a map of its OWN (the node's
+ * tsl::robin_map, lioOptimization.h:274) compares frame by frame instead of walking both maps: for every point the voxel it belongs to
+ * (key = short(float(p) / voxel_size), lioOptimization.cpp:403-405) contributes srl_probe_mix(key, points in the voxel, position of the
+ * voxel's LAST stored point); a point without a voxel contributes 0; the checksum is the sum modulo 2^64 (points of one voxel count
+ * once each: no deduplication on either side).  world_xyz = host points (n x 3), or NULL: the world points the last srl_frame_commit
+ * left in HBM (n is then ignored; the empty sum when a newer frame has been uploaded since).  stride >= 1: only the points 0, stride,
+ * 2 stride, ... take part (a sample keeps the caller's side of the comparison cheap).  Waits for a deferred insertion to finish. */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline uint64_t srl_probe_mix(int16_t kx, int16_t ky, int16_t kz, int32_t count, float lx, float ly, float lz) {
+    union { float f; uint32_t u; } a, b, c;
+    a.f = lx; b.f = ly; c.f = lz;
+    uint64_t h = (uint64_t)(uint16_t)kx | ((uint64_t)(uint16_t)ky << 16) | ((uint64_t)(uint16_t)kz << 32) | ((uint64_t)(uint32_t)count << 48);
+    h = (h ^ (h >> 31)) * 0x9E3779B97F4A7C15ull;
+    h ^= ((uint64_t)a.u << 32) | b.u;
+    h = (h ^ (h >> 29)) * 0xBF58476D1CE4E5B9ull;
+    h ^= c.u;
+    h = (h ^ (h >> 32)) * 0x94D049BB133111EBull;
+    return h ^ (h >> 30);
+}
+int srl_map_probe_checksum(srl_ctx *ctx, const double *world_xyz, int n, int stride, double voxel_size, uint64_t *checksum);
 
 /* ------------------------------------------------------------------ sweep
  * replaces: the `keypoints` vector handed to updateIEKF (optimize.cpp:133; point3D::raw_point,

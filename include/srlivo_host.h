@@ -48,6 +48,8 @@ int srl_lio_eskf_observe(srl_lio *lio, const double dx[17]);
 int srl_lio_add_points_to_map(srl_lio *lio, const double *world_xyz, int n, double voxel_size,
                               int max_num_points_in_voxel, double min_distance_points, int min_num_points);
 int srl_lio_map_size(srl_lio *lio, int64_t *num_points);
+/* srl_map_probe_checksum over the world points the last srl_lio_commit_frame left in HBM (the frame the node inserts next) */
+int srl_lio_probe_checksum_of_committed_frame(srl_lio *lio, int stride, double voxel_size, uint64_t *checksum, int32_t *num_voxels);
 
 /* keep a sweep resident in HBM for the next srl_lio_update_iekf (pass raw_xyz = NULL there) */
 int srl_lio_resident_sweep(srl_lio *lio, const double *raw_xyz, int n);

@@ -24,8 +24,10 @@
 // optimize() succeeded is committed on the device inside optimize(), from the very world points the node inserts right after it
 // (lioOptimization.cpp:1003-1027); the frames before frame_id 2, which stateEstimation inserts without calling optimize, are
 // uploaded and inserted before the next solve (srl_map_insert reproduces addPointToMap's order-dependent semantics bit for bit).
-// mapSize() of the two maps is compared during the first calls and every 32nd afterwards (the node's mapSize walks every voxel):
-// on a difference the device copy is rebuilt from voxel_map (the node's map is the truth), with one line on stderr -- never a silent drift.
+// EVERY call compares the two maps where the frame inserted last touched them (a sample of its points: voxel, point count, last stored
+// point -- srl_map_probe_checksum -- and the voxel totals); mapSize() of both whole maps is compared during the first calls and every
+// 32nd afterwards (the node's mapSize walks every voxel).  On a difference the device copy is rebuilt from voxel_map (the node's map is
+// the truth), with one line on stderr -- never a silent drift, and never one that outlives the next frame.
 //
 // tests/test_gpu_integration.py compiles this file together with the reference's own translation units
 // (oracle/Makefile, target refnode_hip) and drives the reference's run() over the 40-sweep replay stream.
@@ -63,6 +65,8 @@ struct HipBinding {
     double *pinned_world = nullptr;           // point3D::point of the committed frame (download target), page-locked, kept across calls
     long calls = 0;
     long resyncs = 0;                         // times the device map had to be rebuilt from voxel_map (sync_device_map)
+    int last_commit_frame_id = -1;            // the frame optimize() committed last on the device (the node inserts it right after the call) ...
+    int last_commit_n = 0;                    // ... and its number of points
     // (freed by srl_integration_release, not by a destructor: a binding still alive at process exit would call into a HIP runtime that is
     // already shutting down)
     void free_buffers() { if (pinned_raw) srl_pinned_free(pinned_raw); if (pinned_world) srl_pinned_free(pinned_world); pinned_raw = pinned_world = nullptr; pinned_cap = 0; }
@@ -210,11 +214,47 @@ static void sync_device_map(lioOptimization *self, HipBinding &b, const std::vec
         }
         b.last_frame_handled = f->frame_id;
     }
-    if (!(b.calls < 16 || b.calls % 32 == 0)) return;       // the node's mapSize() walks every voxel of its map
+    // EVERY call: the frame committed by the previous optimize() has since been inserted by the node too (lioOptimization.cpp:1027).  Both
+    // maps are probed with a sample of that frame's points -- every 16th: the voxel it falls into, how many points the voxel holds and
+    // where its last stored point lies (srl_map_probe_checksum; the device side is one small kernel over the world points still in HBM,
+    // the node's side ~n/16 finds) -- and the voxel counts are compared (tsl::robin_map::size() is O(1)).  A divergence is caught on the
+    // frame after it happened; the walk over both whole maps (mapSize) stays as the slow, exhaustive check every 32nd call.
+    bool differ = false;
+    if (b.last_commit_frame_id >= 0) {
+        const cloudFrame *prev = nullptr;
+        for (const cloudFrame *f : window) if (f != current && f->frame_id == b.last_commit_frame_id) prev = f;
+        if (prev && (int)prev->point_frame.size() == b.last_commit_n) {
+            constexpr int STRIDE = 16;
+            uint64_t on_dev = 0, on_host = 0;
+            int32_t dev_voxels = 0;
+            const int rcp = srl_lio_probe_checksum_of_committed_frame(b.lio, STRIDE, oo.optimize_options.size_voxel_map, &on_dev, &dev_voxels);
+            if (rcp != SRL_OK) fail(b.lio, rcp, "srl_lio_probe_checksum_of_committed_frame");
+            const double vs = oo.optimize_options.size_voxel_map;
+            for (size_t k = 0; k < prev->point_frame.size(); k += STRIDE) {
+                const float fx = (float)prev->point_frame[k].point[0], fy = (float)prev->point_frame[k].point[1], fz = (float)prev->point_frame[k].point[2];
+                const short kx = static_cast<short>((double)fx / vs), ky = static_cast<short>((double)fy / vs), kz = static_cast<short>((double)fz / vs);
+                auto it = host_map.find(voxel(kx, ky, kz));
+                if (it == host_map.end()) continue;
+                voxelBlock &blk = it.value();                 // (getPosition() is not const-qualified in the reference's rgbPoint)
+                const int c = blk.NumPoints();
+                if (c <= 0) continue;
+                const Eigen::Vector3d last = blk.points[c - 1].getPosition();
+                on_host += srl_probe_mix(kx, ky, kz, c, (float)last[0], (float)last[1], (float)last[2]);
+            }
+            differ = on_dev != on_host || (size_t)dev_voxels != host_map.size();
+        }
+        b.last_commit_frame_id = -1;
+    }
     int64_t on_device = 0;
-    const int rc = srl_lio_map_size(b.lio, &on_device);
-    if (rc != SRL_OK) fail(b.lio, rc, "srl_lio_map_size");
-    if ((size_t)on_device != self->mapSize(host_map)) {
+    if (!differ) {
+        if (!(b.calls < 16 || b.calls % 32 == 0)) return;       // the node's mapSize() walks every voxel of its map
+        const int rc = srl_lio_map_size(b.lio, &on_device);
+        if (rc != SRL_OK) fail(b.lio, rc, "srl_lio_map_size");
+        differ = (size_t)on_device != self->mapSize(host_map);
+    } else {
+        (void)srl_lio_map_size(b.lio, &on_device);
+    }
+    if (differ) {
         // The device copy has fallen out of step with voxel_map (something other than addPointsToMap touched one of them): the node's map is
         // the truth -- rebuild the device copy from it, voxel by voxel in the stored point order, and say so once.
         static bool said = false;
@@ -312,6 +352,8 @@ optimizeSummary lioOptimization::optimize(cloudFrame *p_frame, const icpOptions 
                                          odometry_options.min_distance_points, 0, n > 0 ? b.pinned_world : nullptr, nullptr);
     if (rcc != SRL_OK) fail(lio, rcc, "srl_lio_commit_frame");
     b.committed[p_frame->frame_id] = true;
+    b.last_commit_frame_id = p_frame->frame_id;
+    b.last_commit_n = n;
     if (b.committed.size() > 64) b.committed.erase(b.committed.begin());
     for (int k = 0; k < n; k++) p_frame->point_frame[k].point = Eigen::Vector3d(b.pinned_world[3 * (size_t)k], b.pinned_world[3 * (size_t)k + 1], b.pinned_world[3 * (size_t)k + 2]);
     return optimize_summary;

@@ -115,6 +115,7 @@ def load_library():
         "srl_map_insert": ([p, p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)], C.c_int),
         "srl_map_size": ([p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)], C.c_int),
         "srl_map_download": ([p, p, p, p, C.c_int], C.c_int),
+        "srl_map_probe_checksum": ([p, p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_uint64)], C.c_int),
         "srl_sweep_upload": ([p, p, C.c_int], C.c_int),
         "srl_sweep_shard": ([p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_sweep_prefetch": ([p, p, C.c_int], C.c_int),
@@ -189,6 +190,7 @@ def load_library():
         "srl_lio_eskf_observe": ([p, dp], C.c_int),
         "srl_lio_add_points_to_map": ([p, p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int], C.c_int),
         "srl_lio_map_size": ([p, C.POINTER(C.c_int64)], C.c_int),
+        "srl_lio_probe_checksum_of_committed_frame": ([p, C.c_int, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)], C.c_int),
         "srl_lio_resident_sweep": ([p, p, C.c_int], C.c_int),
         "srl_lio_prefetch_sweep": ([p, p, C.c_int], C.c_int),
         "srl_lio_swap_sweep": ([p], C.c_int),
@@ -232,7 +234,7 @@ def declared_symbols():
         text = open(os.path.join(INCLUDE_DIR, hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names += re.findall(r"\b(srl_[a-z0-9_]+)\s*\(", text)
-    skip = {"srl_allreduce_fn", "srl_allgather_i64_fn", "srl_normal_eq_provider"}
+    skip = {"srl_allreduce_fn", "srl_allgather_i64_fn", "srl_normal_eq_provider", "srl_probe_mix"}      # (types, and the inline helper of the header)
     return sorted(set(n for n in names if n not in skip))
 
 
@@ -410,6 +412,17 @@ class Context:
         npnt, nv = C.c_int64(), C.c_int32()
         self._chk(self.lib.srl_map_size(self.h, C.byref(npnt), C.byref(nv)), "srl_map_size")
         return npnt.value, nv.value
+
+    def map_probe_checksum(self, world_xyz=None, stride=1, voxel_size=1.0):
+        """srl_map_probe_checksum: world_xyz None = the world points of the last committed frame"""
+        out = C.c_uint64()
+        if world_xyz is None:
+            rc = self.lib.srl_map_probe_checksum(self.h, None, 0, int(stride), float(voxel_size), C.byref(out))
+        else:
+            w = _f64(world_xyz, (-1, 3))
+            rc = self.lib.srl_map_probe_checksum(self.h, _ptr(w), len(w), int(stride), float(voxel_size), C.byref(out))
+        self._chk(rc, "srl_map_probe_checksum")
+        return out.value
 
     def map_download(self, cap=20):
         _, nv = self.map_size()

@@ -218,6 +218,15 @@ int srl_lio_map_size(srl_lio *h, int64_t *num_points) {
     return SRL_OK;
 }
 
+int srl_lio_probe_checksum_of_committed_frame(srl_lio *h, int stride, double voxel_size, uint64_t *checksum, int32_t *num_voxels) {
+    if (!h || !checksum) return SRL_ERR_BAD_ARG;
+    srl_ctx *ctx = h->lio->context();
+    if (!ctx) return SRL_ERR_NO_DEVICE;
+    int rc = srl_map_probe_checksum(ctx, nullptr, 0, stride, voxel_size, checksum);
+    if (rc == SRL_OK && num_voxels) rc = srl_map_size(ctx, nullptr, num_voxels);
+    return rc;
+}
+
 int srl_lio_resident_sweep(srl_lio *h, const double *raw_xyz, int n) {
     if (!h || n < 0 || (n > 0 && !raw_xyz)) return SRL_ERR_BAD_ARG;
     return h->lio->residentSweep(raw_xyz, n);

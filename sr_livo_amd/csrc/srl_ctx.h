@@ -62,6 +62,7 @@ struct srl_ctx {
     double *d_frame_world = nullptr;   // AoS n x 3
     int frame_cap = 0;
     int frame_n = -1;
+    int frame_world_n = -1;            // points of d_frame_world as the last srl_frame_commit left them (-1: none, or a newer frame uploaded since)
     // undistorted sweep (srl_frame_undistort): inputs, imu_point, corrected raw_point
     double *d_corr_in = nullptr, *d_corr_rel = nullptr, *d_corr_imu = nullptr, *d_corr_raw = nullptr;
     int *d_corr_seg = nullptr;

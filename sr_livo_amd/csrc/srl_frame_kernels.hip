@@ -437,6 +437,7 @@ int srl_frame_take(srl_ctx *ctx, const int32_t *index, int m) {
     int rc = ensure_frame(ctx, m);
     if (rc) return rc;
     ctx->frame_n = m;
+    ctx->frame_world_n = -1;
     if (m > 0) {
         DevBuf b_sel;
         HIPCHK(ctx, b_sel.alloc(ctx, (size_t)m * 4));
@@ -455,6 +456,7 @@ int srl_frame_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     int rc0 = ensure_frame(ctx, n);
     if (rc0) return rc0;
     ctx->frame_n = n;
+    ctx->frame_world_n = -1;
     srl_stage_begin(ctx);
     if (n > 0) {
         if (!srl_ctx_is_pinned(raw_xyz)) {
@@ -631,6 +633,7 @@ int srl_frame_commit(srl_ctx *ctx, const double q[4], const double t[3], const d
     // waited for on their own event, which fires long before the insert behind them is done
     const int rci = srl_map_insert_impl(ctx, ctx->d_frame_world, true, n, voxel_size, min_distance_points, min_num_points, num_added, num_added == nullptr);
     if (world_out) HIPCHK(ctx, hipEventSynchronize(ctx->ev_world));
+    if (rci == SRL_OK) ctx->frame_world_n = n;            // d_frame_world = the frame as inserted (srl_map_probe_checksum)
     return rci;
 }
 

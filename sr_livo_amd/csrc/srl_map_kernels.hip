@@ -277,6 +277,34 @@ __global__ void __launch_bounds__(128) k_replay(const int *seg_start, const unsi
     if (added) atomicAdd(added_total, added);
 }
 
+// srl_map_probe_checksum: every point looks its voxel up and adds srl_probe_mix(key, count, last stored point) to one 64-bit sum
+__global__ void k_probe_checksum(const double *xyz, int n, int stride, double voxel_size, const SrlMapSlot *table, unsigned mask, const unsigned char *slabs,
+                                 unsigned long long *sum) {
+    const long long i = (long long)(blockIdx.x * blockDim.x + threadIdx.x) * stride;
+    unsigned long long mine = 0ull;
+    if (i < n) {
+        const float fx = (float)xyz[(size_t)i * 3], fy = (float)xyz[(size_t)i * 3 + 1], fz = (float)xyz[(size_t)i * 3 + 2];
+        const short kx = (short)(int)((double)fx / voxel_size), ky = (short)(int)((double)fy / voxel_size), kz = (short)(int)((double)fz / voxel_size);
+        const unsigned long long key = srl_pack_key(kx, ky, kz);
+        unsigned h = srl_hash_key(key) & mask;
+        for (unsigned probe = 0; probe <= mask; ++probe) {
+            const SrlMapSlot sl = table[h];
+            if (sl.key == key) {
+                const SrlSlab *sb = reinterpret_cast<const SrlSlab *>(slabs + (size_t)sl.slab * SRL_SLAB_BYTES);
+                const int c = (int)sb->count;
+                if (c > 0) mine = srl_probe_mix(kx, ky, kz, c, sb->xyz[c - 1][0], sb->xyz[c - 1][1], sb->xyz[c - 1][2]);
+                break;
+            }
+            if (sl.key == SRL_EMPTY_KEY) break;
+            h = (h + 1) & mask;
+        }
+    }
+    // wave sum first (integers: order free), one atomic per wave
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & 63) == 0 && mine != 0ull) atomicAdd(sum, mine);
+}
+
 __global__ void k_rebuild_table(const unsigned char *slabs, int V, SrlMapSlot *table, unsigned mask) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
@@ -302,6 +330,38 @@ unsigned next_pow2u(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return 
 }  // namespace
 
 // grow slab storage / hash table so that `need_slabs` voxels fit with load <= 0.5
+extern "C" int srl_map_probe_checksum(srl_ctx *ctx, const double *world_xyz, int n, int stride, double voxel_size, uint64_t *checksum) {
+    if (!ctx || !checksum || !(voxel_size > 0.0) || (world_xyz && n < 0) || stride < 1) return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
+    *checksum = 0;
+    if (!ctx->d_table) return SRL_ERR_NO_MAP;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    { const int rcs = srl_map_settle(ctx); if (rcs) return rcs; }
+    const double *d_pts = nullptr;
+    DevBuf b_pts, b_sum;
+    if (world_xyz) {
+        if (n == 0) return SRL_OK;
+        HIPCHK(ctx, b_pts.alloc(ctx, (size_t)n * 3 * sizeof(double)));
+        HIPCHK(ctx, hipMemcpyAsync(b_pts.p, world_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        d_pts = b_pts.as<double>();
+    } else {
+        if (ctx->frame_world_n <= 0 || !ctx->d_frame_world) return SRL_OK;     // nothing committed (or a newer frame uploaded since): the empty sum
+        n = ctx->frame_world_n;
+        d_pts = ctx->d_frame_world;
+    }
+    HIPCHK(ctx, b_sum.alloc(ctx, 256));
+    HIPCHK(ctx, hipMemsetAsync(b_sum.p, 0, 8, ctx->stream));
+    const int probes = (n + stride - 1) / stride;
+    hipLaunchKernelGGL(k_probe_checksum, dim3((probes + 255) / 256), dim3(256), 0, ctx->stream, d_pts, n, stride, voxel_size, ctx->d_table, ctx->table_cap - 1,
+                       ctx->d_slabs, b_sum.as<unsigned long long>());
+    HIPCHK(ctx, hipGetLastError());
+    unsigned long long out = 0ull;
+    HIPCHK(ctx, hipMemcpyAsync(&out, b_sum.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *checksum = (uint64_t)out;
+    return SRL_OK;
+}
+
 int srl_ctx_grow_map(srl_ctx *ctx, unsigned need_slabs, unsigned need_slots) {
     const unsigned new_slab_cap = ctx->slab_cap >= need_slabs ? ctx->slab_cap : std::max(need_slabs + need_slabs / 2u, 1024u);
     if (new_slab_cap > SRL_MAX_SLABS) { ctx->err = "map too large: slab byte offsets are 32-bit (16.7 M voxels)"; return SRL_ERR_UNSUPPORTED; }

@@ -1706,3 +1706,40 @@ def test_thread_pin_to_gpu_numa_restricts_the_calling_thread_to_the_local_cpus()
     finally:
         os.sched_setaffinity(0, before)
         ctx.close()
+
+
+def test_map_probe_checksum_matches_a_host_walk_of_the_same_map():
+    """srl_map_probe_checksum (what integration/optimize_hip.cpp compares frame by frame with the node's own map): every probed point
+    contributes srl_probe_mix(voxel key, points in the voxel, last stored point); recomputed here from the downloaded map"""
+    M = (1 << 64) - 1
+
+    def mix(kx, ky, kz, count, last):
+        a, b, c = (int(x) for x in np.asarray(last, np.float32).view(np.uint32))
+        h = (kx & 0xFFFF) | ((ky & 0xFFFF) << 16) | ((kz & 0xFFFF) << 32) | ((count & 0xFFFFFFFF) << 48)
+        h &= M
+        h = ((h ^ (h >> 31)) * 0x9E3779B97F4A7C15) & M
+        h ^= (a << 32) | b
+        h = ((h ^ (h >> 29)) * 0xBF58476D1CE4E5B9) & M
+        h ^= c
+        h = ((h ^ (h >> 32)) * 0x94D049BB133111EB) & M
+        return h ^ (h >> 30)
+
+    pts, L = synth.map_candidates(99, 20_000)
+    ctx = srl.Context(0)
+    try:
+        ctx.map_insert(pts)
+        keys, counts, xyz = ctx.map_download()
+        vox = {tuple(int(v) for v in k): (int(c), xyz[i, c - 1]) for i, (k, c) in enumerate(zip(keys, counts)) if c > 0}
+        rng = np.random.default_rng(3)
+        probe = np.concatenate([pts[rng.choice(len(pts), 3000, replace=False)] + rng.normal(0, 0.2, (3000, 3)), rng.uniform(-500, 500, (200, 3))])
+        for stride in (1, 7):
+            want = 0
+            for p in probe[::stride]:
+                k = tuple(int(np.trunc(float(np.float32(v)) / 1.0)) for v in p)
+                if k in vox:
+                    want = (want + mix(k[0], k[1], k[2], vox[k][0], vox[k][1])) & M
+            assert ctx.map_probe_checksum(probe, stride=stride) == want, stride
+        # the committed frame's world points (NULL form): nothing committed on this context -> the empty sum
+        assert ctx.map_probe_checksum(None) == 0
+    finally:
+        ctx.close()
