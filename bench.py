@@ -865,6 +865,8 @@ def main():
                        "us_per_solve_p10_p50_p90_max": [float(np.percentile(per_long, q)) * 1e6 for q in (10, 50, 90, 100)],
                        "arm_stats": {k: arm_a2[k] - arm_b2[k] for k in arm_a2},
                        "solves_over_1ms": int(np.count_nonzero(per_long > 1e-3))}
+    elapsed_rank = elapsed                    # this rank's own clock (the line carries min / max over the ranks)
+    comm_state = lio.ctx.comm_info()          # (read while the communicator / peer table of the timed region is still attached)
     elapsed = max_over_ranks(elapsed)
     launches_per_solve = launches_timed
     # A/B: the same stream with one launch call per ESIKF iteration on the critical path (armed launches off: round 3's form), with the
@@ -1110,8 +1112,22 @@ def main():
                          "srl_sweep_prefetch / srl_sweep_swap); pinned / pageable = upload and solve back to back on one stream"},
         "setup_s": setup_s, "clock_warmup": {"ms": args.clock_warmup_ms, "solves": n_cw},
     }
-    if comm_info:
-        out["comm"] = comm_info
+    if comm_info is not None or world > 1:
+        # every --gpus N line explains what it ran on: the transport the library actually used after bench.py's fallback chain, the ranks
+        # the communicator itself counts, each rank's own per-iteration time (gloo all-gather) and the time behind the association kernel
+        # (reduce / exchange / publish) from the post-region profiling pass
+        ci = dict(comm_info or {})
+        try:
+            ci.update(comm_state)
+        except Exception as e:  # noqa: BLE001
+            ci["info_error"] = repr(e)
+        us_rank = elapsed_rank * 1e6 / max(iters_timed, 1)
+        if dist is not None:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, us_rank)
+            ci["us_per_iter_per_rank"] = {"min": float(min(per_rank)), "max": float(max(per_rank))}
+        ci["behind_association_kernel_us"] = tim_full.sum_reduce_ms / fcalls * 1e3
+        out["comm"] = ci
     if world > 1:
         out["multi_gpu_note"] = "no multi-GPU scaling curve has been measured by the builder (gpurun boxes expose one GPU); this line is it"
     if replicas_rate is not None:

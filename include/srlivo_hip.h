@@ -289,6 +289,11 @@ int srl_comm_destroy(srl_ctx *ctx);
  * process, never two.  origin = path of that shared object, version = ncclGetVersion, preloaded = 1 when it was found in the
  * process.  SRL_ERR_COMM (origin = reason) when no RCCL is available; single-GPU use never needs one. */
 int srl_comm_backend_info(char *origin, int origin_len, int *version, int *preloaded);
+/* What the sharded path of this context runs on, for a run that has to explain itself (bench.py prints it for every --gpus N line):
+ * transport 0 none (unsharded), 1 RCCL all-reduce, 2 direct peer exchange, 3 host callbacks; nranks / rank as attached; ranks_seen = the
+ * communicator's own count (ncclCommCount) or the number of peer inboxes mapped -- equal to nranks when every rank really joined;
+ * passes_armed = armed launches fired on this context so far (0 on a path that never arms).  Any pointer may be NULL. */
+int srl_comm_info(srl_ctx *ctx, int *transport, int *nranks, int *rank, int *ranks_seen, int64_t *passes_armed);
 /* suspend != 0: run unsharded (whole sweep, no collective) while keeping the communicator; 0: back to sharded mode.
  * Re-upload the sweep after switching. */
 int srl_comm_suspend(srl_ctx *ctx, int suspend);

@@ -145,6 +145,7 @@ def load_library():
         "srl_comm_destroy": ([p], C.c_int),
         "srl_comm_set_library": ([C.c_char_p], C.c_int),
         "srl_comm_suspend": ([p, C.c_int], C.c_int),
+        "srl_comm_info": ([p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)], C.c_int),
         "srl_comm_set_host_callbacks": ([p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, p], C.c_int),
         "srl_debug_set_gather_counts": ([p, C.c_int, C.c_int, C.POINTER(C.c_int64)], C.c_int),
         "srl_peer_export": ([p, p, C.POINTER(p)], C.c_int),
@@ -677,6 +678,13 @@ class Context:
         if local_ptrs is not None:
             lp = (C.c_void_p * nranks)(*[C.c_void_p(int(x) if x else None) for x in local_ptrs])
         self._chk(self.lib.srl_peer_attach(self.h, int(nranks), int(rank), hb, lp), "srl_peer_attach")
+
+    def comm_info(self):
+        """srl_comm_info: what the sharded path of this context runs on"""
+        tr, nr, rk, seen, armed = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+        self._chk(self.lib.srl_comm_info(self.h, C.byref(tr), C.byref(nr), C.byref(rk), C.byref(seen), C.byref(armed)), "srl_comm_info")
+        return dict(transport_used=("none", "rccl", "peer", "host-callbacks")[tr.value], nranks=nr.value, rank=rk.value, ranks_seen=seen.value,
+                    passes_armed=armed.value)
 
     def peer_detach(self):
         self._chk(self.lib.srl_peer_detach(self.h), "srl_peer_detach")

@@ -1575,6 +1575,30 @@ int srl_comm_backend_info(char *origin, int origin_len, int *version, int *prelo
     return SRL_OK;
 }
 
+int srl_comm_info(srl_ctx *ctx, int *transport, int *nranks, int *rank, int *ranks_seen, int64_t *passes_armed) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    int tr = 0, seen = 1;
+    if (ctx->peer_on) {
+        tr = 2;
+        seen = ctx->peer_seen;
+    } else if (ctx->comm) {
+        tr = 1;
+        seen = ctx->nranks;
+        const SrlRccl *rc = srl_rccl();
+        int c = 0;
+        if (rc && rc->CommCount && rc->CommCount(ctx->comm, &c) == ncclSuccess) seen = c;
+    } else if (ctx->cb_ar && ctx->nranks > 1) {
+        tr = 3;
+        seen = ctx->nranks;
+    }
+    if (transport) *transport = tr;
+    if (nranks) *nranks = ctx->nranks;
+    if (rank) *rank = ctx->rank;
+    if (ranks_seen) *ranks_seen = seen;
+    if (passes_armed) *passes_armed = (int64_t)ctx->arm_stats[1];
+    return SRL_OK;
+}
+
 int srl_comm_suspend(srl_ctx *ctx, int suspend) {
     if (!ctx) return SRL_ERR_BAD_ARG;
     SRL_DISARM(ctx);
@@ -1670,6 +1694,8 @@ int srl_peer_attach(srl_ctx *ctx, int nranks, int rank, const void *ipc_handles,
     }
     if (!ctx->d_peer) { int rcp = ensure(ctx, ctx->d_peer, 1); if (rcp) return rcp; }
     HIPCHK(ctx, hipMemcpy(ctx->d_peer, &t, sizeof t, hipMemcpyHostToDevice));
+    ctx->peer_seen = 0;
+    for (int r = 0; r < nranks; r++) ctx->peer_seen += t.inbox[r] != nullptr ? 1 : 0;       // inboxes actually mapped (srl_comm_info)
     { int rcg = ensure_gather(ctx, (size_t)nranks); if (rcg) return rcg; }
     ctx->nranks = nranks; ctx->rank = rank;
     ctx->peer_on = nranks > 1;

@@ -179,6 +179,7 @@ struct srl_ctx {
     SrlPeerTable *d_peer = nullptr;            // the table the kernels read (device copy)
     void *peer_mapped[SRL_MAX_PEERS] = {};     // HIP IPC mappings of the other ranks' inboxes (closed at detach)
     bool peer_on = false;
+    int peer_seen = 0;                 // inboxes mapped at srl_peer_attach (srl_comm_info: equal to nranks when every rank's handle opened)
     bool peer_failed = false;          // a row of this session never arrived: no further exchange until srl_peer_export + srl_peer_attach
     unsigned long long peer_seq = 0;           // exchange counter: advances in lock-step on every rank
     SrlMailbox *d_mail = nullptr;              // device-side mailbox: where a FUSED pass leaves its rank's result for the RCCL all-reduce

@@ -24,6 +24,7 @@ bool sym(void *handle, const char *name, F &out) {
 }
 
 bool fill(void *handle) {
+    sym(handle, "ncclCommCount", g_tab.CommCount);          // optional
     return sym(handle, "ncclGetVersion", g_tab.GetVersion) && sym(handle, "ncclGetUniqueId", g_tab.GetUniqueId) &&
            sym(handle, "ncclCommInitRank", g_tab.CommInitRank) && sym(handle, "ncclCommDestroy", g_tab.CommDestroy) &&
            sym(handle, "ncclAllReduce", g_tab.AllReduce) && sym(handle, "ncclAllGather", g_tab.AllGather) &&

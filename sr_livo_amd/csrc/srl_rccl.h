@@ -17,6 +17,7 @@ struct SrlRccl {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     const char *(*GetErrorString)(ncclResult_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);      // optional (null when the instance lacks it): srl_comm_info
     int version;            // ncclGetVersion of the instance in use
     char origin[512];       // path of the shared object the entry points live in (dladdr)
     bool preloaded;         // true: an instance the process already had; false: dlopen'ed by this library

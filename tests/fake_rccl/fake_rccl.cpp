@@ -131,6 +131,13 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) {
+    const FakeComm *c = reinterpret_cast<const FakeComm *>(comm);
+    if (!c || !count) return ncclInvalidArgument;
+    *count = c->sh->joined.load();                                  // the ranks that actually met in the segment
+    return ncclSuccess;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     FakeComm *c = reinterpret_cast<FakeComm *>(comm);
     if (!c) return ncclSuccess;

@@ -59,6 +59,8 @@ while not os.path.exists(idp):
     if time.time() - t0 > 120: raise SystemExit(3)
     time.sleep(0.02)
 ctx.comm_init_rank(G, rank, open(idp, "rb").read())
+ci = ctx.comm_info()                                     # what bench.py prints for every --gpus N line (srl_comm_info)
+assert ci["transport_used"] == "rccl" and ci["nranks"] == G and ci["rank"] == rank and ci["ranks_seen"] == G, ci
 ctx.sweep_upload(g["raw"])                               # keeps this rank's contiguous point range (srl_shard_range)
 f = capi.make_frame(g["q_pred"], g["t_pred"], g["t_last"])
 for _ in range(4):                                       # back-to-back passes: the collectives of pass k + 1 queue behind those of pass k
