@@ -151,7 +151,10 @@ int srl_ctx_create(int device, srl_ctx **out) {
         delete ctx;
         return SRL_ERR_HIP;
     }
-    if (hipMalloc((void **)&ctx->d_granules, (size_t)SRL_FUSED_MAX_BLOCKS * SRL_ROW_GRANULES * 8) != hipSuccess || hipMemset(ctx->d_granules, 0, (size_t)SRL_FUSED_MAX_BLOCKS * SRL_ROW_GRANULES * 8) != hipSuccess) { delete ctx; return SRL_ERR_HIP; }
+    {
+        const size_t row_bytes = (size_t)(SRL_FUSED_MAX_BLOCKS + SRL_FUSED_MAX_GROUPS) * SRL_ROW_GRANULES * 8;     // rows + super rows
+        if (hipMalloc((void **)&ctx->d_granules, row_bytes) != hipSuccess || hipMemset(ctx->d_granules, 0, row_bytes) != hipSuccess) { delete ctx; return SRL_ERR_HIP; }
+    }
     if (hipHostMalloc((void **)&ctx->h_mail, sizeof(SrlMailbox), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         delete ctx;
         return SRL_ERR_HIP;

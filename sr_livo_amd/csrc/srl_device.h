@@ -36,6 +36,8 @@
 #define SRL_PART_STRIDE 32
 #define SRL_ROW_GRANULES 128  // published row of a workgroup (fused final reduction): 64 granules = 32 doubles, 8 = acceptance mask of <= 256 keypoints
 #define SRL_FUSED_MAX_BLOCKS 2048    // workgroups of a fused pass (published rows): 256k keypoints in 256-keypoint workgroups = 1 024
+#define SRL_FUSED_GROUP 256          // grids beyond 2 groups reduce in two levels: the last workgroup of every group of 256 sums its group's rows into a
+#define SRL_FUSED_MAX_GROUPS (SRL_FUSED_MAX_BLOCKS / SRL_FUSED_GROUP)   // "super row" (stored behind the rows); the grid's last workgroup adds the super rows
 #define SRL_FUSED_CUT_MAX_KPB 64   // fused ordered cut: the finisher re-reads one workgroup's records, one granule per thread
 
 struct SrlMapSlot {

@@ -1067,7 +1067,7 @@ __device__ inline void store_granule_pair(unsigned long long *, unsigned, unsign
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(unsigned long long *granules) {
-    return __builtin_amdgcn_make_buffer_rsrc((void *)granules, 0, SRL_FUSED_MAX_BLOCKS * SRL_ROW_GRANULES * 8, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)granules, 0, (SRL_FUSED_MAX_BLOCKS + SRL_FUSED_MAX_GROUPS) * SRL_ROW_GRANULES * 8, 0x00020000);
 }
 __device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t rs, int block, int comp, unsigned epoch, double v) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
@@ -1923,12 +1923,20 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
         int *s_bad = reinterpret_cast<int *>(smem + NPART * 32 * 8);
         if (tid == 0) *s_bad = 0;
         const int comp = tid & 31, part = tid >> 5;
-        const int nbk = (int)gridDim.x;
+        // Grids of more than two groups of SRL_FUSED_GROUP workgroups (sweeps beyond 128k keypoints) reduce in two levels: one compute unit
+        // pulls tagged rows at ~65 GB/s -- the 1 024 rows of a 256k-keypoint pass alone cost the single finisher 8 us (measured: no gain
+        // over the separate reduce kernel).  The last workgroup of every group sums the group's rows -- while the later rounds are still
+        // computing -- and publishes a "super row"; the grid's last workgroup adds its own group's rows and the super rows before it.
+        const bool two_level = (int)gridDim.x > 2 * SRL_FUSED_GROUP;
+        const int my_group = two_level ? (int)blockIdx.x / SRL_FUSED_GROUP : 0;
+        const int row_lo = my_group * SRL_FUSED_GROUP;
+        const int nbk = (int)blockIdx.x + 1;                               // rows row_lo .. blockIdx.x (the own row last: from LDS)
+        const bool is_last = blockIdx.x == gridDim.x - 1;
         const __amdgpu_buffer_rsrc_t rs = rows_rsrc(b.granules);
         const double *s_own = reinterpret_cast<const double *>(smem + SRL_OWN_ROW_OFFSET);          // this workgroup's own row (assoc_body)
         double s0 = 0.0;
         bool timed_out = false;
-        for (int r0 = part; r0 < nbk; r0 += NPART * INF) {
+        for (int r0 = row_lo + part; r0 < nbk; r0 += NPART * INF) {
             unsigned lo[INF], hi[INF];
             unsigned spins = 0;
             for (;;) {
@@ -1960,9 +1968,27 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
         if (tid < 32) {
             double sum = s_part[tid];
             for (int p = 1; p < NPART; ++p) sum += s_part[p * 32 + tid];
+            if (two_level && !is_last) {
+                // a group's finisher: the group's sum leaves as a super row (time-out: the row stays stale, the grid's finisher times out on it)
+                if (!*s_bad) row_store(rs, SRL_FUSED_MAX_BLOCKS + my_group, tid, epoch, sum);
+            } else if (two_level) {
+                // the grid's finisher: the super rows of the groups before its own, in group order
+                for (int g = 0; g < my_group; ++g) {
+                    unsigned spins = 0;
+                    v4u32 x;
+                    for (;;) {
+                        x = row_load(rs, SRL_FUSED_MAX_BLOCKS + g, tid);
+                        if (x.y == epoch && x.w == epoch) break;
+                        if (++spins > (1u << 18)) { atomicOr(s_bad, 1); x = v4u32{0u, 0u, 0u, 0u}; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    sum += __longlong_as_double((long long)(((unsigned long long)x.z << 32) | x.x));
+                }
+            }
             s_part[tid] = sum;                                             // row 0 = the totals
         }
         __syncthreads();
+        if (two_level && !is_last) return;
         arm_stamp(karg, 18);
         SrlDevOut *out = reinterpret_cast<SrlDevOut *>(smem + NPART * 32 * 8 + 64);
         bool peer_done = false;
@@ -2201,7 +2227,9 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
         // lane l publishes component l of the row (row_store: one 16-byte write-through store); the finishing workgroup keeps its own
         // row in LDS -- read back through memory it was the row the finisher's first poll always missed
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (blockIdx.x == gridDim.x - 1) reinterpret_cast<double *>(smem + SRL_OWN_ROW_OFFSET)[tid] = row_v;
+        const bool finishes = blockIdx.x == gridDim.x - 1 ||
+                              (b.cut_max == 0 && (int)gridDim.x > 2 * SRL_FUSED_GROUP && ((int)blockIdx.x % SRL_FUSED_GROUP) == SRL_FUSED_GROUP - 1);
+        if (finishes) reinterpret_cast<double *>(smem + SRL_OWN_ROW_OFFSET)[tid] = row_v;
         else row_store(rows_rsrc(b.granules), (int)blockIdx.x, tid, epoch, row_v);
 #endif
     } else if (tid >= 64 && tid < 72 && b.cut_max > 0) {
@@ -2222,7 +2250,9 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (ARMED) arm_stamp((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), 6);
-    if (blockIdx.x != gridDim.x - 1) return;
+    // the grid's last workgroup finishes; in a grid of more than two groups also the last workgroup of every group (two-level reduction)
+    const bool group_finisher = b.cut_max == 0 && (int)gridDim.x > 2 * SRL_FUSED_GROUP && ((int)blockIdx.x % SRL_FUSED_GROUP) == SRL_FUSED_GROUP - 1;
+    if (blockIdx.x != gridDim.x - 1 && !group_finisher) return;
     int n_total = b.n;
     if constexpr (ARMED) n_total = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(smem + L.off_pose + SRL_POSE_DOUBLES * 8)[1]);   // the count that came with the pose
     finish_rows<KPW, WPB>((KargBytes)__builtin_amdgcn_kernarg_segment_ptr(), epoch, n_total);
