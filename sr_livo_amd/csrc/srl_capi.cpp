@@ -180,7 +180,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->comm);
     if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
-                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_cut_guess, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_stage_cur, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
+                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_stage_cur, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
                     ctx->d_tap_offset, ctx->d_gather, ctx->d_peer, ctx->d_mail};
     for (int r = 0; r < SRL_MAX_PEERS; r++) if (ctx->peer_mapped[r]) hipIpcCloseMemHandle(ctx->peer_mapped[r]);
     if (ctx->d_inbox) hipFree(ctx->d_inbox);
@@ -944,11 +944,6 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             HIPCHK(ctx, hipMemsetAsync(ctx->d_rec_granules, 0, need * sizeof(unsigned long long), ctx->stream));   // no stale tag can match
             ctx->rec_granule_cap = need;
         }
-        if (!ctx->d_cut_guess) {
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_cut_guess, 64));
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_cut_guess, 0, 64, ctx->stream));
-        }
-        a.cut_guess = ctx->d_cut_guess;
         a.rec_granules = ctx->d_rec_granules;
         a.cut_max = o->max_num_residuals;
         a.write_rec = 0;                                    // nobody reads the global records: the finisher has the granules

@@ -114,7 +114,6 @@ struct srl_ctx {
     SrlDevOut *h_out = nullptr;        // pinned
     long long *d_count = nullptr;
     long long *h_count = nullptr;      // pinned
-    int *d_cut_guess = nullptr;                     // fused ordered cut: the previous pass's cut workgroup (SrlAssocArgs::cut_guess)
     unsigned long long *d_rec_granules = nullptr;   // fused ordered cut: 16 tagged granules per keypoint (the record), grown on demand
     size_t rec_granule_cap = 0;
     unsigned long long *d_granules = nullptr;   // published rows of the fused final reduction: 512 workgroups x 64 granules

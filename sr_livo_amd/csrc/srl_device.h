@@ -162,8 +162,6 @@ struct SrlAssocArgs {
     unsigned long long *granules;   // nblocks x SRL_ROW_GRANULES tagged 8-byte granules {epoch, 32-bit payload}: the published rows (null = not fused)
     unsigned long long *rec_granules;   // fused ORDERED CUT: per keypoint 16 tagged granules = the record {J[6], distance, weight} (else null)
     long long cut_max;              // fused ordered cut: max_num_residuals (> 0), the sequential loop's budget (optimize.cpp:107); 0 = no cut possible
-    int *cut_guess;                 // fused ordered cut: device word, the workgroup that held the max-th accepted residual in the previous pass (the
-                                    // finisher fetches that workgroup's records together with the rows, and leaves its own finding for the next pass)
     SrlMailbox *mailbox;        // host-mapped result mailbox (fused + RCCL: a device-side mailbox the all-reduce then works on)
     int mail_tagged;            // 1: the finisher reports in the mailbox's tagged form (host mailbox), 0: plain form + sequence word
     int pad_mail;

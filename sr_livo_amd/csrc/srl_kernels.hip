@@ -1734,55 +1734,24 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
             auto ld = [](const unsigned long long *p) { return __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
             auto fresh = [epoch](unsigned long long x) { return (unsigned)(x >> 32) == epoch; };
             auto as_double = [](unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
-            // ONE memory round trip for everything the finisher needs (round 4 took three in a row: counters -> rows -> records):
-            //   (a) the counters of row tid (accepted residuals, first NaN keypoint),
-            //   (b) this thread's share of the rows -- ALL of them: which rows count (r < c) is only known after the prefix over (a), the
-            //       others are dropped after the fact (they added +0.0 before: the sums keep their bits),
-            //   (c) the acceptance mask and the records of the workgroup GUESSED to hold the max-th accepted residual: the cut workgroup of
-            //       the previous pass (b.cut_guess, a device word the finisher leaves behind) -- from one ESIKF iteration to the next the
-            //       cut hardly moves; a wrong guess costs the second round trip that was always paid before.
+            // (a) four granules per thread, requested together (every poll round is one memory round trip, not four)
             const __amdgpu_buffer_rsrc_t rs = rows_rsrc(b.granules);
             const double *s_own = reinterpret_cast<const double *>(smem + SRL_OWN_ROW_OFFSET);      // this workgroup's own row (assoc_body)
-            int guess = b.cut_guess ? *reinterpret_cast<const volatile int *>(b.cut_guess) : 0;
-            guess = guess < 0 ? 0 : (guess >= nbk ? nbk - 1 : guess);
-            const int comp = tid & 31, part = tid >> 5;
-            const unsigned long long *pg_rec = b.rec_granules + (size_t)guess * KPB * 16 + (tid < KPB * 16 ? tid : 0);
-            const unsigned long long *pg_msk = b.granules + (size_t)guess * SRL_ROW_GRANULES + 64 + (tid & 7);
-            unsigned long long x_rec = 0ull, x_msk = 0ull;
-            unsigned lo[INF], hi[INF];
-            v4u32 x0 = v4u32{0u, 0u, 0u, 0u}, x1 = x0;
-            {
-                unsigned spins = 0;
-                for (;;) {
-                    bool ok = true;
-                    if (tid < nbk - 1) {
-                        x0 = row_load(rs, tid, 28); x1 = row_load(rs, tid, 30);
-                        ok = x0.y == epoch && x0.w == epoch && x1.y == epoch && x1.w == epoch;
-                    }
-#pragma unroll
-                    for (int k = 0; k < INF; ++k) {
-                        const int r = part + NPART * k;
-                        if (r < nbk - 1) {
-                            const v4u32 x = row_load(rs, r, comp);
-                            ok = ok && x.y == epoch && x.w == epoch;
-                            lo[k] = x.x; hi[k] = x.z;
-                        } else if (r == nbk - 1) {                                  // the own row: from LDS
-                            const unsigned long long ob = (unsigned long long)__double_as_longlong(s_own[comp]);
-                            lo[k] = (unsigned)ob; hi[k] = (unsigned)(ob >> 32);
-                        } else { lo[k] = 0u; hi[k] = 0u; }
-                    }
-                    x_rec = ld(pg_rec); x_msk = ld(pg_msk);
-                    ok = ok && fresh(x_rec) && fresh(x_msk);
-                    if (ok) break;
-                    if (++spins > (1u << 18)) { timed_out = true; x0 = x1 = v4u32{0u, 0u, 0u, 0u}; x_rec = 0ull; x_msk = 0ull; break; }
-                    __builtin_amdgcn_s_sleep(4);
-                }
-            }
             long long my_acc = 0;
             if (tid < nbk) {
                 double d_acc, d_nan;
                 if (tid == nbk - 1) { d_acc = s_own[28]; d_nan = s_own[30]; }
-                else { d_acc = as_double(x0.x, x0.z); d_nan = as_double(x1.x, x1.z); }
+                else {
+                    v4u32 x0, x1;
+                    unsigned spins = 0;
+                    for (;;) {
+                        x0 = row_load(rs, tid, 28); x1 = row_load(rs, tid, 30);
+                        if (x0.y == epoch && x0.w == epoch && x1.y == epoch && x1.w == epoch) break;
+                        if (++spins > (1u << 18)) { timed_out = true; x0 = x1 = v4u32{0u, 0u, 0u, 0u}; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    d_acc = as_double(x0.x, x0.z); d_nan = as_double(x1.x, x1.z);
+                }
                 my_acc = (long long)d_acc;
                 const int nanf = (int)d_nan;
                 if (nanf > 0) atomicMin(&s_i[4], tid * KPB + nanf - 1);
@@ -1803,27 +1772,16 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
             __syncthreads();
             const int c = s_i[1];
             const bool cut = c < nbk;
-            if (tid == 0 && b.cut_guess) *b.cut_guess = cut ? c : 0;              // the next pass's guess (a kernel boundary lies in between)
-            // (c) a wrong guess: workgroup c's mask and records after all (second round trip)
-            if (cut && c != guess) {
-                const unsigned long long *p_rec = b.rec_granules + (size_t)c * KPB * 16 + (tid < KPB * 16 ? tid : 0);
-                const unsigned long long *p_msk = b.granules + (size_t)c * SRL_ROW_GRANULES + 64 + (tid & 7);
-                unsigned spins = 0;
-                x_rec = ld(p_rec); x_msk = ld(p_msk);
-                while (!(fresh(x_rec) && fresh(x_msk))) {
-                    if (++spins > (1u << 18)) { timed_out = true; x_rec = 0ull; x_msk = 0ull; break; }
-                    __builtin_amdgcn_s_sleep(8);
-                    x_rec = ld(p_rec); x_msk = ld(p_msk);
-                }
-            }
-            // (b) the rows that count: r < c for the sums, every row for the counters (components 28..31)
+            // (c) workgroup c's acceptance mask and records: requested here, looked at after the row sums below (same round trip)
+            const unsigned long long *p_rec = b.rec_granules + (size_t)(cut ? c : 0) * KPB * 16 + (tid < KPB * 16 ? tid : 0);
+            const unsigned long long *p_msk = b.granules + (size_t)(cut ? c : 0) * SRL_ROW_GRANULES + 64 + (tid & 7);
+            unsigned long long x_rec = 0ull, x_msk = 0ull;
+            if (cut) { x_rec = ld(p_rec); x_msk = ld(p_msk); }
+            // (b)
+            const int comp = tid & 31, part = tid >> 5;
             double s0 = 0.0;
-#pragma unroll
-            for (int k = 0; k < INF; ++k) {
-                const int r = part + NPART * k;
-                if (r < nbk && (comp >= 28 || r < c)) s0 += as_double(lo[k], hi[k]);
-            }
-            for (int r0 = part + NPART * INF; r0 < nbk; r0 += NPART * INF) {      // (more than 256 workgroups: the remaining batches)
+            for (int r0 = part; r0 < nbk; r0 += NPART * INF) {
+                unsigned lo[INF], hi[INF];
                 unsigned spins = 0;
                 for (;;) {
                     bool ok = true;
@@ -1847,9 +1805,15 @@ __device__ __forceinline__ void finish_rows(KargBytes karg, const unsigned epoch
                 for (int k = 0; k < INF; ++k) s0 += as_double(lo[k], hi[k]);
             }
             if (cut) {
+                unsigned spins = 0;
+                while (!(fresh(x_rec) && fresh(x_msk))) {
+                    if (++spins > (1u << 18)) { timed_out = true; x_rec = 0ull; x_msk = 0ull; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                    x_rec = ld(p_rec); x_msk = ld(p_msk);
+                }
                 if (tid < 8) s_i[8 + tid] = (int)(unsigned)x_msk;
-                const unsigned hi2 = __shfl_down((unsigned)x_rec, 1);            // granule 2d + half of keypoint tid >> 4
-                if (tid < KPB * 16 && (tid & 1) == 0) s_recd[tid >> 1] = as_double((unsigned)x_rec, hi2);
+                const unsigned hi = __shfl_down((unsigned)x_rec, 1);            // granule 2d + half of keypoint tid >> 4
+                if (tid < KPB * 16 && (tid & 1) == 0) s_recd[tid >> 1] = as_double((unsigned)x_rec, hi);
             }
             if (timed_out) atomicOr(&s_i[0], 1);
             s_part[part * 32 + comp] = s0;
