@@ -1083,7 +1083,8 @@ def main():
                                   else ("replicas x%d" % world if world > 1 else "single GPU"),
                    "esikf_iterations_per_solve": iters_timed / max(args.steps, 1), "residuals_used": r["num_residuals"],
                    "kernel_launches_per_solve": launches_per_solve,
-                   "launch_mode": "one launch per ESIKF iteration" + ("" if args.no_armed else " (sharded passes are never armed)") if (args.no_armed or sharded) else "armed launches: the kernel of pass k+1 is enqueued while pass k runs and receives its pose through the pose box -- across srl_sweep_swap too (the launch armed behind a sweep's last pass is the next sweep's first pass)",
+                   "launch_mode": ("one launch per ESIKF iteration" + ("" if args.no_armed else " (sharded passes behind an RCCL all-reduce are not armed)")) if (args.no_armed or (sharded and arm_stats["fired"] == 0))
+                                  else "armed launches: the kernel of pass k+1 is enqueued while pass k runs and receives its pose through the pose box -- across srl_sweep_swap too (the launch armed behind a sweep's last pass is the next sweep's first pass)",
                    "value_is": "SURVEY 8(d)'s metric: sweeps/s of a stream of distinct sweeps, H2D of every sweep included (overlapped with the solve before it). "
                                "Rounds 1-4 printed the rate of ONE sweep re-solved in HBM: now `resident_resolve`; upload-then-solve without overlap:",
                    "pcie_inclusive_sweeps_per_s": {"pipelined_prefetch": rates["pipelined"], "pinned_upload_then_solve": rates["pinned"],

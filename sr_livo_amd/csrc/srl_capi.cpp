@@ -952,7 +952,13 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     // ---- armed launch: fire the kernel that is already waiting for this pass, if its arguments are this pass's
     const bool fast_sel = ctx->select_mode == 0 || ctx->select_mode == 4;
     // (a grid larger than the chip is armed too: its first round waits resident, the later rounds find the pose in the box when they start)
-    const bool arm_ok = ctx->arm_mode != 0 && fused && single_rank && !peer && !coll && wpb == 16 && fast_sel &&
+    // SHARDED passes are armed too where the rank's pass is ONE kernel that reports to this host: the direct peer exchange (the rows of the
+    // ranks meet inside the finishing workgroups; the armed launch carries the tag of the NEXT exchange -- every fused pass is exactly one)
+    // and the host-callback transport.  Every rank arms and fires its own launch from its own copy of the 17-dim update; a rank whose
+    // launch was cancelled or gave up simply launches the pass -- the exchange does not care how a kernel got there.  Not with RCCL
+    // (the all-reduce and the publish kernel sit between two passes on the stream) and not with the ordered cut (three exchanges per pass).
+    const bool host_cb = ctx->nranks > 1 && !coll && !peer && ctx->cb_ar != nullptr && !ctx->dbg_gather;
+    const bool arm_ok = ctx->arm_mode != 0 && fused && (single_rank || peer || host_cb) && !coll && wpb == 16 && fast_sel &&
                         a.ablate == 0 && !prof && !ctx->taps;
     auto signature = [](const SrlAssocArgs &src) {
         SrlAssocArgs sg = src;
@@ -1024,6 +1030,13 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         nx.alt_x = has_alt ? ctx->d_raw_next : nullptr;
         nx.alt_y = has_alt ? ctx->d_raw_next + ctx->next_cap : nullptr;
         nx.alt_z = has_alt ? ctx->d_raw_next + 2 * (size_t)ctx->next_cap : nullptr;
+        if (peer) {                                        // the exchange this launch will take part in: the one after this pass's
+            unsigned long long s2 = ctx->peer_seq + 1;
+            unsigned e2 = (unsigned)(s2 & 0xFFFFFFFFull);
+            if (e2 == 0) { ++s2; e2 = 1; }
+            nx.peer_epoch = e2;
+            nx.peer_slot = (int)(s2 & 1ull);
+        }
         nx.pose_box = ctx->h_pose_box;                    // (host-mapped pinned memory and CPU-visible device memory: one address for both sides)
         nx.pose_relay = ctx->d_pose_relay;
         nx.pose_relayed = ctx->pose_box_kind == 1 ? 0 : 1;
