@@ -554,7 +554,7 @@ int srl_set_profiling(srl_ctx *ctx, int enable) {
     if (ctx->profiling == 2) {
         HIPCHK(ctx, hipSetDevice(ctx->device));
         for (int i = 0; i < srl_ctx::PROF_RING; i++)
-            for (int k = 0; k < 2; k++) if (!ctx->ring[i][k]) HIPCHK(ctx, hipEventCreate(&ctx->ring[i][k]));
+            for (int k = 0; k < 2; k++) if (!ctx->ring[i][k]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ring[i][k], hipEventReleaseToDevice));   // (device-scope release: a timing marker between two kernels must not write the L2 back)
         ctx->ring_head = ctx->ring_tail = 0;
         std::memset(ctx->ring_void, 0, sizeof ctx->ring_void);
     }
