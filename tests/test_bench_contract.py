@@ -205,3 +205,37 @@ def test_gpus_n_without_a_launcher_becomes_its_own_launcher(monkeypatch):
     assert killed == [4243]                                             # the hung first attempt: its process group, nothing else
     out = [a[0] for a, k in printed if k.get("file") is None]
     assert len(out) == 1 and json.loads(out[0])["fallback"].startswith("sharded forms failed") and json.loads(out[0])["n_gpus"] == 4
+
+
+def test_round5_committed_line_times_the_stream_and_says_so():
+    """profiles/r05_bench.json: the line as printed in round 5.  `value` is SURVEY 8(d)'s metric -- a stream of distinct sweeps, each crossing
+    PCIe once per solve -- with the armed launches surviving the swaps (arm_stats: nothing cancelled), every sweep of the stream checked
+    against the oracle, C2@600 / C3@600 present, the untimed clock warm-up disclosed, the CPU baseline's caveat in the line."""
+    path = os.path.join(ROOT, "profiles", "r05_bench.json")
+    raw = open(path).read()
+    assert raw.count("\n") <= 1 and len(raw) < 8192
+
+    def no_constants(x):
+        raise AssertionError(f"non-strict JSON constant {x}")
+    d = json.loads(raw, parse_constant=no_constants)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "sweeps/s" and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "stream of" in d["config"]["workload"] and "crosses PCIe once" in d["config"]["workload"]
+    assert abs(d["value"] - full["value"]) / d["value"] < 1e-6 and abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-9
+    st = d["stream"]
+    assert st["sweeps"] >= 4 and st["solves"] >= 1000 and st["arm_stats"]["cancelled"] <= 2 and st["arm_stats"]["fired"] >= st["arm_stats"]["armed"] - 2
+    assert st["sweeps_per_s_mean"] >= 9500 and st["state_of_sweep0_equals_resident_solve"] is True
+    assert d["arm_stats"]["cancelled"] == 0 and d["arm_stats"]["expired"] == 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and r["profile_stale"] is False and r["traffic"] < r["algorithmic_bytes_per_launch"]
+    assert d["cpu_baseline"]["kind"] == "reference" and "stand-in Eigen" in d["cpu_baseline"]["note"]
+    p = d["parity"]
+    assert p["oracle_equals_reference_tu_bitwise"] is True and p["stream_sweeps_checked"] >= 4 and p["stream_counts_equal"] is True and p["stream_state_rel_err_vs_oracle_max"] < 1e-12
+    assert d["launch_ab"]["state_bitwise_equal"] is True and d["launch_ab"]["sweeps_compared"] >= 4
+    assert d["clock_warmup"]["solves"] > 0
+    names = [c["name"] for c in d["configs"]]
+    assert {"C1", "C2", "C3", "C4", "HEADLINE@600", "C2@600", "C3@600"} <= set(names)
+    assert all(c["parity_ok"] is True and c["armed"] is True for c in d["configs"])         # C4 included: 1 024 workgroups, fused and armed
+    assert all(c.get("issue_frac") is not None for c in d["configs"])
