@@ -19,6 +19,14 @@ extern "C" {
  * 4 Jacobi eigen-solver in phase 2, 5 heap replay (the reference's literal priority_queue sequence) for every keypoint. */
 int srl_debug_set_select_mode(srl_ctx *ctx, int select_mode);
 
+/* Where srl_frame_select_keypoints orders the keypoints (the iteration order of gridSampling's std::tr1::unordered_map,
+ * utility.cpp:167-201): 0 = on the device where it applies (the default: frames whose bucket table fits one scan launch), 1 = always the
+ * host replay of csrc/host/tr1_order.h (what rounds 3-4 shipped; still the path of larger frames and of a bucket with more than 16 voxels).
+ * srl_debug_frame_order_used: what the last selection did -- 1 device order, 2 host replay, 3 device order found an overfull bucket and
+ * the host replay ran behind it.  Both orders are the same permutation (tests/test_gpu_frame_order.py). */
+int srl_debug_set_frame_order_mode(srl_ctx *ctx, int mode);
+int srl_debug_frame_order_used(srl_ctx *ctx, int *used);
+
 /* test hook for the ON-DEVICE budget derivation of the sharded ordered cut (optimize.cpp:107 across ordered shards): the
  * context acts as rank `rank` of `nranks` whose on-stream all-gather of per-rank counts (accepted residuals; keypoints with a
  * plane when max_num_residuals <= 0) has already delivered `counts`; the all-reduce is the identity, so srl_build_residuals

@@ -166,6 +166,9 @@ int srl_grid_sampling(const double *world_xyz, int n, double size_voxel, int32_t
  * inserting n DISTINCT voxel keys in the given order, by the flat replay of the container's bucket moves that
  * srl_frame_select_keypoints uses (csrc/host/tr1_order.h; no container is built).  order_out[r] = index of the r-th element. */
 int srl_debug_tr1_order(const int16_t *keys_xyz, int n, int32_t *order_out);
+/* ... and the same order computed the way the DEVICE does it for frames that fit (csrc/host/tr1_relation.h: the container's iteration
+ * order as a relation between two elements -- no replay; the functions the kernels call, compiled for the host). */
+int srl_debug_tr1_order_by_relation(const int16_t *keys_xyz, int n, int32_t *order_out);
 
 #ifdef __cplusplus
 }

@@ -169,6 +169,8 @@ def load_library():
         "srl_debug_set_launch_shape": ([p, C.c_int, C.c_int], C.c_int),
         "srl_debug_set_search_select_mode": ([p, C.c_int], C.c_int),
         "srl_debug_set_select_mode": ([p, C.c_int], C.c_int),
+        "srl_debug_set_frame_order_mode": ([p, C.c_int], C.c_int),
+        "srl_debug_frame_order_used": ([p, C.POINTER(C.c_int)], C.c_int),
         "srl_debug_heap_topk": ([p, C.c_int, C.c_int, p], C.c_int),
         "srl_debug_device_sqrt": ([p, p, C.c_int, p], C.c_int),
         "srl_set_profiling": ([p, C.c_int], C.c_int),
@@ -219,6 +221,7 @@ def load_library():
                                            C.POINTER(C.c_int), dp, C.POINTER(C.c_int), p], C.c_int),
         "srl_grid_sampling": ([p, C.c_int, C.c_double, p, C.POINTER(C.c_int)], C.c_int),
         "srl_debug_tr1_order": ([p, C.c_int, p], C.c_int),
+        "srl_debug_tr1_order_by_relation": ([p, C.c_int, p], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)
@@ -343,13 +346,15 @@ def grid_sampling(world_xyz, size_voxel):
     return idx[: n.value].copy()
 
 
-def tr1_order(keys_xyz):
-    """Iteration order of std::tr1::unordered_map<voxel, ...> after inserting the distinct int16 keys in order (flat replay)."""
+def tr1_order(keys_xyz, by_relation=False):
+    """Iteration order of std::tr1::unordered_map<voxel, ...> after inserting the distinct int16 keys in order: the flat replay of
+    host/tr1_order.h, or (by_relation) the pairwise relation of host/tr1_relation.h the device ordering evaluates."""
     k = np.ascontiguousarray(keys_xyz, dtype=np.int16).reshape(-1, 3)
     out = np.empty(len(k), dtype=np.int32)
-    rc = load_library().srl_debug_tr1_order(_ptr(k), len(k), _ptr(out))
+    name = "srl_debug_tr1_order_by_relation" if by_relation else "srl_debug_tr1_order"
+    rc = getattr(load_library(), name)(_ptr(k), len(k), _ptr(out))
     if rc:
-        raise SrlError(rc, "srl_debug_tr1_order")
+        raise SrlError(rc, name)
     return out
 
 
@@ -607,11 +612,26 @@ class Context:
         self._chk(self.lib.srl_frame_size(self.h, C.byref(n)), "srl_frame_size")
         return n.value
 
-    def frame_select_keypoints(self, q, t, sample_voxel_size, R_il=None, t_il=None):
+    def set_frame_order_mode(self, mode):
+        """test hook: 0 = keypoint order on the device where it applies (default), 1 = always the host replay (srl_debug_set_frame_order_mode)"""
+        self._chk(self.lib.srl_debug_set_frame_order_mode(self.h, int(mode)), "srl_debug_set_frame_order_mode")
+
+    def frame_order_used(self):
+        """1 = the last selection ordered on the device, 2 = host replay, 3 = device order overflowed a bucket and the host replay ran"""
+        u = C.c_int()
+        self._chk(self.lib.srl_debug_frame_order_used(self.h, C.byref(u)), "srl_debug_frame_order_used")
+        return u.value
+
+    def frame_select_keypoints(self, q, t, sample_voxel_size, R_il=None, t_il=None, want_index=True):
+        """want_index=False: keypoint_index = NULL (the selection stays on the device as the resident sweep; only the count comes back)"""
         R_il = _f64(np.eye(3) if R_il is None else R_il).ravel()
         t_il = _f64(np.zeros(3) if t_il is None else t_il)
-        idx = np.empty(max(self.frame_size(), 1), dtype=np.int32)
         m = C.c_int()
+        if not want_index:
+            self._chk(self.lib.srl_frame_select_keypoints(self.h, _dptr(_f64(q)), _dptr(_f64(t)), _dptr(R_il), _dptr(t_il),
+                                                          float(sample_voxel_size), None, C.byref(m)), "srl_frame_select_keypoints")
+            return m.value
+        idx = np.empty(max(self.frame_size(), 1), dtype=np.int32)
         self._chk(self.lib.srl_frame_select_keypoints(self.h, _dptr(_f64(q)), _dptr(_f64(t)), _dptr(R_il), _dptr(t_il),
                                                       float(sample_voxel_size), _ptr(idx), C.byref(m)), "srl_frame_select_keypoints")
         return idx[: m.value].copy()

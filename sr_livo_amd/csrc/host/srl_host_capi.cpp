@@ -3,6 +3,7 @@
 #include "../../../include/srlivo_host.h"
 #include "lioOptimization.h"
 #include "tr1_order.h"
+#include "tr1_relation.h"
 
 #include <cstring>
 #include <new>
@@ -569,6 +570,36 @@ int srl_debug_tr1_order(const int16_t *keys_xyz, int n, int32_t *order_out) {
     std::vector<int> out((size_t)n);
     srl::Tr1Order::order(h.data(), n, out.data());
     for (int i = 0; i < n; i++) order_out[i] = out[(size_t)i];
+    return SRL_OK;
+}
+
+// debug / parity hook: the same order from the RELATION of host/tr1_relation.h, by the steps of the device ordering of
+// srl_frame_select_keypoints (bucket of every element at the final level -> exclusive scan over the bucket counts -> rank among the
+// elements sharing a bucket), with the very functions the kernels call, compiled for the host.  No bucket-size limit here.
+int srl_debug_tr1_order_by_relation(const int16_t *keys_xyz, int n, int32_t *order_out) {
+    if (n < 0 || (n > 0 && (!keys_xyz || !order_out))) return SRL_ERR_BAD_ARG;
+    if (n == 0) return SRL_OK;
+    std::vector<unsigned long long> h((size_t)n);
+    for (int i = 0; i < n; i++) h[(size_t)i] = (unsigned long long)std::hash<voxel>()(voxel(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]));
+    SrlTr1Sched S;
+    std::memset(&S, 0, sizeof S);
+    S.steps = srl::Tr1Order::export_schedule(n, S.first, S.nb, SRL_TR1_MAX_STEPS);
+    if (S.steps < 0) return SRL_ERR_UNSUPPORTED;
+    const int G = srl_tr1_level(&S, (unsigned)n);
+    const unsigned nb = S.nb[G];
+    std::vector<std::vector<unsigned>> members(nb);
+    for (int e = 0; e < n; e++) members[(size_t)(h[(size_t)e] % nb)].push_back((unsigned)e);
+    size_t start = 0;
+    for (unsigned b = 0; b < nb; b++) {
+        const std::vector<unsigned> &m = members[b];
+        for (size_t j = 0; j < m.size(); j++) {
+            size_t rank = 0;
+            for (size_t i = 0; i < m.size(); i++)
+                if (i != j && srl_tr1_before(&S, h.data(), G, m[i], m[j])) ++rank;
+            order_out[start + rank] = (int32_t)m[j];
+        }
+        start += m.size();
+    }
     return SRL_OK;
 }
 

@@ -83,6 +83,23 @@ public:
         for (int r = 0; r < n; r++) out[r] = trav[(size_t)r];
     }
 
+    // The recorded growth schedule for up to n insertions, for a caller that replays the container elsewhere (the device ordering of
+    // srl_frame_select_keypoints): nb[0] = initial bucket count; the insertion that brings the element count to first[s] rehashes into
+    // nb[s + 1] buckets before it links its own node.  Returns the number of growth steps written (<= max_steps), -1 if they do not fit.
+    static int export_schedule(int n, unsigned *first, unsigned *nb, int max_steps) {
+        const Schedule S = schedule(n);
+        nb[0] = (unsigned)S.initial;
+        int steps = 0;
+        for (const auto &g : S.grow) {
+            if (g.first > (std::size_t)n) break;
+            if (steps >= max_steps || g.second > 0xFFFFFFFFull) return -1;
+            first[steps] = (unsigned)g.first;
+            nb[steps + 1] = (unsigned)g.second;
+            steps++;
+        }
+        return steps;
+    }
+
 private:
     struct Schedule {
         std::size_t initial = 0;

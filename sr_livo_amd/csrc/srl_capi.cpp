@@ -193,6 +193,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->h_frame_x) hipHostFree(ctx->h_frame_x);
     for (SrlEpochTable *t : {&ctx->sel_table, &ctx->ins_table}) { if (t->keyw) hipFree(t->keyw); if (t->minw) hipFree(t->minw); }
     if (ctx->d_frame_sync) hipFree(ctx->d_frame_sync);
+    if (ctx->d_tr1_sched) hipFree(ctx->d_tr1_sched);
     if (ctx->h_insert_cnt) hipHostFree(ctx->h_insert_cnt);
     if (ctx->ev_insert) hipEventDestroy(ctx->ev_insert);
     if (ctx->ev_world) hipEventDestroy(ctx->ev_world);
@@ -1407,6 +1408,16 @@ int srl_debug_set_select_mode(srl_ctx *ctx, int select_mode) {
     if (!ctx || select_mode < 0 || select_mode > 5) return SRL_ERR_BAD_ARG;
     SRL_DISARM(ctx);
     ctx->select_mode = select_mode;
+    return SRL_OK;
+}
+int srl_debug_set_frame_order_mode(srl_ctx *ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 1) return SRL_ERR_BAD_ARG;
+    ctx->frame_order_mode = mode;
+    return SRL_OK;
+}
+int srl_debug_frame_order_used(srl_ctx *ctx, int *used) {
+    if (!ctx || !used) return SRL_ERR_BAD_ARG;
+    *used = ctx->frame_order_used;
     return SRL_OK;
 }
 int srl_debug_set_search_select_mode(srl_ctx *ctx, int select_mode) {

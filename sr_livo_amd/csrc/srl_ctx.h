@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/srlivo_hip.h"
 #include "srl_device.h"
+#include "host/tr1_relation.h"
 
 #include <hip/hip_runtime.h>
 #include "srl_rccl.h"
@@ -96,6 +97,12 @@ struct srl_ctx {
     size_t h_frame_x_bytes = 0;
     unsigned *d_frame_sync = nullptr;            // [0]: blocks of the emitting kernel that are done (reset by the last one)
     unsigned frame_tag = 0;                      // tag of the last exchange (never 0)
+    // keypoint order on the device (srl_frame_kernels.hip): the growth schedule of std::tr1::unordered_map, recorded from a real container
+    SrlTr1Sched *d_tr1_sched = nullptr;
+    int tr1_steps = -1;                          // steps of the uploaded schedule (-1: not uploaded)
+    unsigned tr1_first[SRL_TR1_MAX_STEPS] = {0}, tr1_nb[SRL_TR1_MAX_STEPS + 1] = {0};
+    int frame_order_mode = 0;                    // srl_debug_set_frame_order_mode: 0 = device order where it applies, 1 = the host replay (tests)
+    int frame_order_used = 0;                    // what the last selection did: 1 = device order, 2 = host replay, 3 = device order overflowed -> host replay
     // addPointsToMap on the device: counters of the last insert, folded into num_voxels / num_points lazily (srl_map_settle)
     int *h_insert_cnt = nullptr;                 // pinned: [0] segments, [1] new voxels, [2] points added
     hipEvent_t ev_insert = nullptr, ev_world = nullptr;

@@ -102,8 +102,9 @@ __global__ void k_select_group(const double *raw, int n, const Xf X, double size
 // host's replay of the container's iteration order starts from): every occupied slot marks the index of its first point, an
 // exclusive scan over the marks ranks the voxels, and the keys are written out by rank.
 __global__ void k_select_mark(const unsigned long long *keyw, const unsigned long long *minw, unsigned cap, unsigned epoch16, int *flag,
-                              unsigned long long *key_at) {
+                              unsigned long long *key_at, int *bucket_count, unsigned n_buckets) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_buckets) bucket_count[i] = 0;            // (device ordering below: no fill in front of k_tr1_bucket)
     if (i >= cap) return;
     const unsigned long long k = keyw[i];
     if ((unsigned)(k >> 48) != epoch16) return;
@@ -171,6 +172,133 @@ struct EmitFin {
         }
     }
 };
+
+// ---------------------------------------------------------------------------- keypoint ORDER on the device
+// gridSampling emits the keypoints in the iteration order of a std::tr1::unordered_map (utility.cpp:167-201).  host/tr1_order.h replays
+// the container's moves level by level (one counting sort per rehash: ~70 us of host time for the 14k voxels of a 24k-point frame, on the
+// critical path between selection and the first pass).  host/tr1_relation.h states the same order as a relation between two voxels, which
+// needs no sequential replay: a count per final bucket (k_tr1_bucket), ONE scan over the bucket counts, and per voxel a rank among the
+// handful of voxels sharing its bucket (k_tr1_rank, which also gathers the keypoint's raw point into the resident sweep).  One thread
+// per VOXEL, not per bucket: a lane that ranked all pairs of a 6-voxel bucket held the kernel for 40 us.  A bucket with more than
+// SRL_TR1_BUCKET_SLOTS voxels (adversarial keys) sends the frame to the host replay.
+// the ranks stay on the device: {std::hash<voxel>, first point} by first-occurrence rank; the count goes to sync[1]
+struct RankSink {
+    const unsigned long long *key_at;
+    unsigned long long *hash;
+    unsigned *first;
+    __device__ void operator()(int i, int is_first, int r) const {
+        if (!is_first) return;
+        short x, y, z;
+        srl_unpack_key(key_at[i], &x, &y, &z);
+        const unsigned long long kP1 = 73856093ull, kP2 = 19349669ull, kP3 = 83492791ull;       // size_t arithmetic of the reference's hash (cloudMap.h:173-184)
+        hash[r] = (unsigned long long)(long long)x * kP1 + (unsigned long long)(long long)y * kP2 + (unsigned long long)(long long)z * kP3;
+        first[r] = (unsigned)i;
+    }
+};
+struct CountFin {
+    unsigned *sync;
+    __device__ void operator()(int tile_end) const {
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) sync[1] = (unsigned)tile_end;
+    }
+};
+// per voxel e (first-occurrence rank): bucket at the final level G, and a RECORD in that bucket's member list that carries what nearly
+// every comparison of two voxels of one final bucket ends on -- {e, era(e), bucket at level G - 1} -- so that the ranking lane has
+// everything after one load of its bucket (the kernels of this chain are a few dependent loads long and nothing else: every level of
+// indirection is ~1 us of the frame)
+#define SRL_TR1_REC(e, era, bprev) ((unsigned long long)(e) | ((unsigned long long)(era) << 20) | ((unsigned long long)(bprev) << 32))
+#define SRL_TR1_REC_E(r) ((unsigned)(r) & 0xFFFFFu)
+#define SRL_TR1_REC_ERA(r) (((unsigned)(r) >> 20) & 0x3Fu)
+#define SRL_TR1_REC_BPREV(r) ((unsigned)((r) >> 32))
+static_assert(SRL_SCAN_SMALL_MAX <= (1 << 20), "a record holds a 20-bit voxel rank");
+__global__ void k_tr1_bucket(const SrlTr1Sched *S, unsigned *sync, const unsigned long long *hash, int *bucket_count, unsigned long long *members,
+                             unsigned *bucket_of, unsigned long long *host_ctrl, unsigned tag) {
+    __shared__ SrlTr1Sched sh;                                   // 50 words: level look-ups walk it per lane
+    static_assert(sizeof(SrlTr1Sched) <= 256 * 4, "one word per thread");
+    if (threadIdx.x < sizeof(SrlTr1Sched) / 4) reinterpret_cast<unsigned *>(&sh)[threadIdx.x] = reinterpret_cast<const unsigned *>(S)[threadIdx.x];
+    __syncthreads();
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned total = sync[1];
+    if (e < total) {
+        const int G = srl_tr1_level(&sh, total);
+        if (e == 0) sync[3] = (unsigned)G;
+        const unsigned era = (unsigned)srl_tr1_level(&sh, e + 1);
+        const unsigned long long h = hash[e];
+        const unsigned b = (unsigned)(h % sh.nb[G]);
+        const unsigned bprev = G > 0 ? (unsigned)(h % sh.nb[G - 1]) : 0u;
+        bucket_of[e] = b;
+        const int slot = atomicAdd(&bucket_count[b], 1);
+        if (slot < SRL_TR1_BUCKET_SLOTS) members[(size_t)b * SRL_TR1_BUCKET_SLOTS + slot] = SRL_TR1_REC(e, era, bprev);
+        else __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // more voxels than k_tr1_rank ranks in place
+    }
+    // The host needs two things from this chain -- the voxel count and whether a bucket overflowed -- and both are known HERE: the last
+    // workgroup publishes {tag, overflow, count}; the scan over the bucket counts and k_tr1_rank run on behind the host's back.
+    // (No fence: the overflow marks are agent-scope atomics, acknowledged before the barrier; the host reads nothing but the word itself,
+    // so it is stored relaxed -- a system-scope RELEASE writes the whole L2 back: 9 us on this kernel.)
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (__hip_atomic_fetch_add(sync, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
+    __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned over = __hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(host_ctrl, ((unsigned long long)tag << 32) | ((unsigned long long)(over ? 1u : 0u) << 31) | total, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// T_G(o, me) from the two records; falls back to the general relation below level G - 1 (two voxels sharing their bucket at two levels)
+struct Tr1EraOfSched {
+    const SrlTr1Sched *S;
+    __device__ int operator()(unsigned e) const { return srl_tr1_level(S, e + 1); }
+};
+__device__ __forceinline__ bool tr1_rec_before(const SrlTr1Sched *S, const unsigned long long *hash, int G, unsigned long long ro, unsigned long long rme) {
+    const unsigned o = SRL_TR1_REC_E(ro), me = SRL_TR1_REC_E(rme);
+    if ((int)SRL_TR1_REC_ERA(ro) == G || (int)SRL_TR1_REC_ERA(rme) == G) return me < o;          // T_G(o, me): the larger insertion index first
+    // both older: T_G(o, me) = T_{G-1}(me, o)
+    const unsigned bm = SRL_TR1_REC_BPREV(rme), bo = SRL_TR1_REC_BPREV(ro);
+    if (bm != bo) return bm < bo;
+    return srl_tr1_before_t(G - 1, me, o, Tr1EraOfSched{S}, SrlTr1BucketOfHash{S, hash});      // rare (one pair in ~n_{G-1})
+}
+// one thread per voxel: position = start of its bucket (scan over the bucket counts) + voxels of the bucket that precede it; writes the
+// ordered index list and gathers the keypoint's raw point into the resident sweep
+__global__ void k_tr1_rank(const SrlTr1Sched *S, unsigned *sync, const unsigned long long *hash, const unsigned *first, const unsigned long long *members,
+                           const int *bucket_count, const int *bucket_start, const unsigned *bucket_of, const double *raw,
+                           double *x, double *y, double *z, int *sel) {
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned total = sync[1];
+    if (e < total) {
+        const unsigned b = bucket_of[e];
+        const unsigned fi = first[e];
+        const int G = (int)sync[3];
+        // second level of loads, all independent: the bucket's count, start, its first four records, the raw point
+        const int c = bucket_count[b];
+        const int start = bucket_start[b];
+        const unsigned long long *m = members + (size_t)b * SRL_TR1_BUCKET_SLOTS;
+        const ulonglong2 r01 = *reinterpret_cast<const ulonglong2 *>(m), r23 = *reinterpret_cast<const ulonglong2 *>(m + 2);
+        const double px = raw[(size_t)fi * 3], py = raw[(size_t)fi * 3 + 1], pz = raw[(size_t)fi * 3 + 2];
+        if (c <= SRL_TR1_BUCKET_SLOTS) {            // (an overfull bucket: k_tr1_bucket has told the host, which orders the frame itself)
+            int rank = 0;
+            if (c > 1) {
+                // own record: rebuilt from the others' point of view is not possible without its era -> find it among the members
+                unsigned long long rme = r01.x;
+                if (SRL_TR1_REC_E(r01.y) == e && c > 1) rme = r01.y;
+                if (SRL_TR1_REC_E(r23.x) == e && c > 2) rme = r23.x;
+                if (SRL_TR1_REC_E(r23.y) == e && c > 3) rme = r23.y;
+                for (int i = 4; i < c; ++i) { const unsigned long long r = m[i]; if (SRL_TR1_REC_E(r) == e) rme = r; }
+                if (SRL_TR1_REC_E(r01.x) != e && tr1_rec_before(S, hash, G, r01.x, rme)) ++rank;
+                if (c > 1 && SRL_TR1_REC_E(r01.y) != e && tr1_rec_before(S, hash, G, r01.y, rme)) ++rank;
+                if (c > 2 && SRL_TR1_REC_E(r23.x) != e && tr1_rec_before(S, hash, G, r23.x, rme)) ++rank;
+                if (c > 3 && SRL_TR1_REC_E(r23.y) != e && tr1_rec_before(S, hash, G, r23.y, rme)) ++rank;
+                for (int i = 4; i < c; ++i) {
+                    const unsigned long long r = m[i];
+                    if (SRL_TR1_REC_E(r) != e && tr1_rec_before(S, hash, G, r, rme)) ++rank;
+                }
+            }
+            const int k = start + rank;
+            sel[k] = (int)fi;
+            x[k] = px;
+            y[k] = py;
+            z[k] = pz;
+        }
+    }
+}
 
 __global__ void k_gather_soa(const double *raw, const int *sel, int m, double *x, double *y, double *z) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -498,35 +626,95 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
     const int n = ctx->frame_n;
     if (num_keypoints) *num_keypoints = 0;
     hipStream_t st = ctx->stream;
-    std::vector<int> order;
     static const bool trace = std::getenv("SRL_FRAME_TIMING") != nullptr;      // stage times on stderr (tools/pipeline_probe.py)
     const auto tp0 = std::chrono::steady_clock::now();
     auto tp1 = tp0, tp2 = tp0, tp3 = tp0;
     srl_stage_begin(ctx);
+    ctx->frame_order_used = 0;
+    int m = 0;
     if (n > 0) {
+        // the selection becomes the resident sweep (SoA, gathered on the device): at most n keypoints
+        if (n > ctx->sweep_cap) {
+            if (ctx->d_raw) { HIPCHK(ctx, hipFree(ctx->d_raw)); ctx->d_raw = nullptr; }
+            const int cap = std::max(n, 1024);
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_raw, (size_t)cap * 3 * sizeof(double)));
+            ctx->sweep_cap = cap;
+        }
+        int rc = srl_ctx_ensure_work(ctx, n);
+        if (rc) return rc;
         Xf X;
         fill_xf(X, q, t, R_il, t_il);
         // group by sampling voxel in a scratch table of >= 2 n slots (epoch-tagged: never cleared between frames, srl_frame_scratch.h)
         unsigned cap = 1024;
         while (cap < 2u * (unsigned)n) cap <<= 1;
-        DevBuf b_flag, b_rank, b_keyat, b_tmp;
-        HIPCHK(ctx, b_flag.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_rank.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_keyat.alloc(ctx, (size_t)n * 8));
+        // the keypoint ORDER on the device (see "keypoint ORDER on the device" above) when the bucket table of n voxels fits one scan launch
+        unsigned nb_max = 0;
+        bool dev_order = ctx->frame_order_mode == 0 && n <= SRL_SCAN_SMALL_MAX;
+        if (dev_order) {
+            if (ctx->tr1_steps < 0) {
+                SrlTr1Sched S;
+                std::memset(&S, 0, sizeof S);
+                const int steps = srl::Tr1Order::export_schedule(SRL_SCAN_SMALL_MAX, S.first, S.nb, SRL_TR1_MAX_STEPS);
+                if (steps >= 0) {
+                    S.steps = steps;
+                    HIPCHK(ctx, hipMalloc((void **)&ctx->d_tr1_sched, sizeof S));
+                    HIPCHK(ctx, hipMemcpy(ctx->d_tr1_sched, &S, sizeof S, hipMemcpyHostToDevice));
+                    std::memcpy(ctx->tr1_first, S.first, sizeof S.first);
+                    std::memcpy(ctx->tr1_nb, S.nb, sizeof S.nb);
+                    ctx->tr1_steps = steps;
+                } else {
+                    ctx->tr1_steps = -2;                                      // a growth policy this table cannot hold: host replay from now on
+                }
+            }
+            if (ctx->tr1_steps >= 0) {
+                int g = 0;
+                while (g < ctx->tr1_steps && ctx->tr1_first[g] <= (unsigned)n) ++g;
+                nb_max = ctx->tr1_nb[g];
+            }
+            dev_order = ctx->tr1_steps >= 0 && nb_max > 0 && nb_max <= SRL_SCAN_SMALL_MAX;
+        }
+        DevBuf b_flag, b_rank, b_keyat, b_tmp, b_hash, b_first, b_bcnt, b_members, b_elem, b_bstart, b_sel;
+        HIPCHK(ctx, b_flag.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_keyat.alloc(ctx, (size_t)n * 8));
+        if (dev_order) {
+            HIPCHK(ctx, b_hash.alloc(ctx, (size_t)n * 8)); HIPCHK(ctx, b_first.alloc(ctx, (size_t)n * 4));
+            HIPCHK(ctx, b_bcnt.alloc(ctx, (size_t)nb_max * 4)); HIPCHK(ctx, b_members.alloc(ctx, (size_t)nb_max * SRL_TR1_BUCKET_SLOTS * 8));
+            HIPCHK(ctx, b_elem.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_bstart.alloc(ctx, (size_t)nb_max * 4));
+            HIPCHK(ctx, b_sel.alloc(ctx, (size_t)n * 4));
+        } else {
+            HIPCHK(ctx, b_rank.alloc(ctx, (size_t)n * 4));
+        }
         int rct = srl_epoch_table_begin(ctx, ctx->sel_table, cap, true);
         if (rct) return rct;
         const SrlEpochTable &T = ctx->sel_table;
-        // host exchange block: [0] control word {tag, count} | hashes (8 B) | first indices (4 B) | ordered index list for the gather (4 B)
+        // host exchange block: [0] control word {tag, count} | hashes (8 B) | first indices (4 B) | ordered index list (4 B)
         int rcx = ensure_frame_exchange(ctx, 64 + (size_t)n * 16);
         if (rcx) return rcx;
         unsigned long long *h_ctrl = reinterpret_cast<unsigned long long *>(ctx->h_frame_x);
         unsigned long long *h_hash = reinterpret_cast<unsigned long long *>(ctx->h_frame_x + 64);
         unsigned *first = reinterpret_cast<unsigned *>(ctx->h_frame_x + 64 + (size_t)n * 8);
+        int *h_sel = reinterpret_cast<int *>(ctx->h_frame_x + 64 + (size_t)n * 12);
         if (++ctx->frame_tag == 0) ++ctx->frame_tag;
         const unsigned tag = ctx->frame_tag;
         __atomic_store_n(h_ctrl, 0ull, __ATOMIC_RELEASE);
+        double *sx = ctx->d_raw, *sy = ctx->d_raw + ctx->sweep_cap, *sz = ctx->d_raw + 2 * (size_t)ctx->sweep_cap;
         hipLaunchKernelGGL(k_select_group, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, n, X, sample_voxel_size, T.keyw, T.minw, cap - 1, T.epoch16,
                            T.counter32, b_flag.as<int>());
-        hipLaunchKernelGGL(k_select_mark, dim3((cap + 255) / 256), dim3(256), 0, st, T.keyw, T.minw, cap, T.epoch16, b_flag.as<int>(), b_keyat.as<unsigned long long>());
-        if (n <= SRL_SCAN_SMALL_MAX) {
+        const unsigned mark_threads = dev_order && nb_max > cap ? nb_max : cap;
+        hipLaunchKernelGGL(k_select_mark, dim3((mark_threads + 255) / 256), dim3(256), 0, st, T.keyw, T.minw, cap, T.epoch16, b_flag.as<int>(),
+                           b_keyat.as<unsigned long long>(), dev_order ? b_bcnt.as<int>() : (int *)nullptr, dev_order ? nb_max : 0u);
+        if (dev_order) {
+            // ranks (first-occurrence order) -> bucket of every voxel at the table's final size, {tag, overflow, count} to the host -> scan
+            // over the bucket counts -> per voxel: rank inside its bucket, ordered index list, gather of the raw point
+            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, RankSink, CountFin>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, SrlIntArrayIn{b_flag.as<int>()},
+                               RankSink{b_keyat.as<unsigned long long>(), b_hash.as<unsigned long long>(), b_first.as<unsigned>()}, n, CountFin{ctx->d_frame_sync});
+            hipLaunchKernelGGL(k_tr1_bucket, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_tr1_sched, ctx->d_frame_sync, b_hash.as<unsigned long long>(),
+                               b_bcnt.as<int>(), b_members.as<unsigned long long>(), b_elem.as<unsigned>(), h_ctrl, tag);
+            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, SrlIntArraySink>), dim3(srl_scan_small_grid((int)nb_max)), dim3(1024), 0, st,
+                               SrlIntArrayIn{b_bcnt.as<int>()}, SrlIntArraySink{b_bstart.as<int>()}, (int)nb_max, SrlNoFin());
+            hipLaunchKernelGGL(k_tr1_rank, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_tr1_sched, ctx->d_frame_sync, b_hash.as<unsigned long long>(),
+                               b_first.as<unsigned>(), b_members.as<unsigned long long>(), b_bcnt.as<int>(), b_bstart.as<int>(), b_elem.as<unsigned>(),
+                               ctx->d_frame_raw, sx, sy, sz, b_sel.as<int>());
+        } else if (n <= SRL_SCAN_SMALL_MAX) {
             // ranks, hand-over to the host and the completion word in ONE launch
             hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, EmitSink, EmitFin>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, SrlIntArrayIn{b_flag.as<int>()},
                                EmitSink{b_keyat.as<unsigned long long>(), h_hash, first}, n, EmitFin{ctx->d_frame_sync, h_ctrl, tag});
@@ -553,50 +741,57 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
                 }
             }
         }
-        const int S = (int)(unsigned)ctrl;
+        const int S = (int)((unsigned)ctrl & 0x7FFFFFFFu);
+        const bool overflow = dev_order && (((unsigned)ctrl >> 31) & 1u);
         srl_stage_end(ctx, 2);
         tp2 = std::chrono::steady_clock::now();
-        // the voxels arrive in FIRST-OCCURRENCE order (= the order subSampleFrame's loop creates them): ordered on the device.
-        // Iteration order of the std::tr1::unordered_map of subSampleFrame, by replaying its bucket moves on flat arrays
-        // (host/tr1_order.h) for the S distinct voxels (not the N points)
-        static_assert(sizeof(std::size_t) == sizeof(unsigned long long), "hashes are exchanged as 64-bit words");
-        std::vector<int> perm((size_t)S);
-        srl::Tr1Order::order(reinterpret_cast<const std::size_t *>(h_hash), S, perm.data());
-        order.resize((size_t)S);
-        for (int r = 0; r < S; r++) order[(size_t)r] = (int)first[(size_t)perm[(size_t)r]];
+        m = S;
+        ctx->frame_order_used = dev_order ? (overflow ? 3 : 1) : 2;
+        if (!dev_order || overflow) {
+            if (overflow) {
+                // a bucket with more voxels than the device ranks in place: fetch {hash, first index} and order on the host like larger frames
+                HIPCHK(ctx, hipMemcpyAsync(h_hash, b_hash.p, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipMemcpyAsync(first, b_first.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+            }
+            // the voxels arrive in FIRST-OCCURRENCE order (= the order subSampleFrame's loop creates them): ordered on the device.
+            // Iteration order of the std::tr1::unordered_map of subSampleFrame, by replaying its bucket moves on flat arrays
+            // (host/tr1_order.h) for the S distinct voxels (not the N points)
+            static_assert(sizeof(std::size_t) == sizeof(unsigned long long), "hashes are exchanged as 64-bit words");
+            std::vector<int> perm((size_t)S);
+            srl::Tr1Order::order(reinterpret_cast<const std::size_t *>(h_hash), S, perm.data());
+            // the gather reads the ordered index list straight out of the exchange block (its own region: nothing is written there before
+            // the next frame's list, and that is produced behind a wait on a later kernel of this stream)
+            for (int r = 0; r < S; r++) h_sel[r] = (int)first[(size_t)perm[(size_t)r]];
+            srl_stage_end(ctx, 3);
+            tp3 = std::chrono::steady_clock::now();
+            if (m > 0) {
+                hipLaunchKernelGGL(k_gather_soa, dim3((m + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, h_sel, m, sx, sy, sz);
+                HIPCHK(ctx, hipGetLastError());
+            }
+        } else {
+            srl_stage_end(ctx, 3);
+            tp3 = tp2;
+            if (keypoint_index && m > 0) {
+                // the ordered index list is wanted on the host (tests, tools; the host mirror passes NULL): one copy behind the chain
+                HIPCHK(ctx, hipMemcpyAsync(h_sel, b_sel.p, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+            }
+        }
+        if (keypoint_index) std::memcpy(keypoint_index, h_sel, (size_t)m * 4);
+    } else {
+        srl_stage_end(ctx, 3);
     }
-    srl_stage_end(ctx, 3);
-    tp3 = std::chrono::steady_clock::now();
-    const int m = (int)order.size();
     if (num_keypoints) *num_keypoints = m;
-    if (keypoint_index) for (int k = 0; k < m; k++) keypoint_index[k] = order[k];
-
-    // the selection becomes the resident sweep: gather raw points on the device (SoA)
     ctx->total_n = m; ctx->shard_begin = 0; ctx->n = m; ctx->sweep_loaded = true; ctx->taps_valid = false;
-    if (m > ctx->sweep_cap) {
-        if (ctx->d_raw) { HIPCHK(ctx, hipFree(ctx->d_raw)); ctx->d_raw = nullptr; }
-        const int cap = std::max(m, 1024);
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_raw, (size_t)cap * 3 * sizeof(double)));
-        ctx->sweep_cap = cap;
-    }
-    int rc = srl_ctx_ensure_work(ctx, m);
-    if (rc) return rc;
-    if (m > 0) {
-        // the gather reads the ordered index list straight out of the exchange block (its own region: nothing is written there before
-        // the next frame's list, and that is produced behind a wait on a later kernel of this stream)
-        int *h_sel = reinterpret_cast<int *>(ctx->h_frame_x + 64 + (size_t)n * 12);
-        std::memcpy(h_sel, order.data(), (size_t)m * 4);
-        hipLaunchKernelGGL(k_gather_soa, dim3((m + 255) / 256), dim3(256), 0, st, ctx->d_frame_raw, h_sel, m,
-                           ctx->d_raw, ctx->d_raw + ctx->sweep_cap, ctx->d_raw + 2 * (size_t)ctx->sweep_cap);
-        HIPCHK(ctx, hipGetLastError());
-    }
+    ctx->soa_valid_n = m; ctx->passes_in_solve = 0;
     if (n > 0) { const int rcm = srl_mark_frame_read(ctx); if (rcm) return rcm; }
     srl_stage_end(ctx, 4);
     if (trace) {
         const auto tp4 = std::chrono::steady_clock::now();
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        std::fprintf(stderr, "[srl_frame_select_keypoints] n %d -> %d: enqueue keys+sort+heads %.0f us, wait + D2H %.0f us, host order replay %.0f us, gather + sync %.0f us\n",
-                     n, m, us(tp0, tp1), us(tp1, tp2), us(tp2, tp3), us(tp3, tp4));
+        std::fprintf(stderr, "[srl_frame_select_keypoints] n %d -> %d (order %d): enqueue %.0f us, wait %.0f us, host order replay %.0f us, gather + rest %.0f us\n",
+                     n, m, ctx->frame_order_used, us(tp0, tp1), us(tp1, tp2), us(tp2, tp3), us(tp3, tp4));
     }
     return SRL_OK;
 }

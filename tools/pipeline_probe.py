@@ -17,7 +17,7 @@ import sr_livo_amd as srl  # noqa: E402
 from sr_livo_amd import capi, synth  # noqa: E402
 
 
-def run(ctx, cands, n_frame, reps=7):
+def run(ctx, cands, n_frame, reps=7, want_index=False):
     rng = np.random.default_rng(3 + n_frame)
     frame = cands[rng.choice(len(cands), n_frame, replace=False)] + rng.normal(0, 0.03, (n_frame, 3))
     pin = srl.PinnedArray(frame.shape)
@@ -33,7 +33,7 @@ def run(ctx, cands, n_frame, reps=7):
         t0 = time.perf_counter()
         ctx.frame_upload(pin.array)
         t1 = time.perf_counter()
-        k = ctx.frame_select_keypoints(q, t, 1.5)
+        k = ctx.frame_select_keypoints(q, t, 1.5, want_index=want_index)
         t2 = time.perf_counter()
         neq, _ = ctx.build_residuals(f, opts)
         neq, _ = ctx.build_residuals(f, opts)
@@ -42,7 +42,7 @@ def run(ctx, cands, n_frame, reps=7):
         ctx.frame_commit(q, t, want_world=True, want_added=False, world_out=pin_world.array)
         t4 = time.perf_counter()
         st = ctx.frame_timing(False)
-        return len(k), (t1 - t0, t2 - t1, t3 - t2, t4 - t3), st
+        return (len(k) if want_index else k), (t1 - t0, t2 - t1, t3 - t2, t4 - t3), st
 
     one(False); one(True)
     t_loop = time.perf_counter()
@@ -63,6 +63,7 @@ def run(ctx, cands, n_frame, reps=7):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", default="6000,24000,65536")
+    ap.add_argument("--want-index", action="store_true", help="ask srl_frame_select_keypoints for the index list (the host mirror does not need it)")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "pipeline_probe.json"))
     args = ap.parse_args()
     cands, L = synth.map_candidates(7, 1_000_000)
@@ -71,7 +72,7 @@ def main():
     lio.add_points_to_map(cands)
     res = []
     for n in [int(x) for x in args.frames.split(",")]:
-        r = run(lio.ctx, cands, n)
+        r = run(lio.ctx, cands, n, want_index=args.want_index)
         res.append(r)
         u = r["us"]
         print(f"frame {n:6d} pts -> {r['keypoints']:5d} keypoints: upload {u['upload']:.0f}  select {u['select']:.0f}  two passes {u['two_passes']:.0f}  commit {u['commit']:.0f}"
