@@ -429,7 +429,7 @@ def run_pipeline(device, frame_points=(24_000, 65_536), reps=9):
                 t0 = time.perf_counter()
                 ctx.frame_upload(pin.array)
                 t1 = time.perf_counter()
-                k = ctx.frame_select_keypoints(q, t, 1.5)
+                k = ctx.frame_select_keypoints(q, t, 1.5, want_index=False)      # like the host mirror: the selection stays on the device
                 t2 = time.perf_counter()
                 ctx.build_residuals(f, opts)
                 ctx.build_residuals(f, opts)
@@ -437,7 +437,7 @@ def run_pipeline(device, frame_points=(24_000, 65_536), reps=9):
                 t3 = time.perf_counter()
                 ctx.frame_commit(q, t, want_world=True, want_added=False, world_out=pin_world.array)      # addPointsToMap returns nothing either
                 t4 = time.perf_counter()
-                return len(k), (t1 - t0, t2 - t1, t3 - t2, t4 - t3), ctx.frame_timing(False)
+                return int(k), (t1 - t0, t2 - t1, t3 - t2, t4 - t3), ctx.frame_timing(False)
 
             one(False); one(True)
             t_loop = time.perf_counter()

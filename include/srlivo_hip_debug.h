@@ -24,6 +24,11 @@ int srl_debug_set_select_mode(srl_ctx *ctx, int select_mode);
  * host replay of csrc/host/tr1_order.h (what rounds 3-4 shipped; still the path of larger frames and of a bucket with more than 16 voxels).
  * srl_debug_frame_order_used: what the last selection did -- 1 device order, 2 host replay, 3 device order found an overfull bucket and
  * the host replay ran behind it.  Both orders are the same permutation (tests/test_gpu_frame_order.py). */
+/* The frame path's own stable sort of (key, position) pairs over the low `bits` (1..18) key bits, n <= 131072 (two one-launch radix
+ * passes, csrc/srl_frame_scratch.h; what srl_frame_commit's addPointsToMap groups a frame's points with) on caller data: keys_sorted and
+ * positions_sorted (the position 0..n-1 each key came from) as a stable sort by (key & ((1 << bits) - 1)) would leave them. */
+int srl_debug_radix_sort_pairs(srl_ctx *ctx, const uint32_t *keys, int n, int bits, uint32_t *keys_sorted, uint32_t *positions_sorted);
+
 int srl_debug_set_frame_order_mode(srl_ctx *ctx, int mode);
 int srl_debug_frame_order_used(srl_ctx *ctx, int *used);
 

@@ -170,6 +170,7 @@ def load_library():
         "srl_debug_set_search_select_mode": ([p, C.c_int], C.c_int),
         "srl_debug_set_select_mode": ([p, C.c_int], C.c_int),
         "srl_debug_set_frame_order_mode": ([p, C.c_int], C.c_int),
+        "srl_debug_radix_sort_pairs": ([p, p, C.c_int, C.c_int, p, p], C.c_int),
         "srl_debug_frame_order_used": ([p, C.POINTER(C.c_int)], C.c_int),
         "srl_debug_heap_topk": ([p, C.c_int, C.c_int, p], C.c_int),
         "srl_debug_device_sqrt": ([p, p, C.c_int, p], C.c_int),
@@ -611,6 +612,13 @@ class Context:
         n = C.c_int()
         self._chk(self.lib.srl_frame_size(self.h, C.byref(n)), "srl_frame_size")
         return n.value
+
+    def radix_sort_pairs(self, keys, bits):
+        """test hook: the frame path's stable (key, position) sort over the low `bits` bits -> (keys_sorted, positions_sorted)"""
+        k = np.ascontiguousarray(keys, dtype=np.uint32)
+        ks = np.empty_like(k); ps = np.empty_like(k)
+        self._chk(self.lib.srl_debug_radix_sort_pairs(self.h, _ptr(k), len(k), int(bits), _ptr(ks), _ptr(ps)), "srl_debug_radix_sort_pairs")
+        return ks, ps
 
     def set_frame_order_mode(self, mode):
         """test hook: 0 = keypoint order on the device where it applies (default), 1 = always the host replay (srl_debug_set_frame_order_mode)"""

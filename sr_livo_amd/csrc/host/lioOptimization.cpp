@@ -658,11 +658,13 @@ optimizeSummary lioOptimization::optimizeBuiltFrame(cloudFrame *p_frame, const i
     const double qv[4] = {q.w, q.x, q.y, q.z};
     int frame_n = 0;
     check(ctx, srl_frame_size(ctx, &frame_n), "srl_frame_size");
-    std::vector<int32_t> idx((size_t)std::max(frame_n, 1));        // capacity = points of the resident frame
+    // the index list is fetched only for a caller that asks for it: the selection itself stays on the device as the resident sweep
+    std::vector<int32_t> idx(keypoint_index ? (size_t)std::max(frame_n, 1) : 0);        // capacity = points of the resident frame
     int m = 0;
     check(ctx, srl_frame_select_keypoints(ctx, qv, p_frame->p_state->translation.a, R_imu_lidar.a, t_imu_lidar.a, sample_voxel_size,
-                                          idx.data(), &m), "srl_frame_select_keypoints");
+                                          keypoint_index ? idx.data() : nullptr, &m), "srl_frame_select_keypoints");
     if (keypoint_index) keypoint_index->assign(idx.begin(), idx.begin() + m);
+    last_frame_keypoints = m;
     resident_n = m;
     sweep_pinned = true;
     optimizeSummary s = solveIEKF(cur_icp_options, p_frame);
@@ -677,9 +679,7 @@ optimizeSummary lioOptimization::stateEstimation(cloudFrame *p_frame) {
     state commit_pose;                                   // identity: what buildFrame gave point3D::point for index_frame <= 2
     if (p_frame->frame_id > 1) {
         const double svs = p_frame->frame_id < init_num_frames ? init_sample_voxel_size : sample_voxel_size;
-        std::vector<int> kidx;
-        optimize_summary = optimizeBuiltFrame(p_frame, optimize_options, svs, &kidx);
-        last_frame_keypoints = (int)kidx.size();
+        optimize_summary = optimizeBuiltFrame(p_frame, optimize_options, svs, nullptr);      // (sets last_frame_keypoints)
         if (!optimize_summary.success) return optimize_summary;
         commit_pose = *p_frame->p_state;                 // optimize() re-transformed the frame with the final pose
     } else {

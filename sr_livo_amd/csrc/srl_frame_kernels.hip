@@ -28,11 +28,12 @@
 #include <vector>
 
 int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, int n, double voxel_size,
-                        double min_distance_points, int min_num_points, int *num_added, bool defer_counters);
+                        double min_distance_points, int min_num_points, int *num_added, bool defer_counters,
+                        const SrlFrameTransform *xf = nullptr, int (*after_first_kernel)(srl_ctx *, void *) = nullptr, void *user = nullptr);
 
 namespace {
 
-struct Xf { double R[9], t[3], R_il[9], t_il[3]; };
+using Xf = SrlXf;
 
 // point = R(q) * (R_il * raw + t_il) + t (utility.cpp:314-318), key = short(point / size) (utility.cpp:171-173)
 __global__ void k_frame_keys(const double *raw, int n, const Xf X, double size, double *world, unsigned long long *keys, unsigned *idx) {
@@ -806,28 +807,43 @@ int srl_frame_commit(srl_ctx *ctx, const double q[4], const double t[3], const d
     const int n = ctx->frame_n;
     if (num_added) *num_added = 0;
     if (n == 0) return SRL_OK;
-    Xf X;
-    fill_xf(X, q, t, R_il, t_il);
+    SrlFrameTransform xf;
+    xf.raw = ctx->d_frame_raw; xf.world = ctx->d_frame_world;
+    fill_xf(xf.X, q, t, R_il, t_il);
+    struct Download { double *world_out; int n; } dl = {world_out, n};
+    // what has to happen as soon as the world points exist: the frame's raw points are free for the next upload, point3D::point leaves on
+    // the copy stream beside the insertion
+    auto world_ready = [](srl_ctx *c, void *user) -> int {
+        const Download *d = static_cast<const Download *>(user);
+        { const int rcm = srl_mark_frame_read(c); if (rcm) return rcm; }       // (= the world points are ready)
+        if (d->world_out) {
+            int rcc = ensure_copy_stream(c);
+            if (rcc) return rcc;
+            HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_frame_read, 0));
+            HIPCHK(c, hipMemcpyAsync(d->world_out, c->d_frame_world, (size_t)d->n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
+            if (!c->ev_world) HIPCHK(c, hipEventCreateWithFlags(&c->ev_world, hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(c->ev_world, c->copy_stream));
+        }
+        return SRL_OK;
+    };
     srl_stage_begin(ctx);
-    hipLaunchKernelGGL(k_frame_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_frame_raw, n, X, 1.0, ctx->d_frame_world,
-                       (unsigned long long *)nullptr, (unsigned *)nullptr);
-    HIPCHK(ctx, hipGetLastError());
-    srl_stage_end(ctx, 5);
-    { const int rcm = srl_mark_frame_read(ctx); if (rcm) return rcm; }       // (= the world points are ready)
-    if (world_out) {
-        // point3D::point leaves on the copy stream, beside the insertion
-        int rcc = ensure_copy_stream(ctx);
-        if (rcc) return rcc;
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_frame_read, 0));
-        HIPCHK(ctx, hipMemcpyAsync(world_out, ctx->d_frame_world, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
-        if (!ctx->ev_world) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_world, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_world, ctx->copy_stream));
+    // A frame-sized batch outside the stage-timing mode: the re-transform is the first thing the insertion's first kernel does (one launch
+    // less on a chain whose cost is its launches); otherwise a kernel of its own, as stage 5 of srl_debug_frame_timing.
+    const bool fused = n <= 131072 && !ctx->frame_timing;
+    if (!fused) {
+        hipLaunchKernelGGL(k_frame_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_frame_raw, n, xf.X, 1.0, ctx->d_frame_world,
+                           (unsigned long long *)nullptr, (unsigned *)nullptr);
+        HIPCHK(ctx, hipGetLastError());
+        srl_stage_end(ctx, 5);
+        const int rcw = world_ready(ctx, &dl);
+        if (rcw) return rcw;
+        srl_stage_end(ctx, 6);
     }
-    srl_stage_end(ctx, 6);
     // num_added == NULL: the insert is only enqueued (its counters are folded in later, srl_map_settle); the caller's world points are
     // waited for on their own event, which fires long before the insert behind them is done
-    const int rci = srl_map_insert_impl(ctx, ctx->d_frame_world, true, n, voxel_size, min_distance_points, min_num_points, num_added, num_added == nullptr);
-    if (world_out) HIPCHK(ctx, hipEventSynchronize(ctx->ev_world));
+    const int rci = srl_map_insert_impl(ctx, ctx->d_frame_world, true, n, voxel_size, min_distance_points, min_num_points, num_added, num_added == nullptr,
+                                        fused ? &xf : nullptr, fused ? +world_ready : nullptr, &dl);
+    if (world_out && rci == SRL_OK) HIPCHK(ctx, hipEventSynchronize(ctx->ev_world));
     if (rci == SRL_OK) ctx->frame_world_n = n;            // d_frame_world = the frame as inserted (srl_map_probe_checksum)
     return rci;
 }

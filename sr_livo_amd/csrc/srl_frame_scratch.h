@@ -19,6 +19,15 @@
 
 #define SRL_KEY48_MASK 0xFFFFFFFFFFFFull
 
+// transformPoint's operands (utility.cpp:314-318): point = R(q) * (R_il * raw + t_il) + t
+struct SrlXf { double R[9], t[3], R_il[9], t_il[3]; };
+// srl_frame_commit hands the re-transform of the frame (optimize.cpp:441-445) to the first kernel of the insertion behind it
+struct SrlFrameTransform {
+    const double *raw;       // the resident frame's raw points (AoS)
+    double *world;           // where point3D::point goes (AoS); the insertion reads it from there
+    SrlXf X;
+};
+
 // (struct SrlEpochTable: srl_ctx.h -- the context owns one for the selection and one for the insertion)
 
 // make the table ready for a frame that needs `want_cap` slots (power of two); returns the epoch to tag this frame's entries with
@@ -85,7 +94,17 @@ __global__ void __launch_bounds__(1024) k_scan_small(In in, Sink sink, int n, Fi
     const int base = blockIdx.x * 1024;
     // everything in front of this workgroup
     int front = 0;
-    for (int j = t; j < base; j += 1024) front += in(j);
+    {
+        // eight elements in flight per thread: a trip per element is a chain of base / 1024 load latencies (~1 us each at frame size)
+        constexpr int U = 8;
+        for (int j0 = t; j0 < base; j0 += U * 1024) {
+            int v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int j = j0 + u * 1024; v[u] = j < base ? in(j) : 0; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) front += v[u];
+        }
+    }
     for (int d = 32; d >= 1; d >>= 1) front += __shfl_xor(front, d);
     // own tile
     const int i = base + t;
@@ -108,6 +127,91 @@ __global__ void __launch_bounds__(1024) k_scan_small(In in, Sink sink, int n, Fi
     fin(tile_end);
 }
 inline int srl_scan_small_grid(int n) { return (n + 1023) / 1024; }
+
+// One STABLE least-significant-digit radix pass over `bits` (<= 9) key bits at `shift`, n <= SRL_SCAN_SMALL_MAX pairs, in ONE launch and
+// again without any dependency between workgroups: workgroup b (tile [1024 b, 1024 b + 1024)) histograms ALL keys itself -- what lies in
+// front of its tile and the rest, separately -- so it knows where every digit starts and how many equal digits precede its tile; inside
+// the tile the rank is (equal digits in earlier waves) + (equal digits in lower lanes), by ballot matching.  n / 1024 LDS atomics per
+// thread (24 at a 24k-point frame).  The library's sort of a frame is a block sort + 5 merge launches + 2 helper kernels (35 us of
+// device time and 8 launches on a chain whose cost is its launches); two of these passes sort (slot, index) over <= 18 bits.
+#define SRL_RADIX_MAX_BITS 9
+static __global__ void __launch_bounds__(1024) k_radix_pass(const unsigned *keys_in, const unsigned *vals_in, unsigned *keys_out, unsigned *vals_out, int n,
+                                                      unsigned shift, unsigned bits) {
+    constexpr int DMAX = 1 << SRL_RADIX_MAX_BITS;
+    __shared__ int s_front[DMAX], s_rest[DMAX], s_base[DMAX], s_wsum[16];
+    __shared__ int s_wave[16][DMAX];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int D = 1 << bits;
+    const unsigned dmask = (unsigned)D - 1u;
+    for (int d = t; d < D; d += 1024) { s_front[d] = 0; s_rest[d] = 0; }
+    for (int d = t; d < 16 * DMAX; d += 1024) (&s_wave[0][0])[d] = 0;
+    __syncthreads();
+    // histogram of everything: the tiles in front of this one, then this one and the tiles behind it
+    // (eight loads in flight per thread before their atomics: one key per trip is a chain of n / 1024 load latencies, 1 us each)
+    const int tiles = (n + 1023) / 1024;
+    constexpr int U = 8;
+    for (int k0 = 0; k0 < tiles; k0 += U) {
+        unsigned kk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = (k0 + u) * 1024 + t;
+            kk[u] = j < n ? keys_in[j] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u;
+            if (k * 1024 + t < n) atomicAdd(k < (int)blockIdx.x ? &s_front[(kk[u] >> shift) & dmask] : &s_rest[(kk[u] >> shift) & dmask], 1);
+        }
+    }
+    __syncthreads();
+    // s_base[d] = keys with a smaller digit anywhere + keys with digit d in front of this tile
+    {
+        const int v = t < D ? s_front[t] + s_rest[t] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wsum[w] = incl;
+        __syncthreads();
+        int run = 0;
+        for (int k = 0; k < w; k++) run += s_wsum[k];
+        if (t < D) s_base[t] = run + incl - v + s_front[t];
+    }
+    // own tile: stable rank of every key among the tile's keys with the same digit
+    const int i = blockIdx.x * 1024 + t;
+    const bool valid = i < n;
+    const unsigned key = valid ? keys_in[i] : 0u;
+    const unsigned dg = (key >> shift) & dmask;
+    unsigned long long same = __ballot(valid);
+    for (unsigned b = 0; b < bits; ++b) {
+        const bool bit = (dg >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        same &= bit ? bal : ~bal;
+    }
+    const int below = __popcll(same & ((1ull << lane) - 1ull));
+    if (valid && below == 0) s_wave[w][dg] = __popcll(same);
+    __syncthreads();
+    if (!valid) return;
+    int pos = s_base[dg] + below;
+    for (int k = 0; k < w; k++) pos += s_wave[k][dg];
+    keys_out[pos] = key;
+    vals_out[pos] = vals_in ? vals_in[i] : (unsigned)i;
+}
+// stable sort of (key, value) pairs by the low `bits` (<= 18) bits of the key, n <= SRL_SCAN_SMALL_MAX: two launches (one when bits <= 9).
+// vals == nullptr: the values are the positions 0..n-1.  tmp_keys / tmp_vals: n words each (untouched by the one-pass case).
+inline void srl_radix_sort_pairs(const unsigned *keys, const unsigned *vals, unsigned *keys_sorted, unsigned *vals_sorted, unsigned *tmp_keys,
+                                 unsigned *tmp_vals, int n, unsigned bits, hipStream_t st) {
+    const dim3 grid((n + 1023) / 1024), block(1024);
+    if (bits <= SRL_RADIX_MAX_BITS) {
+        hipLaunchKernelGGL(k_radix_pass, grid, block, 0, st, keys, vals, keys_sorted, vals_sorted, n, 0u, bits);
+        return;
+    }
+    const unsigned lo = (bits + 1) / 2;
+    hipLaunchKernelGGL(k_radix_pass, grid, block, 0, st, keys, vals, tmp_keys, tmp_vals, n, 0u, lo);
+    hipLaunchKernelGGL(k_radix_pass, grid, block, 0, st, (const unsigned *)tmp_keys, (const unsigned *)tmp_vals, keys_sorted, vals_sorted, n, lo, bits - lo);
+}
 struct SrlIntArrayIn {
     const int *p;
     __device__ int operator()(int i) const { return p[i]; }

@@ -37,17 +37,34 @@ __global__ void k_point_keys(const double *xyz, int n, double voxel_size, unsign
 // addressing, compare-and-swap; one slot per distinct key), and the stable radix sort runs over log2(slots) bits: 2 passes for a
 // 24k-point frame instead of 6.  Which segment comes first is irrelevant downstream (creation order = first-point rank, replay =
 // per segment).
+// XF: the points are first re-transformed (optimize.cpp:441-445: point = R(q) * (R_il * raw + t_il) + t, the operation order of
+// k_frame_keys / transformPoint) and stored where the rest of the insertion -- and the download of point3D::point -- reads them
+template <bool XF>
 __global__ void k_point_slots(const double *xyz, int n, double voxel_size, unsigned long long *keyw, unsigned mask, unsigned epoch16, unsigned *slot_out,
-                              unsigned *idx, int *new_flag) {
+                              unsigned *idx, int *new_flag, const SrlFrameTransform T) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float fx = (float)xyz[(size_t)i * 3], fy = (float)xyz[(size_t)i * 3 + 1], fz = (float)xyz[(size_t)i * 3 + 2];
+    double wx, wy, wz;
+    if (XF) {
+        const SrlXf &X = T.X;
+        const double rx = T.raw[(size_t)i * 3], ry = T.raw[(size_t)i * 3 + 1], rz = T.raw[(size_t)i * 3 + 2];
+        const double ix = (X.R_il[0] * rx + X.R_il[1] * ry) + X.R_il[2] * rz + X.t_il[0];
+        const double iy = (X.R_il[3] * rx + X.R_il[4] * ry) + X.R_il[5] * rz + X.t_il[1];
+        const double iz = (X.R_il[6] * rx + X.R_il[7] * ry) + X.R_il[8] * rz + X.t_il[2];
+        wx = (X.R[0] * ix + X.R[1] * iy) + X.R[2] * iz + X.t[0];
+        wy = (X.R[3] * ix + X.R[4] * iy) + X.R[5] * iz + X.t[1];
+        wz = (X.R[6] * ix + X.R[7] * iy) + X.R[8] * iz + X.t[2];
+        T.world[(size_t)i * 3] = wx; T.world[(size_t)i * 3 + 1] = wy; T.world[(size_t)i * 3 + 2] = wz;
+    } else {
+        wx = xyz[(size_t)i * 3]; wy = xyz[(size_t)i * 3 + 1]; wz = xyz[(size_t)i * 3 + 2];
+    }
+    const float fx = (float)wx, fy = (float)wy, fz = (float)wz;
     const short kx = (short)(int)((double)fx / voxel_size);
     const short ky = (short)(int)((double)fy / voxel_size);
     const short kz = (short)(int)((double)fz / voxel_size);
     const unsigned long long key = srl_pack_key(kx, ky, kz);
     slot_out[i] = srl_epoch_claim(keyw, mask, epoch16, key, srl_hash_key(key));     // (epoch-tagged scratch table: no fill per frame)
-    idx[i] = (unsigned)i;
+    if (idx) idx[i] = (unsigned)i;         // (the frame path sorts positions: srl_radix_sort_pairs needs no value array)
     new_flag[i] = 0;                       // (the segment scan, behind the sort, sets the marks: no fill in front of this one)
 }
 // head flag of sorted position i / the per-element work of the scan over them: segment starts, and the voxel key of every sorted
@@ -396,7 +413,26 @@ int srl_ctx_grow_map(srl_ctx *ctx, unsigned need_slabs, unsigned need_slots) {
 }
 
 int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, int n, double voxel_size,
-                        double min_distance_points, int min_num_points, int *num_added, bool defer_counters);
+                        double min_distance_points, int min_num_points, int *num_added, bool defer_counters,
+                        const SrlFrameTransform *xf = nullptr, int (*after_first_kernel)(srl_ctx *, void *) = nullptr, void *user = nullptr);
+
+// debug / parity hook: the frame path's own stable sort (srl_frame_scratch.h) on caller data
+extern "C" int srl_debug_radix_sort_pairs(srl_ctx *ctx, const uint32_t *keys, int n, int bits, uint32_t *keys_sorted, uint32_t *positions_sorted) {
+    if (!ctx || n < 0 || n > SRL_SCAN_SMALL_MAX || bits < 1 || bits > 2 * SRL_RADIX_MAX_BITS || (n > 0 && (!keys || !keys_sorted || !positions_sorted)))
+        return SRL_ERR_BAD_ARG;
+    if (n == 0) return SRL_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf b_in, b_k, b_v, b_tk, b_tv;
+    HIPCHK(ctx, b_in.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_k.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_v.alloc(ctx, (size_t)n * 4));
+    HIPCHK(ctx, b_tk.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_tv.alloc(ctx, (size_t)n * 4));
+    HIPCHK(ctx, hipMemcpyAsync(b_in.p, keys, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    srl_radix_sort_pairs(b_in.as<unsigned>(), nullptr, b_k.as<unsigned>(), b_v.as<unsigned>(), b_tk.as<unsigned>(), b_tv.as<unsigned>(), n, (unsigned)bits, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(keys_sorted, b_k.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(positions_sorted, b_v.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SRL_OK;
+}
 
 int srl_map_insert_device(srl_ctx *ctx, const double *world_xyz, int n, double voxel_size, int cap,
                           double min_distance_points, int min_num_points, int *num_added) {
@@ -417,7 +453,8 @@ int srl_map_insert_device(srl_ctx *ctx, const double *world_xyz, int n, double v
 // map's totals by srl_map_settle() -- at the next insert, srl_map_size, srl_map_download.  The solve that follows needs none of them
 // and is ordered behind the insert on the stream.
 int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, int n, double voxel_size,
-                        double min_distance_points, int min_num_points, int *num_added, bool defer_counters) {
+                        double min_distance_points, int min_num_points, int *num_added, bool defer_counters,
+                        const SrlFrameTransform *xf, int (*after_first_kernel)(srl_ctx *, void *), void *user) {
     if (num_added) *num_added = 0;
     if (n == 0) return SRL_OK;
     if (!(voxel_size > 0.0)) return SRL_ERR_BAD_ARG;
@@ -480,15 +517,20 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
         const SrlEpochTable &T = ctx->ins_table;
         DevBuf b_slot_in, b_slot_sorted;
         HIPCHK(ctx, b_slot_in.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_slot_sorted.alloc(ctx, (size_t)n * 4));
-        hipLaunchKernelGGL(k_point_slots, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, voxel_size, T.keyw, cap2 - 1, T.epoch16,
-                           b_slot_in.as<unsigned>(), b_idx.as<unsigned>(), b_newflag.as<int>());
+        if (xf) {
+            hipLaunchKernelGGL(k_point_slots<true>, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, voxel_size, T.keyw, cap2 - 1, T.epoch16,
+                               b_slot_in.as<unsigned>(), (unsigned *)nullptr, b_newflag.as<int>(), *xf);
+        } else {
+            hipLaunchKernelGGL(k_point_slots<false>, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, voxel_size, T.keyw, cap2 - 1, T.epoch16,
+                               b_slot_in.as<unsigned>(), (unsigned *)nullptr, b_newflag.as<int>(), SrlFrameTransform());
+        }
         HIPCHK(ctx, hipGetLastError());
-        hipcub::DeviceRadixSort::SortPairs(nullptr, need, b_slot_in.as<unsigned>(), b_slot_sorted.as<unsigned>(), b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, (int)bits, st);
-        tmp_bytes = need + 4096;
-        HIPCHK(ctx, b_tmp.alloc(ctx, tmp_bytes));
-        tb = tmp_bytes;
-        HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_slot_in.as<unsigned>(), b_slot_sorted.as<unsigned>(), b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0,
-                                                       (int)bits, st));
+        if (after_first_kernel) { const int rca = after_first_kernel(ctx, user); if (rca) return rca; }
+        // (slot, position) sorted stably over log2(slots) bits: two launches of our own (srl_frame_scratch.h) instead of the library's eight
+        static_assert(SRL_SCAN_SMALL_MAX >= 131072, "frame-sized batches fit the one-launch passes");
+        srl_radix_sort_pairs(b_slot_in.as<unsigned>(), nullptr, b_slot_sorted.as<unsigned>(), b_idx2.as<unsigned>(), b_prefix.as<unsigned>(), b_idx.as<unsigned>(), n,
+                             bits, st);
+        HIPCHK(ctx, hipGetLastError());
         srl_stage_end(ctx, 7);                                    // slots + sort
         hipLaunchKernelGGL((k_scan_small<HeadFlag32, SegmentSink>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, HeadFlag32{b_slot_sorted.as<unsigned>()},
                            SegmentSink{b_slot_sorted.as<unsigned>(), b_idx2.as<unsigned>(), T.keyw, b_start.as<int>(), b_keys2.as<unsigned long long>(), ctx->d_table,

@@ -147,3 +147,30 @@ def test_resident_sweep_of_the_device_order_gives_the_same_normal_equations():
                 assert np.array_equal(np.array(n_dev.HtH), np.array(a.HtH)) and np.array_equal(np.array(n_dev.Hth), np.array(a.Hth))
     finally:
         ctx.close(); ctx2.close()
+
+
+@pytest.mark.parametrize("n,bits", [(1, 10), (63, 5), (64, 9), (1000, 10), (1024, 11), (1025, 12), (5000, 14), (24_000, 16), (24_000, 9), (65_536, 17),
+                                    (100_000, 18), (131_072, 18)])
+def test_own_radix_sort_is_a_stable_sort(n, bits):
+    """srl_frame_commit groups a frame's points by scratch-table slot with two one-launch radix passes of our own (srl_frame_scratch.h)
+    instead of the library sort: (key, position) pairs must come out exactly as a stable sort leaves them"""
+    ctx = srl.Context(0)
+    try:
+        for seed, kind in ((0, "uniform"), (1, "few"), (2, "one"), (3, "high_bits_set"), (4, "sorted_desc")):
+            rng = np.random.default_rng(1000 * n + seed)
+            if kind == "uniform":
+                keys = rng.integers(0, 1 << bits, n, dtype=np.uint32)
+            elif kind == "few":
+                keys = rng.choice(rng.integers(0, 1 << bits, 7, dtype=np.uint32), n)
+            elif kind == "one":
+                keys = np.full(n, (1 << bits) - 1, dtype=np.uint32)
+            elif kind == "high_bits_set":                    # bits above `bits` must be ignored by the order and carried along
+                keys = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+            else:
+                keys = np.sort(rng.integers(0, 1 << bits, n, dtype=np.uint32))[::-1].copy()
+            ks, ps = ctx.radix_sort_pairs(keys, bits)
+            order = np.argsort(keys & np.uint32((1 << bits) - 1), kind="stable")
+            assert np.array_equal(ps, order.astype(np.uint32)), (kind, n, bits)
+            assert np.array_equal(ks, keys[order]), (kind, n, bits)
+    finally:
+        ctx.close()
