@@ -319,11 +319,23 @@ int srl_comm_set_host_callbacks(srl_ctx *ctx, int nranks, int rank, srl_allreduc
  *                     peers (NULL entries fall back to the handle).  Sets the shard layout like srl_comm_init_rank: upload the
  *                     sweep afterwards.  nranks <= 8.  Mutually exclusive with srl_comm_init_rank / host callbacks.
  *   srl_peer_detach : back to an unsharded context (unmaps the peers' inboxes).
- * All ranks must call srl_build_residuals the same number of times with the same options (as with any collective); a rank whose
- * peers never deliver gets SRL_ERR_COMM after a bounded spin (~1 s), it does not hang the GPU. */
+ * All ranks must call srl_build_residuals the same number of times with the same options (as with any collective).
+ *
+ * A late rank is not a failure.  The kernel that waits for the rows gives up after a bounded spin (0.3-1 s: it must not hold the GPU for
+ * ever), but what follows is decided on the HOST: srl_build_residuals repeats the pass with the same exchange tags -- this rank's rows are
+ * in every inbox already, the repeat only polls again; nobody can run ahead, the next exchange needs a row of this rank -- until the
+ * missing row is there (every rank then returns SRL_OK, the late one included) or until the wall-clock deadline of
+ *   srl_peer_set_deadline_ms (default 10 000 ms, measured from the start of the pass; 0 = give up at the first time-out)
+ * has passed.  Then the SESSION is given up for every rank: this rank sets the poison word of every inbox and returns SRL_ERR_COMM; a rank
+ * whose own pass times out looks at its word first and returns SRL_ERR_COMM at once instead of waiting for its own deadline (a rank that
+ * had already completed the exchange -- the rows were there -- fails at its next one).  After that every srl_build_residuals on the session
+ * returns SRL_ERR_COMM until srl_peer_detach + srl_peer_export + srl_peer_attach on every rank start a new one.
+ *   srl_peer_stats : passes repeated because a row had not arrived within one kernel's spin (since the attach), whether the session failed. */
 #define SRL_PEER_HANDLE_BYTES 64
 int srl_peer_export(srl_ctx *ctx, void *ipc_handle, void **local_ptr);
 int srl_peer_attach(srl_ctx *ctx, int nranks, int rank, const void *ipc_handles, void *const *local_ptrs);
+int srl_peer_set_deadline_ms(srl_ctx *ctx, int deadline_ms);
+int srl_peer_stats(srl_ctx *ctx, int64_t *passes_repeated, int *session_failed);
 int srl_peer_detach(srl_ctx *ctx);
 
 /* pure helpers of the sharded path (also used internally): the contiguous point range of a rank

@@ -150,6 +150,8 @@ def load_library():
         "srl_debug_set_gather_counts": ([p, C.c_int, C.c_int, C.POINTER(C.c_int64)], C.c_int),
         "srl_peer_export": ([p, p, C.POINTER(p)], C.c_int),
         "srl_peer_attach": ([p, C.c_int, C.c_int, p, C.POINTER(p)], C.c_int),
+        "srl_peer_set_deadline_ms": ([p, C.c_int], C.c_int),
+        "srl_peer_stats": ([p, C.POINTER(C.c_int64), C.POINTER(C.c_int)], C.c_int),
         "srl_peer_detach": ([p], C.c_int),
         "srl_shard_range": ([C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], None),
         "srl_shard_budget": ([C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)], None),
@@ -706,6 +708,16 @@ class Context:
         if local_ptrs is not None:
             lp = (C.c_void_p * nranks)(*[C.c_void_p(int(x) if x else None) for x in local_ptrs])
         self._chk(self.lib.srl_peer_attach(self.h, int(nranks), int(rank), hb, lp), "srl_peer_attach")
+
+    def peer_set_deadline_ms(self, ms):
+        """how long a pass keeps re-polling for a late rank's row before the session is given up on every rank (srl_peer_set_deadline_ms)"""
+        self._chk(self.lib.srl_peer_set_deadline_ms(self.h, int(ms)), "srl_peer_set_deadline_ms")
+
+    def peer_stats(self):
+        """(passes repeated because a row had not arrived within one kernel's spin, session failed)"""
+        rep, failed = C.c_int64(), C.c_int()
+        self._chk(self.lib.srl_peer_stats(self.h, C.byref(rep), C.byref(failed)), "srl_peer_stats")
+        return rep.value, bool(failed.value)
 
     def comm_info(self):
         """srl_comm_info: what the sharded path of this context runs on"""

@@ -757,6 +757,7 @@ int srl_get_arm_stats(srl_ctx *ctx, uint64_t out[4]) {
 // ------------------------------------------------------------------------------------------ hot path
 // one association + reduction pass over the first n_eff keypoints of this rank's shard (n_eff == ctx->n: all of them)
 #define SRL_INTERNAL_FUSED_TIMEOUT 1      // build_residuals_pass only: never leaves srl_build_residuals
+#define SRL_INTERNAL_PEER_TIMEOUT 3       // ... a peer's row had not arrived within the kernel's bounded spin: the HOST decides what follows
 #define SRL_INTERNAL_ARM_EXPIRED 2        // the armed launch this pass fired had given up waiting: the pass is repeated with a normal launch
 
 // the kernel arguments of one pass
@@ -1202,11 +1203,11 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             if (ctx->cb_ar(reinterpret_cast<double *>(ctx->h_out), n_red, ctx->cb_user) != 0) { ctx->err = "allreduce callback failed"; return SRL_ERR_COMM; }
         }
         if (ctx->h_out->pad == SRL_PEER_TIMEOUT_MARK) {
-            // The peers may have completed this exchange (a late rank still finds every row): this rank must not run ahead of them into the
-            // slot they may still be reading, so the session ends here -- they find no row of the next exchange and end theirs.
-            ctx->peer_failed = true;
-            ctx->err = "direct peer exchange: a rank's row never arrived";
-            return SRL_ERR_COMM;
+            // A rank's row had not arrived when the kernel's bounded spin ran out (~0.3-1 s: a kernel must not hold the GPU for ever).  Whether
+            // that rank is late or gone is not decided in the kernel: srl_build_residuals repeats the pass with the SAME exchange tags until
+            // the wall-clock deadline of srl_peer_set_deadline_ms, then gives the session up for every rank (peer_pass_timed_out below).
+            ctx->err = "direct peer exchange: a rank's row has not arrived yet";
+            return SRL_INTERNAL_PEER_TIMEOUT;
         }
         if (ctx->h_out->pad != 0 || ctx->h_out->d_timeout > 0.5) {     // (summed over the ranks: all of them repeat the pass together)
             // the finishing workgroup gave up waiting for a row (bounded spin: another process holding compute units back, a
@@ -1504,12 +1505,49 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         const long long pre = ((4LL * o->max_num_residuals + 2048 + 63) / 64) * 64;
         if (pre < (long long)ctx->n) n_eff = (int)pre;
     }
+    // One attempt at a pass = build_residuals_pass, repeated while a PEER's row has not arrived (direct peer exchange only).
+    auto attempt = [&](int n_pass) -> int {
+        const unsigned long long peer_seq0 = ctx->peer_seq;              // (a repeated pass re-polls the SAME exchanges)
+        const long long t_first = steady_ns();
+        int r = build_residuals_pass(ctx, f, o, out, n_pass);
+        while (r == SRL_INTERNAL_PEER_TIMEOUT) {
+            // Direct peer exchange, a row missing.  Skew between ranks (a first launch, a map insertion, a host stall on the other side) is
+            // not a failure: this rank's own rows are in every inbox already (stores of one exchange are idempotent), so the pass is simply
+            // run again with the same tags until the late rank's row is there -- the late rank finds every row and returns SRL_OK as well.
+            // No rank runs ahead meanwhile: the next exchange needs a row of THIS rank.  Past the deadline the session is given up for
+            // everybody: the poison word of every inbox is set, and a rank that times out looks at its own word first.
+            const int rcd = ctx->armed ? srl_ctx_disarm(ctx) : SRL_OK;
+            if (rcd) return rcd;
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            unsigned long long poisoned = 0;
+            HIPCHK(ctx, hipMemcpy(&poisoned, ctx->d_inbox + SRL_PEER_POISON_WORD, sizeof poisoned, hipMemcpyDeviceToHost));
+            const bool expired = (steady_ns() - t_first) / 1000000ll >= (long long)ctx->peer_deadline_ms;
+            if (poisoned || expired) {
+                if (!poisoned) {
+                    const unsigned long long mark = 1ull + (unsigned long long)ctx->rank;
+                    for (int rk = 0; rk < ctx->nranks; rk++)
+                        if (ctx->peer_inbox[rk] && hipMemcpy(ctx->peer_inbox[rk] + SRL_PEER_POISON_WORD, &mark, sizeof mark, hipMemcpyHostToDevice) != hipSuccess)
+                            (void)hipGetLastError();                      // (a dead peer's mapping: nothing left to tell it)
+                }
+                ctx->peer_failed = true;
+                ctx->err = poisoned ? "direct peer exchange: another rank has given this session up (its deadline for a missing row expired); "
+                                      "srl_peer_detach, srl_peer_export and srl_peer_attach on every rank start a new one"
+                                    : "direct peer exchange: a rank's row did not arrive within the deadline (srl_peer_set_deadline_ms); the session "
+                                      "is given up on every rank -- srl_peer_detach, srl_peer_export and srl_peer_attach start a new one";
+                return SRL_ERR_COMM;
+            }
+            ctx->peer_retries++;
+            ctx->peer_seq = peer_seq0;
+            r = build_residuals_pass(ctx, f, o, out, n_pass);
+        }
+        return r;
+    };
     // a pass whose fused reduction timed out is repeated once with the separate reduce kernel (stream-ordered: it cannot time out)
     auto pass = [&](int n_pass) -> int {
-        int r = build_residuals_pass(ctx, f, o, out, n_pass);
+        int r = attempt(n_pass);
         if (r == SRL_INTERNAL_ARM_EXPIRED) {                 // nobody was listening: the same pass with a normal launch
             SRL_DISARM(ctx);
-            r = build_residuals_pass(ctx, f, o, out, n_pass);
+            r = attempt(n_pass);
             if (r == SRL_INTERNAL_ARM_EXPIRED) r = SRL_ERR_HIP;
         }
         if (r == SRL_INTERNAL_FUSED_TIMEOUT) {
@@ -1523,7 +1561,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
                 ctx->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(es);
                 return SRL_ERR_HIP;
             }
-            r = build_residuals_pass(ctx, f, o, out, n_pass);
+            r = attempt(n_pass);
             ctx->fuse_reduce = fuse;
             if (r == SRL_INTERNAL_FUSED_TIMEOUT || r == SRL_INTERNAL_ARM_EXPIRED) r = SRL_ERR_HIP;
         }
@@ -1653,7 +1691,7 @@ int srl_peer_export(srl_ctx *ctx, void *ipc_handle, void **local_ptr) {
     SRL_DISARM(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (ctx->peer_on) { ctx->err = "srl_peer_export: peers are attached (srl_peer_detach first)"; return SRL_ERR_BAD_ARG; }
-    const size_t bytes = (size_t)SRL_PEER_INBOX_GRANULES * sizeof(unsigned long long);
+    const size_t bytes = (size_t)SRL_PEER_INBOX_ALLOC_GRANULES * sizeof(unsigned long long);      // rows + the session's poison word
     if (!ctx->d_inbox)       // fine-grained: a peer's store is visible to this device's polling loads without cache maintenance
         HIPCHK(ctx, hipExtMallocWithFlags((void **)&ctx->d_inbox, bytes, hipDeviceMallocFinegrained));
     // Every export starts a new session: tag 0 = "nothing here", exchange tags start at 1 again at srl_peer_attach.  The reset
@@ -1672,12 +1710,26 @@ int srl_peer_export(srl_ctx *ctx, void *ipc_handle, void **local_ptr) {
     return SRL_OK;
 }
 
+int srl_peer_set_deadline_ms(srl_ctx *ctx, int deadline_ms) {
+    if (!ctx || deadline_ms < 0) return SRL_ERR_BAD_ARG;
+    ctx->peer_deadline_ms = deadline_ms;
+    return SRL_OK;
+}
+
+int srl_peer_stats(srl_ctx *ctx, int64_t *passes_repeated, int *session_failed) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    if (passes_repeated) *passes_repeated = (int64_t)ctx->peer_retries;
+    if (session_failed) *session_failed = ctx->peer_failed ? 1 : 0;
+    return SRL_OK;
+}
+
 int srl_peer_detach(srl_ctx *ctx) {
     if (!ctx) return SRL_ERR_BAD_ARG;
     SRL_DISARM(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (ctx->stream) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int r = 0; r < SRL_MAX_PEERS; r++) if (ctx->peer_mapped[r]) { hipIpcCloseMemHandle(ctx->peer_mapped[r]); ctx->peer_mapped[r] = nullptr; }
+    for (int r = 0; r < SRL_MAX_PEERS; r++) ctx->peer_inbox[r] = nullptr;
     if (ctx->peer_on) { ctx->peer_on = false; ctx->nranks = 1; ctx->rank = 0; }
     return SRL_OK;
 }
@@ -1716,6 +1768,8 @@ int srl_peer_attach(srl_ctx *ctx, int nranks, int rank, const void *ipc_handles,
     }
     if (!ctx->d_peer) { int rcp = ensure(ctx, ctx->d_peer, 1); if (rcp) return rcp; }
     HIPCHK(ctx, hipMemcpy(ctx->d_peer, &t, sizeof t, hipMemcpyHostToDevice));
+    for (int r = 0; r < SRL_MAX_PEERS; r++) ctx->peer_inbox[r] = r < nranks ? t.inbox[r] : nullptr;
+    ctx->peer_retries = 0;
     ctx->peer_seen = 0;
     for (int r = 0; r < nranks; r++) ctx->peer_seen += t.inbox[r] != nullptr ? 1 : 0;       // inboxes actually mapped (srl_comm_info)
     { int rcg = ensure_gather(ctx, (size_t)nranks); if (rcg) return rcg; }

@@ -19,6 +19,11 @@ struct SrlEpochTable {
     unsigned counter32 = 0;
 };
 
+// The word behind a rank's inbox rows that any rank sets when it gives a session up (srl_peer_set_deadline_ms): a rank whose pass times
+// out looks at its own inbox's word and ends the session at once instead of waiting for its own deadline.
+#define SRL_PEER_POISON_WORD SRL_PEER_INBOX_GRANULES
+#define SRL_PEER_INBOX_ALLOC_GRANULES (SRL_PEER_INBOX_GRANULES + 8)
+
 struct srl_ctx {
     int device = 0;
     bool counted = false;              // this context is in the per-device census (srl_capi.cpp: g_live_ctx)
@@ -187,6 +192,9 @@ struct srl_ctx {
     bool peer_on = false;
     int peer_seen = 0;                 // inboxes mapped at srl_peer_attach (srl_comm_info: equal to nranks when every rank's handle opened)
     bool peer_failed = false;          // a row of this session never arrived: no further exchange until srl_peer_export + srl_peer_attach
+    unsigned long long *peer_inbox[SRL_MAX_PEERS] = {};     // every rank's inbox as mapped into this process (host copy of SrlPeerTable::inbox)
+    int peer_deadline_ms = 10000;      // srl_peer_set_deadline_ms: how long a pass keeps re-polling for a late rank's row before the session is given up
+    unsigned long long peer_retries = 0;       // passes repeated because a row had not arrived within one kernel's bounded spin (srl_comm_info)
     unsigned long long peer_seq = 0;           // exchange counter: advances in lock-step on every rank
     SrlMailbox *d_mail = nullptr;              // device-side mailbox: where a FUSED pass leaves its rank's result for the RCCL all-reduce
     bool dbg_gather = false;           // srl_debug_set_gather_counts: d_gather is preloaded (no all-gather)

@@ -40,7 +40,7 @@ def _single(golden, raw, max_res, passes=1):
         ctx.close()
 
 
-def _peer_threads(golden, raw, G, max_res, passes=3, fused=True, skip_rank=None):
+def _peer_threads(golden, raw, G, max_res, passes=3, fused=True, skip_rank=None, deadline_ms=None):
     """G contexts on device 0, one thread each; returns the per-rank results of the LAST pass (or the exception per rank)."""
     ctxs = [srl.Context(0) for _ in range(G)]
     ptrs = [c.peer_export()[1] for c in ctxs]
@@ -52,6 +52,8 @@ def _peer_threads(golden, raw, G, max_res, passes=3, fused=True, skip_rank=None)
         try:
             ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
             ctx.peer_attach(G, rank, local_ptrs=ptrs)
+            if deadline_ms is not None:
+                ctx.peer_set_deadline_ms(deadline_ms)
             ctx.set_fused_reduce(1 if fused else 0)
             ctx.sweep_upload(raw)
             f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
@@ -162,8 +164,8 @@ def test_a_second_session_does_not_see_the_rows_of_the_first(golden):
 
 
 def test_a_missing_peer_is_an_error_not_a_hang(golden):
-    """Rank 1 of 2 never calls: rank 0's exchange gives up after its bounded spin and srl_build_residuals returns SRL_ERR_COMM."""
-    out, errors = _peer_threads(golden, golden["raw"], 2, INT_MAX, passes=1, skip_rank=1)
+    """Rank 1 of 2 never calls: rank 0 re-polls until its deadline (srl_peer_set_deadline_ms) and srl_build_residuals returns SRL_ERR_COMM."""
+    out, errors = _peer_threads(golden, golden["raw"], 2, INT_MAX, passes=1, skip_rank=1, deadline_ms=1200)
     assert out[0] is None and isinstance(errors[0], srl.SrlError) and errors[0].status == capi.SRL_ERR_COMM, (out, errors)
     assert "peer" in str(errors[0])
 
@@ -181,6 +183,7 @@ def test_a_failed_session_stays_failed_until_it_is_started_again(golden):
         ptrs = [c.peer_export()[1] for c in ctxs]
         for r, c in enumerate(ctxs):
             c.peer_attach(2, r, local_ptrs=ptrs)
+            c.peer_set_deadline_ms(500)
             c.sweep_upload(golden["raw"])
         with pytest.raises(srl.SrlError) as e1:
             ctxs[0].build_residuals(f, opts)                               # rank 1 never calls
@@ -205,6 +208,83 @@ def test_a_failed_session_stays_failed_until_it_is_started_again(golden):
         ref = _single(golden, golden["raw"], INT_MAX)
         assert out[0] is not None and out[1] is not None and out[0].num_residuals == ref.num_residuals == out[1].num_residuals
         assert np.array_equal(np.array(out[0].HtH), np.array(out[1].HtH))
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_a_late_rank_is_not_a_failure(golden, fused):
+    """Rank 1 starts its pass 2.5 s late -- longer than the bounded spin of the kernel that waits for its row.  Rank 0 must not fail and
+    must not run ahead: it repeats the pass with the same exchange tags (srl_peer_stats counts the repeats) until the row is there; both
+    ranks return SRL_OK with the single-context result, and the passes behind it run in lock step as if nothing had happened."""
+    import time
+    ctxs = [srl.Context(0) for _ in range(2)]
+    f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    out, errors = [None, None], [None, None]
+    try:
+        ptrs = [c.peer_export()[1] for c in ctxs]
+        for r, c in enumerate(ctxs):
+            c.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+            c.peer_attach(2, r, local_ptrs=ptrs)
+            c.peer_set_deadline_ms(30_000)
+            c.set_fused_reduce(1 if fused else 0)
+            c.sweep_upload(golden["raw"])
+
+        def worker(r):
+            try:
+                if r == 1:
+                    time.sleep(2.5)
+                for _ in range(4):
+                    out[r] = ctxs[r].build_residuals(f, opts)[0]
+            except Exception as e:  # noqa: BLE001
+                errors[r] = e
+
+        ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert errors == [None, None], errors
+        ref = _single(golden, golden["raw"], INT_MAX)
+        for r in range(2):
+            assert out[r].num_residuals == ref.num_residuals and rel(np.array(out[r].HtH), np.array(ref.HtH)) < 1e-12
+        assert np.array_equal(np.array(out[0].HtH), np.array(out[1].HtH)) and np.array_equal(np.array(out[0].Hth), np.array(out[1].Hth))
+        rep0, failed0 = ctxs[0].peer_stats()
+        rep1, failed1 = ctxs[1].peer_stats()
+        assert rep0 >= 1 and not failed0 and not failed1, (rep0, rep1)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_a_rank_that_gives_up_poisons_the_session_for_the_others(golden):
+    """Rank 0 (deadline 0.6 s) gives the session up while rank 1 (deadline 60 s) is away.  Rank 1's first pass still completes -- rank 0's
+    rows of that exchange had been delivered --, its second finds no row, and instead of re-polling for a minute it sees the poison word
+    rank 0 left in its inbox and returns SRL_ERR_COMM within the kernel's bounded spin."""
+    import time
+    ctxs = [srl.Context(0) for _ in range(2)]
+    f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    try:
+        ptrs = [c.peer_export()[1] for c in ctxs]
+        for r, c in enumerate(ctxs):
+            c.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+            c.peer_attach(2, r, local_ptrs=ptrs)
+            c.peer_set_deadline_ms(600 if r == 0 else 60_000)
+            c.sweep_upload(golden["raw"])
+        with pytest.raises(srl.SrlError) as e0:
+            ctxs[0].build_residuals(f, opts)
+        assert e0.value.status == capi.SRL_ERR_COMM and "deadline" in str(e0.value)
+        assert ctxs[0].peer_stats()[1]
+        neq, _ = ctxs[1].build_residuals(f, opts)                          # exchange 1: rank 0's rows are there
+        assert neq.num_residuals > 0
+        t0 = time.perf_counter()
+        with pytest.raises(srl.SrlError) as e1:
+            ctxs[1].build_residuals(f, opts)                               # exchange 2: nobody is coming
+        dt = time.perf_counter() - t0
+        assert e1.value.status == capi.SRL_ERR_COMM and "another rank" in str(e1.value), str(e1.value)
+        assert dt < 5.0, dt
+        assert ctxs[1].peer_stats()[1]
     finally:
         for c in ctxs:
             c.close()
