@@ -543,7 +543,7 @@ def compact_line(out):
     line["ms_per_esikf_iter"] = out.get("ms_per_esikf_iter")
     r = out.get("roofline") or {}
     roof = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-    roof.update(_pick(r, ("kernel", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch", "compulsory_bytes_per_launch",
+    roof.update(_pick(r, ("kernel", "avg_launch_ms", "launches", "launches_in_region", "event_period", "algorithmic_bytes_per_launch", "compulsory_bytes_per_launch",
                           "hbm_measured_GBs", "traffic_source", "profile_stale", "launch_duration_includes")))
     if isinstance(r.get("issue"), dict):
         roof["issue"] = _pick(r["issue"], ("bound", "frac", "floor_us", "valu_floor_us", "salu_floor_us", "lds_floor_us"))
@@ -671,6 +671,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="HEADLINE", choices=sorted(synth.CONFIGS))
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replay"])
+    ap.add_argument("--event-period", type=int, default=0,
+                    help="HIP-event timing of the association kernel inside the timed region: every N-th launch (0 = 5 when --steps >= 10, else every launch)")
     ap.add_argument("--max-num-residuals", type=int, default=INT_MAX,
                     help="2^31-1 = throughput headline (every keypoint contributes); 600 = shipped yaml value")
     ap.add_argument("--frame-id", type=int, default=100, help="< 20: init mode (r = 2, >= 16 iterations)")
@@ -819,6 +821,11 @@ def main():
     # back lazily after the region (mode 2) -- the full per-call breakdown (mode 1: four events + a sync per call, ~20 us
     # of host time per iteration) is taken on a few extra solves after the timed region instead.
     lio.ctx.set_profiling(2)          # (reads back the clock warm-up's several hundred event pairs -- milliseconds of idle GPU -- BEFORE the W warm-up steps)
+    # ... of every `event_period` launches ONE is timed (two event records: the launch before it leaves its end event as the start); an
+    # event record behind every launch costs the loop ~2.5 us per launch (HISTORY.md, round 5).  Odd period: first and second iterations
+    # of the solves are sampled alike.  Short regions time every launch.
+    event_period = args.event_period if args.event_period > 0 else (5 if args.steps >= 10 else 1)
+    lio.ctx.set_profiling_period(event_period)
     for _ in range(args.warmup):
         r = stream_step()
     tim_w = lio.ctx.timing()          # the warm-up steps' launches, subtracted below: the figures are those of the timed region alone
@@ -842,6 +849,7 @@ def main():
     launches_timed = lio.last_solve_launches()
     arm_stats = {k: arm_after[k] - arm_before[k] for k in arm_after}
     lio.ctx.set_profiling(0)
+    lio.ctx.set_profiling_period(1)   # (the legs behind the timed region time every launch)
     # the same loop for >= 1 000 solves with a stamp per solve (a 20-step region lasts 2 ms): median- and mean-based rates, the states
     # every sweep of the stream was solved to (compared with the oracle and with the launch-per-iteration form further down)
     n_long = 0 if args.no_aux_legs else max(1000, args.steps)
@@ -867,6 +875,9 @@ def main():
                        "solves_over_1ms": int(np.count_nonzero(per_long > 1e-3))}
     elapsed_rank = elapsed                    # this rank's own clock (the line carries min / max over the ranks)
     comm_state = lio.ctx.comm_info()          # (read while the communicator / peer table of the timed region is still attached)
+    if comm_state.get("transport_used") == "peer":
+        rep, failed = lio.ctx.peer_stats()    # passes repeated because a rank's row was late (srl_peer_set_deadline_ms), session state
+        comm_state.update(passes_repeated_for_a_late_rank=rep, session_failed=failed)
     elapsed = max_over_ranks(elapsed)
     launches_per_solve = launches_timed
     # A/B: the same stream with one launch call per ESIKF iteration on the critical path (armed launches off: round 3's form), with the
@@ -1029,7 +1040,8 @@ def main():
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": f"srl_assoc_armed_kernel<{nb}>" if (not args.no_armed and world == 1) else f"srl_assoc_kernel<{nb}>",
-            "avg_launch_ms": assoc_ms, "launches": tim.calls, "passes_per_launch": passes / calls, "avg_pass_ms": tim.sum_assoc_ms / passes,
+            "avg_launch_ms": assoc_ms, "launches": tim.calls, "launches_in_region": iters_timed, "event_period": event_period,
+            "passes_per_launch": passes / calls, "avg_pass_ms": tim.sum_assoc_ms / passes,
             "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_pass": tim.sum_algorithmic_bytes / passes,
             "profile_stale": bool(load_profile()[1]) if headline_default else None,
             "reduce_kernel_avg_ms": tim_full.sum_reduce_ms / fcalls, "device_total_avg_ms": tim_full.sum_total_ms / fcalls,

@@ -374,6 +374,11 @@ int srl_set_profiling(srl_ctx *ctx, int mode);     /* 0 off (default); 1 full: f
                                                       * sum_host_total_us = the whole call, sum_assoc_ms / sum_reduce_ms = argument
                                                       * preparation / launch returned -> everything enqueued (tools/host_hop_probe.py).
                                                       * Switching on resets the sums. */
+/* Mode 2 looks at every association launch by default (one event record behind each: ~2.5 us of the loop per launch).  With a period
+ * P > 1 only every P-th launch is timed (the launch before it leaves its end event as the start): 2 records per P launches.  calls,
+ * sum_assoc_ms, sum_algorithmic_bytes, sum_passes then cover the timed launches and their passes only.  1 <= P <= 64; pick an odd P where
+ * the launches of a solve alternate (first / second iteration), so that both kinds are sampled. */
+int srl_set_profiling_period(srl_ctx *ctx, int period);
 
 #ifdef __cplusplus
 }

@@ -177,6 +177,7 @@ def load_library():
         "srl_debug_heap_topk": ([p, C.c_int, C.c_int, p], C.c_int),
         "srl_debug_device_sqrt": ([p, p, C.c_int, p], C.c_int),
         "srl_set_profiling": ([p, C.c_int], C.c_int),
+        "srl_set_profiling_period": ([p, C.c_int], C.c_int),
         # host mirror handles
         "srl_lio_create": ([C.c_int, C.POINTER(p)], C.c_int),
         "srl_lio_destroy": ([p], C.c_int),
@@ -466,6 +467,10 @@ class Context:
 
     def set_profiling(self, on):
         self._chk(self.lib.srl_set_profiling(self.h, int(on)), "srl_set_profiling")
+
+    def set_profiling_period(self, period):
+        """light profiling (mode 2): time every period-th association launch only (2 event records per period launches)"""
+        self._chk(self.lib.srl_set_profiling_period(self.h, int(period)), "srl_set_profiling_period")
 
     def timing(self):
         t = Timing()

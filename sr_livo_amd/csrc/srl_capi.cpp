@@ -531,7 +531,10 @@ int drain_ring(srl_ctx *ctx, bool all) {
         if (!all && hipEventQuery(e[1]) != hipSuccess) break;
         if (all) HIPCHK(ctx, hipEventSynchronize(e[1]));
         const unsigned slot = ctx->ring_tail % srl_ctx::PROF_RING;
-        if (ctx->ring_void[slot]) { ctx->ring_void[slot] = false; ctx->ring_tail++; continue; }   // a cancelled armed launch
+        if (ctx->ring_void[slot] || ctx->ring_marker[slot]) {      // a cancelled armed launch / an entry that was only the next launch's start
+            ctx->ring_void[slot] = false; ctx->ring_marker[slot] = false; ctx->ring_tail++;
+            continue;
+        }
         float ms = 0.f;
         // an armed launch has no start event of its own: it is enqueued behind the launch of the pass before it and the stream turns
         // to it the moment that one completes -- its start IS the end event of its predecessor in the ring
@@ -558,7 +561,18 @@ int srl_set_profiling(srl_ctx *ctx, int enable) {
             for (int k = 0; k < 2; k++) if (!ctx->ring[i][k]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ring[i][k], hipEventReleaseToDevice));   // (device-scope release: a timing marker between two kernels must not write the L2 back)
         ctx->ring_head = ctx->ring_tail = 0;
         std::memset(ctx->ring_void, 0, sizeof ctx->ring_void);
+        std::memset(ctx->ring_marker, 0, sizeof ctx->ring_marker);
+        ctx->prof_count = 0; ctx->ring_last_count = -2; ctx->armed_measured = false; ctx->cur_measured = true;
     }
+    return SRL_OK;
+}
+
+int srl_set_profiling_period(srl_ctx *ctx, int period) {
+    if (!ctx || period < 1 || period > 64) return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
+    if (ctx->profiling == 2) { int rc = drain_ring(ctx, true); if (rc) return rc; }
+    ctx->prof_period = period;
+    ctx->prof_count = 0; ctx->ring_last_count = -2; ctx->armed_measured = false; ctx->cur_measured = true;
     return SRL_OK;
 }
 
@@ -998,12 +1012,30 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         }
     }
     const auto t_prep = std::chrono::steady_clock::now();
-    if (!fired) {
+    // Light profiling with a period P > 1 (srl_set_profiling_period): of every P association launches the second is TIMED and the first only
+    // leaves its end event as the second's start; the others carry no event at all (an event record costs ~2.5 us of the loop).
+    auto prof_role = [&](unsigned long long count) -> int {        // 2 = timed, 1 = start marker of the next launch, 0 = no events
+        if (ctx->prof_period <= 1) return 2;
+        const unsigned long long r = count % (unsigned long long)ctx->prof_period;
+        return r == 1 ? 2 : (r == 0 ? 1 : 0);
+    };
+    if (fired) {
+        ctx->cur_measured = ctx->armed_measured;
+    } else {
+        const int role = prof_light ? prof_role(ctx->prof_count) : 0;
         if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-        if (prof_light) HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
+        if (role == 2) HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
         HIPCHK(ctx, srl_launch_assoc(a, nb, kpw, wpb, ctx->stream));
         if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-        if (prof_light) { HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream)); ctx->ring_prev[ctx->ring_head % srl_ctx::PROF_RING] = -1; ctx->ring_head++; }
+        if (role != 0) {
+            const unsigned slot = ctx->ring_head % srl_ctx::PROF_RING;
+            HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream));
+            ctx->ring_prev[slot] = -1; ctx->ring_marker[slot] = role == 1; ctx->ring_void[slot] = false;
+            ctx->ring_last_count = (long long)ctx->prof_count;
+            ctx->ring_head++;
+        }
+        if (prof_light) ctx->prof_count++;
+        ctx->cur_measured = !prof_light || role == 2;
     }
     const auto t_launched = std::chrono::steady_clock::now();
     if (ctx->h_arm_stamps) {
@@ -1046,23 +1078,30 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         nx.arm_linger_ticks = ctx->arm_linger_ticks;
         hipEvent_t *nev = nullptr;
         bool own_start = true;
-        if (prof_light) {
+        const int arole = prof_light ? prof_role(ctx->prof_count) : 0;
+        if (arole != 0) {
             if (ctx->ring_head - ctx->ring_tail >= (unsigned)srl_ctx::PROF_RING - 2) { int rc = drain_ring(ctx, true); if (rc) return rc; }
             nev = ctx->ring[ctx->ring_head % srl_ctx::PROF_RING];
-            // the launch of THIS pass is the ring entry before: its end event is the armed launch's start (an event record between
-            // the two kernels would sit on the path the armed launch is there to shorten: measured +5 us per iteration)
-            own_start = ctx->ring_head == 0 || ctx->ring_void[(ctx->ring_head - 1) % srl_ctx::PROF_RING];
-            if (own_start) HIPCHK(ctx, hipEventRecord(nev[0], ctx->stream));
+            // the launch before this one is the ring entry before (if it left one): its end event is the armed launch's start (an event
+            // record between the two kernels would sit on the path the armed launch is there to shorten: measured +5 us per iteration)
+            own_start = ctx->ring_head == 0 || ctx->ring_void[(ctx->ring_head - 1) % srl_ctx::PROF_RING] ||
+                        ctx->ring_last_count != (long long)ctx->prof_count - 1;
+            if (own_start && arole == 2) HIPCHK(ctx, hipEventRecord(nev[0], ctx->stream));
         }
         HIPCHK(ctx, srl_launch_assoc(nx, nb, kpw, wpb, ctx->stream));
         ctx->armed_ring = -1;
-        if (prof_light) {
+        ctx->armed_measured = !prof_light;
+        if (arole != 0) {
             HIPCHK(ctx, hipEventRecord(nev[1], ctx->stream));
             ctx->armed_ring = (int)(ctx->ring_head % srl_ctx::PROF_RING);
             ctx->ring_void[ctx->armed_ring] = false;
+            ctx->ring_marker[ctx->armed_ring] = arole == 1;
             ctx->ring_prev[ctx->armed_ring] = own_start ? -1 : (int)((ctx->ring_head - 1) % srl_ctx::PROF_RING);
+            ctx->ring_last_count = (long long)ctx->prof_count;
             ctx->ring_head++;
+            ctx->armed_measured = arole == 2;
         }
+        if (prof_light) ctx->prof_count++;
         ctx->armed_sig = signature(nx);
         ctx->armed_nb = nb; ctx->armed_kpw = kpw; ctx->armed_nblocks = nblocks;
         ctx->armed_raw = nx.raw_x; ctx->armed_raw_cap = ctx->sweep_cap;
@@ -1273,7 +1312,10 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         const long long per_kp = 24 + 12 * side * side * side;
         const double pk_share = (ctx->nranks > 1 && ctx->total_n > 0) ? r.d_sum_pk * ((double)ctx->n / (double)ctx->total_n) : r.d_sum_pk;
         ctx->timing.algorithmic_bytes = per_kp * (long long)n_eff + (long long)(12.0 * pk_share);
-        if (prof || prof_light) { ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes; ctx->timing.sum_keypoints += prof_light ? n_eff : 0; ctx->timing.sum_passes += 1; }
+        // (light profiling with a period: only the passes whose launch is one of the timed ones count, so bytes and durations pair up)
+        if (prof || (prof_light && ctx->cur_measured)) {
+            ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes; ctx->timing.sum_keypoints += prof_light ? n_eff : 0; ctx->timing.sum_passes += 1;
+        }
     }
     if (ctx->profiling == 3) {
         // host stamps only (no events): argument preparation, the launch call itself, the wait for the result

@@ -160,6 +160,11 @@ struct srl_ctx {
                                                 // synchronisation from outside this library waits that long at most)
     unsigned long long arm_stats[4] = {0, 0, 0, 0};   // armed, fired, cancelled, expired
     bool ring_void[512] = {};
+    bool ring_marker[512] = {};                 // light profiling with a period: an entry that only serves as the NEXT launch's start (not timed itself)
+    int prof_period = 1;                        // srl_set_profiling_period: the light profiling times every prof_period-th association launch
+    unsigned long long prof_count = 0;          // association launches seen by the light profiling (own and armed)
+    long long ring_last_count = -2;             // prof_count of the launch behind the newest ring entry
+    bool armed_measured = false, cur_measured = true;     // is the armed launch / the launch of the pass now running one of the timed ones?
     int ring_prev[512] = {};                    // light profiling: ring slot whose END event is this launch's start (armed launches), -1 = own start event
     long long *h_arm_stamps = nullptr;          // srl_debug_pass_stamps: 64 rows x 16 slots the armed kernels file (host-mapped)
     long long arm_host_stamps[64][4] = {};      // per pass (row seq & 63), steady-clock ns: call entry, pose written / launch returned, result seen, fired?                   // light profiling: event pairs of cancelled armed launches (not counted)
