@@ -710,6 +710,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
+    torch.cuda.synchronize()          # torch's lazy CUDA initialisation happens HERE, not inside the barrier in front of the timed region
+                                      # (hundreds of ms of idle GPU there: the first timed step then ran at 147 us instead of 100)
     pin_info = {"pinned": False, "disabled": True} if args.no_numa_pin else pin_to_gpu_numa_node(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:
@@ -828,8 +830,10 @@ def main():
     lio.ctx.set_profiling_period(event_period)
     for _ in range(args.warmup):
         r = stream_step()
-    tim_w = lio.ctx.timing()          # the warm-up steps' launches, subtracted below: the figures are those of the timed region alone
-    tim_w = {k: getattr(tim_w, k) for k in ("calls", "sum_assoc_ms", "sum_algorithmic_bytes", "sum_passes", "sum_keypoints")}
+    lio.ctx.timing_mark()             # the figures are those of the timed region alone: the warm-up's launches are left out when their events
+                                      # are read -- WITHOUT reading anything back here (srl_get_timing waits for every event and cancels the
+                                      # armed launch: the GPU then idled for ~300 us in front of the region and its first step ran at 147 us)
+    tim_w = {k: 0 for k in ("calls", "sum_assoc_ms", "sum_algorithmic_bytes", "sum_passes", "sum_keypoints")}
     step_end = np.empty(args.steps)
     barrier()
     arm_before = lio.ctx.arm_stats()

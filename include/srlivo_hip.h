@@ -379,6 +379,11 @@ int srl_set_profiling(srl_ctx *ctx, int mode);     /* 0 off (default); 1 full: f
  * sum_assoc_ms, sum_algorithmic_bytes, sum_passes then cover the timed launches and their passes only.  1 <= P <= 64; pick an odd P where
  * the launches of a solve alternate (first / second iteration), so that both kinds are sampled. */
 int srl_set_profiling_period(srl_ctx *ctx, int period);
+/* "The sums of srl_get_timing start HERE" (mode 2) without a read-back: no event is waited for, an armed launch stays armed.  Launches
+ * enqueued before the mark -- the one armed behind the last pass included -- are left out of calls / sum_assoc_ms when their events are
+ * read later, and their passes out of the byte sums.  (srl_get_timing itself waits for every outstanding event and cancels an armed
+ * launch: called between warm-up and a timed region it idles the GPU for a few hundred microseconds.) */
+int srl_timing_mark(srl_ctx *ctx);
 
 #ifdef __cplusplus
 }

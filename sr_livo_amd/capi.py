@@ -178,6 +178,7 @@ def load_library():
         "srl_debug_device_sqrt": ([p, p, C.c_int, p], C.c_int),
         "srl_set_profiling": ([p, C.c_int], C.c_int),
         "srl_set_profiling_period": ([p, C.c_int], C.c_int),
+        "srl_timing_mark": ([p], C.c_int),
         # host mirror handles
         "srl_lio_create": ([C.c_int, C.POINTER(p)], C.c_int),
         "srl_lio_destroy": ([p], C.c_int),
@@ -467,6 +468,10 @@ class Context:
 
     def set_profiling(self, on):
         self._chk(self.lib.srl_set_profiling(self.h, int(on)), "srl_set_profiling")
+
+    def timing_mark(self):
+        """the light profiling's sums start here (no read-back, an armed launch stays armed): srl_timing_mark"""
+        self._chk(self.lib.srl_timing_mark(self.h), "srl_timing_mark")
 
     def set_profiling_period(self, period):
         """light profiling (mode 2): time every period-th association launch only (2 event records per period launches)"""

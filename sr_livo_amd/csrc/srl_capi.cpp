@@ -535,6 +535,7 @@ int drain_ring(srl_ctx *ctx, bool all) {
             ctx->ring_void[slot] = false; ctx->ring_marker[slot] = false; ctx->ring_tail++;
             continue;
         }
+        if (ctx->ring_gen[slot] != ctx->timing_gen) { ctx->ring_tail++; continue; }      // enqueued before the last srl_timing_mark
         float ms = 0.f;
         // an armed launch has no start event of its own: it is enqueued behind the launch of the pass before it and the stream turns
         // to it the moment that one completes -- its start IS the end event of its predecessor in the ring
@@ -564,6 +565,13 @@ int srl_set_profiling(srl_ctx *ctx, int enable) {
         std::memset(ctx->ring_marker, 0, sizeof ctx->ring_marker);
         ctx->prof_count = 0; ctx->ring_last_count = -2; ctx->armed_measured = false; ctx->cur_measured = true;
     }
+    return SRL_OK;
+}
+
+int srl_timing_mark(srl_ctx *ctx) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    ctx->timing_gen++;
+    std::memset(&ctx->timing, 0, sizeof ctx->timing);
     return SRL_OK;
 }
 
@@ -1021,7 +1029,9 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     };
     if (fired) {
         ctx->cur_measured = ctx->armed_measured;
+        ctx->cur_gen = ctx->armed_gen;
     } else {
+        ctx->cur_gen = ctx->timing_gen;
         const int role = prof_light ? prof_role(ctx->prof_count) : 0;
         if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
         if (role == 2) HIPCHK(ctx, hipEventRecord(ring_ev[0], ctx->stream));
@@ -1030,7 +1040,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         if (role != 0) {
             const unsigned slot = ctx->ring_head % srl_ctx::PROF_RING;
             HIPCHK(ctx, hipEventRecord(ring_ev[1], ctx->stream));
-            ctx->ring_prev[slot] = -1; ctx->ring_marker[slot] = role == 1; ctx->ring_void[slot] = false;
+            ctx->ring_prev[slot] = -1; ctx->ring_marker[slot] = role == 1; ctx->ring_void[slot] = false; ctx->ring_gen[slot] = ctx->timing_gen;
             ctx->ring_last_count = (long long)ctx->prof_count;
             ctx->ring_head++;
         }
@@ -1091,11 +1101,13 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         HIPCHK(ctx, srl_launch_assoc(nx, nb, kpw, wpb, ctx->stream));
         ctx->armed_ring = -1;
         ctx->armed_measured = !prof_light;
+        ctx->armed_gen = ctx->timing_gen;
         if (arole != 0) {
             HIPCHK(ctx, hipEventRecord(nev[1], ctx->stream));
             ctx->armed_ring = (int)(ctx->ring_head % srl_ctx::PROF_RING);
             ctx->ring_void[ctx->armed_ring] = false;
             ctx->ring_marker[ctx->armed_ring] = arole == 1;
+            ctx->ring_gen[ctx->armed_ring] = ctx->timing_gen;
             ctx->ring_prev[ctx->armed_ring] = own_start ? -1 : (int)((ctx->ring_head - 1) % srl_ctx::PROF_RING);
             ctx->ring_last_count = (long long)ctx->prof_count;
             ctx->ring_head++;
@@ -1313,7 +1325,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         const double pk_share = (ctx->nranks > 1 && ctx->total_n > 0) ? r.d_sum_pk * ((double)ctx->n / (double)ctx->total_n) : r.d_sum_pk;
         ctx->timing.algorithmic_bytes = per_kp * (long long)n_eff + (long long)(12.0 * pk_share);
         // (light profiling with a period: only the passes whose launch is one of the timed ones count, so bytes and durations pair up)
-        if (prof || (prof_light && ctx->cur_measured)) {
+        if (prof || (prof_light && ctx->cur_measured && ctx->cur_gen == ctx->timing_gen)) {
             ctx->timing.sum_algorithmic_bytes += ctx->timing.algorithmic_bytes; ctx->timing.sum_keypoints += prof_light ? n_eff : 0; ctx->timing.sum_passes += 1;
         }
     }

@@ -165,6 +165,10 @@ struct srl_ctx {
     unsigned long long prof_count = 0;          // association launches seen by the light profiling (own and armed)
     long long ring_last_count = -2;             // prof_count of the launch behind the newest ring entry
     bool armed_measured = false, cur_measured = true;     // is the armed launch / the launch of the pass now running one of the timed ones?
+    // srl_timing_mark: "the sums start here" without a read-back -- launches enqueued before the mark carry an older generation and are
+    // left out when their events are read (their passes' bytes likewise)
+    unsigned timing_gen = 0, armed_gen = 0, cur_gen = 0;
+    unsigned ring_gen[512] = {};
     int ring_prev[512] = {};                    // light profiling: ring slot whose END event is this launch's start (armed launches), -1 = own start event
     long long *h_arm_stamps = nullptr;          // srl_debug_pass_stamps: 64 rows x 16 slots the armed kernels file (host-mapped)
     long long arm_host_stamps[64][4] = {};      // per pass (row seq & 63), steady-clock ns: call entry, pose written / launch returned, result seen, fired?                   // light profiling: event pairs of cancelled armed launches (not counted)

@@ -1,6 +1,7 @@
 """Soak test of the frame pipeline (GPU box): frames of five sizes in a long back-to-back loop -- page-locked upload on the copy stream,
-keypoint selection (voxel list stored straight into host memory, host waits on the tagged word), one pass, deferred commit with the world
-points coming back on the copy stream.  Every frame's keypoint list and world points must equal the first ones of its size bit for bit
+keypoint selection (grouping, first-occurrence ranks and the std::tr1::unordered_map iteration order on the device; the host waits on a
+tagged word for the count and fetches the index list), one pass, deferred commit (own radix passes, re-transform fused into the first
+insertion kernel) with the world points coming back on the copy stream.  Every frame's keypoint list and world points must equal the first ones of its size bit for bit
 (they depend on the frame and the pose only, not on the map), the map after the first CHECK frames must equal the map a second context
 builds with the synchronous form, and the loop is long enough for the scratch tables' 16-bit epoch to wrap (65 535 frames) at least once
 when run with the default count.
