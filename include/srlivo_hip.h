@@ -381,7 +381,8 @@ int srl_set_profiling(srl_ctx *ctx, int mode);     /* 0 off (default); 1 full: f
 int srl_set_profiling_period(srl_ctx *ctx, int period);
 /* "The sums of srl_get_timing start HERE" (mode 2) without a read-back: no event is waited for, an armed launch stays armed.  Launches
  * enqueued before the mark -- the one armed behind the last pass included -- are left out of calls / sum_assoc_ms when their events are
- * read later, and their passes out of the byte sums.  (srl_get_timing itself waits for every outstanding event and cancels an armed
+ * read later, and their passes out of the byte sums.  With a period P > 1 the launches timed behind the mark are the 4th, the (4 + P)-th,
+ * ... (the first step behind a barrier -- an un-armed launch into an idle GPU -- is no steady-state sample).  (srl_get_timing itself waits for every outstanding event and cancels an armed
  * launch: called between warm-up and a timed region it idles the GPU for a few hundred microseconds.) */
 int srl_timing_mark(srl_ctx *ctx);
 

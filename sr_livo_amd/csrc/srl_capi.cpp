@@ -572,6 +572,10 @@ int srl_timing_mark(srl_ctx *ctx) {
     if (!ctx) return SRL_ERR_BAD_ARG;
     ctx->timing_gen++;
     std::memset(&ctx->timing, 0, sizeof ctx->timing);
+    // with a period, the first timed launch behind the mark is the FOURTH (then every period-th): the launches of the first step behind a
+    // barrier -- an un-armed launch into an idle GPU and the pass behind it -- would otherwise be one sample in eight of a 20-step region
+    ctx->prof_count = ctx->prof_period > 1 ? (unsigned long long)(ctx->prof_period - 2) : 0ull;
+    ctx->ring_last_count = -2;
     return SRL_OK;
 }
 
