@@ -309,7 +309,11 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         arm1 = lio.ctx.arm_stats()
         it, nr, state = states[0] if 0 in states else (rr["iters"], rr["num_residuals"], rr["state"].copy())
         # kernel time of the same solves: a second pass with one event pair around every association launch
-        lio.ctx.set_profiling(2)
+        lio.ctx.set_profiling(2)     # (first use on this context: a thousand event creations, milliseconds of idle GPU ...)
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.01:
+            step()                   # (... so the clocks are brought back up before the launches that count)
+        lio.ctx.timing_mark()
         for _ in range(min(steps, 20)):
             step()
         tim = lio.ctx.timing()
