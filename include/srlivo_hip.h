@@ -167,7 +167,12 @@ int srl_sweep_shard(srl_ctx *ctx, int *begin, int *count, int *total);
  * srl_frame_upload            replaces handing p_frame->point_frame (raw points) to optimize() (optimize.cpp:428)
  * srl_frame_select_keypoints  replaces gridSampling / subSampleFrame (utility.cpp:167-201) applied to
  *                             point = R(q) (R_il raw + t_il) + t (utility.cpp:314-318): same keypoints in the same
- *                             (std::tr1::unordered_map iteration) order; they become the resident sweep.
+ *                             (std::tr1::unordered_map iteration) order; they become the resident sweep.  The order is
+ *                             computed on the device (csrc/host/tr1_relation.h; frames beyond 131 072 points or buckets, or
+ *                             with more than 16 voxels in one bucket of the container, through the host replay of
+ *                             csrc/host/tr1_order.h).  keypoint_index == NULL: only the count comes back (the call returns
+ *                             while the last kernels of the selection still run; the passes queue behind them) -- the
+ *                             index list costs a copy and a stream synchronisation, ask for it only if the caller needs it.
  * srl_frame_commit            replaces the re-transform loop (optimize.cpp:441-445) + addPointsToMap
  *                             (lioOptimization.cpp:520-554) with the final pose, without leaving the device.
  * A page-locked raw_xyz (srl_pinned_alloc) is copied by the DMA engine on the context's copy stream, beside whatever the compute stream
