@@ -437,7 +437,7 @@ def run_pipeline(device, frame_points=(24_000, 65_536), reps=9):
                 t2 = time.perf_counter()
                 ctx.build_residuals(f, opts)
                 ctx.build_residuals(f, opts)
-                ctx.disarm()
+                ctx.solve_end()                                   # (like the host mirror: the arming policy learns that a solve is two passes -> no launch left waiting)
                 t3 = time.perf_counter()
                 ctx.frame_commit(q, t, want_world=True, want_added=False, world_out=pin_world.array)      # addPointsToMap returns nothing either
                 t4 = time.perf_counter()
