@@ -1453,8 +1453,18 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         if constexpr (ARMED) arm_stamp(karg, 21);
         double ev[3];
         D3 nrm;
-        if (b.select_mode == 4) { eig3_jacobi(C, ev, nrm); nrm = normalized3(nrm); }   // .col(0).normalized() (optimize.cpp:340)
-        else eig3_closed(C, ev, nrm);                              // already unit length (re-normalised once more at :93 below)
+        // Closed form first (5x fewer FP64 instructions, no data-dependent loop).  It resolves the two SMALLER eigenvalues only down to
+        // ~sqrt(eps) of the largest (a near-double root of the characteristic cubic: error ~ eps p^2 / gap): on a line-like neighbourhood
+        // -- a cable, a pole: e0 ~ e1 << e2 -- the eigenvector of e0 inside that near-null plane comes out arbitrary, while the
+        // reference's iterative solver (optimize.cpp:339) still resolves it, and such a keypoint is NOT weightless (optimize.cpp:87-88:
+        // lambda_neighborhood * exp(...) does not vanish with a2D).  There the Jacobi sweeps run -- high relative accuracy on the small
+        // eigenvalues; never on a planar patch (e1 ~ e2), so the benchmark scenes do not pay for it.
+        bool jacobi = b.select_mode == 4;
+        if (!jacobi) {
+            eig3_closed(C, ev, nrm);                               // already unit length (re-normalised once more at :93 below)
+            jacobi = (ev[1] - ev[0]) < 1e-3 * ev[2];
+        }
+        if (jacobi) { eig3_jacobi(C, ev, nrm); nrm = normalized3(nrm); }   // .col(0).normalized() (optimize.cpp:340)
         if constexpr (ARMED) arm_stamp(karg, 22);
         const double sigma_1 = sqrt(fabs(ev[2]));
         const double sigma_2 = sqrt(fabs(ev[1]));
