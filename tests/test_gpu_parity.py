@@ -1745,40 +1745,6 @@ def test_map_probe_checksum_matches_a_host_walk_of_the_same_map():
         ctx.close()
 
 
-def _pole_scene(seed, n_keypoints=6000, pole_share=0.2):
-    """A scene with ILL-POSED neighbourhoods: a noisy ground plane and two walls (well-posed planes) plus thin straight cables high above
-    the ground, along the space diagonal, with a point every 0.16 m (the map keeps points at least min_distance_points = 0.15 m apart and
-    20 per voxel: a 3 x 3 x 3-voxel search box holds ~30 points of a diagonal line and nothing else up there).  A keypoint next to a cable
-    finds its 20 neighbours ON the cable: collinear, the two small eigenvalues of the neighbourhood (almost) equal, the plane normal
-    undetermined (computeNeighborhoodDistribution, optimize.cpp:316-353: a2D ~ 0)."""
-    rng = np.random.default_rng(seed)
-    g = np.column_stack([rng.uniform(-12, 12, 60_000), rng.uniform(-12, 12, 60_000), rng.normal(0.0, 0.01, 60_000)])
-    w1 = np.column_stack([np.full(20_000, 11.0) + rng.normal(0, 0.01, 20_000), rng.uniform(-12, 12, 20_000), rng.uniform(0, 3, 20_000)])
-    w2 = np.column_stack([rng.uniform(-12, 12, 20_000), np.full(20_000, -11.0) + rng.normal(0, 0.01, 20_000), rng.uniform(0, 3, 20_000)])
-    d = np.ones(3) / np.sqrt(3.0)
-    gx, gy = np.meshgrid([-9.0, -3.0, 3.0], [-9.0, -3.0, 3.0], indexing="ij")          # nine cables, 4.9 m apart: no neighbourhood sees two of them
-    starts = np.column_stack([gx.ravel(), gy.ravel(), np.full(9, 6.0) + rng.uniform(0, 0.5, 9)])
-    s_along = np.arange(0.0, 9.0, 0.16)
-    cables = [st + s_along[:, None] * d + rng.normal(0, 2e-4, (len(s_along), 3)) for st in starts]
-    pts = np.vstack([g, w1, w2] + cables)
-    rng.shuffle(pts, axis=0)
-    # keypoints: on the planes (well posed) and next to the cables (ill posed)
-    n_pole = int(n_keypoints * pole_share)
-    kg = np.column_stack([rng.uniform(-10, 10, n_keypoints - n_pole), rng.uniform(-10, 10, n_keypoints - n_pole), rng.normal(0, 0.01, n_keypoints - n_pole)])
-    third = len(kg) // 3
-    kg[:third] = np.column_stack([np.full(third, 11.0) + rng.normal(0, 0.01, third), rng.uniform(-10, 10, third), rng.uniform(0.3, 2.7, third)])
-    which = rng.integers(0, len(starts), n_pole)
-    side = np.cross(d, [0.0, 0.0, 1.0]); side /= np.linalg.norm(side)
-    kp = starts[which] + rng.uniform(2.5, 6.5, n_pole)[:, None] * d + 0.03 * side + rng.normal(0, 0.003, (n_pole, 3))
-    world = np.vstack([kg, kp])
-    world = world[rng.permutation(len(world))]
-    q_gt = synth.quat_from_rotvec([0.01, -0.02, 0.3]); t_gt = np.array([0.4, -0.3, 1.2])
-    R = synth.quat_to_rot(q_gt)
-    raw = (world - t_gt) @ R                                       # world = R raw + t (identity extrinsics)
-    q_pred = synth.quat_mul(synth.quat_from_rotvec([0.003, -0.002, 0.004]), q_gt); t_pred = t_gt + np.array([0.03, -0.02, 0.02])
-    return pts, dict(raw=raw, q_gt=q_gt, t_gt=t_gt, q_pred=q_pred, t_pred=t_pred, t_last=t_gt - np.array([0.1, 0.0, 0.0]), vel=np.zeros(3))
-
-
 @pytest.mark.parametrize("max_res", [INT_MAX, 600])
 def test_state_parity_where_the_plane_normal_is_undetermined(oracle_lib, oracle_backend, max_res):
     """phase 2 decomposes the 3x3 covariance in closed form where the reference runs an iterative solver, and the
@@ -1787,7 +1753,7 @@ def test_state_parity_where_the_plane_normal_is_undetermined(oracle_lib, oracle_
     neighbours, the two small eigenvalues 1e-7 of the large one and 1e-8 apart): the single pass must agree with the oracle on status,
     a2D and normals, and the full ESIKF solve must land on the oracle's state (1e-9) with the same iteration and residual counts, with
     and without the ordered cut."""
-    pts, sw = _pole_scene(77)
+    pts, sw = synth.cable_scene(77)
     m = oracle_lib.Map(oracle_backend)
     m.add_points(pts)
     lio = srl.Lio(0)
