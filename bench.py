@@ -247,7 +247,9 @@ class Streamer:
         rc2, it, nr = e["solve"]()
         rc = rc or rc2 or self._swap(self._h)
         if rc:
-            raise RuntimeError(f"stream step failed with status {rc} on sweep {k % self.S} of the stream")
+            lib = self.lio.lib
+            why = (lib.srl_lio_last_error(self.lio.h) or b"").decode(errors="replace") or (lib.srl_last_error(self.lio.ctx.h) or b"").decode(errors="replace")
+            raise RuntimeError(f"stream step failed with status {rc} on sweep {k % self.S} of the stream: {why}")
         self.pos = k + 1
         return {"iters": it, "num_residuals": nr, "state": e["solve"].state, "sweep": k % self.S}
 
