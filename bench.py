@@ -794,7 +794,8 @@ def main():
     def solve():
         rc, it, nr = _solve()
         if rc:
-            raise SystemExit(f"update_iekf failed with status {rc}")
+            why = (lio.lib.srl_lio_last_error(lio.h) or b"").decode(errors="replace") or (lio.lib.srl_last_error(lio.ctx.h) or b"").decode(errors="replace")
+            raise SystemExit(f"update_iekf failed with status {rc}: {why}")
         return {"iters": it, "num_residuals": nr, "state": _solve.state}
 
     # one step of the stream: the NEXT sweep starts crossing PCIe (copy stream) -> full ESIKF solve of the current one from its own prior ->
