@@ -13,7 +13,7 @@ def real_order(keys):
     return srl.grid_sampling(pts, 1.0)
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 10, 11, 12, 23, 24, 47, 48, 97, 98, 199, 1000, 5000, 14000, 60000])
+@pytest.mark.parametrize("n", [0, 1, 2, 10, 11, 12, 23, 24, 47, 48, 97, 98, 199, 1000, 5000, 14000, 60000, 131072])
 def test_replay_equals_the_real_container(n):
     rng = np.random.default_rng(n)
     keys = np.unique(rng.integers(-300, 300, size=(int(n * 1.3) + 8, 3)).astype(np.int16), axis=0)
