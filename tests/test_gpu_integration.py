@@ -202,7 +202,8 @@ def _record(name, payload):
     import json
     out = os.path.join(os.path.dirname(HERE), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    json.dump(payload, open(os.path.join(out, name), "w"), indent=1)
+    with open(os.path.join(out, name), "w") as fh:
+        json.dump(payload, fh, indent=1)
 
 
 def test_optimize_through_the_binding_against_the_reference_optimize_on_the_replay_streams(hip_node_lib):

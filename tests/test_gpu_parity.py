@@ -1699,7 +1699,9 @@ def test_thread_pin_to_gpu_numa_restricts_the_calling_thread_to_the_local_cpus()
         else:
             assert node >= 0 and after and after <= before
             local = set()
-            for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            with open(f"/sys/devices/system/node/node{node}/cpulist") as fh:
+                cpulist = fh.read().strip()
+            for part in cpulist.split(","):
                 a, _, b = part.partition("-")
                 local.update(range(int(a), int(b or a) + 1))
             assert after <= local
