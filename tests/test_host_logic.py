@@ -237,3 +237,32 @@ int main() {
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
+
+
+def test_the_product_tree_never_reaches_for_the_oracle():
+    """oracle/ is test infrastructure: nothing under sr_livo_amd/ (library sources, host mirror, Python layer), include/ or integration/
+    may import, link, dlopen or spawn anything from it (comments that NAME the oracle or its Makefile are not reaches), and bench.py may
+    only touch it behind its timed region (cpu_baseline / parity legs)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    reach = re.compile(r"(from\s+oracle\b|import\s+oracle\b|pyoracle|pyref|liboracle|libref_path|libref_node|dlopen\([^)]*oracle)")
+    bad = []
+    for top in ("sr_livo_amd", "include", "integration"):
+        for dp, _dn, fns in os.walk(os.path.join(root, top)):
+            if "__pycache__" in dp or os.sep + "build" in dp:
+                continue
+            for fn in fns:
+                if not fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                    continue
+                path = os.path.join(dp, fn)
+                for ln, line in enumerate(open(path, errors="replace"), 1):
+                    code = line.split("//")[0].split("#")[0] if not fn.endswith(".py") else line.split("#")[0]
+                    if reach.search(code):
+                        bad.append(f"{os.path.relpath(path, root)}:{ln}: {line.strip()[:100]}")
+    assert not bad, bad
+    # bench.py: every mention of the oracle sits behind the timed region's closing barrier
+    src = open(os.path.join(root, "bench.py")).read()
+    main = src[src.index("def main("):]
+    region_end = main.index("elapsed = time.perf_counter() - t1")
+    before = main[:region_end]
+    assert not re.search(r"\bpo\.(Map|Eskf|update_iekf|build_plane_residuals)\(|\bpr\.", before), "bench.py touches the oracle before its timed region has ended"
