@@ -95,6 +95,14 @@ int lioOptimization::prefetchSweep(const double *raw_xyz, int n) {
 
 int lioOptimization::swapSweep() {
     if (!voxel_map.ctx) return SRL_ERR_NO_DEVICE;
+    if (pending_prefetch_rc != SRL_OK) {
+        // the upload a solve issued on the caller's behalf (prefetchSweepDuringSolve) failed: that status -- and srl_last_error's text of
+        // the failed call -- is what the caller gets here, not a "nothing prefetched" from the swap
+        const int rc = pending_prefetch_rc;
+        pending_prefetch_rc = SRL_OK;
+        prefetched_n = -1;
+        return rc;
+    }
     const int rc = srl_sweep_swap(voxel_map.ctx);
     resident_n = (rc == SRL_OK) ? prefetched_n : -1;
     sweep_pinned = (rc == SRL_OK);

@@ -185,7 +185,7 @@ public:
     int prefetchSweep(const double *raw_xyz, int n);
     int swapSweep();
     // ... the same upload issued by the next solveIEKF() beside the kernel of its first pass (srl_lio_prefetch_sweep_during_solve)
-    void prefetchSweepDuringSolve(const double *raw_xyz, int n) { pending_prefetch_raw = raw_xyz; pending_prefetch_n = n; }
+    void prefetchSweepDuringSolve(const double *raw_xyz, int n) { pending_prefetch_raw = raw_xyz; pending_prefetch_n = n; pending_prefetch_rc = 0; }
     bool sweepPinned(int n) const { return sweep_pinned && resident_n == n; }
     // updateIEKF on the sweep already resident in HBM (no keypoint vector needed)
     optimizeSummary solveIEKF(const icpOptions &cur_icp_options, cloudFrame *p_frame);

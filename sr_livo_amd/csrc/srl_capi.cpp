@@ -637,6 +637,15 @@ bool device_memory_is_host_writable(int device, const void *p) {
     return ok;
 }
 
+// a word that names the device within this node: FNV-1a of its PCI bus id (never 0)
+unsigned long long device_identity(int device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); std::snprintf(bus, sizeof bus, "device-%d", device); }
+    unsigned long long h = 1469598103934665603ull;
+    for (const char *c = bus; *c; ++c) { h ^= (unsigned char)(*c >= 'A' && *c <= 'Z' ? *c - 'A' + 'a' : *c); h *= 1099511628211ull; }
+    return h ? h : 1ull;
+}
+
 int ensure_pose_box(srl_ctx *ctx) {
     if (ctx->h_pose_box) return SRL_OK;
     if (!ctx->d_pose_relay) {
@@ -986,7 +995,10 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     // launch was cancelled or gave up simply launches the pass -- the exchange does not care how a kernel got there.  Not with RCCL
     // (the all-reduce and the publish kernel sit between two passes on the stream) and not with the ordered cut (three exchanges per pass).
     const bool host_cb = ctx->nranks > 1 && !coll && !peer && ctx->cb_ar != nullptr && !ctx->dbg_gather;
-    const bool arm_ok = ctx->arm_mode != 0 && fused && (single_rank || peer || host_cb) && !coll && wpb == 16 && fast_sel &&
+    // RCCL: armed as well when the pass is fused -- the launch is enqueued BEHIND this pass's all-reduce and publish kernel (stream order),
+    // so it is resident about when the host reads the result; a launch that gave up contributes a time-out flag to the reduced range
+    // (assoc_body's prologue) so that every rank repeats the pass.
+    const bool arm_ok = ctx->arm_mode != 0 && fused && (single_rank || peer || host_cb || coll) && wpb == 16 && fast_sel &&
                         a.ablate == 0 && !prof && !ctx->taps;
     auto signature = [](const SrlAssocArgs &src) {
         SrlAssocArgs sg = src;
@@ -1063,16 +1075,17 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     // srl_solve_end -- unless a prefetched sweep is waiting, in which case the launch becomes the first pass of THAT sweep
     // (srl_sweep_swap); and not while another context of this process lives on the same device.  arm_mode 2: always.
     const bool arm_wanted = ctx->arm_mode == 2 ||
-                            (live_contexts(ctx->device) <= 1 &&
+                            (live_contexts(ctx->device) <= 1 && !ctx->peer_shares_device && !ctx->comm_shares_device &&
                              (ctx->next_n >= 0 || ctx->expected_passes == 0 || ctx->passes_in_solve + 1 < ctx->expected_passes));
-    if (arm_ok && arm_wanted) {
+    auto arm_next = [&]() -> int {
         // ... and arm the next pass now, while this one runs: same arguments, the sequence number this context hands out next
         int rcp = ensure_pose_box(ctx);
         if (rcp) return rcp;
         SrlAssocArgs nx = a;
         nx.seq = ctx->seq + 1;
         // the context's other sweep buffer, if it exists: the launch can then be fired for the sweep srl_sweep_swap makes current
-        const bool has_alt = ctx->d_raw_next != nullptr && ctx->next_cap > 0 && ctx->d_stage_next != nullptr && ctx->nranks == 1;
+        // (sharded ranks too: every rank prefetches and swaps its own point range, the launch learns its count with the pose)
+        const bool has_alt = ctx->d_raw_next != nullptr && ctx->next_cap > 0 && ctx->d_stage_next != nullptr;
         nx.aos = nullptr;                                  // (its own buffer's planes are valid once this pass has run)
         nx.alt_aos = has_alt ? ctx->d_stage_next : nullptr;
         nx.alt_x = has_alt ? ctx->d_raw_next : nullptr;
@@ -1125,7 +1138,9 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         ctx->armed_at_ns = steady_ns();
         ctx->armed = true;
         ctx->arm_stats[0]++;
-    }
+        return SRL_OK;
+    };
+    if (arm_ok && arm_wanted && !coll) { const int rca = arm_next(); if (rca) return rca; }
 
     // residual budget of this rank (sequential early exit, optimize.cpp:107, across ordered shards)
     int64_t budget = o->max_num_residuals;
@@ -1208,6 +1223,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         SrlDevOut *mine = fused ? &ctx->d_mail->out : ctx->d_out;
         NCCLCHK(ctx, AllReduce(mine, mine, n_red, ncclDouble, ncclSum, ctx->comm, ctx->stream));
         HIPCHK(ctx, srl_launch_publish(mine, ctx->h_mail, ra.seq, ctx->stream));
+        if (arm_ok && arm_wanted) { const int rca = arm_next(); if (rca) return rca; }       // (behind the collective: see arm_ok)
     }
     const bool host_reduce = ctx->nranks > 1 && !coll && !peer;      // the caller's all-reduce callback (CPU / gloo tests, foreign transports)
     if (coll || mailbox || peer) {
@@ -1288,6 +1304,17 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
 
     // total visited keypoints over all shards (part of the reduced range) -> global index of the last visited one
     const long long visited_total = (long long)(ctx->h_out->d_visited + 0.5);
+    if (fused && !can_fuse_cut) {
+        // a fused pass without a cut visits every keypoint it was given, on every rank: anything else means workgroups ran on another
+        // keypoint count than the host fired them with (a relayed pose box once lost the count of a swapped-in sweep)
+        const long long expect = ctx->nranks > 1 ? (long long)ctx->total_n : (long long)n_eff;
+        if (visited_total != expect) {
+            char buf[160];
+            std::snprintf(buf, sizeof buf, "fused pass visited %lld of %lld keypoints (fired %d, seq %llu)", visited_total, expect, (int)fired, (unsigned long long)seq_now);
+            ctx->err = buf;
+            return SRL_ERR_HIP;
+        }
+    }
 
     const SrlDevOut &r = *ctx->h_out;
     std::memcpy(out->HtH, r.HtH, sizeof out->HtH);
@@ -1602,9 +1629,14 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
     };
     // a pass whose fused reduction timed out is repeated once with the separate reduce kernel (stream-ordered: it cannot time out)
     auto pass = [&](int n_pass) -> int {
+        const unsigned long long peer_seq_in = ctx->peer_seq;
         int r = attempt(n_pass);
         if (r == SRL_INTERNAL_ARM_EXPIRED) {                 // nobody was listening: the same pass with a normal launch
             SRL_DISARM(ctx);
+            // ... and with the SAME exchange tag: the expired launch left in its prologue, it never stored this rank's row for the exchange the
+            // attempt above counted -- the peers are still polling for that one (a relaunch one exchange ahead of its peers
+            // would have made both sides spin until the deadline)
+            ctx->peer_seq = peer_seq_in;
             r = attempt(n_pass);
             if (r == SRL_INTERNAL_ARM_EXPIRED) r = SRL_ERR_HIP;
         }
@@ -1681,7 +1713,20 @@ int srl_comm_init_rank(srl_ctx *ctx, int nranks, int rank, const void *id) {
     ctx->cb_ar = nullptr; ctx->cb_ag = nullptr; ctx->cb_user = nullptr;
     { const char *fc = std::getenv("SRL_FORCE_COLLECTIVES"); ctx->force_coll = fc && std::atoi(fc) != 0; }
     int rc = ensure_gather(ctx, (size_t)nranks);
-    return rc;
+    if (rc) return rc;
+    // which devices do the ranks sit on?  One all-gather of the device identities (as for the peer exchange: ranks that share a device
+    // -- a test arrangement -- do not arm launches)
+    ctx->comm_shares_device = false;
+    if (nranks > 1) {
+        const long long mine = (long long)device_identity(ctx->device);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_count, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+        NCCLCHK(ctx, AllGather(ctx->d_count, ctx->d_gather, 1, ncclInt64, ctx->comm, ctx->stream));
+        std::vector<long long> all((size_t)nranks, 0);
+        HIPCHK(ctx, hipMemcpyAsync(all.data(), ctx->d_gather, (size_t)nranks * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int r = 0; r < nranks; r++) if (r != rank && all[(size_t)r] == mine) ctx->comm_shares_device = true;
+    }
+    return SRL_OK;
 }
 
 int srl_comm_backend_info(char *origin, int origin_len, int *version, int *preloaded) {
@@ -1740,6 +1785,7 @@ int srl_comm_destroy(srl_ctx *ctx) {
     if (ctx->comm && srl_rccl()) { srl_rccl()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
     ctx->nranks = 1; ctx->rank = 0;
     ctx->cb_ar = nullptr; ctx->cb_ag = nullptr; ctx->cb_user = nullptr;
+    ctx->comm_shares_device = false;
     return SRL_OK;
 }
 
@@ -1757,6 +1803,7 @@ int srl_peer_export(srl_ctx *ctx, void *ipc_handle, void **local_ptr) {
     // time, when a faster peer may already have delivered the first row of the session.
     if (ctx->stream) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemset(ctx->d_inbox, 0, bytes));
+    { const unsigned long long id = device_identity(ctx->device); HIPCHK(ctx, hipMemcpy(ctx->d_inbox + SRL_PEER_DEVICE_WORD, &id, sizeof id, hipMemcpyHostToDevice)); }
     if (ipc_handle) {
         static_assert(sizeof(hipIpcMemHandle_t) <= SRL_PEER_HANDLE_BYTES, "IPC handle does not fit");
         hipIpcMemHandle_t h;
@@ -1789,6 +1836,7 @@ int srl_peer_detach(srl_ctx *ctx) {
     for (int r = 0; r < SRL_MAX_PEERS; r++) if (ctx->peer_mapped[r]) { hipIpcCloseMemHandle(ctx->peer_mapped[r]); ctx->peer_mapped[r] = nullptr; }
     for (int r = 0; r < SRL_MAX_PEERS; r++) ctx->peer_inbox[r] = nullptr;
     if (ctx->peer_on) { ctx->peer_on = false; ctx->nranks = 1; ctx->rank = 0; }
+    ctx->peer_shares_device = false;
     return SRL_OK;
 }
 
@@ -1826,6 +1874,17 @@ int srl_peer_attach(srl_ctx *ctx, int nranks, int rank, const void *ipc_handles,
     }
     if (!ctx->d_peer) { int rcp = ensure(ctx, ctx->d_peer, 1); if (rcp) return rcp; }
     HIPCHK(ctx, hipMemcpy(ctx->d_peer, &t, sizeof t, hipMemcpyHostToDevice));
+    // does a peer's inbox live on this very device?  (its export left the device's identity behind the rows)
+    ctx->peer_shares_device = false;
+    {
+        const unsigned long long mine = device_identity(ctx->device);
+        for (int r = 0; r < nranks; r++) {
+            if (r == rank || !t.inbox[r]) continue;
+            unsigned long long theirs = 0;
+            HIPCHK(ctx, hipMemcpy(&theirs, t.inbox[r] + SRL_PEER_DEVICE_WORD, sizeof theirs, hipMemcpyDeviceToHost));
+            if (theirs == mine) ctx->peer_shares_device = true;
+        }
+    }
     for (int r = 0; r < SRL_MAX_PEERS; r++) ctx->peer_inbox[r] = r < nranks ? t.inbox[r] : nullptr;
     ctx->peer_retries = 0;
     ctx->peer_seen = 0;

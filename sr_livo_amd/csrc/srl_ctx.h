@@ -22,6 +22,10 @@ struct SrlEpochTable {
 // The word behind a rank's inbox rows that any rank sets when it gives a session up (srl_peer_set_deadline_ms): a rank whose pass times
 // out looks at its own inbox's word and ends the session at once instead of waiting for its own deadline.
 #define SRL_PEER_POISON_WORD SRL_PEER_INBOX_GRANULES
+// ... and the word behind it: an identity of the DEVICE the inbox lives on (hash of its PCI bus id, never 0), written at srl_peer_export.
+// srl_peer_attach compares the peers' words with its own: ranks that share a device (a test arrangement -- production is one process per
+// GPU) do not arm launches, whose waiting workgroups would hold the compute units the other rank's kernel needs.
+#define SRL_PEER_DEVICE_WORD (SRL_PEER_INBOX_GRANULES + 1)
 #define SRL_PEER_INBOX_ALLOC_GRANULES (SRL_PEER_INBOX_GRANULES + 8)
 
 struct srl_ctx {
@@ -200,6 +204,8 @@ struct srl_ctx {
     void *peer_mapped[SRL_MAX_PEERS] = {};     // HIP IPC mappings of the other ranks' inboxes (closed at detach)
     bool peer_on = false;
     int peer_seen = 0;                 // inboxes mapped at srl_peer_attach (srl_comm_info: equal to nranks when every rank's handle opened)
+    bool peer_shares_device = false;   // a peer rank's inbox lives on THIS device (SRL_PEER_DEVICE_WORD): launches are not armed (arm_mode 1)
+    bool comm_shares_device = false;   // ... the same for the RCCL transport (device identities all-gathered at srl_comm_init_rank)
     bool peer_failed = false;          // a row of this session never arrived: no further exchange until srl_peer_export + srl_peer_attach
     unsigned long long *peer_inbox[SRL_MAX_PEERS] = {};     // every rank's inbox as mapped into this process (host copy of SrlPeerTable::inbox)
     int peer_deadline_ms = 10000;      // srl_peer_set_deadline_ms: how long a pass keeps re-polling for a late rank's row before the session is given up

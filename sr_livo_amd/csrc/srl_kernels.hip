@@ -2095,7 +2095,8 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
             if (relayed && leader && act) {
                 // the verdict of the poll for the other workgroups: the pose as it arrived, or a control granule that ends them
                 unsigned long long y = x;
-                if (code != SRL_ARM_GO) y = ((unsigned long long)epoch << 32) | (lane == SRL_POSE_BOX_CTRL ? code : 0u);
+                // (a launch fired for the swapped-in sweep carries GO | ALT: the flag travels on with the pose)
+                if ((code & SRL_ARM_CODE_MASK) != SRL_ARM_GO) y = ((unsigned long long)epoch << 32) | (lane == SRL_POSE_BOX_CTRL ? code : 0u);
                 __hip_atomic_store((gu64a *)(a.pose_relay + lane), y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const unsigned hi = (unsigned)__shfl_down((unsigned)x, 1);
@@ -2126,8 +2127,14 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
                             D3 raw;
                             if (alt) {
                                 // the other buffer's points arrived AoS by DMA (srl_sweep_prefetch): this pass files its SoA planes (SrlAssocArgs::aos)
-                                const double *p = a.alt_aos + 3 * (size_t)g;
-                                raw = d3(p[0], p[1], p[2]);
+                                // (system-scope loads: this kernel was resident BEFORE the DMA that wrote them had finished -- no kernel-boundary
+                                //  acquire lies between the copy engine's write and these reads, so they must not be served by a cache line an
+                                //  earlier reader of the same staging buffer left behind)
+                                typedef const __attribute__((address_space(1))) double gf64c;
+                                gf64c *p = (gf64c *)(a.alt_aos + 3 * (size_t)g);
+                                raw = d3(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
+                                         __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
+                                         __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
                                 const_cast<double *>(a.alt_x)[g] = raw.x; const_cast<double *>(a.alt_y)[g] = raw.y; const_cast<double *>(a.alt_z)[g] = raw.z;
                             } else {
                                 raw = d3(a.raw_x[g], a.raw_y[g], a.raw_z[g]);
@@ -2144,6 +2151,17 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
                     // relaunches.  (NOT through the result record: this launch leaves on its own schedule, possibly while the host -- descheduled
                     // for longer than the bound -- has not yet read the result of the pass before it; found by the 10^6-launch soak.)
                     __hip_atomic_store(&a.mailbox->expired, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (code == (int)SRL_ARM_EXPIRED && blockIdx.x == gridDim.x - 1 && tid < 64 && !a.mail_tagged && a.peer == nullptr) {
+                    // the RCCL form (plain record in DEVICE memory, an all-reduce behind this kernel on the stream): the host cannot see the
+                    // word above, and the collective runs whatever this launch did -- so the launch contributes an empty record whose
+                    // time-out flag is part of the reduced range: EVERY rank sees it in the sum and repeats the pass, together
+                    constexpr int NW = (int)(sizeof(SrlDevOut) / 8);
+                    unsigned long long w = 0ull;
+                    if (tid == (int)(offsetof(SrlDevOut, d_timeout) / 8)) w = (unsigned long long)__double_as_longlong(1.0);
+                    if (tid == (int)(offsetof(SrlDevOut, pad) / 8)) w = 0x7117ull;
+                    if (tid == (int)(offsetof(SrlDevOut, last_visited) / 8)) w = ~0ull;
+                    if (tid < NW) reinterpret_cast<unsigned long long *>(&a.mailbox->out)[tid] = w;
                 }
                 return;
             }

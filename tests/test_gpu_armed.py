@@ -226,15 +226,19 @@ def scene_L(scene):
     return scene
 
 
+@pytest.mark.parametrize("box", [-1, 0])
 @pytest.mark.parametrize("max_res", [INT_MAX, 600])
-def test_a_launch_armed_behind_the_last_pass_becomes_the_first_pass_of_the_next_sweep(scene_L, max_res):
+def test_a_launch_armed_behind_the_last_pass_becomes_the_first_pass_of_the_next_sweep(scene_L, max_res, box):
     """four distinct sweeps streamed through prefetch / swap: in steady state every pass -- the first pass of a sweep included -- fires
     a waiting launch, nothing is cancelled, and every solved state and covariance equals, bit for bit, the one launch per
-    iteration produces on the same sweep"""
+    iteration produces on the same sweep.  box = 0: the pose box in host memory, relayed by workgroup 0 (hosts without a large BAR) --
+    the launch fired for the swapped-in sweep carries GO | ALT through the relay (the relay once dropped it, and every
+    workgroup but the first ran on an empty tile; the host now also checks the visited count of every fused pass)"""
     sc = scene_L
     lio = sc["lio"]
     sw = _sweeps(sc, 4)
     opts = srl.default_opts(max_num_residuals=max_res)
+    lio.ctx.set_pose_box(box)
     try:
         lio.ctx.set_armed_launch(False)
         ref = _stream(sc, sw, opts, 8)
@@ -253,6 +257,7 @@ def test_a_launch_armed_behind_the_last_pass_becomes_the_first_pass_of_the_next_
         assert s1["cancelled"] - s0["cancelled"] <= 2, (s0, s1)
         assert s1["expired"] == s0["expired"]
     finally:
+        lio.ctx.set_pose_box(-1)
         lio.ctx.set_armed_launch(True)
         lio.resident_sweep(sc["sweep"]["raw"])
         for s in sw:

@@ -122,6 +122,160 @@ def test_peer_exchange_many_passes_and_a_headline_sized_sweep():
         assert np.array_equal(np.array(neq.HtH), np.array(out[0][0].HtH))
 
 
+def _big_raw(golden, seed, copies=4):
+    """the golden sweep `copies` times over with a little noise: 4 096 keypoints per rank of two -- sixteen-wave workgroups, the fused
+    pass that is armed (the golden sweep alone gives a rank 1 024 keypoints: four-wave workgroups, never armed)"""
+    rng = np.random.default_rng(seed)
+    return np.concatenate([golden["raw"] + rng.normal(0, 2e-3, golden["raw"].shape) for _ in range(copies)])
+
+
+def _peer_threads_body(golden, G, body):
+    """G contexts on device 0 (map uploaded, peers attached), one thread each running body(ctx, rank) -> result"""
+    ctxs = [srl.Context(0) for _ in range(G)]
+    ptrs = [c.peer_export()[1] for c in ctxs]
+    out, errors = [None] * G, [None] * G
+    start = threading.Barrier(G)
+
+    def worker(rank):
+        ctx = ctxs[rank]
+        try:
+            ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+            ctx.peer_attach(G, rank, local_ptrs=ptrs)
+            start.wait()
+            out[rank] = body(ctx, rank)
+        except Exception as e:  # noqa: BLE001
+            errors[rank] = e
+            try:
+                start.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for c in ctxs:
+        c.close()
+    return out, errors
+
+
+def test_an_expired_armed_launch_repeats_its_pass_on_the_same_exchange(golden):
+    """rank 0's armed launch gives up on the device (kernel-side bound 200 us) while its host sleeps; the host then fires
+    it, learns that nobody was listening and launches the pass again -- with the tag of the SAME exchange: the launch that left never
+    stored a row, and rank 1 is still polling for that one.  (One exchange ahead, both sides would spin until the deadline.)"""
+    import time
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+    raw = _big_raw(golden, 5)
+    ref = _single(golden, raw, INT_MAX)
+
+    def body(ctx, rank):
+        ctx.peer_set_deadline_ms(8000)
+        ctx.set_armed_launch(2)                    # (two contexts of one process: the default policy would not arm)
+        ctx.set_arm_linger(host_linger_us=3.6e9, kernel_linger_us=200.0)
+        ctx.sweep_upload(raw)
+        ctx.build_residuals(f, opts)
+        s0 = ctx.arm_stats()
+        assert s0["armed"] >= 1
+        if rank == 0:
+            time.sleep(0.05)                        # the launch armed by the pass above expires meanwhile
+        t0 = time.perf_counter()
+        neq, _ = ctx.build_residuals(f, opts)
+        dt = time.perf_counter() - t0
+        neq2, _ = ctx.build_residuals(f, opts)     # ... and the exchange after it is in step again
+        s1 = ctx.arm_stats()
+        ctx.disarm()
+        return neq, neq2, s1["expired"] - s0["expired"], dt, ctx.peer_stats()
+
+    out, errors = _peer_threads_body(golden, 2, body)
+    assert not any(errors), errors
+    assert out[0][2] == 1 and out[1][2] == 0, (out[0][2], out[1][2])
+    assert out[0][3] < 2.0 and out[1][3] < 2.0, (out[0][3], out[1][3])          # nobody waited for a deadline
+    for r in range(2):
+        for neq in out[r][:2]:
+            assert neq.num_residuals == ref.num_residuals and neq.sum_candidates == ref.sum_candidates
+            assert rel(np.array(neq.HtH), np.array(ref.HtH)) < 1e-12
+            assert np.array_equal(np.array(neq.HtH), np.array(out[0][0].HtH)) and np.array_equal(np.array(neq.Hth), np.array(out[0][0].Hth))
+        assert out[r][4][1] == 0                                                # session alive
+
+
+def test_a_sharded_stream_keeps_its_armed_launch_across_the_swap(golden):
+    """in the sharded stream every srl_sweep_swap cancelled the waiting launch (999 of 1 000) -- the launch carried no
+    alternate sweep buffer on a sharded context.  It does now: every rank prefetches and swaps its own point range, the launch armed
+    behind the last pass of sweep k is fired with SRL_ARM_ALT as the first pass of sweep k + 1.  Sums equal the single-context pass on
+    the same sweep, bit-identical across the ranks and to the same stream without armed launches."""
+    sweeps = [_big_raw(golden, 77 + j) for j in range(3)]
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+    refs = [_single(golden, sw, INT_MAX) for sw in sweeps]
+    rounds, passes = 9, 2
+
+    def make_body(armed):
+        def body(ctx, rank):
+            pins = []
+            for sw in sweeps:
+                p = srl.PinnedArray(sw.shape); p.array[:] = sw; pins.append(p)
+            ctx.set_armed_launch(2 if armed else 0)
+            ctx.sweep_prefetch(pins[0].array); ctx.sweep_swap()
+            res = []
+            s0 = ctx.arm_stats()
+            for k in range(rounds):
+                ctx.sweep_prefetch(pins[(k + 1) % 3].array)
+                for _ in range(passes):
+                    neq, _ = ctx.build_residuals(f, opts)
+                res.append(neq)
+                ctx.solve_end()
+                ctx.sweep_swap()
+            s1 = ctx.arm_stats()
+            ctx.disarm()
+            for p in pins:
+                p.close()
+            return res, {k: s1[k] - s0[k] for k in s0}
+        return body
+
+    plain, errors = _peer_threads_body(golden, 2, make_body(False))
+    assert not any(errors), errors
+    got, errors = _peer_threads_body(golden, 2, make_body(True))
+    assert not any(errors), errors
+    for r in range(2):
+        res, st = got[r]
+        # every pass but the very first fires a waiting launch -- the first pass of every swapped-in sweep included
+        assert st["fired"] >= rounds * passes - 1 and st["cancelled"] <= 1 and st["expired"] == 0, st
+        for k, neq in enumerate(res):
+            ref = refs[k % 3]
+            assert neq.num_residuals == ref.num_residuals and neq.sum_candidates == ref.sum_candidates, (r, k)
+            assert rel(np.array(neq.HtH), np.array(ref.HtH)) < 1e-12
+            assert np.array_equal(np.array(neq.HtH), np.array(got[0][0][k].HtH))
+            assert np.array_equal(np.array(neq.HtH), np.array(plain[r][0][k].HtH)) and np.array_equal(np.array(neq.Hth), np.array(plain[r][0][k].Hth))
+
+
+def test_ranks_that_share_a_device_do_not_arm_by_default(golden):
+    """srl_peer_export leaves the device's identity behind the inbox rows, srl_peer_attach compares: peers on ONE device (this test
+    arrangement; production is one process per GPU) must not arm launches under the default policy -- a waiting launch holds a workgroup
+    per compute unit that the other rank's kernel needs."""
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    f = capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"])
+
+    def body(ctx, rank):
+        ctx.sweep_upload(raw)
+        ctx.set_armed_launch(1)
+        for _ in range(4):
+            ctx.build_residuals(f, opts)
+        s1 = ctx.arm_stats()
+        ctx.set_armed_launch(2)
+        for _ in range(4):
+            ctx.build_residuals(f, opts)
+        s2 = ctx.arm_stats()
+        ctx.disarm()
+        return s1, s2
+
+    raw = _big_raw(golden, 9)
+    out, errors = _peer_threads_body(golden, 2, body)
+    assert not any(errors), errors
+    for r in range(2):
+        assert out[r][0]["armed"] == 0, out[r]
+        assert out[r][1]["armed"] == 4, out[r]                              # (the passes ARE eligible: forced, they arm)
+
+
 def test_a_second_session_does_not_see_the_rows_of_the_first(golden):
     """Detach, export again (the export resets the inbox), attach again with the ranks SWAPPED and another sweep: exchange tags
     start at 1 again, so a stale row of the first session would be taken for a fresh one if the reset were missing."""
@@ -344,7 +498,7 @@ f = capi.make_frame(g["q_pred"], g["t_pred"], g["t_last"])
 for _ in range(5):
     neq, rc = ctx.build_residuals(f, srl.default_opts(max_num_residuals=max_res))
 np.savez(os.path.join(d, f"out{rank}.npz"), HtH=np.array(neq.HtH), Hth=np.array(neq.Hth), loss=neq.loss_sum, n=neq.num_residuals, last=neq.last_visited,
-         pk=neq.sum_candidates)
+         pk=neq.sum_candidates, armed=ctx.arm_stats()["armed"])
 # nobody unmaps an inbox a peer may still be storing into
 open(os.path.join(d, f"done{rank}"), "w").close()
 t0 = time.time()
@@ -402,3 +556,6 @@ def test_peer_exchange_four_processes_headline_sweep_fused(tmp_path):
         assert int(res[r]["n"]) == ref.num_residuals and int(res[r]["pk"]) == ref.sum_candidates
         assert rel(res[r]["HtH"], np.array(ref.HtH)) < 1e-12 and rel(res[r]["Hth"], np.array(ref.Hth)) < 1e-12
         assert np.array_equal(res[r]["HtH"], res[0]["HtH"])
+        # one device under four rank processes: srl_peer_attach saw the peers' inboxes on its own device -- nobody armed a launch (default
+        # policy; on one process per GPU every one of these fused passes arms its successor)
+        assert int(res[r]["armed"]) == 0
