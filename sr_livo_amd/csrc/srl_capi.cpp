@@ -1284,6 +1284,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
             // the finishing workgroup gave up waiting for a row (bounded spin: another process holding compute units back, a
             // preempted queue): not an error of the data -- the caller repeats the pass with the reduction in its own kernel
             ctx->err = "fused final reduction timed out waiting for a workgroup's row";
+            if (fired && coll) ctx->arm_stats[3]++;      // (RCCL form: this is how a fired launch that had given up shows -- its record carries the flag)
             return SRL_INTERNAL_FUSED_TIMEOUT;
         }
     } else {
@@ -1309,8 +1310,9 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         // keypoint count than the host fired them with (a relayed pose box once lost the count of a swapped-in sweep)
         const long long expect = ctx->nranks > 1 ? (long long)ctx->total_n : (long long)n_eff;
         if (visited_total != expect) {
-            char buf[160];
-            std::snprintf(buf, sizeof buf, "fused pass visited %lld of %lld keypoints (fired %d, seq %llu)", visited_total, expect, (int)fired, (unsigned long long)seq_now);
+            char buf[256];
+            std::snprintf(buf, sizeof buf, "fused pass visited %lld of %lld keypoints (fired %d, seq %llu; residuals %.0f, time-out flag %.0f, marker %lld)", visited_total, expect,
+                          (int)fired, (unsigned long long)seq_now, ctx->h_out->d_num_res, ctx->h_out->d_timeout, (long long)ctx->h_out->pad);
             ctx->err = buf;
             return SRL_ERR_HIP;
         }

@@ -2161,7 +2161,9 @@ __device__ __forceinline__ void assoc_body(const SrlAssocArgs &a) {
                     if (tid == (int)(offsetof(SrlDevOut, d_timeout) / 8)) w = (unsigned long long)__double_as_longlong(1.0);
                     if (tid == (int)(offsetof(SrlDevOut, pad) / 8)) w = 0x7117ull;
                     if (tid == (int)(offsetof(SrlDevOut, last_visited) / 8)) w = ~0ull;
-                    if (tid < NW) reinterpret_cast<unsigned long long *>(&a.mailbox->out)[tid] = w;
+                    // (system-scope stores like mail_out's: plain stores of this early-exit path were observed NOT to reach the all-reduce's read --
+                    //  the record word written through, d_mail->expired above, arrived; the plain ones did not)
+                    if (tid < NW) __hip_atomic_store(reinterpret_cast<unsigned long long *>(&a.mailbox->out) + tid, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 return;
             }

@@ -284,6 +284,8 @@ CONFIGS = {
     "C3": (16384, 2_000_000, "ouster16", 20250304 + 3),
     "C4": (262144, 10_000_000, "livox", 20250304 + 4),
     "HEADLINE": (65536, 1_000_000, "livox", 20250304 + 5),
+    # not a BASELINE configuration: the off-cache aux workload (make_spread_sweep over C4's map)
+    "SPREAD": (65536, 10_000_000, "livox", 20250304 + 4),
 }
 
 
@@ -353,3 +355,25 @@ def make_sequence(seed, n_moving, n_pts, L, imu_rate=200.0, sweep_dt=0.1, rest_t
                          time_sweep_begin=tb, time_sweep_offset=sweep_dt))
         gt.append((q, p))
     return meas, gt, (q0, p0)
+
+
+def make_spread_sweep(seed, n, cands, L, radius=None):
+    """An OFF-CACHE workload (never a lidar pattern): n keypoints drawn area-uniformly from the scene's surfaces within `radius` of the
+    sensor (default: the whole map) in RANDOM order -- about one keypoint per voxel, consecutive keypoints far apart, so that a pass probes
+    tens of thousands of distinct voxels (tens of MB of slabs) instead of the ~2 000 a 70-degree cone touches.  `cands` = map_candidates()
+    of the scene (area-uniform surface samples).  Same return as make_sweep."""
+    rng = np.random.default_rng(seed)
+    yaw = rng.uniform(-math.pi, math.pi)
+    q_gt = quat_mul(quat_from_rotvec([0, 0, yaw]), quat_from_rotvec(rng.normal(0, 0.02, 3)))
+    t_gt = np.array([rng.uniform(-3, 3) + 2.3, rng.uniform(-3, 3) + 1.7, rng.uniform(-0.1, 0.1)])
+    pool = cands
+    if radius is not None:
+        pool = cands[np.hypot(cands[:, 0] - t_gt[0], cands[:, 1] - t_gt[1]) < radius]
+    world = pool[rng.choice(len(pool), n, replace=len(pool) < n)] + rng.normal(0.0, SIGMA, (n, 3))
+    raw = (world - t_gt) @ quat_to_rot(q_gt)                          # world = R raw + t (identity extrinsics)
+    dv = rng.normal(size=3); dv *= 0.05 / np.linalg.norm(dv)
+    ax = rng.normal(size=3); ax *= math.radians(0.5) / np.linalg.norm(ax)
+    q_pred = quat_mul(q_gt, quat_from_rotvec(ax))
+    t_pred = t_gt + dv
+    vel = rng.normal(0, 0.5, 3)
+    return dict(raw=raw, q_gt=q_gt, t_gt=t_gt, q_pred=q_pred, t_pred=t_pred, t_last=t_pred - 0.1 * vel, vel=vel)

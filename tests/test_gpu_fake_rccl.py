@@ -127,6 +127,95 @@ def _check_ranks(golden, res, G, max_res):
         assert np.array_equal(res[r]["HtH"], res[0]["HtH"]) and np.array_equal(res[r]["Hth"], res[0]["Hth"]) and float(res[r]["loss"]) == float(res[0]["loss"])
 
 
+_SCRIPT_ARMED = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import sr_livo_amd as srl
+from sr_livo_amd import capi
+rank, G, d, fake, expire = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], int(sys.argv[6])
+srl.comm_set_library(fake)
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "golden_small.npz"))
+rng = np.random.default_rng(11)
+raw = np.concatenate([g["raw"] + rng.normal(0, 2e-3, g["raw"].shape) for _ in range(2 * G)])     # 4 096 keypoints per rank: sixteen-wave workgroups, fused
+ctx = srl.Context(0)
+ctx.map_upload(g["map_keys"], g["map_counts"], g["map_xyz"])
+idp = os.path.join(d, "uid.bin")
+if rank == 0:
+    uid = srl.Context.comm_unique_id()
+    open(idp + ".tmp", "wb").write(uid); os.replace(idp + ".tmp", idp)
+t0 = time.time()
+while not os.path.exists(idp):
+    if time.time() - t0 > 120: raise SystemExit(3)
+    time.sleep(0.02)
+ctx.comm_init_rank(G, rank, open(idp, "rb").read())
+ctx.sweep_upload(raw)
+f = capi.make_frame(g["q_pred"], g["t_pred"], g["t_last"])
+opts = srl.default_opts(max_num_residuals=2**31 - 1)
+ctx.set_armed_launch(1)
+for _ in range(3):
+    ctx.build_residuals(f, opts)
+default_armed = ctx.arm_stats()["armed"]                 # ranks share the device (identities all-gathered at srl_comm_init_rank): nothing armed
+ctx.set_armed_launch(2)
+if expire:
+    ctx.set_arm_linger(host_linger_us=3.6e9, kernel_linger_us=200.0)
+s0 = ctx.arm_stats()
+res = []
+for k in range(8):
+    if expire and k == 4 and rank == 0:
+        time.sleep(0.05)                                 # rank 0's waiting launch gives up; the record it leaves carries the time-out flag
+    neq, rc = ctx.build_residuals(f, opts)
+    res.append(np.array(neq.HtH))
+s1 = ctx.arm_stats()
+ctx.disarm()
+np.savez(os.path.join(d, f"out{rank}.npz"), HtH=np.stack(res), n=neq.num_residuals, pk=neq.sum_candidates, default_armed=default_armed,
+         fired=s1["fired"] - s0["fired"], armed=s1["armed"] - s0["armed"], cancelled=s1["cancelled"] - s0["cancelled"])
+ctx.close()
+print("OK", rank, flush=True)
+"""
+
+
+@pytest.mark.parametrize("expire", [0, 1])
+def test_rccl_passes_are_armed_behind_the_collective(golden, tmp_path, fake_lib, expire):
+    """the fused pass of a sharded sweep behind RCCL arms its successor too -- the launch is enqueued behind this pass's
+    all-reduce and publish kernel and fired through the pose box.  Same sums as un-armed passes, bit-identical across ranks and passes.
+    expire = 1: rank 0's waiting launch gives up on the device; it contributes an empty record with the time-out flag to the all-reduce, so
+    BOTH ranks repeat that pass (a rank repeating alone would leave the collectives of the ranks out of step)."""
+    G = 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", _SCRIPT_ARMED, ROOT, str(r), str(G), str(tmp_path), fake_lib, str(expire)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(G)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        outs.append((p.returncode, o.decode(errors="replace")[-2000:]))
+    assert all(rc == 0 for rc, _ in outs), outs
+    res = [np.load(tmp_path / f"out{r}.npz") for r in range(G)]
+    rng = np.random.default_rng(11)
+    raw = np.concatenate([golden["raw"] + rng.normal(0, 2e-3, golden["raw"].shape) for _ in range(2 * G)])
+    ctx = srl.Context(0)
+    try:
+        ctx.map_upload(golden["map_keys"], golden["map_counts"], golden["map_xyz"])
+        ctx.sweep_upload(raw)
+        ref, _rc = ctx.build_residuals(capi.make_frame(golden["q_pred"], golden["t_pred"], golden["t_last"]), srl.default_opts(max_num_residuals=INT_MAX))
+    finally:
+        ctx.close()
+    for r in range(G):
+        assert int(res[r]["default_armed"]) == 0
+        assert int(res[r]["n"]) == ref.num_residuals and int(res[r]["pk"]) == ref.sum_candidates
+        assert int(res[r]["armed"]) >= 8 and int(res[r]["fired"]) >= (6 if expire else 7), {k: int(res[r][k]) for k in ("armed", "fired", "cancelled")}
+        for k in range(8):
+            # (the repeated pass of the expiry case runs un-fused: another summation order, same value to 1e-12)
+            assert rel(res[r]["HtH"][k], np.array(ref.HtH)) < 1e-12
+            assert np.array_equal(res[r]["HtH"][k], res[0]["HtH"][k])
+            if not (expire and k == 4):
+                assert np.array_equal(res[r]["HtH"][k], res[r]["HtH"][0])
+
+
 def test_the_stand_in_can_only_be_chosen_before_the_first_communicator_call():
     """one RCCL instance per process: once resolved (here: the process's real RCCL, through a 1-rank communicator id) it stays"""
     code = ("import sys; sys.path.insert(0, %r); import sr_livo_amd as srl\n"
