@@ -203,9 +203,10 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     ctx->pool_free.clear();
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < srl_ctx::PROF_RING; i++) for (int k = 0; k < 2; k++) if (ctx->ring[i][k]) hipEventDestroy(ctx->ring[i][k]);
-    if (ctx->next_ready) hipEventDestroy(ctx->next_ready);
+    for (int sl = 0; sl < 2; sl++) for (int k = 0; k < 2; k++) if (ctx->up_ev[sl][k]) hipEventDestroy(ctx->up_ev[sl][k]);
     if (ctx->upload_ev) hipEventDestroy(ctx->upload_ev);
     if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->prefix_stream) { hipStreamSynchronize(ctx->prefix_stream); hipStreamDestroy(ctx->prefix_stream); }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return SRL_OK;
@@ -308,13 +309,16 @@ int srl_map_insert(srl_ctx *ctx, const double *world_xyz, int n, double voxel_si
 namespace {
 // AoS keypoints host -> device staging buffer `d_stage` on stream `st` (no synchronisation): one DMA from page-locked memory,
 // else through the pinned ring (CPU copy of chunk i + 1 overlaps the DMA of chunk i; the caller's buffer is consumed on return)
-int upload_aos(srl_ctx *ctx, const char *src, size_t bytes, double *d_stage, hipStream_t st) {
-    if (srl_is_pinned(src)) {
+int upload_aos(srl_ctx *ctx, const char *src, size_t bytes, double *d_stage, hipStream_t st, bool last = true, int pinned = -1) {
+    if (pinned < 0 ? srl_is_pinned(src) : pinned != 0) {
         HIPCHK(ctx, hipMemcpyAsync(d_stage, src, bytes, hipMemcpyHostToDevice, st));
         // the caller's buffer is being read by the DMA engine: srl_sweep_wait() returns once it is free again
-        if (!ctx->upload_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventRecord(ctx->upload_ev, st));
-        ctx->upload_pending = true;
+        // (`last`: the final piece of an upload that goes out in several DMAs -- one event behind all of them)
+        if (last) {
+            if (!ctx->upload_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventRecord(ctx->upload_ev, st));
+            ctx->upload_pending = true;
+        }
         return SRL_OK;
     }
     int rc2 = srl_ring_init(ctx);
@@ -356,6 +360,7 @@ int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     ctx->sweep_loaded = true;
     ctx->taps_valid = false;
     ctx->passes_in_solve = 0;
+    ctx->tail_pending = false;
     if (cnt > ctx->sweep_cap) {
         const int cap = std::max(cnt, 1024);
         int rc = ensure(ctx, ctx->d_raw, (size_t)cap * 3);
@@ -386,6 +391,7 @@ int srl_sweep_wait(srl_ctx *ctx) {
     if (ctx->upload_pending) {
         HIPCHK(ctx, hipSetDevice(ctx->device));
         HIPCHK(ctx, hipEventSynchronize(ctx->upload_ev));
+        if (ctx->prefix_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->prefix_stream));      // (a prefix-first upload: its first piece travelled there)
         ctx->upload_pending = false;
     }
     return SRL_OK;
@@ -397,9 +403,12 @@ int srl_sweep_prefetch(srl_ctx *ctx, const double *raw_xyz, int n) {
     // it is fired for that sweep (srl_sweep_swap).  (Its prologue may read the buffer it was armed on while this upload rewrites it:
     // those values are discarded -- a launch fired for another sweep recomputes them, assoc_body's prologue.)
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!ctx->copy_stream || !ctx->next_ready) SRL_DISARM(ctx);       // first use: stream / event creation may synchronise the device
+    if (!ctx->copy_stream) SRL_DISARM(ctx);       // first use: stream / event creation may synchronise the device
     { const int rcc = ensure_copy_stream(ctx); if (rcc) return rcc; }
-    if (!ctx->next_ready) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->next_ready, hipEventDisableTiming));
+    if (!ctx->up_ev[0][0]) {
+        SRL_DISARM(ctx);
+        for (int sl = 0; sl < 2; sl++) for (int k = 0; k < 2; k++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->up_ev[sl][k], hipEventDisableTiming));
+    }
     int b = 0, cnt = 0;
     srl_shard_range(n, ctx->nranks, ctx->rank, &b, &cnt);
     if (cnt > ctx->next_cap || cnt > ctx->stage_next_cap) {
@@ -410,14 +419,37 @@ int srl_sweep_prefetch(srl_ctx *ctx, const double *raw_xyz, int n) {
         if (cnt > ctx->next_cap) { if ((rc = ensure(ctx, ctx->d_raw_next, (size_t)cap * 3))) return rc; ctx->next_cap = cap; HIPCHK(ctx, hipMemsetAsync(ctx->d_raw_next, 0, (size_t)cap * 3 * sizeof(double), ctx->copy_stream)); }
         if (cnt > ctx->stage_next_cap) { if ((rc = ensure(ctx, ctx->d_stage_next, (size_t)cap * 3))) return rc; ctx->stage_next_cap = cap; }
     }
+    // DMA only: the points stay AoS in the staging buffer and are transposed by the first pass that reads them (SrlAssocArgs::aos) --
+    // a transpose kernel on the copy stream would wait for compute units the association kernels (resident back to back, armed
+    // launches included) do not release before the solve it is meant to overlap has ended.
+    // Prefix first: what the first pass over this sweep will visit (the prefix the running solve's passes visit) gets its own DMA and event
+    const int slot = ctx->next_slot ^ 1;
+    const int pre = (ctx->prefix_hint > 0 && ctx->prefix_hint < cnt) ? ctx->prefix_hint : cnt;
     if (cnt > 0) {
-        // DMA only: the points stay AoS in the staging buffer and are transposed by the first pass that reads them (SrlAssocArgs::aos) --
-        // a transpose kernel on the copy stream would wait for compute units the association kernels (resident back to back, armed
-        // launches included) do not release before the solve it is meant to overlap has ended
-        int rcu = upload_aos(ctx, reinterpret_cast<const char *>(raw_xyz + (size_t)b * 3), (size_t)cnt * 3 * sizeof(double), ctx->d_stage_next, ctx->copy_stream);
-        if (rcu) return rcu;
+        const char *src = reinterpret_cast<const char *>(raw_xyz + (size_t)b * 3);
+        const int pinned = srl_is_pinned(src) ? 1 : 0;                  // (asked of the runtime once per sweep, not per piece)
+        if (pre < cnt && pinned) {
+            // two DMAs side by side: the prefix on its own stream (its event: up_ev[slot][0]), the rest on the copy stream
+            if (!ctx->prefix_stream) { SRL_DISARM(ctx); HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->prefix_stream, hipStreamNonBlocking)); }
+            int rcu = upload_aos(ctx, src, (size_t)pre * 3 * sizeof(double), ctx->d_stage_next, ctx->prefix_stream, false, 1);
+            if (rcu) return rcu;
+            HIPCHK(ctx, hipEventRecord(ctx->up_ev[slot][0], ctx->prefix_stream));
+            rcu = upload_aos(ctx, src + (size_t)pre * 3 * sizeof(double), (size_t)(cnt - pre) * 3 * sizeof(double), ctx->d_stage_next + (size_t)pre * 3, ctx->copy_stream, true, 1);
+            if (rcu) return rcu;
+            ctx->up_one_dma[slot] = false;
+        } else {
+            // (pageable memory goes through the one pinned ring, chunk by chunk, on one stream)
+            int rcu = upload_aos(ctx, src, (size_t)cnt * 3 * sizeof(double), ctx->d_stage_next, ctx->copy_stream, true, pinned);
+            if (rcu) return rcu;
+            ctx->up_one_dma[slot] = true;
+        }
+    } else {
+        ctx->up_one_dma[slot] = true;
     }
-    HIPCHK(ctx, hipEventRecord(ctx->next_ready, ctx->copy_stream));
+    // (one DMA: its event is both the prefix's and the tail's -- every event record is ~1.5 us of the host's time beside the first kernel)
+    HIPCHK(ctx, hipEventRecord(ctx->up_ev[slot][1], ctx->copy_stream));
+    ctx->next_ready = ctx->up_ev[slot][1];
+    ctx->next_slot = slot; ctx->next_prefix_n = ctx->up_one_dma[slot] ? cnt : pre;
     ctx->next_n = cnt; ctx->next_begin = b; ctx->next_total = n;
     return SRL_OK;
 }
@@ -430,17 +462,30 @@ int srl_sweep_swap(srl_ctx *ctx) {
     // usual case: it was issued a whole solve ago) the launch stays and becomes the first pass of the sweep swapped in -- fired through
     // the pose box with SRL_ARM_ALT, no launch on the critical path of the new solve.  An upload still in flight is awaited by the
     // compute stream as before, and a launch already waiting in front of that dependency is cancelled (it could start too early).
-    hipError_t up = hipEventQuery(ctx->next_ready);
-    if (up == hipErrorNotReady && ctx->armed && ctx->next_n <= ctx->work_cap) {
-        // the last bytes of the upload are still on their way and a launch is waiting that could serve the new sweep: cancelling it and
-        // launching afresh costs ~8 us -- give the DMA up to 25 us first (a short solve behind a long sweep: the shipped max_num_residuals
-        // = 600 reads 4 480 keypoints of a sweep whose 64k points cross PCIe in ~40 us)
+    // A waiting launch only needs the PREFIX of the new sweep (it serves a pass of at most as many keypoints as the pass it was armed
+    // behind -- with a finite max_num_residuals the first few thousand): the prefix went out first with an event of its own.  The rest may
+    // still be crossing PCIe; `tail_pending` makes the first pass that needs it order the stream behind the full event (build_residuals_pass).
+    const bool one_dma = ctx->up_one_dma[ctx->next_slot];
+    hipEvent_t ev_full = ctx->up_ev[ctx->next_slot][1], ev_pre = ctx->up_ev[ctx->next_slot][one_dma ? 1 : 0];
+    hipError_t up_pre = hipEventQuery(ev_pre);                           // (the prefix travels on a stream of its own: asked first)
+    hipError_t up = (one_dma || up_pre != hipSuccess) ? up_pre : hipEventQuery(ev_full);
+    if (up_pre == hipErrorNotReady && ctx->armed && ctx->next_n <= ctx->work_cap) {
+        // the prefix itself is still on its way (a 100 KB DMA behind the tail of the sweep before it) and a launch is waiting that could
+        // serve the new sweep: cancelling it and launching afresh costs ~8 us -- give the DMA up to 25 us first
         const long long t_give_up = steady_ns() + 25000;
-        while ((up = hipEventQuery(ctx->next_ready)) == hipErrorNotReady && steady_ns() < t_give_up) { }
+        while ((up_pre = hipEventQuery(ev_pre)) == hipErrorNotReady && steady_ns() < t_give_up) { }
     }
-    if (up != hipSuccess && up != hipErrorNotReady) { ctx->err = std::string("hipEventQuery: ") + hipGetErrorString(up); return SRL_ERR_HIP; }
-    if (up != hipSuccess || ctx->next_n > ctx->work_cap) SRL_DISARM(ctx);   // (growing the work buffers frees them: never under a waiting launch)
-    if (up != hipSuccess) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->next_ready, 0));       // compute waits for the upload; the host does not
+    for (hipError_t e : {up, up_pre})
+        if (e != hipSuccess && e != hipErrorNotReady) { ctx->err = std::string("hipEventQuery: ") + hipGetErrorString(e); return SRL_ERR_HIP; }
+    if (up_pre != hipSuccess || ctx->next_n > ctx->work_cap) SRL_DISARM(ctx);   // (growing the work buffers frees them: never under a waiting launch)
+    if (up_pre != hipSuccess) {
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ev_full, 0));       // compute waits for the upload; the host does not
+        if (!one_dma) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ev_pre, 0));
+        up = hipSuccess;                                               // (the stream is ordered behind everything)
+    }
+    ctx->tail_pending = up != hipSuccess;
+    ctx->cur_slot = ctx->next_slot;
+    ctx->cur_prefix_n = up == hipSuccess ? ctx->next_n : ctx->next_prefix_n;
     ctx->passes_in_solve = 0;
     std::swap(ctx->d_raw, ctx->d_raw_next);
     std::swap(ctx->sweep_cap, ctx->next_cap);
@@ -1009,6 +1054,14 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         sg.raw_x = sg.raw_y = sg.raw_z = nullptr; sg.alt_x = sg.alt_y = sg.alt_z = nullptr; sg.n = 0; sg.aos = nullptr; sg.alt_aos = nullptr;
         return sg;
     };
+    // The current sweep was swapped in when only its PREFIX had landed (srl_sweep_swap): a pass inside the prefix may fire a waiting launch;
+    // anything else is launched normally BEHIND the full upload (a resident kernel cannot be made to wait for an event)
+    bool needs_tail = false;
+    if (ctx->tail_pending) {
+        if (hipEventQuery(ctx->up_ev[ctx->cur_slot][1]) == hipSuccess) { ctx->tail_pending = false; ctx->cur_prefix_n = ctx->n; }
+        else needs_tail = n_eff > ctx->cur_prefix_n;
+        (void)hipGetLastError();
+    }
     bool fired = false;
     if (ctx->armed) {
         const SrlAssocArgs sg = signature(a);
@@ -1018,7 +1071,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         const bool on_raw = a.raw_x == ctx->armed_raw && ctx->sweep_cap == ctx->armed_raw_cap && a.aos == nullptr;
         const bool on_alt = !on_raw && ctx->armed_alt != nullptr && a.raw_x == ctx->armed_alt && ctx->sweep_cap == ctx->armed_alt_cap &&
                             a.aos != nullptr && a.aos == ctx->armed_alt_aos;
-        if (arm_ok && age_us < ctx->arm_host_linger_us && nb == ctx->armed_nb && kpw == ctx->armed_kpw && nblocks <= ctx->armed_nblocks && (on_raw || on_alt) &&
+        if (arm_ok && !needs_tail && age_us < ctx->arm_host_linger_us && nb == ctx->armed_nb && kpw == ctx->armed_kpw && nblocks <= ctx->armed_nblocks && (on_raw || on_alt) &&
             std::memcmp(&sg, &ctx->armed_sig, sizeof sg) == 0) {
             pose_box_write(ctx, a.Rn, a.R, a.t, (unsigned)seq_now, SRL_ARM_GO | (on_alt ? SRL_ARM_ALT : 0u), (unsigned)a.n, a.t_last);
             ctx->armed = false;
@@ -1047,6 +1100,10 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         ctx->cur_measured = ctx->armed_measured;
         ctx->cur_gen = ctx->armed_gen;
     } else {
+        if (ctx->tail_pending) {             // a normal launch reads whatever it likes of the sweep: behind the whole upload
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->up_ev[ctx->cur_slot][1], 0));
+            ctx->tail_pending = false; ctx->cur_prefix_n = ctx->n;
+        }
         ctx->cur_gen = ctx->timing_gen;
         const int role = prof_light ? prof_role(ctx->prof_count) : 0;
         if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
@@ -1592,6 +1649,7 @@ int srl_build_residuals(srl_ctx *ctx, const srl_frame *f, const srl_icp_opts *o,
         const long long pre = ((4LL * o->max_num_residuals + 2048 + 63) / 64) * 64;
         if (pre < (long long)ctx->n) n_eff = (int)pre;
     }
+    ctx->prefix_hint = n_eff < ctx->n ? n_eff : 0;      // what the next prefetch sends first (srl_sweep_prefetch)
     // One attempt at a pass = build_residuals_pass, repeated while a PEER's row has not arrived (direct peer exchange only).
     auto attempt = [&](int n_pass) -> int {
         const unsigned long long peer_seq0 = ctx->peer_seq;              // (a repeated pass re-polls the SAME exchanges)

