@@ -17,7 +17,6 @@
 #include "host/srl_la.h"
 #include "host/tr1_order.h"
 
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -116,29 +115,6 @@ __global__ void k_select_mark(const unsigned long long *keyw, const unsigned lon
 // The voxels leave the device HERE: {std::hash<voxel> (cloudMap.h:173-184, what the host's replay of the container needs), index of the
 // first point} by rank, stored straight into page-locked host memory; the last block to finish publishes {tag, count} in one 8-byte
 // word the host waits on.  No copy command, no stream synchronisation (a D2H copy + hipStreamSynchronize cost ~25 us per frame).
-__global__ void k_select_emit(const int *flag, const int *rank, const unsigned long long *key_at, int n, unsigned long long *host_hash,
-                              unsigned *host_first, unsigned *done, unsigned long long *host_ctrl, unsigned tag) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) {
-        short x, y, z;
-        srl_unpack_key(key_at[i], &x, &y, &z);
-        const unsigned long long kP1 = 73856093ull, kP2 = 19349669ull, kP3 = 83492791ull;       // size_t arithmetic of the reference's hash
-        const int r = rank[i];
-        host_hash[r] = (unsigned long long)(long long)x * kP1 + (unsigned long long)(long long)y * kP2 + (unsigned long long)(long long)z * kP3;
-        host_first[r] = (unsigned)i;
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == gridDim.x - 1) {
-            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // ready for the next frame
-            const unsigned count = (unsigned)(rank[n - 1] + flag[n - 1]);
-            __threadfence_system();
-            __hip_atomic_store(host_ctrl, ((unsigned long long)tag << 32) | count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
 
 // ... the same hand-over as the per-element work (EmitSink) and the "tile done" step (EmitFin) of the one-launch scan over the marks
 // (frames up to SRL_SCAN_SMALL_MAX points): no rank array, no launch of its own
@@ -650,12 +626,12 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         while (cap < 2u * (unsigned)n) cap <<= 1;
         // the keypoint ORDER on the device (see "keypoint ORDER on the device" above) when the bucket table of n voxels fits one scan launch
         unsigned nb_max = 0;
-        bool dev_order = ctx->frame_order_mode == 0 && n <= SRL_SCAN_SMALL_MAX;
+        bool dev_order = ctx->frame_order_mode == 0 && n <= SRL_SCAN_MAX;
         if (dev_order) {
             if (ctx->tr1_steps < 0) {
                 SrlTr1Sched S;
                 std::memset(&S, 0, sizeof S);
-                const int steps = srl::Tr1Order::export_schedule(SRL_SCAN_SMALL_MAX, S.first, S.nb, SRL_TR1_MAX_STEPS);
+                const int steps = srl::Tr1Order::export_schedule(SRL_SCAN_MAX, S.first, S.nb, SRL_TR1_MAX_STEPS);
                 if (steps >= 0) {
                     S.steps = steps;
                     HIPCHK(ctx, hipMalloc((void **)&ctx->d_tr1_sched, sizeof S));
@@ -672,17 +648,16 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
                 while (g < ctx->tr1_steps && ctx->tr1_first[g] <= (unsigned)n) ++g;
                 nb_max = ctx->tr1_nb[g];
             }
-            dev_order = ctx->tr1_steps >= 0 && nb_max > 0 && nb_max <= SRL_SCAN_SMALL_MAX;
+            dev_order = ctx->tr1_steps >= 0 && nb_max > 0 && nb_max <= (1u << 23);       // (srl_scan takes any size; the member lists are 128 B per bucket)
         }
-        DevBuf b_flag, b_rank, b_keyat, b_tmp, b_hash, b_first, b_bcnt, b_members, b_elem, b_bstart, b_sel;
+        DevBuf b_flag, b_keyat, b_hash, b_first, b_bcnt, b_members, b_elem, b_bstart, b_sel, b_sc;
         HIPCHK(ctx, b_flag.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_keyat.alloc(ctx, (size_t)n * 8));
+        HIPCHK(ctx, b_sc.alloc(ctx, srl_scan_scratch_ints(std::max(n, (int)nb_max)) * 4));      // tile sums of the scans beyond one launch (srl_scan)
         if (dev_order) {
             HIPCHK(ctx, b_hash.alloc(ctx, (size_t)n * 8)); HIPCHK(ctx, b_first.alloc(ctx, (size_t)n * 4));
             HIPCHK(ctx, b_bcnt.alloc(ctx, (size_t)nb_max * 4)); HIPCHK(ctx, b_members.alloc(ctx, (size_t)nb_max * SRL_TR1_BUCKET_SLOTS * 8));
             HIPCHK(ctx, b_elem.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_bstart.alloc(ctx, (size_t)nb_max * 4));
             HIPCHK(ctx, b_sel.alloc(ctx, (size_t)n * 4));
-        } else {
-            HIPCHK(ctx, b_rank.alloc(ctx, (size_t)n * 4));
         }
         int rct = srl_epoch_table_begin(ctx, ctx->sel_table, cap, true);
         if (rct) return rct;
@@ -706,26 +681,18 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         if (dev_order) {
             // ranks (first-occurrence order) -> bucket of every voxel at the table's final size, {tag, overflow, count} to the host -> scan
             // over the bucket counts -> per voxel: rank inside its bucket, ordered index list, gather of the raw point
-            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, RankSink, CountFin>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, SrlIntArrayIn{b_flag.as<int>()},
-                               RankSink{b_keyat.as<unsigned long long>(), b_hash.as<unsigned long long>(), b_first.as<unsigned>()}, n, CountFin{ctx->d_frame_sync});
+            srl_scan(SrlIntArrayIn{b_flag.as<int>()}, RankSink{b_keyat.as<unsigned long long>(), b_hash.as<unsigned long long>(), b_first.as<unsigned>()}, n,
+                     b_sc.as<int>(), st, CountFin{ctx->d_frame_sync});
             hipLaunchKernelGGL(k_tr1_bucket, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_tr1_sched, ctx->d_frame_sync, b_hash.as<unsigned long long>(),
                                b_bcnt.as<int>(), b_members.as<unsigned long long>(), b_elem.as<unsigned>(), h_ctrl, tag);
-            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, SrlIntArraySink>), dim3(srl_scan_small_grid((int)nb_max)), dim3(1024), 0, st,
-                               SrlIntArrayIn{b_bcnt.as<int>()}, SrlIntArraySink{b_bstart.as<int>()}, (int)nb_max, SrlNoFin());
+            srl_scan(SrlIntArrayIn{b_bcnt.as<int>()}, SrlIntArraySink{b_bstart.as<int>()}, (int)nb_max, b_sc.as<int>(), st);
             hipLaunchKernelGGL(k_tr1_rank, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_tr1_sched, ctx->d_frame_sync, b_hash.as<unsigned long long>(),
                                b_first.as<unsigned>(), b_members.as<unsigned long long>(), b_bcnt.as<int>(), b_bstart.as<int>(), b_elem.as<unsigned>(),
                                ctx->d_frame_raw, sx, sy, sz, b_sel.as<int>());
-        } else if (n <= SRL_SCAN_SMALL_MAX) {
-            // ranks, hand-over to the host and the completion word in ONE launch
-            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, EmitSink, EmitFin>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, SrlIntArrayIn{b_flag.as<int>()},
-                               EmitSink{b_keyat.as<unsigned long long>(), h_hash, first}, n, EmitFin{ctx->d_frame_sync, h_ctrl, tag});
         } else {
-            size_t scan_bytes = 0;
-            hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, b_flag.as<int>(), b_rank.as<int>(), n, st);
-            HIPCHK(ctx, b_tmp.alloc(ctx, scan_bytes + 256));
-            HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, scan_bytes, b_flag.as<int>(), b_rank.as<int>(), n, st));
-            hipLaunchKernelGGL(k_select_emit, dim3((n + 255) / 256), dim3(256), 0, st, b_flag.as<int>(), b_rank.as<int>(), b_keyat.as<unsigned long long>(), n,
-                               h_hash, first, ctx->d_frame_sync, h_ctrl, tag);
+            // ranks, hand-over to the host and the completion word in the scan's own pass
+            srl_scan(SrlIntArrayIn{b_flag.as<int>()}, EmitSink{b_keyat.as<unsigned long long>(), h_hash, first}, n, b_sc.as<int>(), st,
+                     EmitFin{ctx->d_frame_sync, h_ctrl, tag});
         }
         HIPCHK(ctx, hipGetLastError());
         srl_stage_end(ctx, 1);
@@ -829,7 +796,7 @@ int srl_frame_commit(srl_ctx *ctx, const double q[4], const double t[3], const d
     srl_stage_begin(ctx);
     // A frame-sized batch outside the stage-timing mode: the re-transform is the first thing the insertion's first kernel does (one launch
     // less on a chain whose cost is its launches); otherwise a kernel of its own, as stage 5 of srl_debug_frame_timing.
-    const bool fused = n <= 131072 && !ctx->frame_timing;
+    const bool fused = n <= SRL_SCAN_MAX && !ctx->frame_timing;
     if (!fused) {
         hipLaunchKernelGGL(k_frame_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_frame_raw, n, xf.X, 1.0, ctx->d_frame_world,
                            (unsigned long long *)nullptr, (unsigned *)nullptr);

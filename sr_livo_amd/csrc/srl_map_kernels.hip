@@ -15,22 +15,11 @@
 #include "srl_frame_scratch.h"
 #include "srl_hash.h"
 
-#include <hipcub/hipcub.hpp>
 
 #include <vector>
 
 namespace {
 
-__global__ void k_point_keys(const double *xyz, int n, double voxel_size, unsigned long long *keys, unsigned *idx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float fx = (float)xyz[(size_t)i * 3], fy = (float)xyz[(size_t)i * 3 + 1], fz = (float)xyz[(size_t)i * 3 + 2];
-    const short kx = (short)(int)((double)fx / voxel_size);
-    const short ky = (short)(int)((double)fy / voxel_size);
-    const short kz = (short)(int)((double)fz / voxel_size);
-    keys[i] = srl_pack_key(kx, ky, kz);
-    idx[i] = (unsigned)i;
-}
 
 // Frame-sized batches: the sort only has to bring the points of a voxel TOGETHER, in their original order -- not the voxels into
 // key order.  So the 48-bit key is first replaced by the slot the voxel claims in a scratch table of >= 2 n slots (open
@@ -79,7 +68,7 @@ struct SegmentSink {
     const unsigned long long *keyw;
     int *seg_start;
     unsigned long long *keys_sorted;          // written at segment heads only: the voxel key of the segment
-    const SrlMapSlot *table;                  // the map's table: the lookup of k_lookup happens here, at the head of every segment
+    const SrlMapSlot *table;                  // the map's table: the table lookup happens here, at the head of every segment
     unsigned mask;
     int *seg_slot;
     unsigned char *is_new;
@@ -112,7 +101,7 @@ struct SegmentSink {
     }
 };
 // ... and the per-element work of the scan over the new-voxel marks (point-index space): the exclusive prefix IS the creation rank
-// (the sequential loop of lioOptimization.cpp:520-554 creates voxels in the order their first points arrive) -- k_create's work
+// (the sequential loop of lioOptimization.cpp:520-554 creates voxels in the order their first points arrive)
 struct CreateSink {
     const int *seg_of_first;
     const int *seg_start;
@@ -149,70 +138,6 @@ struct CreateSink {
     }
 };
 
-// ---- segments of the (key, index)-sorted batch.  A segment = the points of one voxel, in their original order (stable sort).
-// head flag of sorted position i, as an iterator the scan reads directly (no flag array)
-struct HeadFlag {
-    const unsigned long long *keys;
-    __host__ __device__ int operator()(int i) const { return (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0; }
-};
-// seg_start[s] = sorted position of the first point of segment s (s = exclusive prefix of the head flags); counters[0] = S
-__global__ void k_seg_starts(const unsigned long long *keys_sorted, const int *head_prefix, int n, int *seg_start, int *counters) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const bool head = i == 0 || keys_sorted[i] != keys_sorted[i - 1];
-    if (head) seg_start[head_prefix[i]] = i;
-    if (i == n - 1) counters[0] = head_prefix[i] + (head ? 1 : 0);
-}
-
-// per touched voxel: table slot (or -1), flag new, first point index; a NEW voxel marks the index of its first point in new_flag:
-// the exclusive prefix over those marks is the voxel's creation rank (the sequential loop of lioOptimization.cpp:520-554 creates
-// voxels in the order their first points arrive)
-__global__ void k_lookup(const unsigned long long *keys_sorted, const int *seg_start, const unsigned *sorted_idx, const int *counters,
-                         const SrlMapSlot *table, unsigned mask, int *seg_slot, unsigned char *is_new, unsigned *first_idx, int *new_flag) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= counters[0]) return;
-    const int j0 = seg_start[s];
-    const unsigned long long key = keys_sorted[j0];
-    unsigned h = srl_hash_key(key) & mask;
-    int slot = -1;
-    for (unsigned probe = 0; probe <= mask; ++probe) {
-        const unsigned long long k = table[h].key;
-        if (k == key) { slot = (int)h; break; }
-        if (k == SRL_EMPTY_KEY) break;
-        h = (h + 1) & mask;
-    }
-    const unsigned first = sorted_idx[j0];
-    seg_slot[s] = slot;
-    is_new[s] = slot < 0 ? 1 : 0;
-    first_idx[s] = first;
-    if (slot < 0 && new_flag) new_flag[first] = 1;
-}
-
-// new voxels: slab = V + creation rank; header written, key CAS-inserted into the table.  counters[1] = number of new voxels.
-__global__ void k_create(const unsigned long long *keys_sorted, const int *seg_start, const int *counters_in, const unsigned char *is_new,
-                         const unsigned *first_idx, const int *new_rank, const int *new_flag, int n, int V,
-                         SrlMapSlot *table, unsigned mask, unsigned char *slabs, int *seg_slot, int *counters) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s == 0) counters[1] = new_rank[n - 1] + new_flag[n - 1];
-    if (s >= counters_in[0] || !is_new[s]) return;
-    const unsigned long long key = keys_sorted[seg_start[s]];
-    const unsigned slab = (unsigned)(V + new_rank[first_idx[s]]);
-    SrlSlab *sl = reinterpret_cast<SrlSlab *>(slabs + (size_t)slab * SRL_SLAB_BYTES);
-    sl->count = 0;
-    sl->pad = 0;
-    sl->key = key;
-    unsigned h = srl_hash_key(key) & mask;
-    for (unsigned probe = 0; probe <= mask; ++probe) {
-        const unsigned long long prev = atomicCAS(&table[h].key, SRL_EMPTY_KEY, key);
-        if (prev == SRL_EMPTY_KEY) {
-            table[h].slab = slab;
-            table[h].count = 0;
-            seg_slot[s] = (int)h;
-            return;
-        }
-        h = (h + 1) & mask;
-    }
-}
 
 // sequential replay of one voxel's segment (lioOptimization.cpp:409-445), one thread per voxel.  The kernel is latency bound,
 // not work bound: a 1 M-point batch touches 67 k voxels = ONE wave per SIMD, and every point costs its thread two dependent
@@ -418,15 +343,18 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
 
 // debug / parity hook: the frame path's own stable sort (srl_frame_scratch.h) on caller data
 extern "C" int srl_debug_radix_sort_pairs(srl_ctx *ctx, const uint32_t *keys, int n, int bits, uint32_t *keys_sorted, uint32_t *positions_sorted) {
-    if (!ctx || n < 0 || n > SRL_SCAN_SMALL_MAX || bits < 1 || bits > 2 * SRL_RADIX_MAX_BITS || (n > 0 && (!keys || !keys_sorted || !positions_sorted)))
+    if (!ctx || n < 0 || n > (1 << 25) || bits < 1 || bits > 3 * SRL_RADIX_MAX_BITS || (n > 0 && (!keys || !keys_sorted || !positions_sorted)))
         return SRL_ERR_BAD_ARG;
     if (n == 0) return SRL_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DevBuf b_in, b_k, b_v, b_tk, b_tv;
     HIPCHK(ctx, b_in.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_k.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_v.alloc(ctx, (size_t)n * 4));
     HIPCHK(ctx, b_tk.alloc(ctx, (size_t)n * 4)); HIPCHK(ctx, b_tv.alloc(ctx, (size_t)n * 4));
+    DevBuf b_sc;
+    HIPCHK(ctx, b_sc.alloc(ctx, srl_radix_scratch_ints(n) * 4));
     HIPCHK(ctx, hipMemcpyAsync(b_in.p, keys, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    srl_radix_sort_pairs(b_in.as<unsigned>(), nullptr, b_k.as<unsigned>(), b_v.as<unsigned>(), b_tk.as<unsigned>(), b_tv.as<unsigned>(), n, (unsigned)bits, ctx->stream);
+    srl_radix_sort_pairs(b_in.as<unsigned>(), nullptr, b_k.as<unsigned>(), b_v.as<unsigned>(), b_tk.as<unsigned>(), b_tv.as<unsigned>(), n, (unsigned)bits, ctx->stream,
+                         b_sc.as<int>());
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(keys_sorted, b_k.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(positions_sorted, b_v.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -470,7 +398,10 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
         int rc = srl_ctx_grow_map(ctx, 4096u, 8192u);
         if (rc) return rc;
     }
-    const bool frame_sized = n <= 131072;
+    // frame_sized: storage is grown beforehand for the worst case (every point a new voxel) and nothing is read back before the end; a bulk
+    // load (> 1 M points) reads the segment count once to size the map.  The KERNELS are the same for both (round 6: frames beyond 131 072
+    // points and bulk loads used to leave for hipcub's radix sort and scans): own radix passes and scans of any size (srl_frame_scratch.h).
+    const bool frame_sized = n <= SRL_SCAN_MAX;
     if (frame_sized) {
         const unsigned need_slabs = (unsigned)ctx->num_voxels + (unsigned)n;
         if (need_slabs > ctx->slab_cap || SRL_TABLE_FACTOR * need_slabs > ctx->table_cap) {
@@ -479,14 +410,13 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
         }
     }
 
-    DevBuf b_xyz, b_keys, b_keys2, b_idx, b_idx2, b_prefix, b_start, b_cnt, b_tmp, b_slot, b_isnew, b_first, b_newflag, b_newrank;
+    DevBuf b_xyz, b_keys2, b_idx, b_idx2, b_prefix, b_start, b_cnt, b_slot, b_isnew, b_first, b_newflag;
     const double *d_xyz = world_xyz;
     if (!on_device) {
         HIPCHK(ctx, b_xyz.alloc(ctx, (size_t)n * 3 * sizeof(double)));
         HIPCHK(ctx, hipMemcpyAsync(b_xyz.p, world_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
         d_xyz = b_xyz.as<double>();
     }
-    HIPCHK(ctx, b_keys.alloc(ctx, (size_t)n * 8));
     HIPCHK(ctx, b_keys2.alloc(ctx, (size_t)n * 8));
     HIPCHK(ctx, b_idx.alloc(ctx, (size_t)n * 4));
     HIPCHK(ctx, b_idx2.alloc(ctx, (size_t)n * 4));
@@ -497,19 +427,14 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
     HIPCHK(ctx, b_isnew.alloc(ctx, (size_t)n));
     HIPCHK(ctx, b_first.alloc(ctx, (size_t)n * 4));
     HIPCHK(ctx, b_newflag.alloc(ctx, (size_t)n * 4));
-    HIPCHK(ctx, b_newrank.alloc(ctx, (size_t)n * 4));
     int *cnt = b_cnt.as<int>();
     srl_stage_begin(ctx);
-    if (!frame_sized) {             // (a frame's kernels initialise what they accumulate into themselves: k_point_slots, SegmentSink)
-        HIPCHK(ctx, hipMemsetAsync(cnt, 0, 64, st));
-        HIPCHK(ctx, hipMemsetAsync(b_newflag.p, 0, (size_t)n * 4, st));
-    }
-    hipcub::CountingInputIterator<int> positions(0);
-    size_t tmp_bytes = 0, need = 0;
-    size_t tb = 0;
-    if (frame_sized) {
+    DevBuf b_sc;
+    HIPCHK(ctx, b_sc.alloc(ctx, (srl_radix_scratch_ints(n) + srl_scan_scratch_ints(n)) * 4));
+    int *sc_radix = b_sc.as<int>(), *sc_scan = b_sc.as<int>() + srl_radix_scratch_ints(n);
+    {
         // group by scratch-table slot, stable sort over log2(slots) bits (k_point_slots); the scan over the head flags writes
-        // the segment starts in the same pass
+        // the segment starts in the same pass.  (The kernels initialise what they accumulate into themselves: k_point_slots, SegmentSink.)
         unsigned cap2 = 1024, bits = 10;
         while (cap2 < 2u * (unsigned)n) { cap2 <<= 1; ++bits; }
         int rct = srl_epoch_table_begin(ctx, ctx->ins_table, cap2, false);
@@ -526,39 +451,16 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
         }
         HIPCHK(ctx, hipGetLastError());
         if (after_first_kernel) { const int rca = after_first_kernel(ctx, user); if (rca) return rca; }
-        // (slot, position) sorted stably over log2(slots) bits: two launches of our own (srl_frame_scratch.h) instead of the library's eight
-        static_assert(SRL_SCAN_SMALL_MAX >= 131072, "frame-sized batches fit the one-launch passes");
+        // (slot, position) sorted stably over log2(slots) bits: passes of our own (srl_frame_scratch.h: one launch each up to 131 072 points,
+        // two up to 1 M, five for bulk loads) instead of the library's sort
         srl_radix_sort_pairs(b_slot_in.as<unsigned>(), nullptr, b_slot_sorted.as<unsigned>(), b_idx2.as<unsigned>(), b_prefix.as<unsigned>(), b_idx.as<unsigned>(), n,
-                             bits, st);
+                             bits, st, sc_radix);
         HIPCHK(ctx, hipGetLastError());
         srl_stage_end(ctx, 7);                                    // slots + sort
-        hipLaunchKernelGGL((k_scan_small<HeadFlag32, SegmentSink>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, HeadFlag32{b_slot_sorted.as<unsigned>()},
-                           SegmentSink{b_slot_sorted.as<unsigned>(), b_idx2.as<unsigned>(), T.keyw, b_start.as<int>(), b_keys2.as<unsigned long long>(), ctx->d_table,
-                                       ctx->table_cap - 1, b_slot.as<int>(), b_isnew.as<unsigned char>(), min_num_points <= 0 ? b_newflag.as<int>() : (int *)nullptr,
-                                       b_first.as<int>(), cnt, n}, n);
-        HIPCHK(ctx, hipGetLastError());
-    } else {
-        hipLaunchKernelGGL(k_point_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, voxel_size,
-                           b_keys.as<unsigned long long>(), b_idx.as<unsigned>());
-        HIPCHK(ctx, hipGetLastError());
-        // stable sort by key (48 significant bits): original order survives inside each voxel
-        hipcub::TransformInputIterator<int, HeadFlag, hipcub::CountingInputIterator<int>> heads(positions, HeadFlag{b_keys2.as<unsigned long long>()});
-        hipcub::DeviceRadixSort::SortPairs(nullptr, need, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
-                                           b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st);
-        tmp_bytes = need;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, need, heads, b_prefix.as<int>(), n, st);
-        tmp_bytes = std::max(tmp_bytes, need);
-        hipcub::DeviceScan::ExclusiveSum(nullptr, need, b_newflag.as<int>(), b_newrank.as<int>(), n, st);
-        tmp_bytes = std::max(tmp_bytes, need) + 4096;
-        HIPCHK(ctx, b_tmp.alloc(ctx, tmp_bytes));
-        tb = tmp_bytes;
-        HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, b_keys.as<unsigned long long>(), b_keys2.as<unsigned long long>(),
-                                                       b_idx.as<unsigned>(), b_idx2.as<unsigned>(), n, 0, 48, st));
-        srl_stage_end(ctx, 7);                                    // keys + sort
-        tb = tmp_bytes;
-        HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, heads, b_prefix.as<int>(), n, st));
-        hipLaunchKernelGGL(k_seg_starts, dim3((n + 255) / 256), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_prefix.as<int>(), n,
-                           b_start.as<int>(), cnt);
+        srl_scan(HeadFlag32{b_slot_sorted.as<unsigned>()},
+                 SegmentSink{b_slot_sorted.as<unsigned>(), b_idx2.as<unsigned>(), T.keyw, b_start.as<int>(), b_keys2.as<unsigned long long>(), ctx->d_table,
+                             ctx->table_cap - 1, b_slot.as<int>(), b_isnew.as<unsigned char>(), min_num_points <= 0 ? b_newflag.as<int>() : (int *)nullptr,
+                             b_first.as<int>(), cnt, n}, n, sc_scan, st);
         HIPCHK(ctx, hipGetLastError());
     }
 
@@ -578,25 +480,12 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
     }
     const unsigned mask = ctx->table_cap - 1;
     const bool create_new = min_num_points <= 0;             // min_num_points > 0: a point never opens a voxel (lioOptimization.cpp:437)
-    const int seg_grid = (n + 255) / 256;                    // (one thread per POSSIBLE segment; the kernels stop at the device-side count)
-    if (frame_sized) {
+    {
         // the lookup has happened at the segment heads of the scan above; creation = the per-element work of the scan over the new-voxel marks
         if (create_new) {
-            hipLaunchKernelGGL((k_scan_small<SrlIntArrayIn, CreateSink>), dim3(srl_scan_small_grid(n)), dim3(1024), 0, st, SrlIntArrayIn{b_newflag.as<int>()},
-                               CreateSink{b_first.as<int>(), b_start.as<int>(), b_keys2.as<unsigned long long>(), ctx->num_voxels, ctx->d_table, mask, ctx->d_slabs,
-                                          b_slot.as<int>(), cnt, n}, n);
-            HIPCHK(ctx, hipGetLastError());
-        }
-    } else {
-        hipLaunchKernelGGL(k_lookup, dim3(seg_grid), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_start.as<int>(), b_idx2.as<unsigned>(), cnt,
-                           ctx->d_table, mask, b_slot.as<int>(), b_isnew.as<unsigned char>(), b_first.as<unsigned>(), create_new ? b_newflag.as<int>() : (int *)nullptr);
-        HIPCHK(ctx, hipGetLastError());
-        if (create_new) {
-            tb = tmp_bytes;
-            HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tb, b_newflag.as<int>(), b_newrank.as<int>(), n, st));
-            hipLaunchKernelGGL(k_create, dim3(seg_grid), dim3(256), 0, st, b_keys2.as<unsigned long long>(), b_start.as<int>(), cnt, b_isnew.as<unsigned char>(),
-                               b_first.as<unsigned>(), b_newrank.as<int>(), b_newflag.as<int>(), n, ctx->num_voxels, ctx->d_table, mask, ctx->d_slabs,
-                               b_slot.as<int>(), cnt);
+            srl_scan(SrlIntArrayIn{b_newflag.as<int>()},
+                     CreateSink{b_first.as<int>(), b_start.as<int>(), b_keys2.as<unsigned long long>(), ctx->num_voxels, ctx->d_table, mask, ctx->d_slabs,
+                                b_slot.as<int>(), cnt, n}, n, sc_scan, st);
             HIPCHK(ctx, hipGetLastError());
         }
     }

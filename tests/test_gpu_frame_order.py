@@ -2,7 +2,7 @@
 gridSampling's std::tr1::unordered_map, utility.cpp:167-201, as a pairwise relation) against the host replay of the container's moves
 (csrc/host/tr1_order.h) and against the oracle's gridSampling (a real std::tr1::unordered_map): the same permutation, the same resident
 sweep, on random frames, at the rehash boundaries, with adversarial keys (an overfull bucket falls back to the host replay) and for
-frames too large for the one-launch scan."""
+frames beyond the one-launch scan (two launches there, still on the device)."""
 import numpy as np
 import pytest
 
@@ -103,14 +103,25 @@ def test_shared_buckets_and_overfull_bucket_fall_back(oracle_lib, oracle_backend
         ctx.close()
 
 
-def test_frames_beyond_the_one_launch_scan_use_the_host_replay(oracle_lib, oracle_backend):
-    raw = np.random.default_rng(9).normal(size=(140_000, 3)) * np.array([40.0, 40.0, 5.0])
+@pytest.mark.parametrize("n_points,size", [(140_000, 0.7), (262_144, 0.5), (262_144, 0.05), (600_000, 0.4)])
+def test_frames_beyond_the_one_launch_scan_are_ordered_on_the_device_too(oracle_lib, oracle_backend, n_points, size):
+    """a frame of more than 131 072 points (BASELINE config 4's sweep has 262 144) used to fall back to the host replay of
+    the container and to the library's scan.  The scans run in two launches there (tile sums, then the same kernel summing the sums in
+    front of its tile): same device chain, same order as gridSampling's std::tr1::unordered_map -- also where nearly every point is a voxel
+    of its own (size 0.05: ~260 000 voxels, a bucket table of ~410 000)."""
+    raw = np.random.default_rng(9 + n_points).normal(size=(n_points, 3)) * np.array([40.0, 40.0, 5.0])
     ctx = srl.Context(0)
     try:
         ctx.frame_upload(raw)
-        got = ctx.frame_select_keypoints(Q_ID, T0, 0.7)
-        assert ctx.frame_order_used() == 2
-        assert np.array_equal(got, oracle_lib.grid_sampling(raw, 0.7, backend=oracle_backend))
+        got = ctx.frame_select_keypoints(Q_ID, T0, size)
+        assert ctx.frame_order_used() == 1, "the frame should have been ordered on the device"
+        want = oracle_lib.grid_sampling(raw, size, backend=oracle_backend)
+        assert len(got) == len(want) and np.array_equal(got, want)
+        if n_points == 262_144 and size == 0.5:
+            ctx.set_frame_order_mode(1)                        # ... and the host replay (still there for bucket overflows) agrees
+            ctx.frame_upload(raw)
+            host = ctx.frame_select_keypoints(Q_ID, T0, size)
+            assert ctx.frame_order_used() == 2 and np.array_equal(host, want)
     finally:
         ctx.close()
 
@@ -150,10 +161,12 @@ def test_resident_sweep_of_the_device_order_gives_the_same_normal_equations():
 
 
 @pytest.mark.parametrize("n,bits", [(1, 10), (63, 5), (64, 9), (1000, 10), (1024, 11), (1025, 12), (5000, 14), (24_000, 16), (24_000, 9), (65_536, 17),
-                                    (100_000, 18), (131_072, 18)])
+                                    (100_000, 18), (131_072, 18), (131_073, 19), (262_144, 19), (300_001, 20), (1_048_576, 21), (1_048_577, 22),
+                                    (3_000_000, 23), (3_000_000, 27)])
 def test_own_radix_sort_is_a_stable_sort(n, bits):
-    """srl_frame_commit groups a frame's points by scratch-table slot with two one-launch radix passes of our own (srl_frame_scratch.h)
-    instead of the library sort: (key, position) pairs must come out exactly as a stable sort leaves them"""
+    """srl_frame_commit groups a frame's points by scratch-table slot with radix passes of our own (srl_frame_scratch.h) instead of the
+    library sort: (key, position) pairs must come out exactly as a stable sort leaves them.  One launch per pass up to 131 072 pairs,
+    two (tile histograms, then the pass) up to 1 M, five beyond (histograms, their scan, the pass): every form, and three passes (27 bits)."""
     ctx = srl.Context(0)
     try:
         for seed, kind in ((0, "uniform"), (1, "few"), (2, "one"), (3, "high_bits_set"), (4, "sorted_desc")):

@@ -185,7 +185,7 @@ def run_config(name, workload, max_res, frame_id, steps, warmup, device, po, bac
         lio.close()
 
 
-def run_pipeline(device, frame_points=(24_000, 65_536), reps=9):
+def run_pipeline(device, frame_points=(24_000, 65_536, 262_144), reps=9):
     """The frame-resident pipeline either side of the solve: per frame upload of the raw points (page-locked) ->
     keypoint selection on the device in gridSampling order (1.5 m sampling) -> two ESIKF passes on the selected keypoints -> commit
     (re-transform + addPointsToMap on the device, world points downloaded; the insertion itself is only enqueued -- num_added = NULL -- and
