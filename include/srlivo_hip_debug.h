@@ -57,6 +57,11 @@ int srl_debug_set_ablate(srl_ctx *ctx, int bits);
  * prefix pass of the shipped 600).  A finisher that gives up waiting for a row (bounded spin) makes srl_build_residuals repeat
  * the pass once with the separate reduce kernel instead of failing. */
 int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable);
+/* Neighbourhood bounds (default on): every pass leaves, per keypoint, its world position and the exact squared distance of its K-th
+ * nearest neighbour; the next pass over the same sweep and map does not visit voxels that lie further from the keypoint than
+ * sqrt(tau) + |movement| -- the same neighbours (searchNeighbors, optimize.cpp:365-426, keeps the K nearest whatever else it looked at),
+ * fewer candidates evaluated.  0 switches the culling off (A/B in the tests: every bit must agree). */
+int srl_debug_set_bound_culling(srl_ctx *ctx, int enable);
 /* Where the pose box of the armed launches lives.  kind 1: fine-grained DEVICE memory the host writes through the PCIe BAR (every
  * workgroup polls it locally; SRL_ERR_UNSUPPORTED when device memory is not CPU-visible on this system).  kind 0: page-locked host
  * memory -- workgroup 0 of the waiting kernel polls it across PCIe and republishes the pose into device memory for the other

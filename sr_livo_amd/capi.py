@@ -159,6 +159,7 @@ def load_library():
         "srl_debug_block_times": ([p, p, C.c_int, C.POINTER(C.c_int)], C.c_int),
         "srl_debug_set_ablate": ([p, C.c_int], C.c_int),
         "srl_debug_set_fused_reduce": ([p, C.c_int], C.c_int),
+        "srl_debug_set_bound_culling": ([p, C.c_int], C.c_int),
         "srl_debug_set_pose_box": ([p, C.c_int], C.c_int),
         "srl_debug_set_arm_linger": ([p, C.c_double, C.c_double], C.c_int),
         "srl_debug_pass_stamps": ([p, C.c_int, p, p], C.c_int),
@@ -537,6 +538,10 @@ class Context:
 
     def set_fused_reduce(self, on):
         self._chk(self.lib.srl_debug_set_fused_reduce(self.h, 1 if on else 0), "srl_debug_set_fused_reduce")
+
+    def set_bound_culling(self, on):
+        """test hook: 0 = every pass visits every found voxel (no use of the previous pass's neighbourhood bounds)"""
+        self._chk(self.lib.srl_debug_set_bound_culling(self.h, 1 if on else 0), "srl_debug_set_bound_culling")
 
     def set_search_select_mode(self, mode):
         self._chk(self.lib.srl_debug_set_search_select_mode(self.h, int(mode)), "srl_debug_set_search_select_mode")

@@ -49,6 +49,8 @@ int ensure_work(srl_ctx *ctx, int n) {
     int rc;
     if ((rc = ensure(ctx, ctx->d_rec, (size_t)cap * 8))) return rc;
     if ((rc = ensure(ctx, ctx->d_status, (size_t)cap))) return rc;
+    if ((rc = ensure(ctx, ctx->d_bound, (size_t)cap * 4))) return rc;
+    ctx->bound_n = 0;
     if ((rc = ensure(ctx, ctx->d_partials, (size_t)nblocks * SRL_PART_STRIDE))) return rc;
     if ((rc = ensure(ctx, ctx->d_binfo, (size_t)nblocks))) return rc;
     ctx->work_cap = cap;
@@ -180,7 +182,7 @@ int srl_ctx_destroy(srl_ctx *ctx) {
     if (ctx->comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->comm);
     if (ctx->parked_comm && srl_rccl()) srl_rccl()->CommDestroy(ctx->parked_comm);
     void *bufs[] = {ctx->d_corr_in, ctx->d_corr_rel, ctx->d_corr_imu, ctx->d_corr_raw, ctx->d_corr_seg, ctx->d_frame_raw, ctx->d_frame_world, ctx->d_table, ctx->d_slabs, ctx->d_raw, ctx->d_rec, ctx->d_status, ctx->d_partials, ctx->d_binfo,
-                    ctx->d_out, ctx->d_count, ctx->d_granules, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_stage_cur, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
+                    ctx->d_out, ctx->d_count, ctx->d_bound, ctx->d_granules, ctx->d_rec_granules, ctx->d_raw_next, ctx->d_stage_next, ctx->d_stage_cur, ctx->d_tap_ids, ctx->d_tap_ncand, ctx->d_tap_normal, ctx->d_tap_a2d,
                     ctx->d_tap_offset, ctx->d_gather, ctx->d_peer, ctx->d_mail};
     for (int r = 0; r < SRL_MAX_PEERS; r++) if (ctx->peer_mapped[r]) hipIpcCloseMemHandle(ctx->peer_mapped[r]);
     if (ctx->d_inbox) hipFree(ctx->d_inbox);
@@ -221,6 +223,7 @@ int srl_map_upload(srl_ctx *ctx, const int16_t *keys_xyz, const int32_t *counts,
     if (cap != SRL_VOXEL_CAP) { ctx->err = "max_num_points_in_voxel must be 20"; return SRL_ERR_UNSUPPORTED; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     { const int rcs = srl_map_settle(ctx); if (rcs) return rcs; }
+    ctx->bound_n = 0;
     // capacity with headroom so that srl_map_insert can add voxels without an immediate rebuild
     const unsigned slab_cap = std::max<unsigned>(1024u, (unsigned)V + (unsigned)V / 2u + 4096u);
     if (slab_cap > SRL_MAX_SLABS) { ctx->err = "map too large: slab byte offsets are 32-bit (16.7 M voxels)"; return SRL_ERR_UNSUPPORTED; }
@@ -361,6 +364,7 @@ int srl_sweep_upload(srl_ctx *ctx, const double *raw_xyz, int n) {
     ctx->taps_valid = false;
     ctx->passes_in_solve = 0;
     ctx->tail_pending = false;
+    ctx->bound_n = 0;
     if (cnt > ctx->sweep_cap) {
         const int cap = std::max(cnt, 1024);
         int rc = ensure(ctx, ctx->d_raw, (size_t)cap * 3);
@@ -484,6 +488,7 @@ int srl_sweep_swap(srl_ctx *ctx) {
         up = hipSuccess;                                               // (the stream is ordered behind everything)
     }
     ctx->tail_pending = up != hipSuccess;
+    ctx->bound_n = 0;                                       // another sweep: the bounds of the old one say nothing about it
     ctx->cur_slot = ctx->next_slot;
     ctx->cur_prefix_n = up == hipSuccess ? ctx->next_n : ctx->next_prefix_n;
     ctx->passes_in_solve = 0;
@@ -898,6 +903,16 @@ static int prepare_assoc_args(srl_ctx *ctx, const srl_frame *f, const srl_icp_op
     a.status = ctx->d_status;
     a.partials = ctx->d_partials;
     a.binfo = ctx->d_binfo;
+    {
+        // bounds of the previous pass: usable when they were written with these options (sweep and map changes reset bound_n themselves)
+        float sv = (float)o->size_voxel_map;
+        int sv_bits; std::memcpy(&sv_bits, &sv, 4);
+        const int sig[4] = {K, nb, thr, sv_bits};
+        if (std::memcmp(sig, ctx->bound_sig, sizeof sig) != 0) { ctx->bound_n = 0; std::memcpy(ctx->bound_sig, sig, sizeof sig); }
+        a.bound_out = ctx->d_bound;
+        a.bound_in = (ctx->bound_mode != 0 && nb == 1) ? ctx->d_bound : nullptr;
+        a.bound_use = a.bound_in ? std::min(ctx->bound_n, n_eff) : 0;
+    }
     nb_out = nb;
     return SRL_OK;
 }
@@ -1052,6 +1067,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         sg.pose_box = nullptr; sg.pose_relay = nullptr; sg.pose_relayed = 0; sg.pose_epoch = 0; sg.arm_linger_ticks = 0;
         // the sweep (either buffer of the context) and its keypoint count travel with the pose: compared separately below
         sg.raw_x = sg.raw_y = sg.raw_z = nullptr; sg.alt_x = sg.alt_y = sg.alt_z = nullptr; sg.n = 0; sg.aos = nullptr; sg.alt_aos = nullptr;
+        sg.bound_use = 0;        // (an armed launch carries its own: the keypoints of the pass it was armed behind)
         return sg;
     };
     // The current sweep was swapped in when only its PREFIX had landed (srl_sweep_swap): a pass inside the prefix may fire a waiting launch;
@@ -1140,6 +1156,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
         if (rcp) return rcp;
         SrlAssocArgs nx = a;
         nx.seq = ctx->seq + 1;
+        nx.bound_use = a.bound_in ? a.n : 0;              // this pass writes the bounds of its a.n keypoints; the kernel drops them if fired for another sweep
         // the context's other sweep buffer, if it exists: the launch can then be fired for the sweep srl_sweep_swap makes current
         // (sharded ranks too: every rank prefetches and swaps its own point range, the launch learns its count with the pose)
         const bool has_alt = ctx->d_raw_next != nullptr && ctx->next_cap > 0 && ctx->d_stage_next != nullptr;
@@ -1387,6 +1404,7 @@ static int build_residuals_pass(srl_ctx *ctx, const srl_frame *f, const srl_icp_
     out->num_fallback = (int32_t)(r.d_fallback + 0.5);
 
     if (a.aos != nullptr && n_eff > ctx->soa_valid_n) ctx->soa_valid_n = n_eff;      // this pass filed the SoA planes of its keypoints
+    ctx->bound_n = n_eff;                                                            // ... and the bounds of its keypoints (entries behind them: an earlier, shorter or longer pass -- never read)
     ctx->last_K = K;
     ctx->last_nb = nb;
     ctx->last_visited_local = visited_local - 1;
@@ -1541,6 +1559,13 @@ int srl_debug_set_launch_shape(srl_ctx *ctx, int keypoints_per_wave, int waves_p
     if (waves_per_workgroup != 0 && waves_per_workgroup != 4 && waves_per_workgroup != 16) return SRL_ERR_BAD_ARG;
     ctx->force_kpw = keypoints_per_wave;
     ctx->force_wpb = waves_per_workgroup;
+    return SRL_OK;
+}
+int srl_debug_set_bound_culling(srl_ctx *ctx, int enable) {
+    if (!ctx) return SRL_ERR_BAD_ARG;
+    SRL_DISARM(ctx);
+    ctx->bound_mode = enable ? 1 : 0;
+    ctx->bound_n = 0;
     return SRL_OK;
 }
 int srl_debug_set_fused_reduce(srl_ctx *ctx, int enable) {

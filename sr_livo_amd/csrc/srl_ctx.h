@@ -79,6 +79,12 @@ struct srl_ctx {
     int next_slot = 0;                    // slot of the prefetch in flight / last issued
     int next_prefix_n = 0;                // points of it covered by the prefix event (== next_n: one DMA)
     int prefix_hint = 0;                  // keypoints the passes of the running solve visit when that is a prefix of the shard (0: whole sweeps)
+    // neighbourhood bounds (SrlAssocArgs::bound_in): 4 floats per keypoint, written by every pass; entries [0, bound_n) were written on the
+    // CURRENT sweep and map with the options of bound_sig -- reset by whatever changes one of them
+    float *d_bound = nullptr;
+    int bound_n = 0;
+    int bound_sig[4] = {0, 0, 0, 0};      // K, voxel neighbourhood, occupancy threshold, (float) voxel size bits
+    int bound_mode = 1;                   // srl_debug_set_bound_culling: 0 = never use them
     bool tail_pending = false;            // the CURRENT sweep's tail may still be in flight: stream not yet ordered behind up_ev[cur_slot][1]
     int cur_slot = 0, cur_prefix_n = 0;   // ... its slot, and how many of its points are known to have landed
 

@@ -182,6 +182,15 @@ struct SrlAssocArgs {
     const SrlPeerTable *peer;   // fused + direct peer exchange: the finishing workgroup exchanges its totals itself (else null)
     unsigned peer_epoch;        // tag of this exchange (exchange counter, never 0)
     int peer_slot;              // exchange counter & 1
+    // NEIGHBOURHOOD BOUNDS (round 6): what every keypoint of the previous pass over THIS sweep and THIS map learnt -- its world position and
+    // the exact squared distance of its K-th nearest neighbour -- as {x, y, z, tau} floats.  The K points found then are still in the map, so
+    // the K nearest of the next pass lie within r = sqrt(tau) + |p_w - p_w_prev| of the new position: voxels whose box is further away than
+    // r are not visited (phase 1, probe_finish) -- same neighbours, same bits, fewer candidate rounds.  bound_use: entries [0, bound_use)
+    // may be read (0 on the first pass over a sweep, after a map change or other options); bound_out is written by every pass.
+    const float *bound_in;
+    float *bound_out;
+    int bound_use;
+    int pad_bound;
     // outputs
     double *rec;            // n x 8
     unsigned char *status;  // n

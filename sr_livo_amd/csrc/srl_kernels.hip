@@ -338,8 +338,12 @@ __device__ __forceinline__ ProbeReq probe_issue(const int *kv, int kl, const Lan
 }
 // Compacts the occupied voxels of both keypoints into their lists (list h at vox + 32 h, visit order kept,
 // zero-filled up to 27 entries so the candidate rounds need no bounds branch).  Returns nv_A | nv_B << 8.
+// cull (wave-uniform): qf_pair / kv_pair = the pair's FP32 queries (8 floats per keypoint, [5] = squared cull radius) and voxel keys (4
+// ints per keypoint); a found voxel whose box lies further from the query than the radius keeps its count in P_k (the reference's loop
+// visits it) but is left out of the candidate list -- none of its points can be among the K nearest (SrlAssocArgs::bound_in)
 __device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, const SrlMapSlot *table, unsigned mask,
-                                            VoxEnt *vox, int lane, int *ncand_pair) {
+                                            VoxEnt *vox, int lane, int *ncand_pair, bool cull = false, const float *qf_pair = nullptr,
+                                            const int *kv_pair = nullptr, const LaneRole *role = nullptr, float size_voxel = 1.0f) {
     const bool prober = (lane & 31) < 27;
     // the 2-slot window by selects (non-probing lanes carry EMPTY keys and match nothing) ...
     const bool m0 = prober && r.s0.key == r.key;
@@ -376,6 +380,25 @@ __device__ __forceinline__ int probe_finish(const ProbeReq &r, int thr_cap, cons
         v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3 -> lane 31: rows 0 + 1, lane 63: rows 2 + 3
         if ((lane & 31) == 31) ncand_pair[lane >> 5] = v;
 #endif
+    }
+    if (cull) {
+        // box of voxel key v along one axis (keys by truncation toward zero, optimize.cpp:372-374): v > 0: [v, v + 1), v < 0: (v - 1, v],
+        // v = 0: (-1, 1), times the voxel size; distance of the FP32 query to it, squared and summed.  The radius carries the slack for
+        // everything rounded here (SrlAssocArgs::bound_in, phase 0).
+        const int hh = lane >> 5;
+        const float *qf = qf_pair + 8 * hh;
+        const int *kv = kv_pair + 4 * hh;
+        const float r2 = qf[5];
+        float bd2 = 0.0f;
+        const int pd[3] = {role->pdx, role->pdy, role->pdz};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const int v = kv[ax] + pd[ax];
+            const float lo = (float)(v > 0 ? v : v - 1) * size_voxel, hi = (float)(v < 0 ? v : v + 1) * size_voxel;
+            const float d = fmaxf(fmaxf(lo - qf[ax], qf[ax] - hi), 0.0f);
+            bd2 += d * d;
+        }
+        found = found && bd2 <= r2;
     }
     const unsigned long long m = __ballot(found);
     const unsigned m_lo = (unsigned)m, m_hi = (unsigned)(m >> 32);
@@ -432,7 +455,7 @@ __device__ __forceinline__ float d2_f32(float px, float py, float pz, float qx, 
 // lane i evaluates survivor i exactly, strict rank by counting, tie check, winners emit.
 template <class Sink>
 __device__ __forceinline__ int finish_survivors(double qx, double qy, double qz, int c, const VoxEnt *vox, int K, void *scratch,
-                                                int lane, Sink &sink) {
+                                                int lane, Sink &sink, double *tau_out = nullptr) {
     SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));            // [64], 16-B aligned
     double *keys = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024);  // [66]
     double *sorted = keys + 66;                                                                    // [K + 1] d2 by rank, behind the key pads
@@ -484,6 +507,7 @@ __device__ __forceinline__ int finish_survivors(double qx, double qy, double qz,
     bool bad = false;
     if (lane >= 1 && lane <= K && lane < c) bad = !(sorted[lane] > sorted[lane - 1] * SRL_NEAR_TIE);
     if (__ballot(bad)) return SEL_TIE;             // the reference's literal heap sequence decides (select_topk_replay)
+    if (tau_out && act && rank == K - 1) *tau_out = my;      // the K-th nearest: the next pass's bound (SrlAssocArgs::bound_out)
     if (win) {
         const VoxEnt ve = vox[me.code >> 5];
         sink.put(rank, me.x, me.y, me.z, ve.slab * SRL_CAP + ((unsigned)me.code & 31u));
@@ -593,7 +617,7 @@ __device__ __forceinline__ int cand_select(const float (&px)[R], const float (&p
     if (c > 64) return SEL_OVERFLOW;       // checked before anything is written: the stores below need no clamp
     cand_compact<R>(px, py, pz, d2f, thr, svm, role, recs);
     if (ablate & 2) return SEL_DONE;
-    return finish_survivors(qx, qy, qz, c, vox, K, scratch, lane, sink);
+    return finish_survivors(qx, qy, qz, c, vox, K, scratch, lane, sink, reinterpret_cast<double *>(const_cast<float *>(qf) + 6));
 }
 
 template <int R, class Sink>
@@ -612,7 +636,7 @@ __device__ __forceinline__ int select_topk_f32_r(double qx, double qy, double qz
 // is paid once per pair instead of once per keypoint.  Scratch: recs[64] (A: 0..31, B: 32..63) | keys[64] | sorted[64].
 // Needs K <= 31 (rank K is filed too).  Returns done_a | done_b << 8.
 __device__ __forceinline__ int finish_pair(const double *qa, const double *qb, int ca, int cb, const VoxEnt *vox, int K, void *scratch, int lane,
-                                           const LdsSink &sink_a, const LdsSink &sink_b) {
+                                           const LdsSink &sink_a, const LdsSink &sink_b, const float *qfa, const float *qfb) {
     SurvRec *recs = reinterpret_cast<SurvRec *>(__builtin_assume_aligned(scratch, 16));
     double *keys = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(scratch) + 1024);
     double *sorted = keys + 64;
@@ -654,6 +678,8 @@ __device__ __forceinline__ int finish_pair(const double *qa, const double *qb, i
         LdsSink s = sink_a;
         if (h) { s.col = sink_b.col; s.tap_ids = sink_b.tap_ids; }
         s.put(rank, me.x, me.y, me.z, ve.slab * SRL_CAP + ((unsigned)me.code & 31u));
+        // the K-th nearest: the next pass's bound (SrlAssocArgs::bound_out); qf[6..7] of the keypoint, a double
+        if (rank == K - 1) *reinterpret_cast<double *>(const_cast<float *>(h ? qfb : qfa) + 6) = my;
     }
     __builtin_amdgcn_wave_barrier();
     return (tie_a ? SEL_TIE : SEL_DONE) | ((tie_b ? SEL_TIE : SEL_DONE) << 8);
@@ -714,18 +740,18 @@ __device__ __forceinline__ int select_pair_f32_r(const double *qa, const double 
     if (ca <= 32 && cb <= 32 && K <= 31 && !(ablate & (2 | 512))) {
         cand_compact<R>(ax, ay, az, da, thr_a, sa, role, recs);
         cand_compact<R>(bx, by, bz, db, thr_b, sb, role, recs + 32);
-        return finish_pair(qa, qb, ca, cb, vox, K, scratch, lane, sink_a, sink_b);
+        return finish_pair(qa, qb, ca, cb, vox, K, scratch, lane, sink_a, sink_b, qfa, qfb);
     }
     // one after the other through the single-keypoint finish (more than 32 survivors, K = 32, or a debug switch)
     int done_a = SEL_OVERFLOW, done_b = SEL_OVERFLOW;
     if (ca <= 64) {
         cand_compact<R>(ax, ay, az, da, thr_a, sa, role, recs);
-        done_a = (ablate & 2) ? SEL_DONE : finish_survivors(qa[0], qa[1], qa[2], ca, vox, K, scratch, lane, sink_a);
+        done_a = (ablate & 2) ? SEL_DONE : finish_survivors(qa[0], qa[1], qa[2], ca, vox, K, scratch, lane, sink_a, reinterpret_cast<double *>(const_cast<float *>(qfa) + 6));
     }
     __builtin_amdgcn_wave_barrier();
     if (cb <= 64) {
         cand_compact<R>(bx, by, bz, db, thr_b, sb, role, recs);
-        done_b = (ablate & 2) ? SEL_DONE : finish_survivors(qb[0], qb[1], qb[2], cb, vox + 32, K, scratch, lane, sink_b);
+        done_b = (ablate & 2) ? SEL_DONE : finish_survivors(qb[0], qb[1], qb[2], cb, vox + 32, K, scratch, lane, sink_b, reinterpret_cast<double *>(const_cast<float *>(qfb) + 6));
     }
     return done_a | (done_b << 8);
 }
@@ -1178,6 +1204,10 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
     auto tile_stamp = [&](int) {};
 #endif
     tile_stamp(10);
+    // bounds of the previous pass may be used when this pass runs on the sweep they were written for: not by an armed launch fired for
+    // the context's other sweep buffer or for another keypoint count (srl_sweep_swap) -- the host vouches for everything else
+    bool use_bounds = A.bound_in != nullptr && A.bound_use > 0;
+    if constexpr (ARMED) use_bounds = use_bounds && reinterpret_cast<const int *>(s_pose + SRL_POSE_DOUBLES)[2] == 0 && n_pass() == A.n;
     const int bbase_kp = tile * KPB;                                      // first keypoint of this tile
     const int wbase_kp = bbase_kp + wave * KPW;                           // first keypoint of this wave's quarter (phases 0 and 2)
 
@@ -1224,6 +1254,19 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
             qf[0] = qxf; qf[1] = qyf; qf[2] = qzf;
             qf[3] = (2.0f * m0) * 1.00001f;                                         // c0
             qf[4] = (1.0f + 2.0f * m1) * 1.00001f;                                  // c1
+            // squared cull radius from the previous pass's bound (SrlAssocArgs::bound_in): r = sqrt(tau) + |p_w - p_w_prev| + slack for
+            // everything that is rounded on the way (the stored FP32 positions -- a point may sit one ulp across its voxel's face --, the
+            // FP32 query and box faces of probe_finish, tau's and the distance's own rounding); +inf = visit every voxel
+            float r2 = __builtin_huge_valf();
+            if (use_bounds && g < A.bound_use) {
+                const float4 bp = reinterpret_cast<const float4 *>(A.bound_in)[g];
+                const float ex = qxf - bp.x, ey = qyf - bp.y, ez = qzf - bp.z;
+                const float mag = fabsf(qxf) + fabsf(qyf) + fabsf(qzf);
+                const float r = sqrtf(bp.w) * 1.000001f + sqrtf(ex * ex + ey * ey + ez * ez) * 1.000001f + (1e-3f + 1e-6f * mag);
+                r2 = (r * r) * 1.00001f;                                            // (tau = +inf: no K-th neighbour was known -- stays +inf)
+            }
+            qf[5] = r2;
+            *reinterpret_cast<double *>(qf + 6) = __builtin_huge_val();             // this pass's tau: set by whoever finishes the keypoint on the fast path
         }
         // static_cast<short>(point / size_voxel_map): truncation toward zero (optimize.cpp:372-374)
         // (x / 1.0 == x exactly: the shipped size_voxel_map = 1.0 skips three FP64 divisions)
@@ -1283,12 +1326,14 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
                 const int nxt = take();
                 // this pair's probes are consumed BEFORE the next pair's are issued: one probe state live at a time (no copy
                 // of the 11-register request per pair); the next pair's table loads still have the whole selection to land
-                const int nv_pair = __builtin_amdgcn_readfirstlane((abl & 8) ? 0 : probe_finish(preq, A.thr_cap, A.table, A.table_mask, vox, lane, s_ncand + 2 * cur));
+                const int nv_pair = __builtin_amdgcn_readfirstlane((abl & 8) ? 0 : probe_finish(preq, A.thr_cap, A.table, A.table_mask, vox, lane, s_ncand + 2 * cur, use_bounds, s_qf + 16 * cur,
+                                                                                                               s_kv + 8 * cur, &role, (float)A.size_voxel));
                 if (!(abl & 32)) preq = probe_issue(s_kv, 2 * (nxt < npairs ? nxt : npairs), role, A.table, A.table_mask, lane);
                 auto file = [&](int kl, int done, int total) {        // lane 0: result of one keypoint
+                    (void)total;
                     if (done == SEL_DONE) {
-                        s_nfound[kl] = total < Kn ? total : Kn;
-                        s_ncand[kl] = total;
+                        // (the candidate total P_k was filed by probe_finish -- every found voxel, also those the bounds let this pass skip;
+                        //  the loads of cand_issue count only what was visited)
                     } else {
                         s_defer[atomicAdd(s_next + 1, 1)] = (unsigned short)(kl | (done == SEL_TIE ? 0x8000 : 0));
                     }
@@ -1301,7 +1346,9 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
                     const int kl = 2 * cur;
                     LdsSink sink_a = make_sink(kl), sink_b = make_sink(kl + 1);
                     int total_a = 0, total_b = 0, done;
-                    if (r_max <= 3) done = select_pair_f32_r<3>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, Kn, surv, lane, role, sink_a, sink_b, total_a, total_b, abl);
+                    // (two rounds: what a pass that starts from the previous pass's bounds typically has left -- ~6 of ~12 occupied voxels)
+                    if (r_max <= 2) done = select_pair_f32_r<2>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, Kn, surv, lane, role, sink_a, sink_b, total_a, total_b, abl);
+                    else if (r_max <= 3) done = select_pair_f32_r<3>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, Kn, surv, lane, role, sink_a, sink_b, total_a, total_b, abl);
                     else done = select_pair_f32_r<4>(s_pw + kl * 3, s_pw + kl * 3 + 3, s_qf + kl * 8, s_qf + kl * 8 + 8, vox, A.slabs, A.inf_off, Kn, surv, lane, role, sink_a, sink_b, total_a, total_b, abl);
                     // (candidate totals: accumulated by probe_finish; neighbour counts: derived from them in phase 2 -- a pair that
                     // finished on the fast path files nothing)
@@ -1510,6 +1557,16 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
         }
     }
     if constexpr (ARMED) arm_stamp(karg, 23);
+    if (g < n2 && sl == 0 && b.bound_out != nullptr) {
+        // what the next pass over this sweep may start from (SrlAssocArgs::bound_in): this pass's world position and the exact squared
+        // distance of the K-th nearest neighbour, rounded UP to FP32 (+inf where the fast path did not finish the keypoint)
+        const float *qf = reinterpret_cast<const float *>(smem + L.off_qf) + kl * 8;
+        const double tau = *reinterpret_cast<const double *>(qf + 6);
+        float4 bo;
+        bo.x = qf[0]; bo.y = qf[1]; bo.z = qf[2];
+        bo.w = (float)tau * 1.0000002f;
+        reinterpret_cast<float4 *>(b.bound_out)[g] = bo;
+    }
     if (g < n2 && b.write_rec && sl == 0) {
         // per-keypoint record {J[6], distance, weight} (ordered cut-off path + taps; never on the throughput path)
         double2 *r = reinterpret_cast<double2 *>(b.rec + (size_t)g * 8);

@@ -386,6 +386,7 @@ int srl_map_insert_impl(srl_ctx *ctx, const double *world_xyz, bool on_device, i
     if (num_added) *num_added = 0;
     if (n == 0) return SRL_OK;
     if (!(voxel_size > 0.0)) return SRL_ERR_BAD_ARG;
+    ctx->bound_n = 0;                // the map changes: what the last pass learnt about its keypoints' neighbourhoods is void
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     { const int rcs = srl_map_settle(ctx); if (rcs) return rcs; }

