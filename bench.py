@@ -109,7 +109,7 @@ def main():
         comm_state.update(passes_repeated_for_a_late_rank=rep, session_failed=failed)
 
     # ---------------- behind the region: the kernel's duration (roofline), the long stamped stream, A/B and PCIe forms
-    tim = aux_legs.kernel_time_leg(run)
+    tim = aux_legs.kernel_time_leg(run, 8 if args.no_aux_legs else 200)        # (profiling runs keep the trace to the timed form: --no-aux-legs)
     stream_long, stream_states = (None, {}) if args.no_aux_legs else aux_legs.long_stream_leg(run, max(1000, args.steps))
     unfiltered = None if (args.no_aux_legs or sharded) else aux_legs.unfiltered_stream_leg(run)
     extra, launch_ab = {}, None

@@ -910,7 +910,7 @@ static int prepare_assoc_args(srl_ctx *ctx, const srl_frame *f, const srl_icp_op
         const int sig[4] = {K, nb, thr, sv_bits};
         if (std::memcmp(sig, ctx->bound_sig, sizeof sig) != 0) { ctx->bound_n = 0; std::memcpy(ctx->bound_sig, sig, sizeof sig); }
         a.bound_out = ctx->d_bound;
-        a.bound_in = (ctx->bound_mode != 0 && nb == 1) ? ctx->d_bound : nullptr;
+        a.bound_in = ctx->bound_mode != 0 ? ctx->d_bound : nullptr;
         a.bound_use = a.bound_in ? std::min(ctx->bound_n, n_eff) : 0;
     }
     nb_out = nb;

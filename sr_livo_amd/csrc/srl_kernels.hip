@@ -71,9 +71,13 @@ __device__ __forceinline__ Cand eval_cand(int e, int nv, const VoxEnt *vox, cons
 }
 
 // ---- (2r+1)^3 hash probes: lanes probe, occupied voxels are compacted (visit order kept) ----
+// qf_cull (the keypoint's FP32 query, [5] = squared cull radius; null = visit everything) and total_all (the candidates of ALL found
+// voxels, P_k of the reference's loop): the fast path of the init mode starts from the previous pass's bounds like the r = 1 path
+// (SrlAssocArgs::bound_in, probe_finish) -- 125 probes, ~45 occupied voxels, ~6 of them within reach of the K nearest
 template <int NB>
 __device__ __forceinline__ int probe_voxels(double qx, double qy, double qz, double size_voxel, int thr_cap,
-                                            const SrlMapSlot *table, unsigned mask, VoxEnt *vox, int lane) {
+                                            const SrlMapSlot *table, unsigned mask, VoxEnt *vox, int lane, const float *qf_cull = nullptr,
+                                            int *total_all = nullptr) {
     constexpr int SIDE = 2 * NB + 1;
     constexpr int NV = SIDE * SIDE * SIDE;
     asm volatile("" : "+v"(lane));   // keep lane-derived constants of this rarely taken path out of the caller's loop preheader
@@ -81,12 +85,13 @@ __device__ __forceinline__ int probe_voxels(double qx, double qy, double qz, dou
     const short kx = (short)(int)(qx / size_voxel);
     const short ky = (short)(int)(qy / size_voxel);
     const short kz = (short)(int)(qz / size_voxel);
-    int nv = 0;
+    int nv = 0, tot = 0;
 #pragma unroll
     for (int base = 0; base < NV; base += 64) {
         const int i = base + lane;
         bool found = false;
         unsigned slab = 0, cnt = 0;
+        float bd2 = 0.0f;
         if (i < NV) {
             // visit order: x outer, y, z inner (optimize.cpp:379-381)
             const int ix = i / (SIDE * SIDE);
@@ -109,13 +114,31 @@ __device__ __forceinline__ int probe_voxels(double qx, double qy, double qz, dou
                 if (s.key == SRL_EMPTY_KEY) break;
                 h = (h + 1) & mask;
             }
+            if (qf_cull) {
+                // distance of the FP32 query to the voxel's box (probe_finish has the derivation), squared
+                const int vv[3] = {(int)vx, (int)vy, (int)vz};
+                const float sz = (float)size_voxel;
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    const int v = vv[ax];
+                    const float lo = (float)(v > 0 ? v : v - 1) * sz, hi = (float)(v < 0 ? v : v + 1) * sz;
+                    const float d = fmaxf(fmaxf(lo - qf_cull[ax], qf_cull[ax] - hi), 0.0f);
+                    bd2 += d * d;
+                }
+            }
         }
+        tot += found ? (int)cnt : 0;
+        if (qf_cull) found = found && bd2 <= qf_cull[5];
         const unsigned long long m = __ballot(found);
         if (found) {
             VoxEnt ve; ve.slab = slab; ve.count = cnt;
             vox[nv + lanes_below(m)] = ve;
         }
         nv += __popcll(m);
+    }
+    if (total_all) {
+        for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+        *total_all = tot;
     }
     __builtin_amdgcn_wave_barrier();
     return nv;
@@ -840,7 +863,7 @@ __device__ __forceinline__ int select_topk_f32_loop(double qx, double qy, double
         }
     }
     if (c > 64) return SEL_OVERFLOW;
-    return finish_survivors(qx, qy, qz, c, vox, K, scratch, lane, sink);
+    return finish_survivors(qx, qy, qz, c, vox, K, scratch, lane, sink, reinterpret_cast<double *>(const_cast<float *>(qf) + 6));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1381,12 +1404,14 @@ __device__ __forceinline__ bool assoc_tile(KargBytes karg, const SrlAssocArgs &A
             auto take = [&]() { int p = 0; if (lane == 0) p = atomicAdd(s_next, 1); return __builtin_amdgcn_readfirstlane(p); };
             for (int kl = take(); kl < n_here; kl = take()) {
                 const double qx = s_pw[kl * 3 + 0], qy = s_pw[kl * 3 + 1], qz = s_pw[kl * 3 + 2];
-                const int nv = probe_voxels<NB>(qx, qy, qz, A.size_voxel, A.thr_cap, A.table, A.table_mask, vox, lane);
+                int total_all = 0;
+                const int nv = probe_voxels<NB>(qx, qy, qz, A.size_voxel, A.thr_cap, A.table, A.table_mask, vox, lane, use_bounds ? s_qf + kl * 8 : nullptr, &total_all);
                 if (lane < 3) { VoxEnt z; z.slab = 0u; z.count = 0u; vox[nv + lane] = z; }      // branch-free reads up to 3 * rounds
                 __builtin_amdgcn_wave_barrier();
                 LdsSink sink = make_sink(kl);
                 int total = 0;
                 const int done = select_topk_f32_loop(qx, qy, qz, s_qf + kl * 8, nv, vox, A.slabs, A.inf_off, Kn, surv, lane, role, sink, total);
+                total = total_all;           // P_k: every found voxel counts, also those the bounds let this pass skip
                 if (lane == 0) {
                     if (done == SEL_DONE) {
                         s_nfound[kl] = total < Kn ? total : Kn;

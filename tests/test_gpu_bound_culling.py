@@ -77,6 +77,33 @@ def test_passes_with_and_without_the_bounds_agree_bit_for_bit(scene, n_kp, max_r
     ctx.set_armed_launch(1)
 
 
+def test_init_mode_passes_agree_bit_for_bit(scene):
+    """frame_id < init_num_frames: r = 2 (125 voxels probed, ~45 occupied), the looped fast path -- with the bounds a pass visits the few
+    voxels within reach of the K nearest; ids, candidate counts and sums equal the passes without them"""
+    ctx = scene["ctx"]
+    sw = synth.make_sweep(4477, 6_000, scene["L"])
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    poses = _poses(sw, 4, 5, jump=2)
+
+    def run():
+        ctx.sweep_upload(sw["raw"])
+        ctx.set_taps(True)
+        res = []
+        for q, t in poses:
+            neq, rc = ctx.build_residuals(capi.make_frame(q, t, sw["t_last"], frame_id=5), opts)
+            res.append((neq, ctx.fetch_neighbors()[0].copy()))
+        ctx.set_taps(False)
+        return res
+    ctx.set_armed_launch(0)
+    ctx.set_bound_culling(0)
+    ref = run()
+    ctx.set_bound_culling(1)
+    got = run()
+    for k, (g, r) in enumerate(zip(got, ref)):
+        _same(g, r, k)
+    ctx.set_armed_launch(1)
+
+
 def test_a_map_change_or_another_sweep_voids_the_bounds(scene):
     """points inserted right next to keypoints between two passes (their K-th neighbour moves closer AND voxels that were empty fill up);
     another sweep uploaded over the old one; the same sweep through prefetch / swap: every pass equals a context that never had bounds"""

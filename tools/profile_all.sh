@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): the un-profiled bench line + rocprofv3 (kernel trace + separate PMC passes) of every
 # configuration quoted in DESIGN.md section 5.  Summaries land in gpurun_out/prof_<tag>/ and gpurun_out/bench_final.json.
-R=${1:-r05}
+R=${1:-r06}
 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; cp gpurun_out/bench_detail.json gpurun_out/bench_final_detail.json
 tools/profile_gpu.sh ${R}_headline 10 "" > /dev/null 2>&1
 tools/profile_gpu.sh ${R}_headline_unarmed 10 "--no-armed" > /dev/null 2>&1
@@ -14,6 +14,7 @@ tools/profile_gpu.sh ${R}_init 3 "--frame-id 5" > /dev/null 2>&1
 tools/profile_gpu.sh ${R}_headline600 10 "--max-num-residuals 600" > /dev/null 2>&1
 tools/profile_gpu.sh ${R}_c2_600 10 "--workload C2 --max-num-residuals 600" > /dev/null 2>&1
 tools/profile_gpu.sh ${R}_c3_600 10 "--workload C3 --max-num-residuals 600" > /dev/null 2>&1
+tools/profile_gpu.sh ${R}_spread 4 "--workload SPREAD --stream-sweeps 2" > /dev/null 2>&1
 for d in gpurun_out/prof_${R}_*; do echo "== $d"; python - "$d" <<'PY'
 import json, sys
 s = json.load(open(sys.argv[1] + "/summary.json"))
