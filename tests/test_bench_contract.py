@@ -246,3 +246,35 @@ def test_round5_committed_line_times_the_stream_and_says_so():
     assert {"C1", "C2", "C3", "C4", "HEADLINE@600", "C2@600", "C3@600"} <= set(names)
     assert all(c["parity_ok"] is True and c["armed"] is True for c in d["configs"])         # C4 included: 1 024 workgroups, fused and armed
     assert all(c.get("issue_frac") is not None for c in d["configs"])
+
+
+def test_the_multi_gpu_line_keeps_both_transports_the_sharded_configuration_and_the_replicas():
+    """what `bench.py --gpus N` measures behind its timed region at N > 1 -- the other transport on the same stream,
+    BASELINE config 4 sharded over the N ranks, the N GPUs as replicas -- must survive the cut to the one printed line (< 8 KB)."""
+    line = _mod("benchlib.line")
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    full.update(n_gpus=8, scaling="strong")
+    full["comm"] = {"transport_used": "rccl", "nranks": 8, "ranks_seen": 8, "us_per_iter_per_rank": {"min": 21.0, "max": 22.5},
+                    "rccl": {"us_per_esikf_iter": 22.5, "sweeps_per_s": 20000.0, "timed_region": True, "arm_stats": {"armed": 40, "fired": 39, "cancelled": 0, "expired": 0}},
+                    "peer": {"us_per_esikf_iter": 19.0, "sweeps_per_s": 24000.0, "ranks_seen": 8, "arm_stats": {"armed": 100, "fired": 99, "cancelled": 0, "expired": 0}}}
+    full["sharded_config"] = {"workload": "C4: 262144 keypoints (livox) sharded over 8 ranks (32768 on rank 0), 9871126-pt map replicated", "transport": "rccl",
+                              "sweeps_per_s": 9000.0, "us_per_esikf_iter": 55.0, "arm_stats": {"armed": 40, "fired": 39, "cancelled": 1, "expired": 0}}
+    full["aux_independent_sweeps_per_s"] = {"value": 80000.0, "what": "replicas"}
+    full["multi_gpu_note"] = "x"
+    text = line.compact_line(full)
+    assert len(text) < line.LINE_LIMIT_BYTES
+    d = json.loads(text)
+    assert d["n_gpus"] == 8 and d["comm"]["rccl"]["timed_region"] is True and d["comm"]["peer"]["us_per_esikf_iter"] == 19.0
+    assert d["sharded_config"]["us_per_esikf_iter"] == 55.0 and "32768 on rank 0" in d["sharded_config"]["workload"]
+    assert d["aux_independent_sweeps_per_s"]["value"] == 80000.0
+
+
+def test_bench_py_is_the_timed_loop_and_little_else():
+    """the file the driver hashes stays small enough to audit -- the loop that produces `value` and the assembly of the
+    line; legs, launcher, CPU baselines and parity live in tools/benchlib"""
+    src = open(os.path.join(ROOT, "bench.py")).read().split("\n")
+    assert len(src) <= 400, len(src)
+    body = "\n".join(src)
+    assert "THE TIMED REGION" in body and body.count("run.barrier()") >= 2
+    region = body[body.index("THE TIMED REGION"):body.index("elapsed = time.perf_counter() - t1")]
+    assert "set_profiling" not in region and "timing_mark" not in region and "Event" not in region       # no event record inside the region
