@@ -1177,6 +1177,45 @@ def test_headline_64k_on_1M(oracle_lib, oracle_backend):
     _full_size_case(oracle_lib, oracle_backend, *synth.CONFIGS["HEADLINE"])
 
 
+def test_spread_sweep_off_cache_parity(oracle_lib, oracle_backend):
+    """the workload whose working set is NOT cache resident -- keypoints area-uniform over the whole scene in random
+    order (synth.make_spread_sweep: about one keypoint per voxel, consecutive keypoints far apart) instead of a lidar cone -- at a size the
+    oracle finishes in seconds: 32 768 keypoints over the 2 M-pt map of config 3.  One pass against the oracle (neighbour ids bit-exact,
+    records 1e-9), the candidate census, and a full solve whose later passes start from the neighbourhood bounds."""
+    n_kp, map_pts, _pattern, seed = 32_768, 2_000_000, "livox", synth.CONFIGS["C3"][3]
+    pts, L = synth.map_candidates(seed, map_pts)
+    sw = synth.make_spread_sweep(seed + 77, n_kp, pts, L)
+    # spread indeed: tens of thousands of distinct keypoint voxels (a 70-degree cone of this size touches a few hundred)
+    R = synth.quat_to_rot(sw["q_pred"] / np.linalg.norm(sw["q_pred"]))
+    kv = np.trunc(sw["raw"] @ R.T + sw["t_pred"]).astype(np.int64)
+    assert len(np.unique(kv, axis=0)) > 20_000
+    m = oracle_lib.Map(oracle_backend)
+    m.add_points(pts)
+    lio = srl.Lio(0)
+    try:
+        lio.add_points_to_map(pts)
+        assert lio.map_size() == m.size()
+        g = gpu_pass(lio.ctx, sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"], max_num_residuals=INT_MAX)
+        with oracle_lib.threads(min(os.cpu_count() or 1, 32)):
+            o = m.build_plane_residuals(oracle_lib.default_opts(max_num_residuals=INT_MAX), sw["raw"], sw["q_pred"], sw["t_pred"], sw["t_last"])
+        ref = {f"x_one_{k}": v for k, v in o.items() if isinstance(v, np.ndarray)}
+        ref.update(x_one_num_ties=o["neq"].num_ties, x_one_num_residuals=o["neq"].num_residuals, x_one_success=o["neq"].success, x_one_loss=o["neq"].loss_sum)
+        check_pass_against(g, ref, "x")
+        assert g["neq"].sum_candidates == o["neq"].sum_candidates and int(g["ncand"].sum()) == g["neq"].sum_candidates
+        e = oracle_lib.Eskf(oracle_backend)
+        synth.eskf_prior(e, sw["q_pred"], sw["t_pred"], sw["vel"])
+        lio.eskf_set_state(e.get_state()); lio.eskf_set_cov(e.get_cov())
+        st = state16(sw)
+        opts = srl.default_opts(max_num_residuals=INT_MAX)
+        r = lio.update_iekf(opts, sw["raw"], st, sw["t_last"])
+        with oracle_lib.threads(min(os.cpu_count() or 1, 32)):
+            u = oracle_lib.update_iekf(m, e, oracle_lib.opts_from_product(opts), sw["raw"], st, sw["t_last"])
+        assert r["rc"] == 0 and r["iters"] == u["rc"] >= 2 and r["num_residuals"] == u["num_residuals"]
+        assert rel(r["state"], u["state"]) < 1e-9 and rel(lio.eskf_get_cov(), e.get_cov()) < 1e-8
+    finally:
+        lio.close()
+
+
 def test_config4_dense_256k_on_10M_logical_shards(oracle_lib, oracle_backend):
     """BASELINE configs[3] on one device: 262 144 keypoints, 10 M-point / ~500 k-voxel map.  Map equality
     with the sequential insert, kernel properties, the oracle over the WHOLE sweep (ids / status bit-exact, records and normal
