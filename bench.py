@@ -66,6 +66,7 @@ def parse_args():
                     help="sharded mode: how the 50-double rows of the ranks are summed.  rccl: ncclAllReduce on the library's own communicator; "
                          "peer: direct stores into the peers' inboxes over xGMI (srl_peer_attach, HIP IPC handles exchanged over gloo)")
     ap.add_argument("--sharded-config", default="C4", choices=sorted(synth.CONFIGS), help="N > 1: the configuration of the sharded-config leg")
+    ap.add_argument("--no-other-transport", action="store_true", help="N > 1: do not run the stream on the transport the timed region did not use")
     ap.add_argument("--force-comm", action="store_true", help="attach an RCCL communicator even at world size 1")
     return ap.parse_args()
 
@@ -115,7 +116,7 @@ def main():
     extra, launch_ab = {}, None
     if world == 1 and not args.no_aux_legs and not args.no_armed:
         launch_ab, extra["tim_unarmed"] = aux_legs.launch_ab_leg(run, stream_states, elapsed * 1e6 / max(iters_timed, 1))
-    other_transport = multi.other_transport_leg(run, args.steps) if (sharded and world > 1 and not args.no_aux_legs) else None
+    other_transport = multi.other_transport_leg(run, args.steps) if (sharded and world > 1 and not args.no_aux_legs and not args.no_other_transport) else None
     r0, res_legs = aux_legs.resident_legs(run)
     extra.update(res_legs)
     rates, medians, stalls, n_pcie = aux_legs.pcie_legs(run, stream_long)

@@ -208,7 +208,7 @@ def test_gpus_n_without_a_launcher_becomes_its_own_launcher(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    assert [c[-2:] for c, _ in seen[1:]] == [["--transport", "peer"], ["--mode", "replay"]]
+    assert [c[-2:] for c, _ in seen[1:]] == [["--transport", "peer"], ["--mode", "replay"]] and "--no-other-transport" in seen[1][0]
     assert killed == [4243]                                             # the hung first attempt: its process group, nothing else
     out = [a[0] for a, k in printed if k.get("file") is None]
     assert len(out) == 1 and json.loads(out[0])["fallback"].startswith("sharded forms failed") and json.loads(out[0])["n_gpus"] == 4

@@ -19,7 +19,8 @@ import torch  # noqa: E402,F401  (same process image as bench.py)
 
 import sr_livo_amd as srl  # noqa: E402
 from sr_livo_amd import synth  # noqa: E402
-from bench import _EskfAdapter  # noqa: E402
+sys.path.insert(0, "tools")
+from benchlib.stream import _EskfAdapter  # noqa: E402
 
 INT_MAX = 2**31 - 1
 

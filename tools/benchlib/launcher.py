@@ -63,7 +63,8 @@ def self_launch(n_gpus):
     env.setdefault("OMP_NUM_THREADS", "8")
     base = [a for a in sys.argv[1:]]
     explicit = any(a in ("--transport", "--mode") or a.startswith("--transport=") or a.startswith("--mode=") for a in base)
-    attempts = [([], None)] if explicit else [([], None), (["--transport", "peer"], "RCCL form failed or hung: direct peer exchange"),
+    # (a fallback attempt does not touch the transport that has just failed or hung again: --no-other-transport)
+    attempts = [([], None)] if explicit else [([], None), (["--no-other-transport", "--transport", "peer"], "RCCL form failed or hung: direct peer exchange"),
                                               (["--mode", "replay"], "sharded forms failed or hung: independent replicas, one sweep per GPU")]
     last_rc = 1
     for extra, note in attempts:

@@ -11,7 +11,8 @@ import numpy as np
 sys.path.insert(0, ".")
 import sr_livo_amd as srl  # noqa: E402
 from sr_livo_amd import synth  # noqa: E402
-from bench import _EskfAdapter  # noqa: E402
+sys.path.insert(0, "tools")
+from benchlib.stream import _EskfAdapter  # noqa: E402
 
 solves = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 cfg = sys.argv[2] if len(sys.argv) > 2 else "C1"
@@ -59,7 +60,9 @@ def run(count, during, check):
 
 
 lio.ctx.set_armed_launch(False)
-run(2 * S, lambda k: False, None)                      # references: one launch per iteration
+lio.ctx.set_bound_culling(0)
+run(2 * S, lambda k: False, None)                      # references: one launch per iteration, every pass visits every found voxel
+lio.ctx.set_bound_culling(1)                           # (round 6) ... the soak: passes after the first start from the neighbourhood bounds
 lio.ctx.set_armed_launch(True)
 s0 = lio.ctx.arm_stats()
 t0 = time.time()

@@ -14,7 +14,8 @@ import torch  # noqa: E402,F401
 
 import sr_livo_amd as srl  # noqa: E402
 from sr_livo_amd import synth  # noqa: E402
-from bench import _EskfAdapter, make_stream  # noqa: E402
+sys.path.insert(0, "tools")
+from benchlib.stream import _EskfAdapter, make_stream  # noqa: E402
 
 INT_MAX = 2**31 - 1
 PLAN = {"HEADLINE": ("HEADLINE", INT_MAX), "C1": ("C1", INT_MAX), "C2": ("C2", INT_MAX), "C3": ("C3", INT_MAX), "HEADLINE@600": ("HEADLINE", 600)}
