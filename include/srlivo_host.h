@@ -74,6 +74,14 @@ int srl_lio_update_iekf(srl_lio *lio, const srl_icp_opts *opts, const double *ra
 /* same update, the per-iteration normal equations coming from `provider` (multi-process CPU tests of
  * the sharded host logic; never used by the product path). */
 typedef int (*srl_normal_eq_provider)(const srl_frame *frame, const srl_icp_opts *opts, srl_normal_eq *out, void *user);
+/* The body of a node's loop over a stream of sweeps (src/lioOptimization.cpp:1003-1027: one optimize() per sweep) as ONE call, for replay
+ * and benchmark loops whose own language would otherwise sit between the calls: reset the filter to the given prior (eskf_state[19],
+ * eskf_cov[289]; NULL: keep what the filter holds), register the upload of the NEXT sweep with the solve (next_raw_xyz / next_n; NULL: none),
+ * solve the resident sweep of n keypoints (srl_lio_update_iekf with raw_xyz = NULL), and make the next sweep the resident one
+ * (srl_lio_swap_sweep; only when one was given).  Same statuses as the calls it stands for; the first failure is returned. */
+int srl_lio_stream_step(srl_lio *lio, const srl_icp_opts *opts, const double eskf_state[19], const double eskf_cov[289], int n, double state_io[16],
+                        const double t_last[3], int frame_id, const double *next_raw_xyz, int next_n, int *iters, int *num_residuals_used);
+
 int srl_lio_update_iekf_provided(srl_lio *lio, const srl_icp_opts *opts, srl_normal_eq_provider provider,
                                  void *user, int n, double state_io[16], const double t_last[3], int frame_id,
                                  double *log, int max_log_iters, int *iters, int *num_residuals_used);

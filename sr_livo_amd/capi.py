@@ -206,6 +206,7 @@ def load_library():
         "srl_lio_prefetch_sweep_during_solve": ([p, p, C.c_int], C.c_int),
         "srl_lio_update_iekf": ([p, C.POINTER(IcpOpts), p, C.c_int, dp, dp, C.c_int, p, C.c_int,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "srl_lio_stream_step": ([p, C.POINTER(IcpOpts), dp, dp, C.c_int, dp, dp, C.c_int, p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_lio_update_iekf_provided": ([p, C.POINTER(IcpOpts), PROVIDER_FN, p, C.c_int, dp, dp, C.c_int, p, C.c_int,
                                           C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "srl_lio_optimize": ([p, C.POINTER(IcpOpts), C.c_double, p, p, C.c_int, dp, dp, C.c_int, p,
@@ -921,6 +922,30 @@ class Lio:
         solve.state = st
         solve._keep = (es, ec, st0, tl, opts)
         return solve
+
+    def bound_stream_step(self, opts, eskf_state, eskf_cov, state, t_last, frame_id, n_resident, next_pinned):
+        """The node's loop body over a stream of sweeps as ONE C call per step (srl_lio_stream_step): prior reset, the upload of the NEXT
+        sweep (`next_pinned`: a page-locked (n, 3) array) registered with the solve, the solve of the resident sweep, the swap.  Every argument
+        is converted once.  Returns (status, iterations, residuals); the solved state is left in `step.state`."""
+        if self.ctx is not None:
+            self.ctx._select(opts)
+        es = _f64(eskf_state).copy(); ec = _f64(eskf_cov).ravel().copy()
+        st0 = _f64(state).copy(); st = st0.copy(); tl = _f64(t_last).copy()
+        iters, nres = C.c_int(), C.c_int()
+        lib, h = self.lib, self.h
+        p_es, p_ec, p_st, p_tl = _dptr(es), _dptr(ec), _dptr(st), _dptr(tl)
+        o = C.byref(opts); bi, bn = C.byref(iters), C.byref(nres)
+        fn = lib.srl_lio_stream_step
+        fid, n = int(frame_id), int(n_resident)
+        nx_ptr, nx_n = next_pinned.ctypes.data_as(C.c_void_p), int(len(next_pinned))
+        copy_state = np.copyto
+
+        def step():
+            copy_state(st, st0)
+            return fn(h, o, p_es, p_ec, n, p_st, p_tl, fid, nx_ptr, nx_n, bi, bn), iters.value, nres.value
+        step.state = st
+        step._keep = (es, ec, st0, tl, opts, next_pinned)
+        return step
 
     def update_iekf_provided(self, opts, provider, n, state, t_last, frame_id=100, log_iters=0,
                              allow=(SRL_ERR_NOT_ENOUGH_RESIDUALS,)):

@@ -265,6 +265,17 @@ int srl_lio_update_iekf(srl_lio *h, const srl_icp_opts *opts, const double *raw_
     return run_update(h, opts, keypoints, state_io, t_last, frame_id, log, max_log_iters, iters, num_residuals_used, true);
 }
 
+int srl_lio_stream_step(srl_lio *h, const srl_icp_opts *opts, const double eskf_state[19], const double eskf_cov[289], int n, double state_io[16],
+                        const double t_last[3], int frame_id, const double *next_raw_xyz, int next_n, int *iters, int *num_residuals_used) {
+    if (!h || !opts || !state_io || !t_last || n < 0 || next_n < 0) return SRL_ERR_BAD_ARG;
+    int rc = SRL_OK;
+    if (eskf_state && (rc = srl_lio_eskf_set_state(h, eskf_state)) != SRL_OK) return rc;
+    if (eskf_cov && (rc = srl_lio_eskf_set_cov(h, eskf_cov)) != SRL_OK) return rc;
+    if (next_raw_xyz && (rc = srl_lio_prefetch_sweep_during_solve(h, next_raw_xyz, next_n)) != SRL_OK) return rc;
+    if ((rc = srl_lio_update_iekf(h, opts, nullptr, n, state_io, t_last, frame_id, nullptr, 0, iters, num_residuals_used)) != SRL_OK) return rc;
+    return next_raw_xyz ? srl_lio_swap_sweep(h) : SRL_OK;
+}
+
 int srl_lio_update_iekf_provided(srl_lio *h, const srl_icp_opts *opts, srl_normal_eq_provider provider, void *user, int n,
                                  double state_io[16], const double t_last[3], int frame_id, double *log, int max_log_iters,
                                  int *iters, int *num_residuals_used) {

@@ -410,3 +410,33 @@ def test_a_sweep_of_more_workgroups_than_compute_units_stays_fused_and_armed(sce
     finally:
         lio.ctx.set_armed_launch(True)
         lio.resident_sweep(sc["sweep"]["raw"])
+
+
+def test_the_fused_stream_step_equals_the_separate_calls(scene_L):
+    """srl_lio_stream_step (prior reset + upload of the next sweep registered with the solve + solve + swap in one C call: the body of a
+    node's loop, what bench.py's stream calls) against the same stream through the separate entry points: same iteration and residual
+    counts, states and covariances bit for bit, armed launches surviving the swaps either way"""
+    sc = scene_L
+    lio = sc["lio"]
+    sw = _sweeps(sc, 4)
+    opts = srl.default_opts(max_num_residuals=INT_MAX)
+    try:
+        lio.ctx.set_armed_launch(True)
+        ref = _stream(sc, sw, opts, 8, during_solve=True)
+        steps = [lio.bound_stream_step(opts, s["prior_state"], sc["prior_cov"], s["state0"], s["sweep"]["t_last"], 100, s["n"], sw[(j + 1) % 4]["pin"].array)
+                 for j, s in enumerate(sw)]
+        lio.prefetch_sweep(sw[0]["pin"].array); lio.swap_sweep()
+        s0 = lio.ctx.arm_stats()
+        for k in range(16):
+            rc, it, nr = steps[k % 4]()
+            r = ref[k % 8]
+            assert rc == 0 and (it, nr) == (r[0], r[1]), (k, rc, it, nr, r[:2])
+            assert np.array_equal(steps[k % 4].state, r[2]) and np.array_equal(lio.eskf_get_cov(), r[3]), k
+        s1 = lio.ctx.arm_stats()
+        lio.ctx.disarm()
+        assert s1["cancelled"] - s0["cancelled"] <= 1 and s1["fired"] - s0["fired"] >= sum(r[0] for r in ref) * 2 - 2
+    finally:
+        lio.ctx.set_armed_launch(True)
+        lio.resident_sweep(sc["sweep"]["raw"])
+        for s_ in sw:
+            s_["pin"].close()

@@ -64,16 +64,14 @@ def make_stream(sweep0, prior_state0, sweep_seed, n_kp, L, pattern, count, itera
 
 class Streamer:
     """the node's loop over a stream of sweeps on one context: prefetch of the next sweep (copy stream) -> full ESIKF solve of the current
-    one from its own prior -> swap.  Every sweep crosses PCIe exactly once per solve; no host synchronisation."""
+    one from its own prior -> swap.  Every sweep crosses PCIe exactly once per solve; no host synchronisation.  One C call per step
+    (srl_lio_stream_step: what the body of a C++ node's loop is -- between separate calls this harness' own language cost ~3 us per solve)."""
 
     def __init__(self, lio, stream, opts, prior_cov, frame_id, n_kp):
-        import ctypes
         self.lio, self.stream, self.S, self.pos = lio, stream, len(stream), 0
-        for e in stream:
-            e["solve"] = lio.bound_solver(opts, e["prior_state"], prior_cov, e["state0"], e["sweep"]["t_last"], frame_id, n_kp)
-            e["ptr"] = e["pin"].array.ctypes.data_as(ctypes.c_void_p)          # arguments converted once: the loop below calls the C entry points directly
-            e["n"] = int(len(e["pin"].array))
-        self._prefetch, self._swap, self._h = lio.lib.srl_lio_prefetch_sweep_during_solve, lio.lib.srl_lio_swap_sweep, lio.h
+        for k, e in enumerate(stream):
+            nx = stream[(k + 1) % self.S]
+            e["step"] = lio.bound_stream_step(opts, e["prior_state"], prior_cov, e["state0"], e["sweep"]["t_last"], frame_id, n_kp, nx["pin"].array)
 
     def begin(self):
         self.lio.prefetch_sweep(self.stream[self.pos % self.S]["pin"].array)
@@ -83,16 +81,13 @@ class Streamer:
         k = self.pos
         e = self.stream[k % self.S]
         # sweep k + 1 arrives during the solve of sweep k: its upload is issued by the solve itself, beside the kernel of the first pass
-        nx = self.stream[(k + 1) % self.S]
-        rc = self._prefetch(self._h, nx["ptr"], nx["n"])
-        rc2, it, nr = e["solve"]()
-        rc = rc or rc2 or self._swap(self._h)
+        rc, it, nr = e["step"]()
         if rc:
             lib = self.lio.lib
             why = (lib.srl_lio_last_error(self.lio.h) or b"").decode(errors="replace") or (lib.srl_last_error(self.lio.ctx.h) or b"").decode(errors="replace")
             raise RuntimeError(f"stream step failed with status {rc} on sweep {k % self.S} of the stream: {why}")
         self.pos = k + 1
-        return {"iters": it, "num_residuals": nr, "state": e["solve"].state, "sweep": k % self.S}
+        return {"iters": it, "num_residuals": nr, "state": e["step"].state, "sweep": k % self.S}
 
     def close(self):
         for e in self.stream:
