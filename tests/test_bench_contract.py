@@ -281,8 +281,8 @@ def test_bench_py_is_the_timed_loop_and_little_else():
 
 
 def test_round6_committed_line_has_no_event_record_in_the_region_and_quotes_its_own_profiles():
-    """profiles/r06_bench.json: the line as printed in round 6.  `value` within 5 % of the 1 000-solve mean (VERDICT r05 item 4 asked for 2 %:
-    the first step behind the barrier costs 116 us instead of 93 in a 20-step region), kernel durations from >= 200 launches behind the region,
+    """profiles/r06_bench.json: the line as printed in round 6.  `value` within 3 % of the 1 000-solve mean (VERDICT r05 item 4 asked for 2 %:
+    the first step behind the barrier costs 107 us instead of 92 in a 20-step region), kernel durations from >= 200 launches behind the region,
     counters of THIS round's kernel (profile_stale false), the unfiltered-seed rate, the off-cache leg, a 256k-point frame in the pipeline."""
     path = os.path.join(ROOT, "profiles", "r06_bench.json")
     raw = open(path).read()
@@ -297,7 +297,7 @@ def test_round6_committed_line_has_no_event_record_in_the_region_and_quotes_its_
     assert d["unit"] == "sweeps/s" and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["steps"] == 20 and d["warmup"] == 5
     assert abs(d["value"] - full["value"]) / d["value"] < 1e-6 and abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-9
     st = d["stream"]
-    assert st["solves"] >= 1000 and st["sweeps_per_s_mean"] >= 10500 and 0.95 <= st["value_over_long_mean"] <= 1.02
+    assert st["solves"] >= 1000 and st["sweeps_per_s_mean"] >= 10500 and 0.97 <= st["value_over_long_mean"] <= 1.02
     assert st["arm_stats"]["cancelled"] <= 2 and st["unfiltered"]["sweeps"] == 8 and st["unfiltered"]["sweeps_per_s"] > 8000
     assert d["arm_stats"]["cancelled"] == 0 and d["arm_stats"]["expired"] == 0
     r = d["roofline"]
