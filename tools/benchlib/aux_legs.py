@@ -30,12 +30,15 @@ def kernel_time_leg(run, min_launches=200):
     ctx.timing_mark()
     solves, t0 = 0, time.perf_counter()
     tim = None
-    for _ in range(40):
+    # N > 1: every rank runs the SAME number of solves (each one is a collective) -- the count of durations read back can differ by a launch
+    # between ranks (a cancelled armed launch voids its event pair), so it must not decide when a rank leaves the loop
+    fixed_batches = None if run.dist is None else max(1, (min_launches * EVENT_PERIOD + 99) // 100)
+    for b in range(40):
         for _ in range(50):
             step()
         solves += 50
         tim = ctx.timing()                # (reads the completed pairs back; cancels the waiting launch: once per 50 solves)
-        if tim.calls >= min_launches or solves >= 2000:
+        if (fixed_batches is None and (tim.calls >= min_launches or solves >= 2000)) or (fixed_batches is not None and b + 1 >= fixed_batches):
             break
     el = time.perf_counter() - t0
     ctx.set_profiling(0)
