@@ -751,7 +751,7 @@ int srl_frame_select_keypoints(srl_ctx *ctx, const double q[4], const double t[3
         srl_stage_end(ctx, 3);
     }
     if (num_keypoints) *num_keypoints = m;
-    ctx->total_n = m; ctx->shard_begin = 0; ctx->n = m; ctx->sweep_loaded = true; ctx->taps_valid = false; ctx->bound_n = 0;
+    ctx->total_n = m; ctx->shard_begin = 0; ctx->n = m; ctx->sweep_loaded = true; ctx->taps_valid = false; ctx->bound_n = 0; ctx->tail_pending = false;
     ctx->soa_valid_n = m; ctx->passes_in_solve = 0;
     if (n > 0) { const int rcm = srl_mark_frame_read(ctx); if (rcm) return rcm; }
     srl_stage_end(ctx, 4);
